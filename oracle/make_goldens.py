@@ -1,0 +1,415 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (read-only at
+/root/reference) on seeded inputs.  Build-container only: the reference never
+travels to the GPU box; the fixtures (data: inputs + expected outputs) do.
+
+    python oracle/make_goldens.py            # all three trees (one subprocess each)
+    python oracle/make_goldens.py burgers    # one tree
+
+What is pinned:
+  * schedule tables (cosine / sigmoid) bit-exact
+  * U-Net epsilon at tiny configs + a handful of intermediate stage outputs
+  * T=8 p_sample_loop trajectories, guided and calibration variants, noise injected
+    by patching torch.randn / torch.randn_like while the reference loop runs
+  * guidance-gradient, weight-normalisation and conformal-quantile KATs
+Weights are NOT stored: both sides rebuild them with oracle.detweights.det_params
+from the (key, shape) list stored in the fixture.
+"""
+import contextlib
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle.detweights import det_params, det_noise, det_tensor  # noqa: E402
+
+
+@contextlib.contextmanager
+def injected_noise(noise):
+    """Route the reference's torch.randn / randn_like draws to noise(i)."""
+    state = {"i": 0}
+    real_randn, real_like = torch.randn, torch.randn_like
+
+    def _next(shape):
+        z = noise(state["i"])
+        assert tuple(z.shape) == tuple(shape), (z.shape, shape)
+        state["i"] += 1
+        return z
+
+    def randn(*shape, **kw):
+        if len(shape) == 1 and not isinstance(shape[0], int):
+            shape = tuple(shape[0])
+        return _next(shape)
+
+    torch.randn, torch.randn_like = randn, (lambda x, **kw: _next(x.shape))
+    try:
+        yield state
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_like
+
+
+def spec_of(module):
+    return [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
+
+
+def load_det(module, seed):
+    spec = spec_of(module)
+    P = det_params(spec, seed)
+    module.load_state_dict(P)
+    module.eval()
+    return spec
+
+
+def spec_arrays(spec):
+    return {"spec_keys": np.array([k for k, _ in spec]),
+            "spec_shapes": np.array([",".join(map(str, s)) for _, s in spec])}
+
+
+def grab_stages(module, names):
+    got, hooks = {}, []
+    mods = dict(module.named_modules())
+    for n in names:
+        hooks.append(mods[n].register_forward_hook(
+            lambda m, i, o, n=n: got.__setitem__(n, o.detach().clone())))
+    return got, hooks
+
+
+def stub_modules(*names):
+    for n in names:
+        if n not in sys.modules:
+            import importlib.machinery
+            m = types.ModuleType(n)
+            m.__spec__ = importlib.machinery.ModuleSpec(n, None)
+            sys.modules[n] = m
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    arrs = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()}
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# ----------------------------------------------------------------------------
+
+def gen_burgers():
+    sys.path.insert(0, os.path.join(REF, "1D"))
+    from model.unet import Unet2D
+    from model.diffusion import GaussianDiffusion
+
+    # schedules (1000 steps)
+    gd = GaussianDiffusion(Unet2D(dim=8, channels=3, resnet_block_groups=1), seq_length=(16, 128),
+                           temporal=True, use_conv2d=True)
+    names = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+             "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+             "posterior_mean_coef1", "posterior_mean_coef2"]
+    save("schedule_cosine", **{n: getattr(gd, n) for n in names})
+    gl = GaussianDiffusion(Unet2D(dim=8, channels=3, resnet_block_groups=1), seq_length=(16, 128),
+                           temporal=True, use_conv2d=True, beta_schedule="linear")
+    save("schedule_linear", **{n: getattr(gl, n) for n in names})
+
+    # U-Net KAT
+    dim = 8
+    net = Unet2D(dim=dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+    spec = load_det(net, seed=100)
+    x = det_tensor((2, 3, 16, 128), 101)
+    t = torch.tensor([7, 512])
+    stages = ["init_conv", "downs.0.0.block1", "downs.0.0", "downs.0.2", "downs.0.3", "downs.3.3",
+              "mid_block1", "mid_attn", "ups.0.3", "ups.3.2", "final_res_block"]
+    got, hooks = grab_stages(net, stages)
+    with torch.no_grad():
+        eps = net(x, t)
+        temb = net.time_mlp(t)
+    for h in hooks:
+        h.remove()
+    save("burgers_unet", dim=dim, x=x, t=t, eps=eps, temb=temb, **spec_arrays(spec),
+         **{"stage:" + k: v for k, v in got.items()})
+
+    # guidance / conformal helpers of the reference (need stubs for absent pip packages
+    # that utils.common pulls in at import time; none is used by the functions called here)
+    stub_modules("h5py", "tensorboardX", "ema_pytorch", "IPython")
+    sys.modules["tensorboardX"].SummaryWriter = object
+    sys.modules["ema_pytorch"].EMA = object
+    sys.modules["IPython"].embed = None
+    ref_guid = None
+    try:
+        from utils.guidance import get_finetune_guidance, calculate_guidance
+        from inference.guidance import get_weight, normalize_weights
+        from inference.conformal import ConformalCalculator
+        ref_guid = True
+    except Exception as e:  # noqa: BLE001
+        print("!! 1D guidance import failed, KAT skipped:", repr(e))
+
+    cfg = types.SimpleNamespace(use_max_safety=True, u_bound=0.8, guidance_weights={"w_score": 500.0}, InfFT_Q=None)
+    if ref_guid:
+        for tag, ums in (("mean", True), ("amax", False)):
+            cfg.use_max_safety = ums
+            xs = det_tensor((6, 3, 16, 128), 110, scale=0.1)
+            xs[:3, 2] += 0.07            # make the hinge active for half the batch
+            Q = 0.01
+            x_ = xs.clone().requires_grad_()
+            grad = get_finetune_guidance(cfg, x_, Q)
+            J = calculate_guidance(xs, Q, cfg)
+            w = get_weight(xs, Q, cfg)
+            save(f"burgers_guidance_{tag}", x=xs, Q=Q, w_score=500.0, u_bound=0.8, grad=grad, J=J, weight=w)
+        # normalize_weights edge cases + quantile
+        cases = {
+            "plain": torch.tensor([0.5, 1.5, 0.25, 3.0, 0.0, 1.0]),
+            "inf": torch.tensor([0.5, float("inf"), 0.25, 3.0, float("inf"), 1.0]),
+            "zero": torch.zeros(6),
+        }
+        out = {}
+        for k, v in cases.items():
+            out["nw_in_" + k] = v.clone()
+            out["nw_out_" + k] = normalize_weights(v.clone())
+        sc = det_tensor((16,), 120).abs()
+        for a in (0.98, 0.9, 0.5, 0.05):
+            out[f"q_{a}"] = ConformalCalculator.calculate_quantile(None, sc, None, None, a)
+        out["q_scores"] = sc
+        save("burgers_conformal", **out)
+
+    # trajectories, T = 8
+    T = 8
+    for tag, kw in (("guided", dict(guidance=True)), ("calib", dict(guidance=False))):
+        net = Unet2D(dim=dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+        load_det(net, seed=100)
+        gd = GaussianDiffusion(net, seq_length=(16, 128), timesteps=T, temporal=True, use_conv2d=True,
+                               is_condition_u0=True, is_condition_uT=True, condition_idx=10,
+                               train_on_padded_locations=False)
+        B = 2
+        u0 = det_tensor((B, 128), 130, 0.1, -0.1, 0.3)
+        uT = det_tensor((B, 128), 131, 0.1, -0.1, 0.3)
+        noise = det_noise((B, 3, 16, 128), 1000)
+        Q = 0.01
+        cfg.use_max_safety = True
+        cfg.u_bound = 0.05   # tiny bound so the hinge is active on random nets
+        if kw["guidance"]:
+            if ref_guid:
+                nablaJ = lambda x: get_finetune_guidance(cfg, x, Q)  # noqa: E731
+            else:
+                from oracle.samplers import burgers_guidance
+                nablaJ = burgers_guidance(Q, 500.0, 0.05)
+            with injected_noise(noise) as st:
+                out = gd.sample(batch_size=B, clip_denoised=True, u_init=u0, u_final=uT, guidance_u0=True,
+                                nablaJ=nablaJ, J_scheduler=lambda t: 1.0, w_scheduler=None, enable_grad=False)
+            save("burgers_traj_guided", out=out, u0=u0, uT=uT, Q=Q, w_score=500.0, u_bound=0.05, T=T,
+                 draws=st["i"], noise_seed=1000, dim=dim, weight_seed=100)
+        else:
+            wgt = det_tensor((B, 16, 128), 132, 0.05)
+            with injected_noise(noise) as st:
+                out = gd.sample(batch_size=B, clip_denoised=True, guidance_u0=False, u_init=u0, u_final=uT,
+                                w_groundtruth=wgt, nablaJ=None, J_scheduler=None, w_scheduler=None,
+                                enable_grad=False)
+            save("burgers_traj_calib", out=out, u0=u0, uT=uT, w_gt=wgt, T=T, draws=st["i"], noise_seed=1000,
+                 dim=dim, weight_seed=100)
+
+
+def gen_tokamak():
+    sys.path.insert(0, os.path.join(REF, "tokamak"))
+    from model.unet import Unet1D
+    from model.diffusion import GaussianDiffusion
+
+    dim = 8
+    net = Unet1D(dim=dim, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+    spec = load_det(net, seed=200)
+    x = det_tensor((2, 12, 128), 201)
+    t = torch.tensor([3, 900])
+    stages = ["init_conv", "downs.0.0", "downs.0.2", "downs.0.3", "downs.3.3", "mid_attn", "ups.0.3", "ups.3.2",
+              "final_res_block"]
+    got, hooks = grab_stages(net, stages)
+    with torch.no_grad():
+        eps = net(x, t)
+    for h in hooks:
+        h.remove()
+    save("tokamak_unet", dim=dim, x=x, t=t, eps=eps, **spec_arrays(spec), **{"stage:" + k: v for k, v in got.items()})
+
+    # guidance: reference module needs the HF dataset for its target; restate-free route:
+    # import calculate_loss through GradientGuidance.__new__ (skip __init__) and set fields.
+    ref_guid = False
+    stub_modules("h5py", "tensorboardX", "ema_pytorch", "IPython")
+    sys.modules["tensorboardX"].SummaryWriter = object
+    sys.modules["ema_pytorch"].EMA = object
+    sys.modules["IPython"].embed = None
+    # utils.metrics imports the TensorFlow KSTAR simulator (evaluation only, TF absent): stub that one module
+    stub_modules("kstar_solver")
+    sys.modules["kstar_solver"].KSTARSolver = object
+    try:
+        from utils.guidance import GradientGuidance, calculate_weight, normalize_weights
+        from inference.conformal import ConformalCalculator
+        ref_guid = True
+    except Exception as e:  # noqa: BLE001
+        print("!! tokamak guidance import failed, KAT skipped:", repr(e))
+
+    B, nt = 4, 122
+    target = det_tensor((B, 3, nt), 210, 0.3) + 1.0
+    def make_guid(w_obj, w_safe, scaler, thr, Q):
+        g = GradientGuidance.__new__(GradientGuidance)
+        g.w_obj, g.w_safe, g.guidance_scaler, g.Q, g.safety_threshold, g.nt = w_obj, w_safe, scaler, Q, thr, nt
+        g.state_target = target
+        return g
+    if ref_guid:
+        xs = det_tensor((B, 12, 128), 211, 0.3) + 0.5
+        for tag, (wo, ws, sc, thr, Q) in {"safe": (0.0, 1.0, 0.01, 4.98, 0.0), "mixed": (0.7, 0.3, 0.5, 3.6, 0.1)}.items():
+            g = make_guid(wo, ws, sc, thr, Q)
+            grad = g(xs)
+            J = g.calculate_loss(xs)
+            w = calculate_weight(xs, target, nt, Q, thr, wo, ws, sc)
+            save(f"tokamak_guidance_{tag}", x=xs, target=target, w_obj=wo, w_safe=ws, scaler=sc, thr=thr, Q=Q,
+                 grad=grad, J=J, weight=w)
+
+    T = 8
+    net = Unet1D(dim=dim, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+    load_det(net, seed=200)
+    gd = GaussianDiffusion(net, seq_length=128, nt=nt, timesteps=T, use_conv2d=False, temporal=False,
+                           guidance_u0=True, is_condition_u0=True, is_condition_uT=True)
+    B = 2
+    u0 = det_tensor((B, 3), 220, 0.1) + 0.6
+    uT = det_tensor((B, 2, nt), 221, 0.1) + 0.6
+    noise = det_noise((B, 12, 128), 2000)
+    target2 = target[:B]
+    if ref_guid:
+        g = make_guid(0.0, 1.0, 0.01, 4.98, 0.0)
+        g.state_target = target2
+        nablaJ = g
+    else:
+        from oracle.samplers import tokamak_guidance
+        nablaJ = tokamak_guidance(target2, nt, 0.0, 4.98, 0.0, 1.0, 0.01)
+    with injected_noise(noise) as st:
+        out = gd.sample(batch_size=B, clip_denoised=True, guidance_u0=True, u_init=u0, u_final=uT, nablaJ=nablaJ,
+                        J_scheduler=lambda t: 1.0, w_scheduler=None, enable_grad=False)
+    save("tokamak_traj_guided", out=out, u0=u0, uT=uT, target=target2, T=T, draws=st["i"], noise_seed=2000,
+         dim=dim, weight_seed=200, w_obj=0.0, w_safe=1.0, scaler=0.01, thr=4.98, Q=0.0)
+    # unguided calibration-style (guidance_u0=False, no w_groundtruth: that path crashes in the reference)
+    with injected_noise(noise) as st:
+        out = gd.sample(batch_size=B, clip_denoised=True, guidance_u0=False, u_init=u0, u_final=uT, nablaJ=None,
+                        J_scheduler=None, w_scheduler=None, enable_grad=False)
+    save("tokamak_traj_calib", out=out, u0=u0, uT=uT, T=T, draws=st["i"], noise_seed=2000, dim=dim, weight_seed=200)
+    # the reference DDPM + w_groundtruth bug -- record that it raises
+    try:
+        with injected_noise(noise):
+            gd.sample(batch_size=B, guidance_u0=False, u_init=u0, u_final=uT, w_groundtruth=torch.zeros(B, 9, 128),
+                      nablaJ=None, enable_grad=False)
+        raised = "none"
+    except Exception as e:  # noqa: BLE001
+        raised = type(e).__name__
+    save("tokamak_wgt_bug", raised=raised)
+
+
+def gen_smoke():
+    sys.path.insert(0, os.path.join(HERE, "_shims"))
+    sys.path.insert(0, os.path.join(REF, "2d"))
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D, RelativePositionBias
+    from ddpm.diffusion_2d import GaussianDiffusion
+
+    net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+    print("Unet3D_with_Conv3D(64,(1,2,4),7): params", sum(p.numel() for p in net.parameters()),
+          "keys", len(net.state_dict()))
+    full_spec = spec_of(net)
+    gd = GaussianDiffusion(net, image_size=64, frames=32, timesteps=1000, loss_type="l2")
+    names = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+             "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+             "posterior_mean_coef1", "posterior_mean_coef2"]
+    save("schedule_sigmoid", **{n: getattr(gd, n) for n in names})
+    save("smoke_fullspec", **spec_arrays(full_spec))
+    del net, gd
+
+    rpb = RelativePositionBias(heads=4, max_distance=32)
+    w = det_tensor((32, 4), 300)
+    rpb.relative_attention_bias.weight.data.copy_(w)
+    with torch.no_grad():
+        save("smoke_relpos", weight=w, bias32=rpb(32, "cpu"), bias8=rpb(8, "cpu"))
+
+    dim = 8
+    net = Unet3D_with_Conv3D(dim=dim, dim_mults=(1, 2, 4), channels=7)
+    spec = load_det(net, seed=300)
+    x = det_tensor((2, 8, 7, 16, 16), 301)
+    t = torch.tensor([11, 700])
+    stages = ["init_conv", "init_temporal_attn", "downs.0.0", "downs.0.2", "downs.0.3", "downs.0.4", "mid_block1",
+              "mid_spatial_attn", "mid_temporal_attn", "ups.0.4", "ups.2.3", "final_conv.0"]
+    got, hooks = grab_stages(net, stages)
+    with torch.no_grad():
+        eps = net(x, t)
+    for h in hooks:
+        h.remove()
+    save("smoke_unet", dim=dim, x=x, t=t, eps=eps, **spec_arrays(spec), **{"stage:" + k: v for k, v in got.items()})
+
+    # guidance KAT from the reference pipeline methods (no model needed)
+    ref_pipe = False
+    try:
+        # inference_2d star-imports the vendored PhiFlow evaluation solver (needs imageio/TF; evaluation only)
+        stub_modules("dataset", "dataset.apps", "dataset.apps.evaluate_solver")
+        import importlib
+        inf = importlib.import_module("inference_2d")
+        ref_pipe = True
+    except Exception as e:  # noqa: BLE001
+        print("!! 2d inference_2d import failed, guidance KAT falls back to text restatement:", repr(e))
+    RES = torch.tensor([2, 19, 20, 17, 20, 1, 1.0]).reshape(1, 1, 7, 1, 1)
+    if ref_pipe:
+        args = types.SimpleNamespace(device="cpu", w_safe=0.9, safe_bound=0.1, standard_fixed_ratio=100.0,
+                                     finetune_lr=1e-4)
+        pipe = inf.InferencePipeline.__new__(inf.InferencePipeline)
+        pipe.args_general, pipe.RESCALER, pipe.Q = args, RES, 0.01
+        xs = det_tensor((4, 8, 7, 16, 16), 310, 0.3)
+        xs[:2, -1, 6] += 0.2
+        x_ = xs.clone().requires_grad_()
+        grad = pipe.design_fn(x_)
+        J = pipe.guidance(xs)
+        wt = pipe.get_weight(xs)
+        out = dict(x=xs, grad=grad, J=J, weight=wt, Q=0.01, w_safe=0.9, safe_bound=0.1, ratio=100.0)
+        for k, v in {"plain": torch.tensor([0.5, 1.5, 0.25, 3.0, 0.0, 1.0]),
+                     "inf": torch.tensor([0.5, float("inf"), 0.25, 3.0, float("inf"), 1.0]),
+                     "zero": torch.zeros(6)}.items():
+            out["nw_in_" + k] = v.clone()
+            out["nw_out_" + k] = pipe.normalize_weights(v.clone())
+        sc = det_tensor((40,), 320).abs()
+        out["q_scores"] = sc
+        for a in (0.04, 0.01, 0.5):
+            out[f"q_{a}"] = pipe.get_quantile(sc, None, None, a)
+        save("smoke_guidance", **out)
+
+    T = 8
+    net = Unet3D_with_Conv3D(dim=dim, dim_mults=(1, 2, 4), channels=7)
+    load_det(net, seed=300)
+    gd = GaussianDiffusion(net, image_size=16, frames=8, timesteps=T, loss_type="l2", standard_fixed_ratio=100.0)
+    gd.eval()
+    B = 2
+    init = det_tensor((B, 16, 16), 330, 0.2).abs()
+    noise = det_noise((B, 8, 7, 16, 16), 3000)
+    if ref_pipe:
+        args = types.SimpleNamespace(device="cpu", w_safe=0.9, safe_bound=-5.0, standard_fixed_ratio=100.0)
+        pipe = inf.InferencePipeline.__new__(inf.InferencePipeline)
+        pipe.args_general, pipe.RESCALER, pipe.Q = args, RES, 0.01
+        design_fn = pipe.design_fn
+    else:
+        from oracle.samplers import smoke_guidance
+        design_fn = smoke_guidance(0.01, 0.9, -5.0)
+    with injected_noise(noise) as st:
+        out = gd.sample(batch_size=B, design_fn=design_fn, enable_grad=False, init=init)
+    save("smoke_traj_guided", out=out, init=init, T=T, draws=st["i"], noise_seed=3000, dim=dim, weight_seed=300,
+         Q=0.01, w_safe=0.9, safe_bound=-5.0, ratio=100.0)
+    control = det_tensor((B, 8, 2, 16, 16), 331, 0.3)
+    with injected_noise(noise) as st:
+        out = gd.sample(batch_size=B, design_fn=None, init=init, control=control)
+    save("smoke_traj_calib", out=out, init=init, control=control, T=T, draws=st["i"], noise_seed=3000, dim=dim,
+         weight_seed=300)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "all":
+        for w in ("burgers", "tokamak", "smoke"):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
+    else:
+        {"burgers": gen_burgers, "tokamak": gen_tokamak, "smoke": gen_smoke}[which]()
