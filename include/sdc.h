@@ -1,0 +1,200 @@
+/*
+ * libsdc_hip.so -- C ABI of the MI355X (gfx950) SafeDiffCon sampler kernels.
+ *
+ * Drop-in boundary: the reference has no native code on the
+ * sampling path -- every stage is a torch.nn op inside
+ *   1D/model/diffusion.py      GaussianDiffusion.p_sample_loop / p_sample
+ *   tokamak/model/diffusion.py (same)
+ *   2d/ddpm/diffusion_2d.py    GaussianDiffusion.p_sample_loop / p_sample
+ * and the three U-Nets (1D/model/unet.py, tokamak/model/unet.py,
+ * 2d/video_diffusion_pytorch/video_diffusion_pytorch_conv3d.py).  Each entry
+ * point below replaces one *stage* of that path and cites the reference lines
+ * whose arithmetic it implements.  The binding a reference maintainer adds is a
+ * ctypes stub; safediffcon_amd/_lib.py is that stub.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types; all tensors fp32 in device memory
+ *    owned by the caller; the library never allocates, frees or retains them
+ *    (except inside an explicit graph object, whose lifetime the caller ties
+ *    to the buffers it captured).
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *    no hidden synchronisation, no host reads of device scalars.  The current
+ *    diffusion timestep is a device-resident int (`t_dev`) so that one captured
+ *    hipGraph replays for all 1000 steps.
+ *  - return 0 on success, negative SDC_E* otherwise; text via sdc_last_error().
+ *  - activation layout: (B, C, D, H, W) addressed through explicit element
+ *    strides, so Conv1d (D=H=1), Conv2d (D=1), Conv3d and the smoke tensor's
+ *    frame-major (B,F,C,H,W) storage all go through the same kernels.
+ */
+#ifndef SDC_H
+#define SDC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDC_OK 0
+#define SDC_EINVAL (-1)      /* bad shape / unsupported configuration */
+#define SDC_EALIGN (-2)      /* misaligned pointer */
+#define SDC_EHIP (-3)        /* HIP runtime error (launch, capture, ...) */
+#define SDC_ENULL (-4)       /* required pointer is null */
+
+int sdc_version(void);
+/* copies the calling thread's last error message; returns its length */
+int sdc_last_error(char* buf, size_t cap);
+
+/* ------------------------------------------------------------------ conv */
+/* Implicit-GEMM N-d convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), gather
+ * straight from the strided input(s):
+ *   y[b,co,o] = bias[co] + sum_{tap,ci} Wp[tap*Cin+ci][co] * xcat[b,ci, o*stride - pad + tap] (+ residual[b,co,o])
+ * xcat = channel-concat of x0 (Cin0 ch) and x1 (Cin1 ch) -- replaces torch.cat
+ * before the up-path ResnetBlocks (1D/model/unet.py:414-418, conv3d.py:553,560).
+ * `up` = virtual nearest-neighbour upsample of the input (nn.Upsample(2) + conv,
+ * 1D/model/unet.py:24-37); up_mode 1 = zero insertion (ConvTranspose3d as a conv
+ * over the zero-stuffed input with flipped taps, conv3d.py:159-160).
+ * Replaces: every nn.Conv1d/2d/3d, nn.Linear and nn.ConvTranspose3d on the path
+ * (1D/model/unet.py:132-134,161-163,189-197,232-236,326,345,370,378;
+ *  conv3d.py:159-163,192,218,239-240,291-292,395,471).
+ * Wp is the caller-repacked weight [K = taps*Cin][Cout] (row-major, Cout fastest).
+ */
+typedef struct SdcConvDesc {
+    int32_t B, Cin0, Cin1, Cout;
+    int32_t iD, iH, iW;          /* stored input spatial size */
+    int32_t oD, oH, oW;          /* output spatial size */
+    int32_t kD, kH, kW;
+    int32_t sD, sH, sW;          /* stride */
+    int32_t pD, pH, pW;          /* padding, in the (virtually upsampled) input space */
+    int32_t uD, uH, uW;          /* virtual input upsample factor, 1 or 2 */
+    int32_t up_mode;             /* 0 nearest, 1 zero-insert */
+    int32_t precision;           /* 0 = exact fp32 MFMA (parity mode); 1 = 3-pass split-bf16 MFMA */
+    int64_t x0s[5], x1s[5], ys[5], rs[5];   /* element strides (b,c,d,h,w) */
+} SdcConvDesc;
+
+int sdc_conv(const SdcConvDesc* d, const float* x0, const float* x1, const float* wp, const float* bias,
+             const float* residual, float* y, void* stream);
+
+/* ------------------------------------------------------------- group norm */
+/* nn.GroupNorm(G, C, eps=1e-5) statistics over contiguous (B, C, S) data:
+ * stats[(b*G+g)*2 + {0,1}] = {mean, rstd}, accumulated in fp64.
+ * 1D/model/unet.py:135,140 ; conv3d.py:193,198. */
+int sdc_gn_stats(const float* x, float* stats, int B, int C, int G, int64_t S, float eps, void* stream);
+/* bytes the caller must allocate for `stats` (mean/rstd pairs + fp64 partial-sum scratch) */
+size_t sdc_gn_stats_bytes(int B, int G);
+
+/* y = SiLU( ((x-mean)*rstd*gamma[c]+beta[c]) * (scale+1) + shift ) (+ residual)
+ * Block.forward + the ResnetBlock residual add: 1D/model/unet.py:138-147,180 ; conv3d.py:196-204,230.
+ * scale/shift come from a time-conditioning table ss (nullable):
+ *   row = (t_dev ? *t_dev : 0) * ss_t_stride + b * ss_b_stride
+ *   scale = ss[row + ss_off + c], shift = ss[row + ss_off + C + c]
+ * (ResnetBlock.mlp output chunked in two, 1D/model/unet.py:169-175). */
+int sdc_gn_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* ss,
+                 const int32_t* t_dev, int64_t ss_t_stride, int64_t ss_b_stride, int64_t ss_off,
+                 const float* residual, float* y, int B, int C, int G, int64_t S, void* stream);
+
+/* ------------------------------------------------------- channel norms */
+/* mode 0: channel LayerNorm, gain only, (x-mean)*rsqrt(var+eps)*g   1D/model/unet.py:53-63, conv3d.py:165-174
+ * mode 1: RMSNorm  x / max(||x||_2,1e-12) * g * sqrt(C)            tokamak/model/unet.py:45-51
+ * over contiguous (B, C, S); optional residual add (Residual(...) wrapper, unet.py:16-22). */
+int sdc_chan_norm(const float* x, const float* g, const float* residual, float* y, int B, int C, int64_t S,
+                  int mode, float eps, void* stream);
+
+/* ---------------------------------------------------- linear attention */
+/* LinearAttention / SpatialLinearAttention core, heads x 32:
+ *   ctx[d,e] = sum_n softmax_n(k)[d,n] v[e,n] ; out[e,n] = sum_d ctx[d,e] softmax_d(q)[d,n]*scale
+ * 1D/model/unet.py:203-221 ; conv3d.py:246-256.
+ * qkv is (outer, 3*heads*32, inner, n) through strides: element(outer o, channel c, inner i, token n) at
+ *   o*so + c*sc + i*si + n  (tokens contiguous).  out uses the same scheme with heads*32 channels.
+ * ctx is workspace of outer*inner*heads*32*32 floats. */
+int sdc_linattn(const float* qkv, float* ctx, float* out, int outer, int inner, int heads, int64_t n,
+                int64_t q_so, int64_t q_sc, int64_t q_si, int64_t o_so, int64_t o_sc, int64_t o_si, void* stream);
+
+/* ------------------------------------------------------- softmax attention */
+/* Attention core (heads x 32): out = softmax(q*scale . k^T + bias) v, optional rotary on q,k.
+ * 1D/model/unet.py:247-251 ; conv3d.py:313-353 (focus_present_mask all-False).
+ * Sequences are indexed (outer, inner); element (o, c, i, tok) at o*so + c*sc + i*si + tok*st.
+ * rot: [ntok][16][2] cos/sin table or null; bias: [heads][ntok][ntok] or null. ntok <= 256. */
+int sdc_attn(const float* qkv, float* out, const float* rot, const float* bias, int outer, int inner, int heads,
+             int ntok, int64_t q_so, int64_t q_sc, int64_t q_si, int64_t q_st,
+             int64_t o_so, int64_t o_sc, int64_t o_si, int64_t o_st, void* stream);
+
+/* ------------------------------------------------------------ elementwise */
+/* kind 0: SiLU, 1: exact (erf) GELU -- time_mlp / ResnetBlock.mlp (unet.py:152-155,310-315) */
+int sdc_act(const float* x, float* y, int64_t n, int kind, void* stream);
+
+/* ----------------------------------------------------- fused DDPM update */
+/* One reverse step for every element, fused with guidance and the conditioning writes:
+ *   x0  = a x - b eps ; eps' = eps + k g(x0) ; x0' = clamp(a x - b eps', -1, 1)
+ *   x-  = c1 x0' + c2 x + sigma z ; then re-impose the conditions (unless last step for burgers/tokamak)
+ * p_sample / p_mean_variance / model_predictions / q_posterior:
+ *   1D/model/diffusion.py:217-306, tokamak/model/diffusion.py:201-266, 2d/ddpm/diffusion_2d.py:242-285;
+ * conditioning writes 1D/model/diffusion.py:336-366,380-394, tokamak/...:295-308,330-336, 2d/...:297-301,310-312.
+ * coef: [T][8] floats {a, b, c1, c2, sigma(0 at t=0), k(J_scheduler), 0, 0}; t_dev: device timestep.
+ * noise: explicit z tensors [n_draw][numel] (parity mode) indexed by *draw_dev, or null -> Philox4x32-10
+ * normal draws keyed by (seed, *draw_dev, element).  gscal: per-sample guidance scalars from sdc_guide_reduce.
+ */
+#define SDC_MODEL_BURGERS 0
+#define SDC_MODEL_TOKAMAK 1
+#define SDC_MODEL_SMOKE 2
+
+typedef struct SdcStepDesc {
+    int32_t model;               /* SDC_MODEL_* */
+    int32_t B;
+    int32_t d0, d1, d2, d3;      /* per-sample dims: burgers (C,H,W,1) ; tokamak (C,L,1,1) ; smoke (F,C,H,W) */
+    int32_t guide;               /* 0 none, 1 built-in closed form, 2 external g tensor */
+    int32_t clip;                /* clip_denoised */
+    int32_t impose;              /* apply conditioning writes to the output */
+    int32_t cond_idx;            /* burgers: condition_idx (10); tokamak: nt (122) */
+    int32_t pad_zero;            /* burgers/tokamak: !train_on_padded_locations */
+    int32_t use_max;             /* burgers: 0 mean-mode (use_max_safety=True), 1 amax mode */
+    int32_t has_wgt;             /* burgers: w_groundtruth given ; smoke: control given */
+    int32_t skip_draws;          /* noise draws consumed per step beyond the one used (calibration branch: 1) */
+    uint64_t seed;
+} SdcStepDesc;
+
+/* gpar: device float[8] of guidance constants (kept on the device so a captured graph survives a new
+ * conformal quantile Q):  burgers {w_score, u_bound^2, Q, 10}; tokamak {w_obj, w_safe, guidance_scaler,
+ * safety_threshold, Q}; smoke {w_safe, safe_bound, Q, standard_fixed_ratio}.
+ * sdc_guide_reduce: per-sample hinge-active flag + arg-extremum of the safety functional evaluated on
+ * x0 = a x - b eps  -> gscal[2*B]   (1D/utils/guidance.py:58-77, tokamak/utils/guidance.py:32-56,
+ * tokamak/utils/metrics.py:144-151, 2d/inference_2d.py:173-186). */
+int sdc_guide_reduce(const SdcStepDesc* d, const float* x, const float* eps, const float* coef, const int32_t* t_dev,
+                     const float* gpar, float* gscal, void* stream);
+/* guide: 0 none | 1 built-in closed-form gradient (needs gpar, gscal[, target]) | 2 external gradient tensor gext
+ * | 3 write x0 = a x - b eps to x0out only (so a caller-supplied nablaJ callable can be evaluated on it). */
+int sdc_step_update(const SdcStepDesc* d, const float* x, const float* eps, const float* gext, const float* coef,
+                    const int32_t* t_dev, const int32_t* draw_dev, const float* noise, int64_t noise_stride,
+                    const float* gpar, const float* gscal, const float* target, const float* c0, const float* c1,
+                    const float* c2, float* xout, float* x0out, void* stream);
+/* conditioning writes only (initial x_T) */
+int sdc_impose(const SdcStepDesc* d, float* x, const float* c0, const float* c1, const float* c2, void* stream);
+/* x = N(0,1) from the same Philox stream (draw index *draw_dev), then (*draw_dev)++ handled by sdc_advance */
+int sdc_randn(float* x, int64_t n, uint64_t seed, const int32_t* draw_dev, void* stream);
+/* *t_dev += dt ; *draw_dev += ddraw   (one thread; keeps the step counter on the device for graph replay) */
+int sdc_advance(int32_t* t_dev, int dt, int32_t* draw_dev, int ddraw, void* stream);
+
+/* ------------------------------------------------------------- conformal */
+/* per-sample conformal score |f(pred) - f(truth)| and weight exp(-J(truth)):
+ * 1D/inference/conformal.py:68-85 + guidance.py:9-46 ; tokamak/inference/conformal.py:79-109 ;
+ * 2d/inference_2d.py:83-92,139-144.  Uses SdcStepDesc for model + constants. */
+int sdc_conformal_score(const SdcStepDesc* d, const float* pred, const float* truth, const float* target,
+                        const float* gpar, float* score, float* weight, void* stream);
+
+/* ----------------------------------------------------------------- graphs */
+int sdc_graph_begin(void* stream);
+int sdc_graph_end(void* stream, void** graph_exec);
+int sdc_graph_launch(void* graph_exec, void* stream);
+int sdc_graph_destroy(void* graph_exec);
+
+/* ------------------------------------------------------ timing (bench only) */
+int sdc_event_create(void** ev);
+int sdc_event_record(void* ev, void* stream);
+int sdc_event_elapsed_ms(void* ev0, void* ev1, float* ms);   /* synchronises on ev1 */
+int sdc_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDC_H */

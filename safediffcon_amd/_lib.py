@@ -1,0 +1,96 @@
+"""ctypes binding of libsdc_hip.so (the C ABI in include/sdc.h).
+
+This is the stub a reference maintainer would add.  There is
+no CPU fallback: if the shared library is missing, loading raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdc_hip.so")
+
+SDC_MODEL_BURGERS, SDC_MODEL_TOKAMAK, SDC_MODEL_SMOKE = 0, 1, 2
+
+_f32p = C.c_void_p       # device pointers travel as integers
+_i32p = C.c_void_p
+_stream = C.c_void_p
+_i64 = C.c_int64
+
+
+class SdcConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "B", "Cin0", "Cin1", "Cout", "iD", "iH", "iW", "oD", "oH", "oW", "kD", "kH", "kW", "sD", "sH", "sW",
+        "pD", "pH", "pW", "uD", "uH", "uW", "up_mode", "precision")] + [
+        ("x0s", C.c_int64 * 5), ("x1s", C.c_int64 * 5), ("ys", C.c_int64 * 5), ("rs", C.c_int64 * 5)]
+
+
+class SdcStepDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "model", "B", "d0", "d1", "d2", "d3", "guide", "clip", "impose", "cond_idx", "pad_zero", "use_max",
+        "has_wgt", "skip_draws")] + [("seed", C.c_uint64)]
+
+
+# name -> (restype, argtypes); every symbol include/sdc.h declares
+SIGNATURES = {
+    "sdc_version": (C.c_int, []),
+    "sdc_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "sdc_conv": (C.c_int, [C.POINTER(SdcConvDesc), _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _stream]),
+    "sdc_gn_stats": (C.c_int, [_f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64, C.c_float, _stream]),
+    "sdc_gn_stats_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "sdc_gn_apply": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _i32p, _i64, _i64, _i64, _f32p, _f32p,
+                               C.c_int, C.c_int, C.c_int, _i64, _stream]),
+    "sdc_chan_norm": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, _i64, C.c_int, C.c_float, _stream]),
+    "sdc_linattn": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, _i64, _i64, _i64,
+                              _i64, _stream]),
+    "sdc_attn": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, _i64,
+                           _i64, _i64, _i64, _i64, _stream]),
+    "sdc_act": (C.c_int, [_f32p, _f32p, _i64, C.c_int, _stream]),
+    "sdc_guide_reduce": (C.c_int, [C.POINTER(SdcStepDesc), _f32p, _f32p, _f32p, _i32p, _f32p, _f32p, _stream]),
+    "sdc_step_update": (C.c_int, [C.POINTER(SdcStepDesc), _f32p, _f32p, _f32p, _f32p, _i32p, _i32p, _f32p, _i64,
+                                  _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _stream]),
+    "sdc_impose": (C.c_int, [C.POINTER(SdcStepDesc), _f32p, _f32p, _f32p, _f32p, _stream]),
+    "sdc_randn": (C.c_int, [_f32p, _i64, C.c_uint64, _i32p, _stream]),
+    "sdc_advance": (C.c_int, [_i32p, C.c_int, _i32p, C.c_int, _stream]),
+    "sdc_conformal_score": (C.c_int, [C.POINTER(SdcStepDesc), _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _stream]),
+    "sdc_graph_begin": (C.c_int, [_stream]),
+    "sdc_graph_end": (C.c_int, [_stream, C.POINTER(C.c_void_p)]),
+    "sdc_graph_launch": (C.c_int, [C.c_void_p, _stream]),
+    "sdc_graph_destroy": (C.c_int, [C.c_void_p]),
+    "sdc_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "sdc_event_record": (C.c_int, [C.c_void_p, _stream]),
+    "sdc_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "sdc_event_destroy": (C.c_int, [C.c_void_p]),
+}
+
+_lib = None
+
+
+class SdcError(RuntimeError):
+    pass
+
+
+def get_lib():
+    """Load libsdc_hip.so once.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SdcError(
+                f"{LIB_PATH} not found: build it with `python -m safediffcon_amd.build` "
+                "(hipcc --offload-arch=gfx950). safediffcon_amd has no CPU/eager fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    get_lib().sdc_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise SdcError(f"{what or 'libsdc_hip'} failed (code {rc}): {last_error()}")

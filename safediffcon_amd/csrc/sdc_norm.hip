@@ -1,0 +1,249 @@
+// GroupNorm (+ time scale/shift + SiLU + residual), channel LayerNorm / RMSNorm, SiLU / GELU.
+// All HBM-bound: one read + one write per element, 16-byte accesses where the extent allows.
+#include "sdc_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---------------------------------------------------------------- GroupNorm statistics
+// One workgroup per (b, g, split): the group's (C/G)*S elements are contiguous.  fp64 accumulation
+// (sum, sum of squares) so that var = E[x^2] - mean^2 keeps fp32-level accuracy for any mean/std
+// ratio; partials of all splits are combined by the last-arriving split via plain fp64 slots
+// + a second tiny kernel (deterministic order, no atomics).
+__global__ __launch_bounds__(NT) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                        int64_t n_per_group, int nsplit) {
+    const int grp = blockIdx.x / nsplit;
+    const int sp = blockIdx.x % nsplit;
+    const int64_t chunk = (n_per_group + nsplit - 1) / nsplit;
+    const int64_t lo = (int64_t)sp * chunk;
+    const int64_t hi = lo + chunk < n_per_group ? lo + chunk : n_per_group;
+    const float* base = x + (int64_t)grp * n_per_group;
+    double s = 0.0, q = 0.0;
+    if (((n_per_group | chunk) & 3) == 0) {
+        const float4* b4 = reinterpret_cast<const float4*>(base);
+        for (int64_t i = lo / 4 + threadIdx.x; i < hi / 4; i += NT) {
+            const float4 v = b4[i];
+            s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+            q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        }
+    } else {
+        for (int64_t i = lo + threadIdx.x; i < hi; i += NT) {
+            const double v = base[i];
+            s += v;
+            q += v * v;
+        }
+    }
+    __shared__ double sh[2][NT / 64];
+    s = sdc::wave_sum(s);
+    q = sdc::wave_sum(q);
+    if ((threadIdx.x & 63) == 0) {
+        sh[0][threadIdx.x >> 6] = s;
+        sh[1][threadIdx.x >> 6] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0, tq = 0;
+        for (int w = 0; w < NT / 64; ++w) { ts += sh[0][w]; tq += sh[1][w]; }
+        part[(int64_t)blockIdx.x * 2] = ts;
+        part[(int64_t)blockIdx.x * 2 + 1] = tq;
+    }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ part, float* __restrict__ stats, int ngroups, int nsplit,
+                                   double inv_n, float eps) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    double s = 0, q = 0;
+    for (int i = 0; i < nsplit; ++i) {
+        s += part[((int64_t)g * nsplit + i) * 2];
+        q += part[((int64_t)g * nsplit + i) * 2 + 1];
+    }
+    const double mean = s * inv_n;
+    double var = q * inv_n - mean * mean;
+    if (var < 0) var = 0;
+    stats[g * 2] = (float)mean;
+    stats[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// ---------------------------------------------------------------- GroupNorm apply
+// grid.x walks 4-element vectors of one (b, c) row, grid.y = b*C + c.
+template <bool VEC>
+__global__ __launch_bounds__(NT) void gn_apply_kernel(const float* x, const float* __restrict__ stats,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ ss, const int32_t* __restrict__ t_dev,
+                                                      int64_t ss_t_stride, int64_t ss_b_stride, int64_t ss_off,
+                                                      const float* res, float* y, int C,
+                                                      int G, int64_t S) {
+    const int bc = blockIdx.y;
+    const int b = bc / C, c = bc - b * C;
+    const int g = c / (C / G);
+    const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+    float mul = rstd * gamma[c];
+    float add = beta[c] - mean * mul;
+    if (ss) {
+        const int64_t row = (t_dev ? (int64_t)(*t_dev) : 0) * ss_t_stride + (int64_t)b * ss_b_stride + ss_off;
+        const float sc = ss[row + c] + 1.0f, sh = ss[row + C + c];
+        mul *= sc;
+        add = add * sc + sh;
+    }
+    const int64_t base = (int64_t)bc * S;
+    if constexpr (VEC) {
+        const int64_t nv = S >> 2;
+        const float4* x4 = reinterpret_cast<const float4*>(x + base);
+        const float4* r4 = res ? reinterpret_cast<const float4*>(res + base) : nullptr;
+        float4* y4 = reinterpret_cast<float4*>(y + base);
+        for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nv; i += (int64_t)gridDim.x * NT) {
+            float4 v = x4[i];
+            v.x = sdc::silu_f(v.x * mul + add);
+            v.y = sdc::silu_f(v.y * mul + add);
+            v.z = sdc::silu_f(v.z * mul + add);
+            v.w = sdc::silu_f(v.w * mul + add);
+            if (r4) {
+                const float4 r = r4[i];
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            y4[i] = v;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < S; i += (int64_t)gridDim.x * NT) {
+            float v = sdc::silu_f(x[base + i] * mul + add);
+            if (res) v += res[base + i];
+            y[base + i] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- channel LayerNorm / RMSNorm
+// 64 positions x 4 channel slices per workgroup; positions are the contiguous axis so every
+// channel row is read in 256-byte wave-wide segments.  Two passes over C (second pass is L2-hot).
+__global__ __launch_bounds__(NT) void chan_norm_kernel(const float* x, const float* __restrict__ g,
+                                                       const float* res, float* y, int C,
+                                                       int64_t S, int mode, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int slice = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int64_t pos = (int64_t)blockIdx.x * 64 + lane;
+    const bool ok = pos < S;
+    const int64_t base = (int64_t)b * C * S + pos;
+    float s = 0.f, q = 0.f;
+    if (ok) {
+        for (int c = slice; c < C; c += 4) {
+            const float v = x[base + (int64_t)c * S];
+            s += v;
+            q += v * v;
+        }
+    }
+    __shared__ float sh[2][4][64];
+    sh[0][slice][lane] = s;
+    sh[1][slice][lane] = q;
+    __syncthreads();
+    s = sh[0][0][lane] + sh[0][1][lane] + sh[0][2][lane] + sh[0][3][lane];
+    q = sh[1][0][lane] + sh[1][1][lane] + sh[1][2][lane] + sh[1][3][lane];
+    float mean, mul;
+    if (mode == 0) {
+        mean = s / C;
+        float var = q / C - mean * mean;
+        // second, centred pass for the variance keeps LN exact when |mean| >> std
+        float q2 = 0.f;
+        if (ok)
+            for (int c = slice; c < C; c += 4) {
+                const float dv = x[base + (int64_t)c * S] - mean;
+                q2 += dv * dv;
+            }
+        __syncthreads();
+        sh[1][slice][lane] = q2;
+        __syncthreads();
+        var = (sh[1][0][lane] + sh[1][1][lane] + sh[1][2][lane] + sh[1][3][lane]) / C;
+        mul = 1.0f / sqrtf(var + eps);
+    } else {
+        mean = 0.f;
+        mul = sqrtf((float)C) / fmaxf(sqrtf(q), 1e-12f);
+    }
+    if (!ok) return;
+    for (int c = slice; c < C; c += 4) {
+        const int64_t o = base + (int64_t)c * S;
+        float v = (x[o] - mean) * mul * g[c];
+        if (res) v += res[o];
+        y[o] = v;
+    }
+}
+
+__global__ __launch_bounds__(NT) void act_kernel(const float* x, float* y, int64_t n,
+                                                 int kind) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float v = x[i];
+        y[i] = kind == 0 ? v / (1.0f + expf(-v)) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    }
+}
+
+// scratch for GroupNorm partials: (b*G) * nsplit * 2 doubles.  Kept tiny and owned by the caller is
+// the ABI rule, so the partial buffer is carved from the *stats* allocation: the caller passes stats
+// with room for ngroups*2 floats + ngroups*nsplit*2 doubles (see safediffcon_amd/engine.py).
+constexpr int MAX_SPLIT = 16;
+
+}  // namespace
+
+extern "C" size_t sdc_gn_stats_bytes(int B, int G) {
+    const size_t ngroups = (size_t)B * G;
+    return ((ngroups * 2 * sizeof(float) + 15) & ~(size_t)15) + ngroups * MAX_SPLIT * 2 * sizeof(double);
+}
+
+extern "C" int sdc_gn_stats(const float* x, float* stats, int B, int C, int G, int64_t S, float eps, void* stream) {
+    SDC_REQUIRE(x && stats, SDC_ENULL, "sdc_gn_stats: null pointer");
+    SDC_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && S > 0, SDC_EINVAL, "sdc_gn_stats: bad shape B=%d C=%d G=%d", B, C, G);
+    const int ngroups = B * G;
+    const int64_t n = (int64_t)(C / G) * S;
+    // enough workgroups to fill 256 CUs a few times over, but >= 16K elements per split
+    int nsplit = 1;
+    while (nsplit < MAX_SPLIT && ngroups * nsplit < 1024 && n / (nsplit * 2) >= 16384) nsplit *= 2;
+    // partials live right after the float stats, 16-byte aligned (caller allocates sdc_gn_stats_floats())
+    const size_t off = (((size_t)ngroups * 2 * sizeof(float)) + 15) & ~(size_t)15;
+    double* part = reinterpret_cast<double*>(reinterpret_cast<char*>(stats) + off);
+    hipStream_t s = sdc::as_stream(stream);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(ngroups * nsplit), dim3(NT), 0, s, x, part, n, nsplit);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((ngroups + 63) / 64), dim3(64), 0, s, part, stats, ngroups, nsplit,
+                       1.0 / (double)n, eps);
+    return sdc::check_launch("sdc_gn_stats");
+}
+
+extern "C" int sdc_gn_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* ss,
+                            const int32_t* t_dev, int64_t ss_t_stride, int64_t ss_b_stride, int64_t ss_off,
+                            const float* residual, float* y, int B, int C, int G, int64_t S, void* stream) {
+    SDC_REQUIRE(x && stats && gamma && beta && y, SDC_ENULL, "sdc_gn_apply: null pointer");
+    SDC_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && S > 0, SDC_EINVAL, "sdc_gn_apply: bad shape");
+    SDC_REQUIRE((int64_t)B * C < 65536, SDC_EINVAL, "sdc_gn_apply: B*C too large for grid.y");
+    hipStream_t s = sdc::as_stream(stream);
+    const bool vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                                       reinterpret_cast<uintptr_t>(residual)) % 16 == 0);
+    const int64_t work = vec ? S / 4 : S;
+    int gx = (int)((work + NT - 1) / NT);
+    if (gx > 64) gx = 64;
+    dim3 grid(gx, B * C);
+    if (vec)
+        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(NT), 0, s, x, stats, gamma, beta, ss, t_dev, ss_t_stride,
+                           ss_b_stride, ss_off, residual, y, C, G, S);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(NT), 0, s, x, stats, gamma, beta, ss, t_dev, ss_t_stride,
+                           ss_b_stride, ss_off, residual, y, C, G, S);
+    return sdc::check_launch("sdc_gn_apply");
+}
+
+extern "C" int sdc_chan_norm(const float* x, const float* g, const float* residual, float* y, int B, int C, int64_t S,
+                             int mode, float eps, void* stream) {
+    SDC_REQUIRE(x && g && y, SDC_ENULL, "sdc_chan_norm: null pointer");
+    SDC_REQUIRE(B > 0 && C > 0 && S > 0 && (mode == 0 || mode == 1), SDC_EINVAL, "sdc_chan_norm: bad arguments");
+    SDC_REQUIRE(B < 65536, SDC_EINVAL, "sdc_chan_norm: B too large for grid.y");
+    dim3 grid((unsigned)((S + 63) / 64), B);
+    hipLaunchKernelGGL(chan_norm_kernel, grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
+    return sdc::check_launch("sdc_chan_norm");
+}
+
+extern "C" int sdc_act(const float* x, float* y, int64_t n, int kind, void* stream) {
+    SDC_REQUIRE(x && y, SDC_ENULL, "sdc_act: null pointer");
+    SDC_REQUIRE(n > 0 && (kind == 0 || kind == 1), SDC_EINVAL, "sdc_act: bad arguments");
+    int64_t blocks = (n + NT - 1) / NT;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(act_kernel, dim3((unsigned)blocks), dim3(NT), 0, sdc::as_stream(stream), x, y, n, kind);
+    return sdc::check_launch("sdc_act");
+}

@@ -1,0 +1,521 @@
+"""Drop-in ``GaussianDiffusion`` samplers for the three SafeDiffCon tasks.
+
+  GaussianDiffusionBurgers   <- 1D/model/diffusion.py:21-607      (sample / p_sample_loop)
+  GaussianDiffusionTokamak   <- tokamak/model/diffusion.py:19-539
+  GaussianDiffusionSmoke     <- 2d/ddpm/diffusion_2d.py:111-414
+
+Same constructor keywords and ``sample(...)`` signatures as the reference.  One
+denoising step = the U-Net plan + sdc_guide_reduce + sdc_step_update +
+sdc_advance, all on the caller's HIP stream; with in-kernel Philox noise the
+whole step is captured once into a hipGraph and replayed for every timestep
+(the timestep and the noise-draw counter live in device memory).
+
+Guidance: the three closed forms the reference's pipelines use are described by
+``GuidanceSpec`` objects (callable, so they also work as plain ``nablaJ`` /
+``design_fn`` closures); the sampler recognises them and fuses the gradient into
+the update kernel.  Any other callable is honoured too: the step is then split
+around the callable (x0 kernel -> callable on device tensors -> update kernel).
+"""
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import SdcStepDesc, check
+from .engine import Plan
+
+_MODEL = {"burgers": _lib.SDC_MODEL_BURGERS, "tokamak": _lib.SDC_MODEL_TOKAMAK, "smoke": _lib.SDC_MODEL_SMOKE}
+
+BURGERS_SCALER = 10.0                                               # 1D/utils/common.py:17
+TOKAMAK_SCALER = (2, 7, 2, 1, 2, 2, 2, 2, 1, 1, 2, 3)              # tokamak/utils/common.py:16
+SMOKE_RESCALER = (2, 19, 20, 17, 20, 1, 1)                          # 2d/ddpm/data_2d.py:38
+
+
+# --------------------------------------------------------------------------- schedules (fp64 on host, cast at the end)
+def _betas(kind, T):
+    if kind == "linear":                                           # 1D/model/model_utils.py:142-146
+        s = 1000.0 / T
+        return torch.linspace(s * 1e-4, s * 2e-2, T, dtype=torch.float64)
+    if kind == "cosine":                                           # 1D/model/model_utils.py:148-158
+        x = torch.linspace(0, T, T + 1, dtype=torch.float64)
+        ac = torch.cos(((x / T) + 0.008) / 1.008 * math.pi * 0.5) ** 2
+        ac = ac / ac[0]
+        return torch.clip(1 - ac[1:] / ac[:-1], 0, 0.999)
+    if kind == "sigmoid":                                          # 2d/ddpm/diffusion_2d.py:95-108 (start -3, end 3, tau 1)
+        t = torch.linspace(0, T, T + 1, dtype=torch.float64) / T
+        v0, v1 = torch.tensor(-3.0).sigmoid(), torch.tensor(3.0).sigmoid()
+        ac = (-(t * 6 - 3).sigmoid() + v1) / (v1 - v0)
+        ac = ac / ac[0]
+        return torch.clip(1 - ac[1:] / ac[:-1], 0, 0.999)
+    raise ValueError(f"unknown beta schedule {kind}")
+
+
+def schedule_tables(kind, T):
+    """The reference's registered buffers (1D/model/diffusion.py:111-156), fp32."""
+    b = _betas(kind, T)
+    a = 1.0 - b
+    ac = torch.cumprod(a, dim=0)
+    acp = torch.cat([torch.ones(1, dtype=torch.float64), ac[:-1]])
+    pv = b * (1.0 - acp) / (1.0 - ac)
+    tabs = dict(betas=b, alphas_cumprod=ac, alphas_cumprod_prev=acp, sqrt_alphas_cumprod=ac.sqrt(),
+                sqrt_one_minus_alphas_cumprod=(1.0 - ac).sqrt(), log_one_minus_alphas_cumprod=(1.0 - ac).log(),
+                sqrt_recip_alphas_cumprod=(1.0 / ac).sqrt(), sqrt_recipm1_alphas_cumprod=(1.0 / ac - 1).sqrt(),
+                posterior_variance=pv, posterior_log_variance_clipped=pv.clamp(min=1e-20).log(),
+                posterior_mean_coef1=b * acp.sqrt() / (1.0 - ac), posterior_mean_coef2=(1.0 - acp) * a.sqrt() / (1.0 - ac))
+    return {k: v.to(torch.float32) for k, v in tabs.items()}
+
+
+# --------------------------------------------------------------------------- guidance specs
+class GuidanceSpec:
+    """Closed-form guidance recognised by the fused update kernel.  Also a plain callable
+    (x0 -> dJ/dx0 via autograd on the device), so it can be passed wherever the reference takes
+    ``nablaJ`` / ``design_fn``."""
+    kind = None
+
+    def gpar(self):
+        raise NotImplementedError
+
+    def J(self, x):
+        raise NotImplementedError
+
+    def __call__(self, x):
+        with torch.enable_grad():
+            x = x.detach().requires_grad_()
+            j = self.J(x)
+            return torch.autograd.grad(j, x, grad_outputs=torch.ones_like(j))[0]
+
+    @staticmethod
+    def _f(v):
+        return float(v.item()) if isinstance(v, torch.Tensor) else float(v)
+
+
+class BurgersGuidance(GuidanceSpec):
+    """J = w_score * max(f(10*x0[:,2,:11,:]) + Q - u_bound^2, 0), f = mean if use_max_safety else amax.
+    1D/utils/guidance.py:58-85 (get_finetune_guidance).  ``Q`` may be reassigned between samples."""
+    kind = "burgers"
+
+    def __init__(self, Q, w_score, u_bound, use_max_safety=True):
+        self.Q, self.w_score, self.u_bound, self.use_max_safety = Q, w_score, u_bound, use_max_safety
+
+    def gpar(self):
+        return [self._f(self.w_score), self._f(self.u_bound) ** 2, self._f(self.Q), BURGERS_SCALER]
+
+    def J(self, x):
+        s = (x * BURGERS_SCALER)[:, 2, :11, :]
+        s = s.mean(dim=(-1, -2)) if self.use_max_safety else s.amax(dim=(-1, -2))
+        return torch.clamp(s + self._f(self.Q) - self._f(self.u_bound) ** 2, min=0) * self._f(self.w_score)
+
+
+class TokamakGuidance(GuidanceSpec):
+    """loss = scaler * (w_obj*(mse(beta_p)+mse(l_i)) + w_safe*max(thr - min_t q95 + Q, 0)).
+    tokamak/utils/guidance.py:32-73; ``target`` (B,3,nt) is cached once (the reference reloads it every step)."""
+    kind = "tokamak"
+
+    def __init__(self, target, nt=122, w_obj=0.0, w_safe=0.0, guidance_scaler=1.0, Q=0.0, safety_threshold=5.0):
+        self.target, self.nt = target, nt
+        self.w_obj, self.w_safe, self.guidance_scaler, self.Q, self.safety_threshold = w_obj, w_safe, guidance_scaler, Q, safety_threshold
+
+    def gpar(self):
+        return [self._f(self.w_obj), self._f(self.w_safe), self._f(self.guidance_scaler), self._f(self.safety_threshold),
+                self._f(self.Q)]
+
+    def J(self, x):
+        sc = torch.tensor(TOKAMAK_SCALER, dtype=x.dtype, device=x.device).reshape(12, 1)
+        st = (x * sc)[:, :3, :self.nt]
+        tg = self.target.to(x.device)
+        obj = (st[:, 0] - tg[:, 0]).square().mean(-1) + (st[:, 2] - tg[:, 2]).square().mean(-1)
+        s = st[:, 1].amin(dim=-1)
+        safe = torch.clamp(self._f(self.safety_threshold) - s + self._f(self.Q), min=0)
+        return (self._f(self.w_obj) * obj + self._f(self.w_safe) * safe) * self._f(self.guidance_scaler)
+
+
+class SmokeGuidance(GuidanceSpec):
+    """guidance = -(1-w_safe)*mean(R5*x[:,:,5]) + w_safe*max(mean(R6*x[:,-1,6]) + Q - safe_bound, 0).
+    2d/inference_2d.py:173-195 (InferencePipeline.guidance / design_fn)."""
+    kind = "smoke"
+
+    def __init__(self, Q, w_safe, safe_bound, standard_fixed_ratio=1.0):
+        self.Q, self.w_safe, self.safe_bound, self.standard_fixed_ratio = Q, w_safe, safe_bound, standard_fixed_ratio
+
+    def gpar(self):
+        return [self._f(self.w_safe), self._f(self.safe_bound), self._f(self.Q), self._f(self.standard_fixed_ratio)]
+
+    def J(self, x):
+        R = torch.tensor(SMOKE_RESCALER, dtype=x.dtype, device=x.device).reshape(1, 1, 7, 1, 1)
+        st = x * R
+        succ = st[:, :, 5].mean((-1, -2, -3))
+        safe = torch.clamp(st[:, -1, 6].mean((-1, -2)) + self._f(self.Q) - self._f(self.safe_bound), min=0)
+        return -(1 - self._f(self.w_safe)) * succ + self._f(self.w_safe) * safe
+
+
+# --------------------------------------------------------------------------- sampler core
+class _State:
+    """Per-(batch size) device state: step counters, guidance scalars, condition buffers, captured graphs."""
+
+    def __init__(self, dev, B, per, T):
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.draw_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.gpar = z(8)
+        self.gscal = z(2 * B)
+        self.noise = None            # single-slot injected-noise buffer
+        self.x0 = None
+        self.cond = {}               # name -> persistent device buffer
+        self.graphs = {}             # config key -> captured graph handle
+        self.tails = {}              # config key -> tail Plan
+
+
+class _SamplerBase(nn.Module):
+    MODEL = None
+
+    def _init_common(self, model, timesteps, sampling_timesteps, beta_schedule, ddim_sampling_eta):
+        self.model = model
+        self.channels = model.channels
+        self.self_condition = model.self_condition
+        tabs = schedule_tables(beta_schedule, timesteps)
+        self.num_timesteps = int(timesteps)
+        self.sampling_timesteps = timesteps if sampling_timesteps is None else sampling_timesteps
+        assert self.sampling_timesteps <= timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+        for k, v in tabs.items():
+            self.register_buffer(k, v)
+        self.register_buffer("loss_weight", torch.ones(timesteps))
+        self._states = {}
+        self._lib = _lib.get_lib()
+        self.use_graph = True
+
+    # -------------------------------------------------------------- helpers
+    def _coef(self, J_scheduler, k_const=1.0):
+        """[T][8] = {a, b, c1, c2, sigma, k, 0, 0}; sigma = exp(0.5*logvar) (0 at t=0: 'no noise if t == 0')."""
+        T = self.num_timesteps
+        c = torch.zeros(T, 8, dtype=torch.float32)
+        c[:, 0] = self.sqrt_recip_alphas_cumprod.cpu()
+        c[:, 1] = self.sqrt_recipm1_alphas_cumprod.cpu()
+        c[:, 2] = self.posterior_mean_coef1.cpu()
+        c[:, 3] = self.posterior_mean_coef2.cpu()
+        c[:, 4] = (0.5 * self.posterior_log_variance_clipped.cpu()).exp()
+        c[0, 4] = 0.0
+        if J_scheduler is None:
+            c[:, 5] = k_const
+        else:
+            c[:, 5] = torch.tensor([float(J_scheduler(t)) for t in range(T)]) * k_const
+        return c.to(self.betas.device)
+
+    def _state(self, B, per):
+        key = (B, per, str(self.betas.device))
+        if key not in self._states:
+            self._states[key] = _State(self.betas.device, B, per, self.num_timesteps)
+        return self._states[key]
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.betas.device).cuda_stream
+
+    def _desc(self, B, dims, **kw):
+        d = SdcStepDesc()
+        d.model, d.B = _MODEL[self.MODEL], B
+        d.d0, d.d1, d.d2, d.d3 = dims
+        d.guide = d.impose = d.pad_zero = d.use_max = d.has_wgt = d.skip_draws = 0
+        d.clip, d.cond_idx, d.seed = 1, 0, 0
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+
+    def _persist(self, st, name, t):
+        """copy a user condition tensor into a persistent device buffer (stable pointer for the graph)."""
+        if t is None:
+            return None
+        t = t.detach().to(self.betas.device, torch.float32).contiguous()
+        buf = st.cond.get(name)
+        if buf is None or buf.shape != t.shape:
+            buf = torch.empty_like(t)
+            st.cond[name] = buf
+            st.graphs.clear()
+            st.tails.clear()
+        buf.copy_(t)
+        return buf
+
+    def _tail(self, st, ent, d, coef, guide_spec, target, c0, c1, c2, noise_buf, advance=True):
+        """Plan with the post-U-Net part of one step: [guide_reduce] -> step_update (x in place) -> advance."""
+        p = Plan(self.betas.device)
+        lib = self._lib
+        x, eps = ent["x"], ent["eps"]
+        ptr = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+        p.keep += [d, coef, x, eps, c0, c1, c2, target, noise_buf]
+        if d.guide == 1:
+            p._emit(lib.sdc_guide_reduce, C.byref(d), ptr(x), ptr(eps), ptr(coef), ptr(st.t_dev), ptr(st.gpar), ptr(st.gscal))
+        p._emit(lib.sdc_step_update, C.byref(d), ptr(x), ptr(eps), 0, ptr(coef), ptr(st.t_dev), ptr(st.draw_dev),
+                ptr(noise_buf), 0, ptr(st.gpar), ptr(st.gscal), ptr(target), ptr(c0), ptr(c1), ptr(c2), ptr(x), 0)
+        if advance:
+            p._emit(lib.sdc_advance, ptr(st.t_dev), -1, ptr(st.draw_dev), 1 + d.skip_draws)
+        return p
+
+    def _reverse_loop(self, B, dims, *, noise, guide, J_scheduler, k_const, cond, flags, impose_last, target=None,
+                      final_update=True):
+        """Shared DDPM loop.  `guide`: None | GuidanceSpec | callable.  `cond`: (c0, c1, c2) tensors or None.
+        `noise`: None (Philox in-kernel) or callable i -> tensor (injected, parity runs)."""
+        dev = self.betas.device
+        if dev.type != "cuda":
+            raise RuntimeError("safediffcon_amd samplers run on MI355X only: call .to('cuda') first; no CPU fallback")
+        # hipGraph capture needs a non-default stream: run the whole loop on a private stream that is
+        # ordered after / before the caller's current stream
+        cur = torch.cuda.current_stream(dev)
+        if getattr(self, "_side", None) is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            out = self._reverse_loop_on_stream(B, dims, noise=noise, guide=guide, J_scheduler=J_scheduler, k_const=k_const,
+                                               cond=cond, flags=flags, impose_last=impose_last, target=target,
+                                               final_update=final_update)
+        cur.wait_stream(self._side)
+        return out
+
+    def _reverse_loop_on_stream(self, B, dims, *, noise, guide, J_scheduler, k_const, cond, flags, impose_last, target,
+                                final_update):
+        dev = self.betas.device
+        lib, stream, T = self._lib, self._stream(), self.num_timesteps
+        per = int(math.prod(dims))
+        shape = self._sample_shape(B)
+        st = self._state(B, per)
+        net = self.model
+        ent = net.entry(shape, T, lut=True)
+        if not ent["lut_valid"]:
+            net.fill_cond(ent, torch.arange(T), stream)
+            ent["lut_valid"] = True
+        if ent["t_dev"] is not st.t_dev:
+            net.bind_cond(ent, st.t_dev)
+            st.graphs.clear()
+        x, eps = ent["x"], ent["eps"]
+        coef = self._coef(J_scheduler, k_const)
+        c0 = self._persist(st, "c0", cond[0])
+        c1 = self._persist(st, "c1", cond[1])
+        c2 = self._persist(st, "c2", cond[2])
+        tgt = self._persist(st, "target", target)
+        fused = isinstance(guide, GuidanceSpec) and guide.kind == self.MODEL
+        external = (guide is not None) and not fused
+        if fused:
+            st.gpar.copy_(torch.tensor(guide.gpar() + [0.0] * (8 - len(guide.gpar())), dtype=torch.float32))
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        injected = noise is not None
+        if injected and (st.noise is None):
+            st.noise = torch.empty(B * per, dtype=torch.float32, device=dev)
+        nbuf = st.noise if injected else None
+
+        # ---- x_T and the initial conditioning writes
+        d0 = self._desc(B, dims, **flags, impose=1, seed=seed)
+        if injected:
+            x.copy_(noise(0).to(dev).reshape(x.shape))
+        else:
+            st.draw_dev.zero_()
+            check(lib.sdc_randn(x.data_ptr(), x.numel(), seed, st.draw_dev.data_ptr(), stream), "sdc_randn")
+        check(lib.sdc_impose(C.byref(d0), x.data_ptr(), c0.data_ptr(), 0 if c1 is None else c1.data_ptr(),
+                             0 if c2 is None else c2.data_ptr(), stream), "sdc_impose")
+        st.t_dev.fill_(T - 1)
+        st.draw_dev.fill_(1)
+
+        skip = flags.get("skip_draws", 0)
+        mk = lambda **kw: self._desc(B, dims, **{**flags, "seed": seed, **kw})  # noqa: E731
+        draw_i = 1
+        if not external:
+            gmode = 1 if fused else 0
+            tail = self._tail(st, ent, mk(guide=gmode, impose=1), coef, guide, tgt, c0, c1, c2, nbuf)
+            tail_last = self._tail(st, ent, mk(guide=gmode, impose=1 if impose_last else 0), coef, guide, tgt, c0, c1, c2, nbuf)
+            n_graph = T if impose_last else T - 1
+            use_graph = self.use_graph and not injected
+            if use_graph:
+                # one capture per sample() call: descriptors carry the per-call seed
+                check(lib.sdc_graph_begin(stream), "sdc_graph_begin")
+                try:
+                    ent["plan"].run(stream)
+                    tail.run(stream)
+                finally:
+                    g = C.c_void_p()
+                    rc = lib.sdc_graph_end(stream, C.byref(g))
+                check(rc, "sdc_graph_end")
+                try:
+                    for _ in range(n_graph):
+                        check(lib.sdc_graph_launch(g, stream), "sdc_graph_launch")
+                finally:
+                    torch.cuda.current_stream(dev).synchronize()
+                    lib.sdc_graph_destroy(g)
+            else:
+                for t in reversed(range(T - n_graph, T)):
+                    if injected and t > 0:
+                        for _ in range(skip):
+                            noise(draw_i)
+                            draw_i += 1
+                        nbuf.copy_(noise(draw_i).to(dev).reshape(-1))
+                        draw_i += 1
+                    ent["plan"].run(stream)
+                    tail.run(stream)
+            if not impose_last:
+                ent["plan"].run(stream)
+                if final_update:
+                    tail_last.run(stream)
+        else:
+            # arbitrary guidance callable: x0 kernel -> callable (torch, on device) -> update kernel
+            if st.x0 is None:
+                st.x0 = torch.empty_like(x)
+            d_x0 = mk(guide=3, impose=0)
+            ptr = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+            for t in reversed(range(T)):
+                last = (t == 0)
+                if injected and t > 0:
+                    nbuf.copy_(noise(draw_i).to(dev).reshape(-1))
+                    draw_i += 1
+                ent["plan"].run(stream)
+                check(lib.sdc_step_update(C.byref(d_x0), ptr(x), ptr(eps), 0, ptr(coef), ptr(st.t_dev), ptr(st.draw_dev),
+                                          0, 0, 0, 0, 0, 0, 0, 0, 0, ptr(st.x0), stream), "sdc_step_update[x0]")
+                g = guide(st.x0.view(shape))
+                gk = (g if isinstance(g, torch.Tensor) else torch.zeros_like(x) + g).to(torch.float32).contiguous()
+                d_up = mk(guide=2, impose=(1 if (impose_last or not last) else 0))
+                check(lib.sdc_step_update(C.byref(d_up), ptr(x), ptr(eps), ptr(gk), ptr(coef), ptr(st.t_dev),
+                                          ptr(st.draw_dev), ptr(nbuf), 0, 0, 0, 0, ptr(c0), ptr(c1), ptr(c2), ptr(x), 0,
+                                          stream), "sdc_step_update[ext]")
+                check(lib.sdc_advance(ptr(st.t_dev), -1, ptr(st.draw_dev), 1 + skip, stream), "sdc_advance")
+        return x.clone()
+
+
+class GaussianDiffusionBurgers(_SamplerBase):
+    """Drop-in for 1D/model/diffusion.py::GaussianDiffusion (temporal=True, use_conv2d=True)."""
+    MODEL = "burgers"
+
+    def __init__(self, model, *, seq_length, timesteps=1000, sampling_timesteps=None, objective="pred_noise",
+                 beta_schedule="cosine", ddim_sampling_eta=0., auto_normalize=False, guidance_u0=True,
+                 conditioned_on_residual=None, residual_on_u0=False, temporal=False, use_conv2d=False,
+                 is_condition_u0=False, is_condition_uT=False, is_condition_u0_zero_pred_noise=True,
+                 is_condition_uT_zero_pred_noise=True, condition_idx=10, recurrence=False, recurrence_k=1,
+                 normalize_beta=False, train_on_padded_locations=False, train_on_partially_observed=None,
+                 set_unobserved_to_zero_during_sampling=False, is_model_w=False, eval_two_models=False,
+                 expand_condition=False, prior_beta=1):
+        super().__init__()
+        if (objective != "pred_noise" or auto_normalize or conditioned_on_residual is not None or recurrence
+                or is_model_w or eval_two_models or expand_condition or set_unobserved_to_zero_during_sampling
+                or not (temporal and use_conv2d)):
+            raise NotImplementedError("only the configuration built by 1D/utils/common.py:110-137 is supported")
+        assert isinstance(seq_length, tuple) and len(seq_length) == 2, "should be a tuple of (Nt, Nx)"
+        self._init_common(model, timesteps, sampling_timesteps, beta_schedule, ddim_sampling_eta)
+        self.temporal, self.conv2d, self.traj_size = True, True, seq_length
+        self.objective = objective
+        self.guidance_u0 = guidance_u0
+        self.is_condition_u0, self.is_condition_uT = is_condition_u0, is_condition_uT
+        self.condition_idx = condition_idx
+        self.train_on_padded_locations = train_on_padded_locations
+
+    def _sample_shape(self, B):
+        return (B, self.channels, *self.traj_size)
+
+    @torch.no_grad()
+    def sample(self, batch_size=16, clip_denoised=True, w_groundtruth=None, enable_grad=True, noise=None, **kwargs):
+        """Reference signature (1D/model/diffusion.py:557-607) + ``noise`` (i -> tensor) for injected-noise parity."""
+        if "guidance_u0" in kwargs:
+            self.guidance_u0 = kwargs["guidance_u0"]
+        if self.is_ddim_sampling:
+            raise NotImplementedError("DDIM sampling is a 'next' row (SURVEY 8f); use sampling_timesteps == timesteps")
+        if not (self.is_condition_u0 and self.is_condition_uT):
+            raise NotImplementedError("built for is_condition_u0 = is_condition_uT = True (1D/configs/*)")
+        assert kwargs.get("u_init") is not None and kwargs.get("u_final") is not None
+        nablaJ, J_sched = kwargs.get("nablaJ"), kwargs.get("J_scheduler")
+        if kwargs.get("proj_guidance") is not None:
+            raise NotImplementedError("proj_guidance is never enabled by the reference configs")
+        C_, (H, W) = self.channels, self.traj_size
+        flags = dict(clip=1 if clip_denoised else 0, cond_idx=self.condition_idx,
+                     pad_zero=0 if self.train_on_padded_locations else 1, has_wgt=0 if w_groundtruth is None else 1)
+        guide = nablaJ
+        if isinstance(guide, BurgersGuidance):
+            flags["use_max"] = 0 if guide.use_max_safety else 1
+        if not self.guidance_u0:
+            if nablaJ is not None:
+                raise NotImplementedError("guidance on x_t (guidance_u0=False with nablaJ) is unused by the reference pipelines")
+            flags["skip_draws"] = 1          # calibration branch draws twice per step (:421-423)
+            guide = None
+        return self._reverse_loop(batch_size, (C_, H, W, 1), noise=noise, guide=guide, J_scheduler=J_sched, k_const=1.0,
+                                  cond=(kwargs["u_init"], kwargs["u_final"], w_groundtruth), flags=flags,
+                                  impose_last=False, final_update=self.guidance_u0 or not enable_grad)
+
+
+class GaussianDiffusionTokamak(_SamplerBase):
+    """Drop-in for tokamak/model/diffusion.py::GaussianDiffusion (temporal=False)."""
+    MODEL = "tokamak"
+
+    def __init__(self, model, *, seq_length, nt=122, timesteps=1000, sampling_timesteps=None, objective="pred_noise",
+                 beta_schedule="cosine", ddim_sampling_eta=0., auto_normalize=False, guidance_u0=True,
+                 residual_on_u0=False, temporal=False, use_conv2d=False, is_condition_u0=True, is_condition_uT=True,
+                 is_condition_u0_zero_pred_noise=True, is_condition_uT_zero_pred_noise=True,
+                 train_on_padded_locations=True, expand_condition=False):
+        super().__init__()
+        if objective != "pred_noise" or auto_normalize or temporal or use_conv2d or expand_condition:
+            raise NotImplementedError("only the configuration built by tokamak/utils/common.py:99-127 is supported")
+        self._init_common(model, timesteps, sampling_timesteps, beta_schedule, ddim_sampling_eta)
+        self.seq_length, self.nt, self.temporal = seq_length, nt, False
+        self.objective = objective
+        self.guidance_u0 = guidance_u0
+        self.is_condition_u0, self.is_condition_uT = is_condition_u0, is_condition_uT
+        self.train_on_padded_locations = train_on_padded_locations
+
+    def _sample_shape(self, B):
+        return (B, self.channels, self.seq_length)
+
+    @torch.no_grad()
+    def sample(self, batch_size=16, clip_denoised=True, w_groundtruth=None, enable_grad=True, noise=None, **kwargs):
+        """Reference signature (tokamak/model/diffusion.py:498-539)."""
+        if "guidance_u0" in kwargs:
+            self.guidance_u0 = kwargs["guidance_u0"]
+        if self.is_ddim_sampling:
+            raise NotImplementedError("DDIM sampling is a 'next' row (SURVEY 8f); use sampling_timesteps == timesteps")
+        if not (self.is_condition_u0 and self.is_condition_uT):
+            raise NotImplementedError("built for is_condition_u0 = is_condition_uT = True")
+        assert kwargs.get("u_init") is not None and kwargs.get("u_final") is not None
+        if w_groundtruth is not None:
+            # the reference's DDPM path executes ``img[:,1,:,:] = w_groundtruth`` on a 3-D tensor (:335-336)
+            raise IndexError("too many indices for tensor of dimension 3")
+        nablaJ, J_sched = kwargs.get("nablaJ"), kwargs.get("J_scheduler")
+        flags = dict(clip=1 if clip_denoised else 0, cond_idx=self.nt, pad_zero=0 if self.train_on_padded_locations else 1)
+        guide, target = nablaJ, None
+        if isinstance(guide, TokamakGuidance):
+            target = guide.target
+            assert tuple(target.shape) == (batch_size, 3, self.nt), "target must be (B, 3, nt)"
+        if not self.guidance_u0:
+            if nablaJ is not None:
+                raise NotImplementedError("guidance on x_t (guidance_u0=False with nablaJ) is unused by the reference pipelines")
+            flags["skip_draws"] = 1
+            guide = None
+        return self._reverse_loop(batch_size, (self.channels, self.seq_length, 1, 1), noise=noise, guide=guide,
+                                  J_scheduler=J_sched, k_const=1.0, cond=(kwargs["u_init"], kwargs["u_final"], None),
+                                  flags=flags, impose_last=False, target=target,
+                                  final_update=self.guidance_u0 or not enable_grad)
+
+
+class GaussianDiffusionSmoke(_SamplerBase):
+    """Drop-in for 2d/ddpm/diffusion_2d.py::GaussianDiffusion."""
+    MODEL = "smoke"
+
+    def __init__(self, model, *, image_size, frames, timesteps=1000, sampling_timesteps=None, loss_type="l1",
+                 beta_schedule="sigmoid", schedule_fn_kwargs=dict(), ddim_sampling_eta=0., min_snr_loss_weight=False,
+                 min_snr_gamma=5, standard_fixed_ratio=1, device=None):
+        super().__init__()
+        if schedule_fn_kwargs:
+            raise NotImplementedError("schedule_fn_kwargs is never set by the reference")
+        self._init_common(model, timesteps, sampling_timesteps, beta_schedule, ddim_sampling_eta)
+        self.image_size, self.frames, self.standard_fixed_ratio, self.loss_type = image_size, frames, standard_fixed_ratio, loss_type
+
+    def _sample_shape(self, B):
+        return (B, self.frames, self.channels, self.image_size, self.image_size)
+
+    @torch.no_grad()
+    def sample(self, batch_size=16, design_fn=None, enable_grad=False, init=None, control=None, device=None, noise=None):
+        """Reference signature (2d/ddpm/diffusion_2d.py:406-414)."""
+        if self.is_ddim_sampling:
+            raise NotImplementedError("DDIM sampling is a 'next' row (SURVEY 8f); use sampling_timesteps == timesteps")
+        assert init is not None and batch_size == init.shape[0]
+        flags = dict(clip=1, has_wgt=0 if control is None else 1)
+        S = self.image_size
+        return self._reverse_loop(batch_size, (self.frames, self.channels, S, S), noise=noise, guide=design_fn,
+                                  J_scheduler=None, k_const=float(self.standard_fixed_ratio),
+                                  cond=(init, control, None), flags=flags, impose_last=True)
+
+
+# reference-compatible alias: each reference tree calls its class ``GaussianDiffusion``
+GaussianDiffusion = GaussianDiffusionBurgers

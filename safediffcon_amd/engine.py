@@ -1,0 +1,223 @@
+"""Stage-level execution engine: turns a U-Net description into a flat list of
+libsdc_hip.so calls with every pointer, stride and size bound ahead of time.
+
+PyTorch is plumbing here (device memory, streams): tensors are allocated once per
+plan from a reuse pool, handed to the kernels as raw pointers, and the recorded
+call list is either replayed from Python or captured into one hipGraph.
+Nothing in this file computes on the CPU or through torch ops on the hot path.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import SdcConvDesc, check
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _s5(t):
+    assert t.dim() == 5, t.shape
+    return tuple(int(s) for s in t.stride())
+
+
+def as5(t):
+    """(B,C,L) / (B,C,H,W) / (B,C,D,H,W) -> 5-D view (B,C,D,H,W)."""
+    while t.dim() < 5:
+        t = t.unsqueeze(2)
+    return t
+
+
+class Pool:
+    """Size-keyed free list so that activation buffers are reused along the plan."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free = {}
+        self.all = []
+        self.bytes = 0
+
+    def get(self, shape):
+        n = int(math.prod(shape))
+        lst = self.free.get(n)
+        if lst:
+            return lst.pop().view(shape)
+        t = torch.empty(n, dtype=torch.float32, device=self.device)
+        self.all.append(t)
+        self.bytes += n * 4
+        return t.view(shape)
+
+    def put(self, t):
+        self.free.setdefault(t.numel(), []).append(t.reshape(-1))
+
+
+class Plan:
+    """Recorded kernel calls.  `run(stream)` replays them; `capture(stream)` turns them into a hipGraph."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.lib = _lib.get_lib()
+        self.calls = []          # (fn, args, keepalive)
+        self.pool = Pool(self.device)
+        self.keep = []           # descriptors / tensors that must outlive the plan
+        self.repackers = []      # (dst tensor, fn() -> src tensor) to refresh repacked weights
+        self.graph = None
+        self._stats = None
+        self._ctx = None
+
+    # ------------------------------------------------------------------ execution
+    def run(self, stream):
+        for fn, args in self.calls:
+            rc = fn(*args, stream)
+            if rc:
+                check(rc, fn.__name__)
+
+    def capture(self, stream):
+        if self.graph is not None:
+            return
+        check(self.lib.sdc_graph_begin(stream), "sdc_graph_begin")
+        try:
+            self.run(stream)
+        finally:
+            g = C.c_void_p()
+            rc = self.lib.sdc_graph_end(stream, C.byref(g))
+        check(rc, "sdc_graph_end")
+        self.graph = g
+
+    def launch(self, stream):
+        check(self.lib.sdc_graph_launch(self.graph, stream), "sdc_graph_launch")
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                self.lib.sdc_graph_destroy(self.graph)
+        except Exception:  # noqa: BLE001
+            pass
+
+    def refresh_weights(self):
+        """Re-run every weight repack (after an optimiser step / load_state_dict)."""
+        with torch.no_grad():
+            for dst, fn in self.repackers:
+                dst.copy_(fn())
+
+    # ------------------------------------------------------------------ scratch
+    def _stats_buf(self, B, G):
+        need = int(self.lib.sdc_gn_stats_bytes(B, G))
+        if self._stats is None or self._stats.numel() * 4 < need:
+            self._stats = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+            self.keep.append(self._stats)
+        return self._stats
+
+    def _ctx_buf(self, n):
+        if self._ctx is None or self._ctx.numel() < n:
+            self._ctx = torch.empty(n, dtype=torch.float32, device=self.device)
+            self.keep.append(self._ctx)
+        return self._ctx
+
+    def _emit(self, fn, *args):
+        self.calls.append((fn, args))
+
+    # ------------------------------------------------------------------ weights
+    def packed(self, src_fn):
+        """Register a repacked weight: src_fn() -> tensor in kernel layout; refreshed by refresh_weights()."""
+        with torch.no_grad():
+            w = src_fn().detach().to(self.device, torch.float32).contiguous().clone()
+        self.repackers.append((w, lambda: src_fn().detach().to(self.device, torch.float32)))
+        self.keep.append(w)
+        return w
+
+    def conv_weight(self, w, kind="conv"):
+        """nn.Conv{1,2,3}d weight (Cout,Cin,*k) -> [taps*Cin][Cout];
+        kind 'convT': nn.ConvTranspose3d weight (Cin,Cout,*k) -> flipped-tap conv weight;
+        kind 'unshuffle': 1x1 conv after 'b c (h p1) (w p2) -> b (c p1 p2) h w' -> 2x2 stride-2 conv."""
+        def fn():
+            t = w() if callable(w) else w
+            if kind == "convT":
+                t5 = as5(t)                                   # (Cin, Cout, kD, kH, kW)
+                t5 = t5.flip(2, 3, 4).permute(2, 3, 4, 0, 1)  # (kD,kH,kW,Cin,Cout)
+                return t5.reshape(-1, t5.shape[-1]).contiguous()
+            if kind == "unshuffle":
+                co, c4 = t.shape[0], t.shape[1]
+                t4 = t.reshape(co, c4 // 4, 2, 2)             # (Cout, C, p1, p2)
+                return t4.permute(2, 3, 1, 0).reshape(-1, co).contiguous()
+            t5 = as5(t)                                       # (Cout, Cin, kD, kH, kW)
+            return t5.permute(2, 3, 4, 1, 0).reshape(-1, t5.shape[0]).contiguous()
+        return self.packed(fn)
+
+    def vec(self, p):
+        return self.packed(lambda: (p() if callable(p) else p).reshape(-1))
+
+    # ------------------------------------------------------------------ stages
+    def conv(self, x, wp, bias, cout, k, *, x1=None, stride=(1, 1, 1), pad=(0, 0, 0), up=(1, 1, 1), up_mode=0,
+             residual=None, out=None):
+        """x (and optional x1, channel-concatenated) are 5-D views; returns out (B,cout,oD,oH,oW)."""
+        B, c0, iD, iH, iW = x.shape
+        c1 = 0 if x1 is None else x1.shape[1]
+
+        def osz(i, u, kk, s, p):
+            v = (i - 1) * u + 1 if up_mode else i * u
+            return (v + 2 * p - kk) // s + 1
+
+        o = tuple(osz(i, u, kk, s, p) for i, u, kk, s, p in zip((iD, iH, iW), up, k, stride, pad))
+        if out is None:
+            out = self.pool.get((B, cout, *o))
+        assert tuple(out.shape) == (B, cout, *o), (out.shape, (B, cout, *o))
+        assert wp.shape == (k[0] * k[1] * k[2] * (c0 + c1), cout), (wp.shape, k, c0, c1, cout)
+        d = SdcConvDesc()
+        d.B, d.Cin0, d.Cin1, d.Cout = B, c0, c1, cout
+        d.iD, d.iH, d.iW = iD, iH, iW
+        d.oD, d.oH, d.oW = o
+        d.kD, d.kH, d.kW = k
+        d.sD, d.sH, d.sW = stride
+        d.pD, d.pH, d.pW = pad
+        d.uD, d.uH, d.uW = up
+        d.up_mode, d.precision = up_mode, 0
+        d.x0s[:] = _s5(x)
+        d.x1s[:] = _s5(x1) if x1 is not None else (0,) * 5
+        d.ys[:] = _s5(out)
+        d.rs[:] = _s5(residual) if residual is not None else (0,) * 5
+        if residual is not None:
+            assert tuple(residual.shape) == tuple(out.shape)
+        self.keep.append(d)
+        self._emit(self.lib.sdc_conv, C.byref(d), _ptr(x), _ptr(x1), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(out))
+        return out
+
+    def gn_silu(self, x, gamma, beta, groups, *, ss=None, t_dev=None, ss_t_stride=0, ss_b_stride=0, ss_off=0,
+                residual=None, out=None, eps=1e-5):
+        """GroupNorm -> (scale+1, shift) -> SiLU (+ residual); x contiguous 5-D; in place by default."""
+        assert x.is_contiguous()
+        B, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (B * Cc)
+        st = self._stats_buf(B, groups)
+        out = x if out is None else out
+        self._emit(self.lib.sdc_gn_stats, _ptr(x), _ptr(st), B, Cc, groups, S, eps)
+        self._emit(self.lib.sdc_gn_apply, _ptr(x), _ptr(st), _ptr(gamma), _ptr(beta), _ptr(ss), _ptr(t_dev),
+                   ss_t_stride, ss_b_stride, ss_off, _ptr(residual), _ptr(out), B, Cc, groups, S)
+        return out
+
+    def chan_norm(self, x, g, mode, *, residual=None, out=None, eps=1e-5):
+        assert x.is_contiguous()
+        B, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (B * Cc)
+        if out is None:
+            out = self.pool.get(tuple(x.shape))
+        self._emit(self.lib.sdc_chan_norm, _ptr(x), _ptr(g), _ptr(residual), _ptr(out), B, Cc, S, mode, eps)
+        return out
+
+    def act(self, x, kind, out=None):
+        out = x if out is None else out
+        self._emit(self.lib.sdc_act, _ptr(x), _ptr(out), x.numel(), kind)
+        return out
+
+    def linattn(self, qkv, heads, outer, inner, n, q_strides, out, o_strides):
+        ctx = self._ctx_buf(outer * inner * heads * 32 * 32)
+        self._emit(self.lib.sdc_linattn, _ptr(qkv), _ptr(ctx), _ptr(out), outer, inner, heads, n, *q_strides, *o_strides)
+        return out
+
+    def attn(self, qkv, out, heads, outer, inner, ntok, q_strides, o_strides, rot=None, bias=None):
+        self._emit(self.lib.sdc_attn, _ptr(qkv), _ptr(out), _ptr(rot), _ptr(bias), outer, inner, heads, ntok,
+                   *q_strides, *o_strides)
+        return out

@@ -1,0 +1,633 @@
+"""Drop-in denoisers: Unet2D (1D Burgers), Unet1D (tokamak), Unet3D_with_Conv3D (2D smoke).
+
+Same constructor arguments, same ``state_dict`` key names and the same
+``forward(x, time)`` contract as the reference classes
+  Unet2D               1D/model/unet.py:263-426
+  Unet1D               tokamak/model/unet.py:263-408
+  Unet3D_with_Conv3D   2d/video_diffusion_pytorch/video_diffusion_pytorch_conv3d.py:357-574
+but ``forward`` runs a pre-bound list of libsdc_hip.so kernels (engine.Plan); there
+is no torch.nn op and no CPU path.  Weights live in ordinary ``nn.Parameter``s, so
+``load_state_dict`` of a reference checkpoint works unchanged; they are repacked
+into kernel layouts when a plan is built (``refresh()`` after weights change).
+"""
+import math
+
+import torch
+from torch import nn
+
+from .engine import Plan, as5
+
+HEADS, DIM_HEAD = 4, 32
+HID = HEADS * DIM_HEAD
+
+
+# --------------------------------------------------------------------------- parameter specs
+def _resnet_spec(p, cin, cout, time_dim, k):
+    s = []
+    if time_dim is not None:
+        s += [(f"{p}.mlp.1.weight", (cout * 2, time_dim)), (f"{p}.mlp.1.bias", (cout * 2,))]
+    for blk, ci in (("block1", cin), ("block2", cout)):
+        s += [(f"{p}.{blk}.proj.weight", (cout, ci, *k)), (f"{p}.{blk}.proj.bias", (cout,)),
+              (f"{p}.{blk}.norm.weight", (cout,)), (f"{p}.{blk}.norm.bias", (cout,))]
+    if cin != cout:
+        s += [(f"{p}.res_conv.weight", (cout, cin, *([1] * len(k)))), (f"{p}.res_conv.bias", (cout,))]
+    return s
+
+
+def spec_lucid(dim, dim_mults, channels, nd):
+    """state_dict layout of Unet2D (nd=2) / Unet1D (nd=1), in the reference's registration order."""
+    one, k3, k7 = [1] * nd, [3] * nd, [7] * nd
+    g = (1, 0, *one)                     # gain shape (1, C, 1[,1]) with C filled below
+    td = dim * 4
+    dims = [dim] + [dim * m for m in dim_mults]
+    io = list(zip(dims[:-1], dims[1:]))
+    gshape = lambda c: (1, c, *one)  # noqa: E731
+    s = []
+    if nd == 1:
+        s += [("init_conv.weight", (dim, channels, *k7)), ("init_conv.bias", (dim,))]
+    s += [("time_mlp.1.weight", (td, dim)), ("time_mlp.1.bias", (td,)),
+          ("time_mlp.3.weight", (td, td)), ("time_mlp.3.bias", (td,))]
+    if nd == 2:
+        s += [("init_conv.weight", (dim, channels, *k7)), ("init_conv.bias", (dim,))]
+
+    def lin_attn(p, c):
+        return [(f"{p}.fn.fn.to_qkv.weight", (HID * 3, c, *one)), (f"{p}.fn.fn.to_out.0.weight", (c, HID, *one)),
+                (f"{p}.fn.fn.to_out.0.bias", (c,)), (f"{p}.fn.fn.to_out.1.g", gshape(c)), (f"{p}.fn.norm.g", gshape(c))]
+
+    def full_attn(p, c):
+        return [(f"{p}.fn.fn.to_qkv.weight", (HID * 3, c, *one)), (f"{p}.fn.fn.to_out.weight", (c, HID, *one)),
+                (f"{p}.fn.fn.to_out.bias", (c,)), (f"{p}.fn.norm.g", gshape(c))]
+
+    downs, ups = [], []
+    for i, (ci, co) in enumerate(io):
+        last = i == len(io) - 1
+        p = f"downs.{i}"
+        downs += _resnet_spec(f"{p}.0", ci, ci, td, k3) + _resnet_spec(f"{p}.1", ci, ci, td, k3) + lin_attn(f"{p}.2", ci)
+        if last:
+            downs += [(f"{p}.3.weight", (co, ci, *k3)), (f"{p}.3.bias", (co,))]
+        elif nd == 2:
+            downs += [(f"{p}.3.1.weight", (co, ci * 4, *one)), (f"{p}.3.1.bias", (co,))]
+        else:
+            downs += [(f"{p}.3.weight", (co, ci, 4)), (f"{p}.3.bias", (co,))]
+    mid = dims[-1]
+    mids = _resnet_spec("mid_block1", mid, mid, td, k3) + full_attn("mid_attn", mid) + _resnet_spec("mid_block2", mid, mid, td, k3)
+    for i, (ci, co) in enumerate(reversed(io)):
+        last = i == len(io) - 1
+        p = f"ups.{i}"
+        ups += _resnet_spec(f"{p}.0", co + ci, co, td, k3) + _resnet_spec(f"{p}.1", co + ci, co, td, k3) + lin_attn(f"{p}.2", co)
+        if last:
+            ups += [(f"{p}.3.weight", (ci, co, *k3)), (f"{p}.3.bias", (ci,))]
+        else:
+            ups += [(f"{p}.3.1.weight", (ci, co, *k3)), (f"{p}.3.1.bias", (ci,))]
+    fin = _resnet_spec("final_res_block", dim * 2, dim, td, k3) + [("final_conv.weight", (channels, dim, *one)),
+                                                                   ("final_conv.bias", (channels,))]
+    if nd == 2:
+        return s + downs + mids + ups + fin
+    # Unet1D registers downs, ups (both ModuleLists created first), then mid blocks
+    return s + downs + ups + mids + fin
+
+
+def spec_smoke(dim, dim_mults, channels):
+    """state_dict layout of Unet3D_with_Conv3D(dim, dim_mults, channels)."""
+    td = dim * 4
+    dims = [dim] + [dim * m for m in dim_mults]
+    io = list(zip(dims[:-1], dims[1:]))
+    k3, one = (3, 3, 3), (1, 1, 1)
+    rot = ("rotary_emb.freqs", (DIM_HEAD // 2,))
+
+    def t_attn(p, c):      # Residual(PreNorm(EinopsToAndFrom(Attention)))
+        return [(f"{p}.fn.fn.fn.{rot[0]}", rot[1]), (f"{p}.fn.fn.fn.to_qkv.weight", (HID * 3, c)),
+                (f"{p}.fn.fn.fn.to_out.weight", (c, HID)), (f"{p}.fn.norm.gamma", (1, c, 1, 1, 1))]
+
+    def s_lin(p, c):       # Residual(PreNorm(SpatialLinearAttention))
+        return [(f"{p}.fn.fn.to_qkv.weight", (HID * 3, c, 1, 1)), (f"{p}.fn.fn.to_out.weight", (c, HID, 1, 1)),
+                (f"{p}.fn.fn.to_out.bias", (c,)), (f"{p}.fn.norm.gamma", (1, c, 1, 1, 1))]
+
+    s = [("time_rel_pos_bias.relative_attention_bias.weight", (32, HEADS)),
+         ("init_conv.weight", (dim, channels, 7, 7, 7)), ("init_conv.bias", (dim,))]
+    s += t_attn("init_temporal_attn", dim)
+    s += [("time_mlp.1.weight", (td, dim)), ("time_mlp.1.bias", (td,)), ("time_mlp.3.weight", (td, td)),
+          ("time_mlp.3.bias", (td,))]
+    downs, ups = [], []
+    for i, (ci, co) in enumerate(io):
+        p = f"downs.{i}"
+        downs += _resnet_spec(f"{p}.0", ci, co, td, k3) + _resnet_spec(f"{p}.1", co, co, td, k3) + s_lin(f"{p}.2", co) + t_attn(f"{p}.3", co)
+        if i < len(io) - 1:
+            downs += [(f"{p}.4.weight", (co, co, 1, 4, 4)), (f"{p}.4.bias", (co,))]
+    for i, (ci, co) in enumerate(reversed(io)):
+        p = f"ups.{i}"
+        ups += _resnet_spec(f"{p}.0", co * 2, ci, td, k3) + _resnet_spec(f"{p}.1", ci, ci, td, k3) + s_lin(f"{p}.2", ci) + t_attn(f"{p}.3", ci)
+        if i < len(io) - 1:
+            ups += [(f"{p}.4.weight", (ci, ci, 1, 4, 4)), (f"{p}.4.bias", (ci,))]
+    mid = dims[-1]
+    mids = _resnet_spec("mid_block1", mid, mid, td, k3)
+    mids += [("mid_spatial_attn.fn.fn.fn.to_qkv.weight", (HID * 3, mid)), ("mid_spatial_attn.fn.fn.fn.to_out.weight", (mid, HID)),
+             ("mid_spatial_attn.fn.norm.gamma", (1, mid, 1, 1, 1))]
+    mids += t_attn("mid_temporal_attn", mid) + _resnet_spec("mid_block2", mid, mid, td, k3)
+    fin = _resnet_spec("final_conv.0", dim * 2, dim, None, k3) + [("final_conv.1.weight", (channels, dim, *one)),
+                                                                 ("final_conv.1.bias", (channels,))]
+    return s + downs + ups + mids + fin
+
+
+# --------------------------------------------------------------------------- nn.Module shell
+def _register(root, key, value):
+    *mods, leaf = key.split(".")
+    m = root
+    for name in mods:
+        if name not in m._modules:
+            m.add_module(name, nn.Module())
+        m = m._modules[name]
+    m.register_parameter(leaf, nn.Parameter(value))
+
+
+def _default_init(spec, gen):
+    """torch.nn default-style init (uniform +-1/sqrt(fan_in); gains 1, norm biases 0)."""
+    out = {}
+    for key, shape in spec:
+        leaf = key.rsplit(".", 1)[-1]
+        if key.endswith("rotary_emb.freqs"):
+            d = 2 * shape[0]
+            v = 1.0 / (10000 ** (torch.arange(0, d, 2)[: d // 2].float() / d))
+        elif key.endswith("relative_attention_bias.weight"):
+            v = torch.randn(shape, generator=gen)
+        elif leaf in ("g", "gamma") or key.endswith("norm.weight"):
+            v = torch.ones(shape)
+        elif key.endswith("norm.bias"):
+            v = torch.zeros(shape)
+        else:
+            wshape = shape if leaf != "bias" else None
+            if wshape is None:   # bias: bound from the sibling weight's fan_in
+                wkey = key[: -len("bias")] + "weight"
+                wshape = dict(spec)[wkey]
+            bound = 1.0 / math.sqrt(max(1, math.prod(wshape[1:])))
+            v = (torch.rand(shape, generator=gen) * 2 - 1) * bound
+        out[key] = v
+    return out
+
+
+def sinusoid_table(times, dim, theta=10000.0):
+    """SinusoidalPosEmb rows for the given timesteps, evaluated on the host exactly like the reference
+    does on CPU (1D/model/unet.py:81-107, conv3d.py:139-151): fp32 exp / sin / cos of t * freq."""
+    t = times.detach().cpu()
+    half = dim // 2
+    f = torch.exp(torch.arange(half) * -(math.log(theta) / (half - 1)))
+    a = t[:, None] * f[None, :]
+    if dim % 2 == 0:
+        return torch.cat((a.sin(), a.cos()), dim=-1)
+    half1 = (dim + 1) // 2
+    f1 = torch.exp(torch.arange(half1) * -(math.log(theta) / (half1 - 1)))
+    return torch.cat((a.sin(), (t[:, None] * f1[None, :]).cos()), dim=-1)
+
+
+class _Builder:
+    """Emits the stage calls of one U-Net forward into a Plan."""
+
+    def __init__(self, net, plan):
+        self.net, self.plan = net, plan
+        self.cond_sites = []       # (index of the sdc_gn_apply call, offset into the conditioning row)
+
+    def W(self, key, kind="conv"):
+        return self.plan.conv_weight(lambda: self.net.P(key), kind)
+
+    def V(self, key):
+        return self.plan.vec(lambda: self.net.P(key))
+
+    def ksize(self, key):
+        shp = tuple(self.net.P(key).shape[2:])
+        return (1,) * (3 - len(shp)) + shp
+
+    def conv(self, x, prefix, *, x1=None, stride=1, pad=None, up=(1, 1, 1), residual=None, out=None, kind="conv",
+             bias=True):
+        wkey = f"{prefix}.weight"
+        w = self.net.P(wkey)
+        if kind == "convT":
+            cout, k = w.shape[1], self.ksize(wkey)
+        elif kind == "unshuffle":
+            cout, k = w.shape[0], (1, 2, 2)
+        else:
+            cout, k = w.shape[0], self.ksize(wkey)
+        if isinstance(stride, int):
+            stride = tuple(stride if kk > 1 else 1 for kk in k)
+        if pad is None:
+            pad = tuple(kk // 2 for kk in k)
+        b = self.V(f"{prefix}.bias") if bias else None
+        return self.plan.conv(x, self.W(wkey, kind), b, cout, k, x1=x1, stride=stride, pad=pad, up=up,
+                              up_mode=1 if kind == "convT" else 0, residual=residual, out=out)
+
+    def gn(self, x, prefix, groups, residual=None, cond_off=None):
+        self.plan.gn_silu(x, self.V(f"{prefix}.weight"), self.V(f"{prefix}.bias"), groups, residual=residual)
+        if cond_off is not None:
+            self.cond_sites.append((len(self.plan.calls) - 1, cond_off))
+
+    def resnet(self, prefix, x, groups, *, x1=None):
+        net, pool = self.net, self.plan.pool
+        h = self.conv(x, f"{prefix}.block1.proj", x1=x1)
+        self.gn(h, f"{prefix}.block1.norm", groups, cond_off=net.cond_offsets.get(prefix))
+        g = self.conv(h, f"{prefix}.block2.proj")
+        pool.put(h)
+        if net.has(f"{prefix}.res_conv.weight"):
+            r = self.conv(x, f"{prefix}.res_conv", x1=x1)
+            self.gn(g, f"{prefix}.block2.norm", groups, residual=r)
+            pool.put(r)
+        else:
+            assert x1 is None
+            self.gn(g, f"{prefix}.block2.norm", groups, residual=x)
+        return g
+
+
+class _HipUNet(nn.Module):
+    """Common shell: parameters under the reference's key names + a cache of engine plans."""
+
+    def __init__(self, spec, dim, seed=None):
+        super().__init__()
+        gen = torch.Generator()
+        gen.manual_seed(int(torch.initial_seed()) & 0x7FFFFFFF if seed is None else seed)
+        for k, v in _default_init(spec, gen).items():
+            _register(self, k, v)
+        self._spec = spec
+        self._plans = {}
+        self.dim = dim
+        self.self_condition = False
+        # every time-conditioned ResnetBlock gets a slot [scale | shift] in the conditioning row
+        self.cond_offsets, off = {}, 0
+        for k, shape in spec:
+            if k.endswith(".mlp.1.weight"):
+                self.cond_offsets[k[: -len(".mlp.1.weight")]] = off
+                off += shape[0]
+        self.cond_width = off
+
+    def P(self, key):
+        m = self
+        *mods, leaf = key.split(".")
+        for name in mods:
+            m = m._modules[name]
+        return m._parameters[leaf]
+
+    def has(self, key):
+        try:
+            return self.P(key) is not None
+        except KeyError:
+            return False
+
+    def _apply(self, fn, *a, **k):
+        self._plans = {}          # device moves invalidate bound pointers
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, sd, strict=True, **kw):
+        # rotary buffers added by newer rotary-embedding-torch releases are tolerated
+        sd = {k: v for k, v in sd.items() if ("rotary_emb." not in k) or k.endswith("rotary_emb.freqs")}
+        r = super().load_state_dict(sd, strict=strict, **kw)
+        self.refresh()
+        return r
+
+    def refresh(self):
+        """Re-pack weights of every cached plan (call after an optimiser step)."""
+        for e in self._plans.values():
+            e["plan"].refresh_weights()
+            e["cond"].refresh_weights()
+            e["lut_valid"] = False
+
+    # ------------------------------------------------------------------ plans
+    def device(self):
+        return next(self.parameters()).device
+
+    def entry(self, shape, rows, lut=False):
+        """Plan for an input of `shape` whose conditioning table has `rows` rows: one row per sample
+        (lut=False, forward(x, time)) or one row per timestep read through a device-side t (lut=True, samplers)."""
+        key = (tuple(shape), rows, bool(lut))
+        if key not in self._plans:
+            dev = self.device()
+            if dev.type != "cuda":
+                raise RuntimeError("safediffcon_amd runs on MI355X only: move the model to a cuda (HIP) device; "
+                                   "there is no CPU fallback")
+            plan = Plan(dev)
+            x = torch.zeros(shape, dtype=torch.float32, device=dev)
+            eps = torch.zeros(shape, dtype=torch.float32, device=dev)
+            b = _Builder(self, plan)
+            self._build(b, x, eps)
+            plan.cond_sites = b.cond_sites
+            # conditioning pipeline: sinusoid rows -> Linear -> GELU -> Linear -> SiLU -> all block MLPs at once
+            cond = Plan(dev)
+            td = self.dim * 4
+            emb = torch.zeros((rows, self.dim, 1, 1, 1), dtype=torch.float32, device=dev)
+            cb = _Builder(self, cond)
+            h = cb.conv(emb, "time_mlp.1")
+            cond.act(h, 1)
+            temb = cb.conv(h, "time_mlp.3")
+            cond.act(temb, 0)
+            prefixes = list(self.cond_offsets)
+            wcat = cond.conv_weight(lambda: torch.cat([self.P(f"{p}.mlp.1.weight") for p in prefixes], 0))
+            bcat = cond.vec(lambda: torch.cat([self.P(f"{p}.mlp.1.bias") for p in prefixes], 0))
+            ss = cond.conv(temb, wcat, bcat, self.cond_width, (1, 1, 1))
+            assert temb.shape[1] == td
+            self._plans[key] = dict(plan=plan, cond=cond, x=x, eps=eps, emb=emb, ss=ss, rows=rows, lut_valid=False,
+                                    t_dev=None)
+        return self._plans[key]
+
+    def bind_cond(self, ent, t_dev):
+        """Point the conditioned GroupNorm calls at ent['ss']: per-sample rows (t_dev None) or LUT[*t_dev]."""
+        plan, ss, W = ent["plan"], ent["ss"], self.cond_width
+        for idx, off in plan.cond_sites:
+            fn, a = plan.calls[idx]
+            a = list(a)
+            # sdc_gn_apply(x, stats, gamma, beta, ss, t_dev, ss_t_stride, ss_b_stride, ss_off, residual, y, B, C, G, S)
+            if t_dev is None:
+                a[4], a[5], a[6], a[7], a[8] = ss.data_ptr(), 0, 0, W, off
+            else:
+                a[4], a[5], a[6], a[7], a[8] = ss.data_ptr(), t_dev.data_ptr(), W, 0, off
+            plan.calls[idx] = (fn, tuple(a))
+        ent["t_dev"] = t_dev
+
+    def fill_cond(self, ent, times, stream):
+        ent["emb"].copy_(sinusoid_table(times, self.dim).reshape(ent["emb"].shape), non_blocking=False)
+        ent["cond"].run(stream)
+
+    def forward(self, x, time, x_self_cond=None, **unused):
+        """eps = model(x, t) -- reference contract; x on the HIP device, time (B,) long/float."""
+        if not x.is_cuda:
+            raise RuntimeError("safediffcon_amd runs on MI355X only: tensors must be on a cuda (HIP) device; "
+                               "there is no CPU fallback")
+        ent = self.entry(tuple(x.shape), x.shape[0])
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.no_grad():
+            if not ent.get("bound"):
+                self.bind_cond(ent, None)
+                ent["bound"] = True
+            ent["x"].copy_(x)
+            self.fill_cond(ent, time, stream)
+            ent["plan"].run(stream)
+            return ent["eps"].clone()
+
+
+class _LucidUNet(_HipUNet):
+    """Unet2D / Unet1D skeleton: forward order of 1D/model/unet.py:382-426 == tokamak/model/unet.py:359-408."""
+    ND = 2
+    NORM_MODE = 0      # 0 channel LayerNorm (1D tree), 1 RMSNorm (tokamak tree)
+
+    def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=3, self_condition=False,
+                 resnet_block_groups=8, learned_variance=False, learned_sinusoidal_cond=False,
+                 random_fourier_features=False, learned_sinusoidal_dim=16, sinusoidal_pos_emb_theta=10000,
+                 attn_dim_head=32, attn_heads=4, condition_on_residual=None):
+        unsupported = dict(init_dim=init_dim, out_dim=out_dim, self_condition=self_condition or None,
+                           learned_variance=learned_variance or None,
+                           learned_sinusoidal_cond=learned_sinusoidal_cond or None,
+                           random_fourier_features=random_fourier_features or None,
+                           condition_on_residual=condition_on_residual)
+        bad = [k for k, v in unsupported.items() if v is not None]
+        if bad or attn_dim_head != 32 or attn_heads != 4 or sinusoidal_pos_emb_theta != 10000:
+            raise NotImplementedError(f"options never enabled by the reference configs are not built: {bad}")
+        super().__init__(spec_lucid(dim, tuple(dim_mults), channels, self.ND), dim)
+        self.channels, self.dim_mults, self.groups = channels, tuple(dim_mults), resnet_block_groups
+        self.out_dim = channels
+        self.random_or_learned_sinusoidal_cond = False
+
+    def _lin_attn(self, b, prefix, x):
+        plan, pool = b.plan, b.plan.pool
+        B, C = x.shape[0], x.shape[1]
+        n = x.numel() // (B * C)
+        xn = plan.chan_norm(x, b.V(f"{prefix}.fn.norm.g"), self.NORM_MODE)
+        qkv = b.conv(xn, f"{prefix}.fn.fn.to_qkv", bias=False)
+        pool.put(xn)
+        o = pool.get((B, HID, *x.shape[2:]))
+        plan.linattn(qkv, HEADS, B, 1, n, (3 * HID * n, n, 0), o, (HID * n, n, 0))
+        pool.put(qkv)
+        y = b.conv(o, f"{prefix}.fn.fn.to_out.0")
+        pool.put(o)
+        plan.chan_norm(y, b.V(f"{prefix}.fn.fn.to_out.1.g"), self.NORM_MODE, residual=x, out=y)
+        return y
+
+    def _full_attn(self, b, prefix, x):
+        plan, pool = b.plan, b.plan.pool
+        B, C = x.shape[0], x.shape[1]
+        n = x.numel() // (B * C)
+        xn = plan.chan_norm(x, b.V(f"{prefix}.fn.norm.g"), self.NORM_MODE)
+        qkv = b.conv(xn, f"{prefix}.fn.fn.to_qkv", bias=False)
+        pool.put(xn)
+        o = pool.get((B, HID, *x.shape[2:]))
+        plan.attn(qkv, o, HEADS, B, 1, n, (3 * HID * n, n, 0, 1), (HID * n, n, 0, 1))
+        pool.put(qkv)
+        y = b.conv(o, f"{prefix}.fn.fn.to_out", residual=x)
+        pool.put(o)
+        return y
+
+    def _build(self, b, x, eps):
+        pool, G = b.plan.pool, self.groups
+        nres = len(self.dim_mults)
+        x5, e5 = as5(x), as5(eps)
+        h = b.conv(x5, "init_conv")
+        r = h
+        hs = []
+        for i in range(nres):
+            p = f"downs.{i}"
+            x1 = b.resnet(f"{p}.0", h, G)
+            if h is not r:
+                pool.put(h)
+            hs.append(x1)
+            x2 = b.resnet(f"{p}.1", x1, G)
+            x3 = self._lin_attn(b, f"{p}.2", x2)
+            pool.put(x2)
+            hs.append(x3)
+            h = self._down(b, f"{p}.3", x3, i == nres - 1)
+        m = b.resnet("mid_block1", h, G)
+        pool.put(h)
+        a = self._full_attn(b, "mid_attn", m)
+        pool.put(m)
+        h = b.resnet("mid_block2", a, G)
+        pool.put(a)
+        for i in range(nres):
+            p = f"ups.{i}"
+            s = hs.pop()
+            y1 = b.resnet(f"{p}.0", h, G, x1=s)
+            pool.put(h), pool.put(s)
+            s = hs.pop()
+            y2 = b.resnet(f"{p}.1", y1, G, x1=s)
+            pool.put(y1), pool.put(s)
+            y3 = self._lin_attn(b, f"{p}.2", y2)
+            pool.put(y2)
+            h = self._up(b, f"{p}.3", y3, i == nres - 1)
+            pool.put(y3)
+        f = b.resnet("final_res_block", h, G, x1=r)
+        pool.put(h), pool.put(r)
+        b.conv(f, "final_conv", out=e5)
+        pool.put(f)
+
+
+class Unet2D(_LucidUNet):
+    """1D Burgers denoiser over the (time, space) image -- 1D/model/unet.py:263-426."""
+    ND, NORM_MODE = 2, 0
+
+    def _down(self, b, p, x, last):
+        if last:
+            return b.conv(x, p)
+        return b.conv(x, f"{p}.1", kind="unshuffle", stride=(1, 2, 2), pad=(0, 0, 0))   # Downsample2d :39-43
+
+    def _up(self, b, p, x, last):
+        if last:
+            return b.conv(x, p)
+        return b.conv(x, f"{p}.1", up=(1, 2, 2))                                          # Upsample2d :33-37
+
+
+class Unet1D(_LucidUNet):
+    """Tokamak denoiser along time -- tokamak/model/unet.py:263-408."""
+    ND, NORM_MODE = 1, 1
+
+    def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=12, **kw):
+        super().__init__(dim, init_dim, out_dim, dim_mults, channels, **kw)
+
+    def _down(self, b, p, x, last):
+        if last:
+            return b.conv(x, p)
+        return b.conv(x, p, stride=(1, 1, 2), pad=(0, 0, 1))                              # Conv1d(k4,s2,p1) :30-31
+
+    def _up(self, b, p, x, last):
+        if last:
+            return b.conv(x, p)
+        return b.conv(x, f"{p}.1", up=(1, 1, 2))                                          # Upsample :24-28
+
+
+def rel_pos_bias_table(weight, n, num_buckets=32, max_distance=32):
+    """RelativePositionBias.forward (conv3d.py:74-112): integer bucket indices on the host, gather of the
+    (32, heads) embedding -> (heads, n, n)."""
+    q = torch.arange(n)
+    rel = q[None, :] - q[:, None]
+    m = -rel
+    nb = num_buckets // 2
+    ret = (m < 0).long() * nb
+    m = m.abs()
+    max_exact = nb // 2
+    small = m < max_exact
+    large = max_exact + (torch.log(m.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    bucket = (ret + torch.where(small, m, large)).to(weight.device)
+    return weight[bucket].permute(2, 0, 1).contiguous()
+
+
+class Unet3D_with_Conv3D(_HipUNet):
+    """2D smoke denoiser -- conv3d.py:357-574.  Input/Output (B, F, C, H, W) frame-major."""
+
+    def __init__(self, dim, cond_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=6, attn_heads=4,
+                 attn_dim_head=32, use_bert_text_cond=False, init_dim=None, init_kernel_size=7,
+                 use_sparse_linear_attn=True, block_type="resnet", resnet_groups=8):
+        if (cond_dim is not None or out_dim is not None or use_bert_text_cond or init_dim is not None
+                or init_kernel_size != 7 or not use_sparse_linear_attn or attn_heads != 4 or attn_dim_head != 32):
+            raise NotImplementedError("options never enabled by the reference's 2D scripts are not built")
+        super().__init__(spec_smoke(dim, tuple(dim_mults), channels), dim)
+        self.channels, self.dim_mults, self.groups = channels, tuple(dim_mults), resnet_groups
+        self.has_cond = False
+        # the reference shares ONE RotaryEmbedding instance between all temporal-attention layers
+        # (conv3d.py:381-383): tie the eight state_dict entries to a single Parameter
+        shared = self.P("init_temporal_attn.fn.fn.fn.rotary_emb.freqs")
+        for k, _ in self._spec:
+            if k.endswith("rotary_emb.freqs"):
+                m = self
+                for name in k.split(".")[:-1]:
+                    m = m._modules[name]
+                m._parameters["freqs"] = shared
+
+    # ---- attention blocks
+    def _attn_tables(self, b, F):
+        plan = b.plan
+        if not hasattr(plan, "_rot"):
+            def rot():
+                fr = self.P("init_temporal_attn.fn.fn.fn.rotary_emb.freqs").detach().float().cpu()
+                ang = torch.arange(F, dtype=torch.float32)[:, None] * fr[None, :]
+                return torch.stack((ang.cos(), ang.sin()), dim=-1).reshape(-1)
+            plan._rot = plan.packed(rot)
+            plan._bias = plan.packed(lambda: rel_pos_bias_table(
+                self.P("time_rel_pos_bias.relative_attention_bias.weight").detach(), F).reshape(-1))
+        return plan._rot, plan._bias
+
+    def _temporal(self, b, prefix, x):
+        plan, pool = b.plan, b.plan.pool
+        B, C, F, H, W = x.shape
+        hw = H * W
+        rot, bias = self._attn_tables(b, F)
+        xn = plan.chan_norm(x, b.V(f"{prefix}.fn.norm.gamma"), 0)
+        qkv = b.conv(xn, f"{prefix}.fn.fn.fn.to_qkv", bias=False)
+        pool.put(xn)
+        o = pool.get((B, HID, F, H, W))
+        plan.attn(qkv, o, HEADS, B, hw, F, (3 * HID * F * hw, F * hw, 1, hw), (HID * F * hw, F * hw, 1, hw), rot, bias)
+        pool.put(qkv)
+        y = b.conv(o, f"{prefix}.fn.fn.fn.to_out", bias=False, residual=x)
+        pool.put(o)
+        return y
+
+    def _spatial_linear(self, b, prefix, x):
+        plan, pool = b.plan, b.plan.pool
+        B, C, F, H, W = x.shape
+        hw = H * W
+        xn = plan.chan_norm(x, b.V(f"{prefix}.fn.norm.gamma"), 0)
+        qkv = b.conv(xn, f"{prefix}.fn.fn.to_qkv", bias=False)
+        pool.put(xn)
+        o = pool.get((B, HID, F, H, W))
+        plan.linattn(qkv, HEADS, B, F, hw, (3 * HID * F * hw, F * hw, hw), o, (HID * F * hw, F * hw, hw))
+        pool.put(qkv)
+        y = b.conv(o, f"{prefix}.fn.fn.to_out", residual=x)
+        pool.put(o)
+        return y
+
+    def _spatial_full(self, b, prefix, x):
+        plan, pool = b.plan, b.plan.pool
+        B, C, F, H, W = x.shape
+        hw = H * W
+        xn = plan.chan_norm(x, b.V(f"{prefix}.fn.norm.gamma"), 0)
+        qkv = b.conv(xn, f"{prefix}.fn.fn.fn.to_qkv", bias=False)
+        pool.put(xn)
+        o = pool.get((B, HID, F, H, W))
+        plan.attn(qkv, o, HEADS, B, F, hw, (3 * HID * F * hw, F * hw, hw, 1), (HID * F * hw, F * hw, hw, 1))
+        pool.put(qkv)
+        y = b.conv(o, f"{prefix}.fn.fn.fn.to_out", bias=False, residual=x)
+        pool.put(o)
+        return y
+
+    def _build(self, b, x, eps):
+        pool, G = b.plan.pool, self.groups
+        nres = len(self.dim_mults)
+        x5 = x.permute(0, 2, 1, 3, 4)          # (B,C,F,H,W) view of the frame-major state: strides do the permute
+        e5 = eps.permute(0, 2, 1, 3, 4)
+        h0 = b.conv(x5, "init_conv")
+        h = self._temporal(b, "init_temporal_attn", h0)
+        pool.put(h0)
+        r = h
+        hs = []
+        for i in range(nres):
+            p = f"downs.{i}"
+            a1 = b.resnet(f"{p}.0", h, G)
+            if h is not r:
+                pool.put(h)
+            a2 = b.resnet(f"{p}.1", a1, G)
+            pool.put(a1)
+            a3 = self._spatial_linear(b, f"{p}.2", a2)
+            pool.put(a2)
+            a4 = self._temporal(b, f"{p}.3", a3)
+            pool.put(a3)
+            hs.append(a4)
+            h = a4
+            if i < nres - 1:
+                h = b.conv(a4, f"{p}.4", stride=(1, 2, 2), pad=(0, 1, 1))
+        m1 = b.resnet("mid_block1", h, G)        # h (== hs[-1]) stays alive as a skip
+        m2 = self._spatial_full(b, "mid_spatial_attn", m1)
+        pool.put(m1)
+        m3 = self._temporal(b, "mid_temporal_attn", m2)
+        pool.put(m2)
+        h = b.resnet("mid_block2", m3, G)
+        pool.put(m3)
+        for i in range(nres):
+            p = f"ups.{i}"
+            s = hs.pop()
+            u1 = b.resnet(f"{p}.0", h, G, x1=s)
+            pool.put(h), pool.put(s)
+            u2 = b.resnet(f"{p}.1", u1, G)
+            pool.put(u1)
+            u3 = self._spatial_linear(b, f"{p}.2", u2)
+            pool.put(u2)
+            u4 = self._temporal(b, f"{p}.3", u3)
+            pool.put(u3)
+            h = u4
+            if i < nres - 1:
+                h = b.conv(u4, f"{p}.4", kind="convT", up=(1, 2, 2), pad=(0, 2, 2))   # ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1)
+                pool.put(u4)
+        f = b.resnet("final_conv.0", h, G, x1=r)
+        pool.put(h), pool.put(r)
+        b.conv(f, "final_conv.1", out=e5)
+        pool.put(f)

@@ -1,0 +1,271 @@
+"""-m gpu: every libsdc_hip.so stage against the CPU oracle / plain torch fp32 ops on the same seeded
+inputs (called through the C ABI via the engine), including the edge cases the path has: ragged tile
+edges, Cin not a multiple of the K chunk, two-input concat, stride/upsample/transposed gathers,
+strided (frame-major) tensors, hinge on/off, empty-ish extents."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import nets as onets
+from oracle import samplers as osam
+from oracle.detweights import det_tensor
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+# fp32 MFMA is an exact fp32 FMA chain; the only differences vs the CPU reference are summation order
+TOL = dict(rtol=2e-4, atol=2e-5)
+
+
+@pytest.fixture(scope="module")
+def plan_cls():
+    from safediffcon_amd.engine import Plan
+    return Plan
+
+
+def _stream():
+    return torch.cuda.current_stream(torch.device(DEV)).cuda_stream
+
+
+def _run(plan):
+    plan.run(_stream())
+    torch.cuda.synchronize()
+
+
+def _conv_case(plan_cls, nd, B, cin, cout, sp, k, stride=1, pad=0, up=1, cin1=0, residual=False, seed=0):
+    from safediffcon_amd.engine import as5
+    x = det_tensor((B, cin, *sp), seed + 1)
+    x1 = det_tensor((B, cin1, *sp), seed + 2) if cin1 else None
+    w = det_tensor((cout, cin + cin1, *([k] * nd)), seed + 3, 0.2)
+    b = det_tensor((cout,), seed + 4, 0.1)
+    xin = x if x1 is None else torch.cat((x, x1), 1)
+    if up > 1:
+        xin = F.interpolate(xin, scale_factor=up, mode="nearest")
+    ref = (F.conv1d, F.conv2d, F.conv3d)[nd - 1](xin, w, b, stride=stride, padding=pad)
+    res = det_tensor(tuple(ref.shape), seed + 5) if residual else None
+    if residual:
+        ref = ref + res
+    plan = plan_cls(DEV)
+    k3 = (1,) * (3 - nd) + (k,) * nd
+    s3 = (1,) * (3 - nd) + (stride,) * nd
+    p3 = (0,) * (3 - nd) + (pad,) * nd
+    u3 = (1,) * (3 - nd) + (up,) * nd
+    wp = plan.conv_weight(w.to(DEV))
+    out = plan.conv(as5(x.to(DEV)), wp, b.to(DEV), cout, k3, x1=None if x1 is None else as5(x1.to(DEV)), stride=s3,
+                    pad=p3, up=u3, residual=None if res is None else as5(res.to(DEV)))
+    _run(plan)
+    torch.testing.assert_close(out.cpu().reshape(ref.shape), ref, **TOL)
+
+
+@pytest.mark.parametrize("case", [
+    dict(nd=1, B=3, cin=12, cout=8, sp=(128,), k=7, pad=3),                 # tokamak init conv, Cin % 16 != 0
+    dict(nd=1, B=2, cin=32, cout=64, sp=(64,), k=4, stride=2, pad=1),       # Downsample k4 s2
+    dict(nd=1, B=2, cin=32, cout=16, sp=(32,), k=3, pad=1, up=2),           # Upsample + conv
+    dict(nd=2, B=2, cin=3, cout=8, sp=(16, 128), k=7, pad=3),               # burgers init conv
+    dict(nd=2, B=2, cin=64, cout=64, sp=(16, 128), k=3, pad=1),             # fast path, 64x128 tile
+    dict(nd=2, B=5, cin=48, cout=130, sp=(8, 20), k=3, pad=1, cin1=16, residual=True),   # ragged M and N, concat
+    dict(nd=2, B=2, cin=16, cout=3, sp=(16, 128), k=1),                     # final 1x1, Cout=3
+    dict(nd=2, B=2, cin=32, cout=16, sp=(4, 32), k=3, pad=1, up=2),         # Upsample2d
+    dict(nd=3, B=1, cin=7, cout=8, sp=(8, 16, 16), k=7, pad=3),             # smoke init conv
+    dict(nd=3, B=2, cin=16, cout=32, sp=(4, 8, 8), k=3, pad=1, cin1=16),    # Conv3d 3^3 with skip concat
+    dict(nd=3, B=36, cin=128, cout=160, sp=(4, 16, 16), k=3, pad=1),        # 128x128 tile path (Ntot >= 32768)
+])
+def test_conv_matches_torch(plan_cls, case):
+    _conv_case(plan_cls, **case)
+
+
+def test_conv_special_gathers(plan_cls):
+    from safediffcon_amd.engine import as5
+    # Downsample2d: pixel-unshuffle + 1x1  (1D/model/unet.py:39-43)
+    x = det_tensor((2, 16, 8, 32), 10)
+    w = det_tensor((24, 64, 1, 1), 11, 0.2)
+    b = det_tensor((24,), 12, 0.1)
+    xs = x.reshape(2, 16, 4, 2, 16, 2).permute(0, 1, 3, 5, 2, 4).reshape(2, 64, 4, 16)
+    ref = F.conv2d(xs, w, b)
+    plan = plan_cls(DEV)
+    out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV), "unshuffle"), b.to(DEV), 24, (1, 2, 2), stride=(1, 2, 2))
+    # ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1)  (conv3d.py:159-160)
+    xt = det_tensor((2, 16, 3, 8, 8), 13)
+    wt = det_tensor((16, 16, 1, 4, 4), 14, 0.2)
+    bt = det_tensor((16,), 15, 0.1)
+    reft = F.conv_transpose3d(xt, wt, bt, stride=(1, 2, 2), padding=(0, 1, 1))
+    outt = plan.conv(xt.to(DEV), plan.conv_weight(wt.to(DEV), "convT"), bt.to(DEV), 16, (1, 4, 4), up=(1, 2, 2),
+                     up_mode=1, pad=(0, 2, 2))
+    # Conv3d (1,4,4) stride (1,2,2) pad (0,1,1)
+    wd = det_tensor((16, 16, 1, 4, 4), 16, 0.2)
+    refd = F.conv3d(xt, wd, bt, stride=(1, 2, 2), padding=(0, 1, 1))
+    outd = plan.conv(xt.to(DEV), plan.conv_weight(wd.to(DEV)), bt.to(DEV), 16, (1, 4, 4), stride=(1, 2, 2), pad=(0, 1, 1))
+    # strided input/output views: frame-major (B,F,C,H,W) storage read and written through strides
+    xf = det_tensor((2, 4, 7, 8, 8), 17)
+    wf = det_tensor((7, 7, 3, 3, 3), 18, 0.2)
+    reff = F.conv3d(xf.permute(0, 2, 1, 3, 4), wf, None, padding=1).permute(0, 2, 1, 3, 4)
+    outf_store = torch.zeros(2, 4, 7, 8, 8, device=DEV)
+    plan.conv(xf.to(DEV).permute(0, 2, 1, 3, 4), plan.conv_weight(wf.to(DEV)), None, 7, (3, 3, 3), pad=(1, 1, 1),
+              out=outf_store.permute(0, 2, 1, 3, 4))
+    _run(plan)
+    torch.testing.assert_close(out.cpu().reshape(ref.shape), ref, **TOL)
+    torch.testing.assert_close(outt.cpu(), reft, **TOL)
+    torch.testing.assert_close(outd.cpu(), refd, **TOL)
+    torch.testing.assert_close(outf_store.cpu(), reff, **TOL)
+
+
+def test_conv_rejects_bad_shapes(plan_cls):
+    from safediffcon_amd._lib import SdcConvDesc, get_lib, last_error
+    d = SdcConvDesc()
+    d.B, d.Cin0, d.Cout = 1, 4, 4
+    d.iD = d.iH = d.iW = 4
+    d.oD = d.oH = d.oW = 5          # inconsistent
+    d.kD = d.kH = d.kW = 3
+    d.sD = d.sH = d.sW = 1
+    d.uD = d.uH = d.uW = 1
+    t = torch.zeros(256, device=DEV)
+    rc = get_lib().sdc_conv(C.byref(d), t.data_ptr(), 0, t.data_ptr(), 0, 0, t.data_ptr(), _stream())
+    assert rc == -1 and "inconsistent" in last_error()
+
+
+@pytest.mark.parametrize("B,Cc,G,sp", [(3, 8, 1, (16, 128)), (2, 64, 8, (4, 8, 8)), (2, 16, 8, (6, 5, 3)), (2, 32, 1, (16,)),
+                                       (1, 8, 8, (32, 64, 64))])
+def test_groupnorm_silu(plan_cls, B, Cc, G, sp):
+    from safediffcon_amd.engine import as5
+    x = det_tensor((B, Cc, *sp), 20) * 3 + 1.5
+    gamma, beta = det_tensor((Cc,), 21) * 0.2 + 1, det_tensor((Cc,), 22) * 0.2
+    ss = det_tensor((B, 2 * Cc + 5), 23, 0.3)
+    res = det_tensor((B, Cc, *sp), 24)
+    y = F.group_norm(x, G, gamma, beta, eps=1e-5)
+    sc = ss[:, 5:5 + Cc].reshape(B, Cc, *([1] * len(sp)))
+    sh = ss[:, 5 + Cc:5 + 2 * Cc].reshape(B, Cc, *([1] * len(sp)))
+    ref = F.silu(y * (sc + 1) + sh) + res
+    plan = plan_cls(DEV)
+    xd = as5(x.to(DEV)).contiguous()
+    out = plan.gn_silu(xd, gamma.to(DEV), beta.to(DEV), G, ss=ss.to(DEV), ss_b_stride=ss.shape[1], ss_off=5,
+                       residual=as5(res.to(DEV)).contiguous())
+    _run(plan)
+    torch.testing.assert_close(out.cpu().reshape(ref.shape), ref, **TOL)
+    # unconditioned, no residual, device-side t indexing
+    plan = plan_cls(DEV)
+    xd = as5(x.to(DEV)).contiguous()
+    t_dev = torch.tensor([2], dtype=torch.int32, device=DEV)
+    lut = torch.zeros(4, 2 * Cc, device=DEV)
+    lut[2] = ss[0, 5:5 + 2 * Cc].to(DEV)
+    out = plan.gn_silu(xd, gamma.to(DEV), beta.to(DEV), G, ss=lut, t_dev=t_dev, ss_t_stride=2 * Cc)
+    _run(plan)
+    sc0 = ss[0, 5:5 + Cc].reshape(1, Cc, *([1] * len(sp)))
+    sh0 = ss[0, 5 + Cc:5 + 2 * Cc].reshape(1, Cc, *([1] * len(sp)))
+    torch.testing.assert_close(out.cpu().reshape(ref.shape), F.silu(y * (sc0 + 1) + sh0), **TOL)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("B,Cc,S", [(2, 8, 2048), (3, 64, 100), (2, 2048, 16), (1, 5, 3)])
+def test_channel_norms(plan_cls, mode, B, Cc, S):
+    x = det_tensor((B, Cc, S), 30) * 2 + 0.7
+    g = det_tensor((1, Cc, 1), 31) * 0.3 + 1
+    res = det_tensor((B, Cc, S), 32)
+    ref = (onets.chan_layernorm(x, g) if mode == 0 else onets.chan_rmsnorm(x, g)) + res
+    plan = plan_cls(DEV)
+    out = plan.chan_norm(x.to(DEV).reshape(B, Cc, 1, 1, S), g.to(DEV).reshape(-1), mode, residual=res.to(DEV))
+    _run(plan)
+    torch.testing.assert_close(out.cpu().reshape(ref.shape), ref, **TOL)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_activations(plan_cls, kind):
+    x = det_tensor((1000,), 40) * 3
+    plan = plan_cls(DEV)
+    xd = x.to(DEV)
+    plan.act(xd, kind)
+    _run(plan)
+    torch.testing.assert_close(xd.cpu(), F.silu(x) if kind == 0 else F.gelu(x), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,inner,n", [(2, 1, 2048), (2, 3, 256), (1, 2, 100), (3, 1, 16)])
+def test_linear_attention_core(plan_cls, B, inner, n):
+    heads = 4
+    qkv = det_tensor((B, 3 * 128, inner, n), 50) * 1.5
+    q, k, v = (t.permute(0, 2, 1, 3).reshape(B * inner, heads, 32, n) for t in qkv.chunk(3, dim=1))
+    qs = q.softmax(dim=-2) * 32 ** -0.5
+    ks = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", ks, v)
+    ref = torch.einsum("bhde,bhdn->bhen", ctx, qs).reshape(B, inner, 128, n).permute(0, 2, 1, 3)
+    plan = plan_cls(DEV)
+    out = torch.zeros(B, 128, inner, n, device=DEV)
+    plan.linattn(qkv.to(DEV), heads, B, inner, n, (384 * inner * n, inner * n, n), out, (128 * inner * n, inner * n, n))
+    _run(plan)
+    torch.testing.assert_close(out.cpu(), ref, **TOL)
+
+
+@pytest.mark.parametrize("contig,B,inner,ntok,rot_bias", [
+    (True, 3, 1, 32, False), (True, 2, 1, 16, False), (True, 2, 4, 256, False), (True, 5, 3, 20, False),
+    (False, 2, 64, 32, True), (False, 1, 12, 8, True), (False, 2, 7, 32, True)])
+def test_softmax_attention_core(plan_cls, contig, B, inner, ntok, rot_bias):
+    heads = 4
+    if contig:     # (B, 384, inner, ntok): tokens contiguous
+        qkv = det_tensor((B, 384, inner, ntok), 60) * 1.2
+        seqs = qkv.permute(0, 2, 3, 1)                      # (B, inner, tok, c)
+    else:          # (B, 384, ntok, inner): tokens strided (temporal attention)
+        qkv = det_tensor((B, 384, ntok, inner), 61) * 1.2
+        seqs = qkv.permute(0, 3, 2, 1)
+    q, k, v = (t.reshape(B, inner, ntok, heads, 32).transpose(-2, -3) for t in seqs.chunk(3, dim=-1))
+    q = q * 32 ** -0.5
+    rot = bias = None
+    if rot_bias:
+        freqs = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+        q, k = onets.rotary(q, freqs), onets.rotary(k, freqs)
+        bias = det_tensor((heads, ntok, ntok), 62, 0.5)
+        ang = torch.arange(ntok, dtype=torch.float32)[:, None] * freqs[None, :]
+        rot = torch.stack((ang.cos(), ang.sin()), dim=-1).reshape(-1).to(DEV)
+    sim = torch.einsum("...hid,...hjd->...hij", q, k)
+    if bias is not None:
+        sim = sim + bias
+    o = torch.einsum("...hij,...hjd->...hid", sim.softmax(dim=-1), v)      # (B, inner, h, tok, d)
+    o = o.transpose(-2, -3).reshape(B, inner, ntok, 128)
+    plan = plan_cls(DEV)
+    if contig:
+        ref = o.permute(0, 3, 1, 2)
+        out = torch.zeros(B, 128, inner, ntok, device=DEV)
+        plan.attn(qkv.to(DEV), out, heads, B, inner, ntok, (384 * inner * ntok, inner * ntok, ntok, 1),
+                  (128 * inner * ntok, inner * ntok, ntok, 1))
+    else:
+        ref = o.permute(0, 3, 2, 1)
+        out = torch.zeros(B, 128, ntok, inner, device=DEV)
+        plan.attn(qkv.to(DEV), out, heads, B, inner, ntok, (384 * inner * ntok, inner * ntok, 1, inner),
+                  (128 * inner * ntok, inner * ntok, 1, inner), rot, None if bias is None else bias.to(DEV))
+    _run(plan)
+    torch.testing.assert_close(out.cpu(), ref, **TOL)
+
+
+def test_philox_normal_statistics():
+    from safediffcon_amd._lib import get_lib, check
+    n = 1 << 22
+    x = torch.empty(n, device=DEV)
+    draw = torch.zeros(1, dtype=torch.int32, device=DEV)
+    check(get_lib().sdc_randn(x.data_ptr(), n, 1234, draw.data_ptr(), _stream()))
+    a = x.clone()
+    draw.fill_(1)
+    check(get_lib().sdc_randn(x.data_ptr(), n, 1234, draw.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    assert abs(a.mean().item()) < 3e-3 and abs(a.std().item() - 1) < 3e-3
+    assert abs((a ** 4).mean().item() - 3) < 0.05          # kurtosis of N(0,1)
+    assert abs((a * x).mean().item()) < 3e-3               # draws are independent
+    assert torch.isfinite(a).all()
+
+
+def test_conformal_scores_and_weights():
+    from safediffcon_amd import conformal
+    pred, state = det_tensor((6, 3, 16, 128), 70, 0.1), det_tensor((6, 3, 16, 128), 71, 0.1)
+    state[:3, 2] += 0.07
+    for ums in (True, False):
+        s, w = conformal.scores_and_weights("burgers", pred.to(DEV), state.to(DEV), [500.0, 0.8 ** 2, 0.01, 10.0], use_max=not ums)
+        torch.testing.assert_close(s.cpu(), osam.burgers_score(pred, state, ums), rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(w.cpu(), osam.burgers_weight(state, 0.01, 500.0, 0.8, ums), rtol=1e-3, atol=1e-30)
+    pred, state = det_tensor((4, 12, 128), 72, 0.3) + 0.5, det_tensor((4, 12, 128), 73, 0.3) + 0.5
+    target = det_tensor((4, 3, 122), 74, 0.3) + 1.0
+    s, w = conformal.scores_and_weights("tokamak", pred.to(DEV), state.to(DEV), [0.7, 0.3, 0.5, 3.6, 0.1], target=target.to(DEV))
+    torch.testing.assert_close(s.cpu(), osam.tokamak_score(pred, state, 122), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(w.cpu(), osam.tokamak_weight(state, target, 122, 0.1, 3.6, 0.7, 0.3, 0.5), rtol=1e-4, atol=0)
+    pred, state = det_tensor((4, 8, 7, 16, 16), 75, 0.3), det_tensor((4, 8, 7, 16, 16), 76, 0.3)
+    state[:2, -1, 6] += 0.2
+    s, w = conformal.scores_and_weights("smoke", pred.to(DEV), state.to(DEV), [0.9, 0.1, 0.01, 100.0])
+    torch.testing.assert_close(s.cpu(), osam.smoke_score(pred, state), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(w.cpu(), osam.smoke_weight(state, 0.01, 0.9, 0.1, 100.0), rtol=1e-3, atol=0)

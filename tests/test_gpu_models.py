@@ -1,0 +1,199 @@
+"""-m gpu: the drop-in U-Nets and samplers against (a) the committed golden fixtures produced by the
+real reference and (b) the CPU oracle on fresh seeded inputs.  Tolerance: fp32 kernels vs fp32 CPU
+reference differ by summation order only; eps-MSE must be <= 1e-5 (BASELINE.json north star)."""
+import pytest
+import torch
+
+import safediffcon_amd as sdc
+from oracle import nets as onets
+from oracle import samplers as osam
+from oracle import schedules as osched
+from oracle.detweights import det_noise, det_params, det_tensor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+EPS_TOL = dict(rtol=5e-4, atol=5e-5)
+TRAJ_TOL = dict(rtol=2e-3, atol=2e-4)
+
+
+def _mse(a, b):
+    return ((a - b) ** 2).mean().item()
+
+
+def _load(net, spec, seed):
+    net.load_state_dict(det_params(spec, seed))
+    return net.to(DEV)
+
+
+def test_unet_burgers_golden(golden):
+    g = golden("burgers_unet")
+    net = _load(sdc.Unet2D(dim=8, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1), g.spec(), 100)
+    eps = net(g["x"].to(DEV), g["t"].to(DEV)).cpu()
+    assert _mse(eps, g["eps"]) <= 1e-5
+    torch.testing.assert_close(eps, g["eps"], **EPS_TOL)
+    # second call with other times reuses the plan
+    t2 = torch.tensor([0, 999])
+    eps2 = net(g["x"].to(DEV), t2.to(DEV)).cpu()
+    ref2 = onets.unet_burgers(det_params(g.spec(), 100), g["x"], t2, dim=8)
+    torch.testing.assert_close(eps2, ref2, **EPS_TOL)
+
+
+def test_unet_tokamak_golden(golden):
+    g = golden("tokamak_unet")
+    net = _load(sdc.Unet1D(dim=8, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1), g.spec(), 200)
+    eps = net(g["x"].to(DEV), g["t"].to(DEV)).cpu()
+    assert _mse(eps, g["eps"]) <= 1e-5
+    torch.testing.assert_close(eps, g["eps"], **EPS_TOL)
+
+
+def test_unet_smoke_golden(golden):
+    g = golden("smoke_unet")
+    net = _load(sdc.Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2, 4), channels=7), g.spec(), 300)
+    eps = net(g["x"].to(DEV), g["t"].to(DEV)).cpu()
+    assert _mse(eps, g["eps"]) <= 1e-5
+    torch.testing.assert_close(eps, g["eps"], **EPS_TOL)
+
+
+def test_unet_burgers_wider_vs_oracle():
+    # dim=32 (channels 32..256, GroupNorm(1)), B=3: exercises the 64- and 128-row conv tiles
+    net = sdc.Unet2D(dim=32, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+    spec = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    P = det_params(spec, 7)
+    net.load_state_dict(P)
+    net.to(DEV)
+    x, t = det_tensor((3, 3, 16, 128), 8), torch.tensor([1, 500, 998])
+    eps = net(x.to(DEV), t.to(DEV)).cpu()
+    ref = onets.unet_burgers(P, x, t, dim=32)
+    assert _mse(eps, ref) <= 1e-5
+    torch.testing.assert_close(eps, ref, **EPS_TOL)
+
+
+def test_refresh_after_weight_update(golden):
+    g = golden("tokamak_unet")
+    net = _load(sdc.Unet1D(dim=8, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1), g.spec(), 200)
+    net(g["x"].to(DEV), g["t"].to(DEV))
+    P2 = det_params(g.spec(), 201)
+    net.load_state_dict(P2)                        # re-packs the cached plans
+    eps = net(g["x"].to(DEV), g["t"].to(DEV)).cpu()
+    torch.testing.assert_close(eps, onets.unet_tokamak(P2, g["x"], g["t"], dim=8), **EPS_TOL)
+
+
+# ------------------------------------------------------------------ trajectories (T = 8, injected noise)
+def test_burgers_trajectories_golden(golden):
+    spec = golden("burgers_unet").spec()
+    g = golden("burgers_traj_guided")
+    net = _load(sdc.Unet2D(dim=8, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1), spec, 100)
+    gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=8, temporal=True, use_conv2d=True,
+                                      is_condition_u0=True, is_condition_uT=True, condition_idx=10,
+                                      train_on_padded_locations=False).to(DEV)
+    noise = det_noise((2, 3, 16, 128), int(g.scalar("noise_seed")))
+    guid = sdc.BurgersGuidance(g.scalar("Q"), g.scalar("w_score"), g.scalar("u_bound"))
+    out = gd.sample(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True, nablaJ=guid,
+                    J_scheduler=lambda t: 1.0, w_scheduler=None, enable_grad=False, noise=noise).cpu()
+    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    # the same guidance passed as an opaque callable takes the split (x0 -> callable -> update) route
+    out2 = gd.sample(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True,
+                     nablaJ=lambda x: guid(x), J_scheduler=lambda t: 1.0, enable_grad=False, noise=noise).cpu()
+    torch.testing.assert_close(out2, g["out"], **TRAJ_TOL)
+    g = golden("burgers_traj_calib")
+    out = gd.sample(batch_size=2, clip_denoised=True, guidance_u0=False, u_init=g["u0"], u_final=g["uT"],
+                    w_groundtruth=g["w_gt"], nablaJ=None, J_scheduler=None, w_scheduler=None, enable_grad=False,
+                    noise=noise).cpu()
+    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+
+
+def test_tokamak_trajectories_golden(golden):
+    spec = golden("tokamak_unet").spec()
+    g = golden("tokamak_traj_guided")
+    net = _load(sdc.Unet1D(dim=8, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1), spec, 200)
+    gd = sdc.GaussianDiffusionTokamak(net, seq_length=128, nt=122, timesteps=8, guidance_u0=True).to(DEV)
+    noise = det_noise((2, 12, 128), int(g.scalar("noise_seed")))
+    guid = sdc.TokamakGuidance(g["target"], 122, g.scalar("w_obj"), g.scalar("w_safe"), g.scalar("scaler"), g.scalar("Q"),
+                               g.scalar("thr"))
+    out = gd.sample(batch_size=2, clip_denoised=True, guidance_u0=True, u_init=g["u0"], u_final=g["uT"], nablaJ=guid,
+                    J_scheduler=lambda t: 1.0, w_scheduler=None, enable_grad=False, noise=noise).cpu()
+    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    g = golden("tokamak_traj_calib")
+    out = gd.sample(batch_size=2, clip_denoised=True, guidance_u0=False, u_init=g["u0"], u_final=g["uT"], nablaJ=None,
+                    enable_grad=False, noise=noise).cpu()
+    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    with pytest.raises(IndexError):     # reference bug reproduced
+        gd.sample(batch_size=2, guidance_u0=False, u_init=g["u0"], u_final=g["uT"], w_groundtruth=torch.zeros(2, 9, 128))
+
+
+def test_smoke_trajectories_golden(golden):
+    spec = golden("smoke_unet").spec()
+    g = golden("smoke_traj_guided")
+    net = _load(sdc.Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2, 4), channels=7), spec, 300)
+    gd = sdc.GaussianDiffusionSmoke(net, image_size=16, frames=8, timesteps=8, loss_type="l2",
+                                    standard_fixed_ratio=g.scalar("ratio")).to(DEV)
+    noise = det_noise((2, 8, 7, 16, 16), int(g.scalar("noise_seed")))
+    guid = sdc.SmokeGuidance(g.scalar("Q"), g.scalar("w_safe"), g.scalar("safe_bound"))
+    out = gd.sample(batch_size=2, design_fn=guid, enable_grad=False, init=g["init"], noise=noise).cpu()
+    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    g = golden("smoke_traj_calib")
+    out = gd.sample(batch_size=2, design_fn=None, init=g["init"], control=g["control"], noise=noise).cpu()
+    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+
+
+def test_tokamak_mixed_guidance_and_amax_vs_oracle(golden):
+    """guidance forms the fixtures do not cover end-to-end: tokamak MSE term + active hinge; burgers amax mode."""
+    spec = golden("tokamak_unet").spec()
+    P = det_params(spec, 200)
+    net = _load(sdc.Unet1D(dim=8, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1), spec, 200)
+    T, B = 6, 3
+    gd = sdc.GaussianDiffusionTokamak(net, seq_length=128, nt=122, timesteps=T).to(DEV)
+    u0, uT = det_tensor((B, 3), 1, 0.1) + 0.6, det_tensor((B, 2, 122), 2, 0.1) + 0.6
+    target = det_tensor((B, 3, 122), 3, 0.3) + 1.0
+    noise = det_noise((B, 12, 128), 500)
+    args = dict(w_obj=0.7, w_safe=0.3, guidance_scaler=0.5, Q=0.1, safety_threshold=3.6)
+    out = gd.sample(batch_size=B, u_init=u0, u_final=uT, nablaJ=sdc.TokamakGuidance(target, 122, **args),
+                    enable_grad=False, noise=noise).cpu()
+    tabs = osched.make_tables("cosine", T)
+    ref = osam.sample_tokamak(lambda x, t: onets.unet_tokamak(P, x, t, dim=8), tabs, B, noise, u_init=u0, u_final=uT,
+                              nablaJ=osam.tokamak_guidance(target, 122, 0.1, 3.6, 0.7, 0.3, 0.5), enable_grad=False)
+    torch.testing.assert_close(out, ref, **TRAJ_TOL)
+
+    spec = golden("burgers_unet").spec()
+    P = det_params(spec, 100)
+    net = _load(sdc.Unet2D(dim=8, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1), spec, 100)
+    gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=T, temporal=True, use_conv2d=True,
+                                      is_condition_u0=True, is_condition_uT=True).to(DEV)
+    u0, uT = det_tensor((B, 128), 4, 0.1), det_tensor((B, 128), 5, 0.1)
+    noise = det_noise((B, 3, 16, 128), 600)
+    out = gd.sample(batch_size=B, u_init=u0, u_final=uT, nablaJ=sdc.BurgersGuidance(0.01, 500.0, 0.05, use_max_safety=False),
+                    enable_grad=False, noise=noise).cpu()
+    tabs = osched.make_tables("cosine", T)
+    ref = osam.sample_burgers(lambda x, t: onets.unet_burgers(P, x, t, dim=8), tabs, B, noise, u_init=u0, u_final=uT,
+                              nablaJ=osam.burgers_guidance(0.01, 500.0, 0.05, False), enable_grad=False)
+    torch.testing.assert_close(out, ref, **TRAJ_TOL)
+
+
+def test_graph_and_eager_paths_agree_and_conditions_hold(golden):
+    """Philox noise: the hipGraph replay and the eager call list must give bit-identical trajectories for one
+    seed, the imposed conditions must survive, and different seeds must differ."""
+    spec = golden("burgers_unet").spec()
+    net = _load(sdc.Unet2D(dim=8, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1), spec, 100)
+    gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=12, temporal=True, use_conv2d=True,
+                                      is_condition_u0=True, is_condition_uT=True).to(DEV)
+    B = 4
+    u0, uT = det_tensor((B, 128), 4, 0.1).to(DEV), det_tensor((B, 128), 5, 0.1).to(DEV)
+    guid = sdc.BurgersGuidance(0.01, 500.0, 0.05)
+    outs = []
+    for use_graph in (True, False, True):
+        gd.use_graph = use_graph
+        torch.manual_seed(1234)
+        outs.append(gd.sample(batch_size=B, u_init=u0, u_final=uT, nablaJ=guid, enable_grad=False))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    torch.manual_seed(99)
+    other = gd.sample(batch_size=B, u_init=u0, u_final=uT, nablaJ=guid, enable_grad=False)
+    assert not torch.equal(other, outs[0])
+    assert torch.isfinite(outs[0]).all() and outs[0].abs().max() <= 1.0 + 1e-6
+
+    # smoke re-imposes its conditions after the last step (2d/ddpm/diffusion_2d.py:310-312)
+    spec = golden("smoke_unet").spec()
+    net = _load(sdc.Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2, 4), channels=7), spec, 300)
+    gs = sdc.GaussianDiffusionSmoke(net, image_size=16, frames=8, timesteps=5).to(DEV)
+    init, control = det_tensor((2, 16, 16), 6, 0.2).abs().to(DEV), det_tensor((2, 8, 2, 16, 16), 7, 0.3).to(DEV)
+    out = gs.sample(batch_size=2, init=init, control=control)
+    assert torch.equal(out[:, 0, 0], init) and torch.equal(out[:, :, 3:5], control)
