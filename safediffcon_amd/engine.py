@@ -181,7 +181,7 @@ class Plan:
         d.rs[:] = _s5(residual) if residual is not None else (0,) * 5
         if residual is not None:
             assert tuple(residual.shape) == tuple(out.shape)
-        self.keep.append(d)
+        self.keep += [d, x, x1, wp, bias, residual, out]     # the call list holds raw pointers only
         self._emit(self.lib.sdc_conv, C.byref(d), _ptr(x), _ptr(x1), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(out))
         return out
 
@@ -193,6 +193,7 @@ class Plan:
         S = x.numel() // (B * Cc)
         st = self._stats_buf(B, groups)
         out = x if out is None else out
+        self.keep += [x, gamma, beta, ss, t_dev, residual, out]
         self._emit(self.lib.sdc_gn_stats, _ptr(x), _ptr(st), B, Cc, groups, S, eps)
         self._emit(self.lib.sdc_gn_apply, _ptr(x), _ptr(st), _ptr(gamma), _ptr(beta), _ptr(ss), _ptr(t_dev),
                    ss_t_stride, ss_b_stride, ss_off, _ptr(residual), _ptr(out), B, Cc, groups, S)
@@ -204,20 +205,24 @@ class Plan:
         S = x.numel() // (B * Cc)
         if out is None:
             out = self.pool.get(tuple(x.shape))
+        self.keep += [x, g, residual, out]
         self._emit(self.lib.sdc_chan_norm, _ptr(x), _ptr(g), _ptr(residual), _ptr(out), B, Cc, S, mode, eps)
         return out
 
     def act(self, x, kind, out=None):
         out = x if out is None else out
+        self.keep += [x, out]
         self._emit(self.lib.sdc_act, _ptr(x), _ptr(out), x.numel(), kind)
         return out
 
     def linattn(self, qkv, heads, outer, inner, n, q_strides, out, o_strides):
         ctx = self._ctx_buf(outer * inner * heads * 32 * 32)
+        self.keep += [qkv, out]
         self._emit(self.lib.sdc_linattn, _ptr(qkv), _ptr(ctx), _ptr(out), outer, inner, heads, n, *q_strides, *o_strides)
         return out
 
     def attn(self, qkv, out, heads, outer, inner, ntok, q_strides, o_strides, rot=None, bias=None):
+        self.keep += [qkv, out, rot, bias]
         self._emit(self.lib.sdc_attn, _ptr(qkv), _ptr(out), _ptr(rot), _ptr(bias), outer, inner, heads, ntok,
                    *q_strides, *o_strides)
         return out

@@ -56,7 +56,8 @@ def _conv_case(plan_cls, nd, B, cin, cout, sp, k, stride=1, pad=0, up=1, cin1=0,
     out = plan.conv(as5(x.to(DEV)), wp, b.to(DEV), cout, k3, x1=None if x1 is None else as5(x1.to(DEV)), stride=s3,
                     pad=p3, up=u3, residual=None if res is None else as5(res.to(DEV)))
     _run(plan)
-    torch.testing.assert_close(out.cpu().reshape(ref.shape), ref, **TOL)
+    # summation-order noise scales with the output magnitude (K up to 3456 products per output)
+    torch.testing.assert_close(out.cpu().reshape(ref.shape), ref, rtol=2e-4, atol=1e-5 * ref.abs().max().item())
 
 
 @pytest.mark.parametrize("case", [
