@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- sampled control trajectories / second of the SafeDiffCon DDPM hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): 1D Burgers, Unet2D dim=64 (1,2,4,8), state (B,3,16,128), B=256
+per GPU, 1000-step DDPM, closed-form safety guidance on, conformal quantile on (Q comes from the HIP
+conformal-score kernel + all-gather + rank select on a synthetic calibration set, and feeds the guidance).
+
+A "step" is ONE denoising step of the whole batch: U-Net epsilon prediction (~190 kernels) + guidance
+reduction + fused posterior update + step counter, replayed from one captured hipGraph.  A trajectory costs
+exactly `timesteps`=1000 such steps, so  value = global_batch / (1000 * seconds_per_step).
+N>1: one process per GPU, the batch axis sharded (weak scaling: 256 trajectories per GPU), no data-path
+collective; the only exchange is the conformal all-gather before the loop.
+
+Also reported: `roofline` for the dominant kernel (the fp32-MFMA implicit-GEMM conv), timed live with HIP
+events on the launch stream, and `cpu_baseline` = the CPU oracle (oracle/, kind "port") on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+T_DDPM = 1000
+
+
+def conv_instance(d):
+    """mirror of the tile selection in csrc/sdc_conv.hip::sdc_conv"""
+    ntot = d.B * d.oD * d.oH * d.oW
+    fast = (d.Cin0 % 16 == 0) and (d.Cin1 % 16 == 0)
+    if d.Cout > 64 and ntot >= 128 * 256:
+        tile = "128,128,2,2"
+    elif d.Cout > 32:
+        tile = "64,128,2,2"
+    else:
+        tile = "32,128,1,4"
+    return f"conv_kernel<{tile},{'true' if fast else 'false'}>"
+
+
+def conv_flops(d):
+    return 2.0 * d.B * d.oD * d.oH * d.oW * d.Cout * (d.Cin0 + d.Cin1) * d.kD * d.kH * d.kW
+
+
+def time_conv_calls(plan, lib, stream, reps=5):
+    """HIP-event timing of every sdc_conv call of the plan, grouped by kernel template instance."""
+    from safediffcon_amd._lib import check
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    check(lib.sdc_event_create(C.byref(e0)))
+    check(lib.sdc_event_create(C.byref(e1)))
+    groups = {}
+    for fn, args in plan.calls:
+        if fn is not lib.sdc_conv:
+            continue
+        d = args[0]._obj
+        fn(*args, stream)                                    # warm
+        check(lib.sdc_event_record(e0, stream))
+        for _ in range(reps):
+            fn(*args, stream)
+        check(lib.sdc_event_record(e1, stream))
+        ms = C.c_float()
+        check(lib.sdc_event_elapsed_ms(e0, e1, C.byref(ms)))
+        g = groups.setdefault(conv_instance(d), dict(launches=0, ms=0.0, flops=0.0))
+        g["launches"] += 1
+        g["ms"] += ms.value / reps
+        g["flops"] += conv_flops(d)
+    lib.sdc_event_destroy(e0)
+    lib.sdc_event_destroy(e1)
+    return groups
+
+
+def cpu_baseline(batch, steps, dim):
+    """the CPU oracle's guided p_sample step (U-Net + autograd guidance + posterior update), torch fp32 on the host cores"""
+    from oracle import nets as onets, samplers as osam, schedules as osched
+    from oracle.detweights import det_params, det_tensor
+    import safediffcon_amd as sdc
+    net = sdc.Unet2D(dim=dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+    spec = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    P = det_params(spec, 0)
+    tabs = osched.make_tables("cosine", T_DDPM)
+    nablaJ = osam.burgers_guidance(0.01, 500.0, 0.8)
+    x = det_tensor((batch, 3, 16, 128), 5)
+    ts = []
+    with torch.no_grad():
+        for i in range(steps + 1):
+            t = T_DDPM - 1 - i
+            t0 = time.perf_counter()
+            eps = onets.unet_burgers(P, x, torch.full((batch,), t, dtype=torch.long), dim=dim)
+            g = nablaJ(osam._x0_from_eps(tabs, x, t, eps))
+            x, _ = osam._posterior_step(tabs, x, t, eps, g, 1.0, True, torch.randn_like(x))
+            ts.append(time.perf_counter() - t0)
+    s_per_step = sum(ts[1:]) / steps
+    return dict(value=batch / (T_DDPM * s_per_step), unit="trajectories/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{steps} guided p_sample steps (after 1 warm-up) at B={batch} of the same workload, "
+                       f"{s_per_step * 1e3:.0f} ms/step, extrapolated x{T_DDPM} steps per trajectory")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="trajectories per GPU")
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    import safediffcon_amd as sdc
+    from safediffcon_amd import _lib, conformal
+    lib = _lib.get_lib()
+
+    torch.manual_seed(0)                                   # weights: default nn-style init under seed 0
+    net = sdc.Unet2D(dim=a.dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1).to(dev)
+    gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=T_DDPM, temporal=True, use_conv2d=True,
+                                      is_condition_u0=True, is_condition_uT=True, condition_idx=10,
+                                      train_on_padded_locations=False).to(dev)
+    B = a.batch
+    torch.manual_seed(1 + rank)                            # conditions: seed 1 (+rank: every shard differs)
+    u0 = (0.1 * torch.randn(B, 128)).clamp(-0.1, 0.3).to(dev)
+    uT = (0.1 * torch.randn(B, 128)).clamp(-0.1, 0.3).to(dev)
+
+    # ---- conformal quantile ("on"): synthetic calibration shard -> HIP score kernel -> all-gather -> rank select
+    n_cal = 1000 // world
+    pred = (0.1 * torch.randn(n_cal, 3, 16, 128)).to(dev)
+    truth = (0.1 * torch.randn(n_cal, 3, 16, 128)).to(dev)
+    gpar = [500.0, 0.8 ** 2, 0.0, 10.0]                    # w_score, u_bound^2, Q, SCALER (1D/configs/inference_config.py:122)
+    s, w = conformal.scores_and_weights("burgers", pred, truth, gpar)
+    Q, _ = conformal.weighted_quantile(s, w, 0.98)
+    Q = float(Q.item())
+
+    guid = sdc.BurgersGuidance(Q, 500.0, 0.8, use_max_safety=True)
+    side = torch.cuda.Stream(device=dev)
+    torch.manual_seed(2 + rank)                            # noise: seed 2
+    with torch.cuda.stream(side), torch.no_grad():
+        S = gd._setup(B, (3, 16, 128, 1), noise=None, guide=guid, J_scheduler=None, k_const=1.0, cond=(u0, uT, None),
+                      flags=dict(clip=1, cond_idx=10, pad_zero=1, has_wgt=0, use_max=0), impose_last=False)
+        S.init()
+
+        def run(n):
+            for _ in range(n):
+                if S.t_host <= 0:
+                    S.init()
+                S.step()
+
+        run(a.warmup)
+        side.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(a.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = tt.item()
+        finite = bool(torch.isfinite(S.x).all().item())
+
+        roof = None
+        if rank == 0:
+            groups = time_conv_calls(S.ent["plan"], lib, side.cuda_stream)
+            name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+            avg_ms = g["ms"] / g["launches"]
+            ach = g["flops"] / g["launches"] / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, launches_per_step=g["launches"],
+                        avg_launch_ms=round(avg_ms, 4), share_of_step=round(g["ms"] / (dt / a.steps * 1e3), 3),
+                        all_conv_instances={k: dict(launches=v["launches"], ms_per_step=round(v["ms"], 3),
+                                                    tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2))
+                                            for k, v in groups.items()})
+        S.close()
+    assert finite, "non-finite state after the timed steps"
+
+    ms_per_step = dt / a.steps * 1e3
+    value = world * B / (T_DDPM * dt / a.steps)
+    if rank == 0:
+        out = {
+            "metric": "sampled control trajectories/sec (1000-step DDPM)", "value": round(value, 4), "unit": "trajectories/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: 1D Burgers Unet2D dim=%d (1,2,4,8) state (B,3,16,128), guided 1000-step DDPM, "
+                                   "conformal quantile on" % a.dim,
+                       "batch_per_gpu": B, "global_batch": world * B, "ddpm_timesteps": T_DDPM,
+                       "step": "one denoising step of the whole batch (U-Net + guidance + posterior update), hipGraph replay",
+                       "parallelism": f"batch-sharded x{world}, no data-path collective", "conformal_Q": round(Q, 6)},
+            "roofline": roof,
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_steps, a.dim)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

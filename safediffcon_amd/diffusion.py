@@ -274,108 +274,153 @@ class _SamplerBase(nn.Module):
 
     def _reverse_loop_on_stream(self, B, dims, *, noise, guide, J_scheduler, k_const, cond, flags, impose_last, target,
                                 final_update):
+        S = self._setup(B, dims, noise=noise, guide=guide, J_scheduler=J_scheduler, k_const=k_const, cond=cond,
+                        flags=flags, impose_last=impose_last, target=target, final_update=final_update)
+        try:
+            S.init()
+            for _ in range(S.n_main):
+                S.step()
+            S.final()
+            return S.x.clone()
+        finally:
+            S.close()
+
+    def _setup(self, B, dims, *, noise, guide, J_scheduler, k_const, cond, flags, impose_last, target=None,
+               final_update=True):
+        """Bind everything one sample() needs and return a _Loop: init() draws x_T and imposes the conditions,
+        step() runs one denoising step (a hipGraph launch when possible), final() the last, un-imposed step."""
         dev = self.betas.device
-        lib, stream, T = self._lib, self._stream(), self.num_timesteps
+        T = self.num_timesteps
         per = int(math.prod(dims))
         shape = self._sample_shape(B)
         st = self._state(B, per)
         net = self.model
         ent = net.entry(shape, T, lut=True)
+        stream = self._stream()
         if not ent["lut_valid"]:
             net.fill_cond(ent, torch.arange(T), stream)
             ent["lut_valid"] = True
         if ent["t_dev"] is not st.t_dev:
             net.bind_cond(ent, st.t_dev)
-            st.graphs.clear()
-        x, eps = ent["x"], ent["eps"]
-        coef = self._coef(J_scheduler, k_const)
-        c0 = self._persist(st, "c0", cond[0])
-        c1 = self._persist(st, "c1", cond[1])
-        c2 = self._persist(st, "c2", cond[2])
-        tgt = self._persist(st, "target", target)
-        fused = isinstance(guide, GuidanceSpec) and guide.kind == self.MODEL
-        external = (guide is not None) and not fused
-        if fused:
-            st.gpar.copy_(torch.tensor(guide.gpar() + [0.0] * (8 - len(guide.gpar())), dtype=torch.float32))
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        injected = noise is not None
-        if injected and (st.noise is None):
+        L = _Loop()
+        L.gd, L.st, L.ent, L.x, L.eps, L.T, L.B, L.shape = self, st, ent, ent["x"], ent["eps"], T, B, shape
+        L.coef = self._coef(J_scheduler, k_const)
+        L.c0 = self._persist(st, "c0", cond[0])
+        L.c1 = self._persist(st, "c1", cond[1])
+        L.c2 = self._persist(st, "c2", cond[2])
+        L.tgt = self._persist(st, "target", target)
+        L.fused = isinstance(guide, GuidanceSpec) and guide.kind == self.MODEL
+        L.external = (guide is not None) and not L.fused
+        L.guide = guide
+        if L.fused:
+            gp = guide.gpar()
+            st.gpar.copy_(torch.tensor(gp + [0.0] * (8 - len(gp)), dtype=torch.float32))
+        L.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        L.noise = noise
+        if noise is not None and st.noise is None:
             st.noise = torch.empty(B * per, dtype=torch.float32, device=dev)
-        nbuf = st.noise if injected else None
+        L.nbuf = st.noise if noise is not None else None
+        L.skip = flags.get("skip_draws", 0)
+        L.impose_last, L.final_update = impose_last, final_update
+        L.n_main = T if impose_last else T - 1
+        L.mk = lambda **kw: self._desc(B, dims, **{**flags, "seed": L.seed, **kw})  # noqa: E731
+        L.d_init = L.mk(impose=1)
+        if not L.external:
+            gmode = 1 if L.fused else 0
+            L.tail = self._tail(st, ent, L.mk(guide=gmode, impose=1), L.coef, guide, L.tgt, L.c0, L.c1, L.c2, L.nbuf)
+            L.tail_last = self._tail(st, ent, L.mk(guide=gmode, impose=1 if impose_last else 0), L.coef, guide, L.tgt,
+                                     L.c0, L.c1, L.c2, L.nbuf)
+        else:
+            if st.x0 is None:
+                st.x0 = torch.empty_like(L.x)
+            L.d_x0 = L.mk(guide=3, impose=0)
+        L.use_graph = self.use_graph and noise is None and not L.external
+        return L
 
-        # ---- x_T and the initial conditioning writes
-        d0 = self._desc(B, dims, **flags, impose=1, seed=seed)
-        if injected:
-            x.copy_(noise(0).to(dev).reshape(x.shape))
+
+class _Loop:
+    """One bound reverse process (see _SamplerBase._setup)."""
+    graph = None
+    draw_i = 1
+    t_host = 0
+
+    def _ptr(self, t):
+        return 0 if t is None else t.data_ptr()
+
+    def init(self):
+        lib, st, x, p = self.gd._lib, self.st, self.x, self._ptr
+        stream = self.gd._stream()
+        if self.noise is not None:
+            x.copy_(self.noise(0).to(x.device).reshape(x.shape))
         else:
             st.draw_dev.zero_()
-            check(lib.sdc_randn(x.data_ptr(), x.numel(), seed, st.draw_dev.data_ptr(), stream), "sdc_randn")
-        check(lib.sdc_impose(C.byref(d0), x.data_ptr(), c0.data_ptr(), 0 if c1 is None else c1.data_ptr(),
-                             0 if c2 is None else c2.data_ptr(), stream), "sdc_impose")
-        st.t_dev.fill_(T - 1)
+            check(lib.sdc_randn(x.data_ptr(), x.numel(), self.seed, st.draw_dev.data_ptr(), stream), "sdc_randn")
+        check(lib.sdc_impose(C.byref(self.d_init), x.data_ptr(), p(self.c0), p(self.c1), p(self.c2), stream), "sdc_impose")
+        st.t_dev.fill_(self.T - 1)
         st.draw_dev.fill_(1)
+        self.draw_i, self.t_host = 1, self.T - 1
+        if self.use_graph and self.graph is None:
+            # one capture per bound loop: the descriptors carry this call's Philox seed
+            check(lib.sdc_graph_begin(stream), "sdc_graph_begin")
+            try:
+                self.ent["plan"].run(stream)
+                self.tail.run(stream)
+            finally:
+                g = C.c_void_p()
+                rc = lib.sdc_graph_end(stream, C.byref(g))
+            check(rc, "sdc_graph_end")
+            self.graph = g
 
-        skip = flags.get("skip_draws", 0)
-        mk = lambda **kw: self._desc(B, dims, **{**flags, "seed": seed, **kw})  # noqa: E731
-        draw_i = 1
-        if not external:
-            gmode = 1 if fused else 0
-            tail = self._tail(st, ent, mk(guide=gmode, impose=1), coef, guide, tgt, c0, c1, c2, nbuf)
-            tail_last = self._tail(st, ent, mk(guide=gmode, impose=1 if impose_last else 0), coef, guide, tgt, c0, c1, c2, nbuf)
-            n_graph = T if impose_last else T - 1
-            use_graph = self.use_graph and not injected
-            if use_graph:
-                # one capture per sample() call: descriptors carry the per-call seed
-                check(lib.sdc_graph_begin(stream), "sdc_graph_begin")
-                try:
-                    ent["plan"].run(stream)
-                    tail.run(stream)
-                finally:
-                    g = C.c_void_p()
-                    rc = lib.sdc_graph_end(stream, C.byref(g))
-                check(rc, "sdc_graph_end")
-                try:
-                    for _ in range(n_graph):
-                        check(lib.sdc_graph_launch(g, stream), "sdc_graph_launch")
-                finally:
-                    torch.cuda.current_stream(dev).synchronize()
-                    lib.sdc_graph_destroy(g)
-            else:
-                for t in reversed(range(T - n_graph, T)):
-                    if injected and t > 0:
-                        for _ in range(skip):
-                            noise(draw_i)
-                            draw_i += 1
-                        nbuf.copy_(noise(draw_i).to(dev).reshape(-1))
-                        draw_i += 1
-                    ent["plan"].run(stream)
-                    tail.run(stream)
-            if not impose_last:
-                ent["plan"].run(stream)
-                if final_update:
-                    tail_last.run(stream)
+    def _feed_noise(self):
+        if self.noise is not None and self.t_host > 0:
+            for _ in range(self.skip):
+                self.noise(self.draw_i)            # the calibration branch's discarded draw
+                self.draw_i += 1
+            self.nbuf.copy_(self.noise(self.draw_i).to(self.nbuf.device).reshape(-1))
+            self.draw_i += 1
+
+    def step(self, last=False):
+        """one denoising step at the current device-side timestep"""
+        lib, stream = self.gd._lib, self.gd._stream()
+        if self.external:
+            return self._step_external(last)
+        if self.graph is not None and not last:
+            check(lib.sdc_graph_launch(self.graph, stream), "sdc_graph_launch")
         else:
-            # arbitrary guidance callable: x0 kernel -> callable (torch, on device) -> update kernel
-            if st.x0 is None:
-                st.x0 = torch.empty_like(x)
-            d_x0 = mk(guide=3, impose=0)
-            ptr = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
-            for t in reversed(range(T)):
-                last = (t == 0)
-                if injected and t > 0:
-                    nbuf.copy_(noise(draw_i).to(dev).reshape(-1))
-                    draw_i += 1
-                ent["plan"].run(stream)
-                check(lib.sdc_step_update(C.byref(d_x0), ptr(x), ptr(eps), 0, ptr(coef), ptr(st.t_dev), ptr(st.draw_dev),
-                                          0, 0, 0, 0, 0, 0, 0, 0, 0, ptr(st.x0), stream), "sdc_step_update[x0]")
-                g = guide(st.x0.view(shape))
-                gk = (g if isinstance(g, torch.Tensor) else torch.zeros_like(x) + g).to(torch.float32).contiguous()
-                d_up = mk(guide=2, impose=(1 if (impose_last or not last) else 0))
-                check(lib.sdc_step_update(C.byref(d_up), ptr(x), ptr(eps), ptr(gk), ptr(coef), ptr(st.t_dev),
-                                          ptr(st.draw_dev), ptr(nbuf), 0, 0, 0, 0, ptr(c0), ptr(c1), ptr(c2), ptr(x), 0,
-                                          stream), "sdc_step_update[ext]")
-                check(lib.sdc_advance(ptr(st.t_dev), -1, ptr(st.draw_dev), 1 + skip, stream), "sdc_advance")
-        return x.clone()
+            self._feed_noise()
+            self.ent["plan"].run(stream)
+            if not last:
+                self.tail.run(stream)
+            elif self.final_update:
+                self.tail_last.run(stream)
+        self.t_host -= 1
+
+    def _step_external(self, last):
+        # arbitrary guidance callable: x0 kernel -> callable (torch, on device) -> update kernel
+        lib, st, p, stream = self.gd._lib, self.st, self._ptr, self.gd._stream()
+        x, eps = self.x, self.eps
+        self._feed_noise()
+        self.ent["plan"].run(stream)
+        check(lib.sdc_step_update(C.byref(self.d_x0), p(x), p(eps), 0, p(self.coef), p(st.t_dev), p(st.draw_dev), 0, 0, 0,
+                                  0, 0, 0, 0, 0, 0, p(st.x0), stream), "sdc_step_update[x0]")
+        g = self.guide(st.x0.view(self.shape))
+        gk = (g if isinstance(g, torch.Tensor) else torch.zeros_like(x) + g).to(torch.float32).contiguous()
+        d_up = self.mk(guide=2, impose=(0 if (last and not self.impose_last) else 1))
+        check(lib.sdc_step_update(C.byref(d_up), p(x), p(eps), p(gk), p(self.coef), p(st.t_dev), p(st.draw_dev),
+                                  p(self.nbuf), 0, 0, 0, 0, p(self.c0), p(self.c1), p(self.c2), p(x), 0, stream),
+              "sdc_step_update[ext]")
+        check(lib.sdc_advance(p(st.t_dev), -1, p(st.draw_dev), 1 + self.skip, stream), "sdc_advance")
+        self.t_host -= 1
+
+    def final(self):
+        if not self.impose_last:
+            self.step(last=True)
+
+    def close(self):
+        if self.graph is not None:
+            torch.cuda.current_stream(self.x.device).synchronize()
+            self.gd._lib.sdc_graph_destroy(self.graph)
+            self.graph = None
 
 
 class GaussianDiffusionBurgers(_SamplerBase):
