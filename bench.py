@@ -34,10 +34,13 @@ def conv_instance(d):
     """mirror of the tile selection in csrc/sdc_conv.hip::sdc_conv"""
     ntot = d.B * d.oD * d.oH * d.oW
     fast = (d.Cin0 % 16 == 0) and (d.Cin1 % 16 == 0)
+    blocks = ((ntot + 127) // 128) * ((d.Cout + 63) // 64)
     if d.Cout > 64 and ntot >= 128 * 256:
         tile = "128,128,2,2"
-    elif d.Cout > 32:
+    elif d.Cout > 32 and blocks >= 1024:
         tile = "64,128,2,2"
+    elif d.Cout > 32:
+        tile = "64,64,2,2"
     else:
         tile = "32,128,1,4"
     return f"conv_kernel<{tile},{'true' if fast else 'false'}>"

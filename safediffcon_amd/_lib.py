@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdc_hip.so")
+LIB_PATH = os.environ.get("SDC_LIB_PATH") or os.path.join(_HERE, "libsdc_hip.so")   # override: kernel experiments only
 
 SDC_MODEL_BURGERS, SDC_MODEL_TOKAMAK, SDC_MODEL_SMOKE = 0, 1, 2
 

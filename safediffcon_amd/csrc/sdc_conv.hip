@@ -23,6 +23,23 @@ constexpr int NT = 256;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// rebuild a pointer from two scalar registers: tells the compiler the base is wave-uniform so that the load
+// can use the (SGPR base + 32-bit VGPR offset) addressing form
+typedef const __attribute__((address_space(1))) float* gfloat_p;     // global (not flat) address space
+__device__ __forceinline__ gfloat_p uniform_ptr(const float* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return (gfloat_p)(((uint64_t)hi << 32) | lo);
+}
+#define SDC_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
+// uniform base + 32-bit per-lane BYTE offset (kept as a byte offset so the zero-extension is exact and the
+// backend can select `global_load_dword v, v_off, s[base:base+1]`)
+__device__ __forceinline__ float ld_sv(gfloat_p base, uint32_t byte_off) {
+    typedef const __attribute__((address_space(1))) char* gchar_p;
+    return *(gfloat_p)((gchar_p)base + byte_off);
+}
+
 struct ConvArgs {
     SdcConvDesc d;
     const float* x0;
@@ -82,47 +99,79 @@ __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs a) {
 
     float breg[BROWS], areg[AROWS];
 
-    auto spatial = [&](int tap, bool& ok, int& id, int& ih, int& iw) {
-        const int kw = tap % d.kW;
-        const int t2 = tap / d.kW;
-        const int kh = t2 % d.kH;
-        const int kd = t2 / d.kH;
+    auto spatial_k = [&](int kd, int kh, int kw, bool& ok, int& id, int& ih, int& iw) {
         const int vd = vd0 + kd, vh = vh0 + kh, vw = vw0 + kw;
         id = vd >> a.lgD; ih = vh >> a.lgH; iw = vw >> a.lgW;
         ok = pvalid && vd >= 0 && vh >= 0 && vw >= 0 && id < d.iD && ih < d.iH && iw < d.iW &&
              ((vd & mD) | (vh & mH) | (vw & mW)) == 0;
     };
+    auto spatial = [&](int tap, bool& ok, int& id, int& ih, int& iw) {
+        const int kw = tap % d.kW;
+        const int t2 = tap / d.kW;
+        spatial_k(t2 / d.kH, t2 % d.kH, kw, ok, id, ih, iw);
+    };
+
+    // Loads only ISSUE here: nothing below consumes a loaded value, so no s_waitcnt lands in front of the
+    // MFMAs of the current chunk.  Out-of-range elements read a clamped (valid) address and are zeroed in
+    // store_chunk, after the MFMAs, where the wait belongs.
+    bool bok = false;        // FAST: validity of this thread's position for the chunk in flight
+    int kload = 0;           // first k of the chunk in flight
+    const int aco_c = acov ? (m0 + aco) : 0;
+
+    // FAST path walks (tap, channel-chunk) incrementally: no integer division and no 64-bit multiply per
+    // chunk -- that VALU work otherwise competes with the fp32 MFMAs for the SIMD's issue slots.
+    int f_kd = 0, f_kh = 0, f_kw = 0, f_ci = 0;
+    bool f_ok = false;
+    // per-thread 32-bit element offsets of (b, id, ih, iw) inside x0 / x1 for the current tap; the channel
+    // part of every address is wave-uniform and stays in scalar registers (global_load saddr + voffset form)
+    uint32_t f_v0 = 0, f_v1 = 0;
+    const int brow_u = __builtin_amdgcn_readfirstlane(brow0);
+    const int arow_u = __builtin_amdgcn_readfirstlane(arow0);
+    // (BM = 32: a wave spans two weight rows, the second one is folded into the per-lane offset)
+    const uint32_t a_v = (uint32_t)((arow0 - arow_u) * d.Cout + aco_c);
+    int a_k = arow_u;                   // weight row of this wave's first A load in the chunk in flight
+    auto fast_tap = [&]() {
+        int id, ih, iw;
+        spatial_k(f_kd, f_kh, f_kw, f_ok, id, ih, iw);
+        f_v0 = f_ok ? (uint32_t)(ob * d.x0s[0] + id * d.x0s[2] + ih * d.x0s[3] + iw * d.x0s[4]) : 0u;
+        if (d.Cin1 > 0)
+            f_v1 = f_ok ? (uint32_t)(ob * d.x1s[0] + id * d.x1s[2] + ih * d.x1s[3] + iw * d.x1s[4]) : 0u;
+    };
+    if constexpr (FAST) fast_tap();
 
     auto load_chunk = [&](int kc) {
         const int kbase = kc * BK;
-        // weights
-#pragma unroll
-        for (int i = 0; i < AROWS; ++i) {
-            const int k = kbase + arow0 + i * ASTEP;
-            areg[i] = (acov && k < a.Ktot) ? a.wp[(int64_t)k * d.Cout + m0 + aco] : 0.0f;
-        }
+        kload = kbase;
         if constexpr (FAST) {
-            // whole chunk shares one tap and one input tensor
-            const int tap = kbase / a.Cin;
-            const int ci0 = kbase - tap * a.Cin;
-            bool ok; int id, ih, iw;
-            spatial(tap, ok, id, ih, iw);
-            const float* src; int64_t sc; int64_t off;
-            if (ci0 < d.Cin0) {
-                src = a.x0; sc = d.x0s[1];
-                off = ob * d.x0s[0] + (int64_t)ci0 * sc + id * d.x0s[2] + ih * d.x0s[3] + iw * d.x0s[4];
-            } else {
-                src = a.x1; sc = d.x1s[1];
-                off = ob * d.x1s[0] + (int64_t)(ci0 - d.Cin0) * sc + id * d.x1s[2] + ih * d.x1s[3] + iw * d.x1s[4];
-            }
-            if (!ok) off = 0;
-            off += (int64_t)brow0 * sc;
+            // Ktot is a multiple of BK here: no k clamp
+            const gfloat_p ab = uniform_ptr(a.wp + (int64_t)a_k * d.Cout);
+            const int astep = SDC_UNIFORM(ASTEP * d.Cout);
 #pragma unroll
-            for (int i = 0; i < BROWS; ++i) {
-                const float v = src[off + (int64_t)(i * BSTEP) * sc];
-                breg[i] = ok ? v : 0.0f;
+            for (int i = 0; i < AROWS; ++i) areg[i] = ld_sv(ab + i * astep, a_v * 4u);
+            a_k = SDC_UNIFORM(a_k + BK);
+            // whole chunk shares one tap and one input tensor
+            const float* bsel; int sc; uint32_t voff;
+            if (f_ci < d.Cin0) { sc = (int)d.x0s[1]; bsel = a.x0 + (int64_t)(f_ci + brow_u) * sc; voff = f_v0; }
+            else { sc = (int)d.x1s[1]; bsel = a.x1 + (int64_t)(f_ci - d.Cin0 + brow_u) * sc; voff = f_v1; }
+            const gfloat_p bb = uniform_ptr(bsel);
+            bok = f_ok;
+            const int step = SDC_UNIFORM(BSTEP * sc);
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i) breg[i] = ld_sv(bb + i * step, voff * 4u);
+            f_ci = SDC_UNIFORM(f_ci + BK);
+            if (f_ci >= a.Cin) {
+                f_ci = 0;
+                if (++f_kw == d.kW) { f_kw = 0; if (++f_kh == d.kH) { f_kh = 0; ++f_kd; } }
+                f_kw = SDC_UNIFORM(f_kw); f_kh = SDC_UNIFORM(f_kh); f_kd = SDC_UNIFORM(f_kd);
+                if (f_kd < d.kD) fast_tap();
             }
         } else {
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) {
+                int k = kbase + arow0 + i * ASTEP;
+                k = k < a.Ktot ? k : a.Ktot - 1;
+                areg[i] = a.wp[(int64_t)k * d.Cout + aco_c];
+            }
 #pragma unroll
             for (int i = 0; i < BROWS; ++i) {
                 const int k = kbase + brow0 + i * BSTEP;
@@ -147,9 +196,17 @@ __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs a) {
 
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < AROWS; ++i) As[buf][arow0 + i * ASTEP][aco] = areg[i];
+        for (int i = 0; i < AROWS; ++i) {
+            const bool kin = FAST || (kload + arow0 + i * ASTEP) < a.Ktot;
+            As[buf][arow0 + i * ASTEP][aco] = (acov && kin) ? areg[i] : 0.0f;
+        }
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) Bs[buf][brow0 + i * BSTEP][bj] = breg[i];
+        for (int i = 0; i < BROWS; ++i) {
+            if constexpr (FAST)
+                Bs[buf][brow0 + i * BSTEP][bj] = bok ? breg[i] : 0.0f;
+            else
+                Bs[buf][brow0 + i * BSTEP][bj] = breg[i];
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -170,47 +227,71 @@ __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs a) {
     const int bn = wn * (TN * 32) + l31;
 
     for (int kc = 0; kc < nchunks; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nchunks) load_chunk(kc + 1);
+#ifndef SDC_EXP
+#define SDC_EXP 0      // timing-only experiment builds (tools/): 1 no gather, 2 +no LDS store/barrier, 3 +no LDS reads
+#endif
+        const int buf = (SDC_EXP >= 2) ? 0 : (kc & 1);
+        if (SDC_EXP < 1 && kc + 1 < nchunks) load_chunk(kc + 1);
+        // all fragments of the chunk are read into registers first (8 k-steps x (TM+TN) ds_read_b32), so the
+        // MFMAs below issue back to back instead of stalling on an LDS round trip every k-step
+        float af[BK / 2][TM], bf[BK / 2][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float af[TM], bf[TN];
+        for (int ks = 0; ks < BK / 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[buf][kk + lh][am + i * 32];
+            for (int i = 0; i < TM; ++i) af[ks][i] = (SDC_EXP >= 3) ? (float)(kc + ks + i) : As[buf][2 * ks + lh][am + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][kk + lh][bn + j * 32];
+            for (int j = 0; j < TN; ++j) bf[ks][j] = (SDC_EXP >= 3) ? (float)(kc - ks + j) : Bs[buf][2 * ks + lh][bn + j * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads ahead of the MFMA block
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
         }
-        if (kc + 1 < nchunks) store_chunk(buf ^ 1);
-        __syncthreads();
+        if (SDC_EXP < 1 && kc + 1 < nchunks) store_chunk(buf ^ 1);
+        if (SDC_EXP < 2) __syncthreads();
     }
 
-    // ---- epilogue: D rows (co) live in registers, columns (positions) on lanes -> coalesced along W
+    // ---- epilogue: D rows (co) live in registers, columns (positions) on lanes -> coalesced along W.
+    // Bias / residual loads are issued as a batch (clamped addresses, no per-element branches) so the
+    // workgroup pays one memory round trip per 16 outputs instead of sixteen.
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int pp = n0 + wn * (TN * 32) + j * 32 + l31;
-        if (pp >= a.Ntot) continue;
-        int r = pp;
-        const int qw = r % d.oW; r /= d.oW;
-        const int qh = r % d.oH; r /= d.oH;
-        const int qd = r % d.oD; const int qb = r / d.oD;
-        const int64_t yoff = qb * d.ys[0] + qd * d.ys[2] + qh * d.ys[3] + qw * d.ys[4];
-        const int64_t roff = a.res ? (qb * d.rs[0] + qd * d.rs[2] + qh * d.rs[3] + qw * d.rs[4]) : 0;
+    for (int i = 0; i < TM; ++i) {
+        const int cob = m0 + wm * (TM * 32) + i * 32 + 4 * lh;
+        float bv[16];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int rr = 0; rr < 16; ++rr) {
+            const int co = cob + (rr & 3) + 8 * (rr >> 2);
+            bv[rr] = a.bias ? a.bias[co < d.Cout ? co : d.Cout - 1] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int pp = n0 + wn * (TN * 32) + j * 32 + l31;
+            const bool pok = pp < a.Ntot;
+            int r = pok ? pp : 0;
+            const int qw = r % d.oW; r /= d.oW;
+            const int qh = r % d.oH; r /= d.oH;
+            const int qd = r % d.oD; const int qb = r / d.oD;
+            const int64_t yoff = qb * d.ys[0] + qd * d.ys[2] + qh * d.ys[3] + qw * d.ys[4];
+            float rv[16];
+            if (a.res) {
+                const int64_t roff = qb * d.rs[0] + qd * d.rs[2] + qh * d.rs[3] + qw * d.rs[4];
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const int co = cob + (rr & 3) + 8 * (rr >> 2);
+                    rv[rr] = a.res[roff + (co < d.Cout ? co : d.Cout - 1) * d.rs[1]];
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) rv[rr] = 0.0f;
+            }
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
-                const int co = m0 + wm * (TM * 32) + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-                if (co < d.Cout) {
-                    float v = acc[i][j][rr];
-                    if (a.bias) v += a.bias[co];
-                    if (a.res) v += a.res[roff + co * d.rs[1]];
-                    a.y[yoff + co * d.ys[1]] = v;
-                }
+                const int co = cob + (rr & 3) + 8 * (rr >> 2);
+                if (pok && co < d.Cout) a.y[yoff + co * d.ys[1]] = acc[i][j][rr] + bv[rr] + rv[rr];
             }
         }
     }
@@ -261,12 +342,21 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
     a.Ntot = (int)ntot;
     a.Cin = d.Cin0 + d.Cin1;
     a.Ktot = d.kD * d.kH * d.kW * a.Cin;
-    const bool fast = (d.Cin0 % BK == 0) && (d.Cin1 % BK == 0);
+    // FAST: whole K chunks share a tap, and every per-thread offset fits the 32-bit voffset of the saddr load form
+    auto span = [](const int64_t* st, int b, int dd, int h, int w) {
+        return (int64_t)(b - 1) * st[0] + (int64_t)(dd - 1) * st[2] + (int64_t)(h - 1) * st[3] + (int64_t)(w - 1) * st[4];
+    };
+    const bool small = span(d.x0s, d.B, d.iD, d.iH, d.iW) < (1ll << 30) &&
+                       (d.Cin1 == 0 || span(d.x1s, d.B, d.iD, d.iH, d.iW) < (1ll << 30));
+    const bool fast = (d.Cin0 % BK == 0) && (d.Cin1 % BK == 0) && small && d.Cout < (1 << 30);
     hipStream_t s = sdc::as_stream(stream);
+    const int64_t blocks64x128 = (int64_t)((a.Ntot + 127) / 128) * ((d.Cout + 63) / 64);
     if (d.Cout > 64 && a.Ntot >= 128 * 256)
         launch<128, 128, 2, 2>(a, fast, s);
-    else if (d.Cout > 32)
+    else if (d.Cout > 32 && blocks64x128 >= 1024)
         launch<64, 128, 2, 2>(a, fast, s);
+    else if (d.Cout > 32)
+        launch<64, 64, 2, 2>(a, fast, s);      // small-N layers: twice the workgroups, >= 2 per CU
     else
         launch<32, 128, 1, 4>(a, fast, s);
     return sdc::check_launch("sdc_conv");
