@@ -37,6 +37,8 @@ def conv_instance(d):
     blocks = ((ntot + 127) // 128) * ((d.Cout + 63) // 64)
     if d.Cout > 64 and ntot >= 128 * 256:
         tile = "128,128,2,2"
+    elif 32 < d.Cout <= 64 and ntot >= 256 * 1024:
+        tile = "64,256,1,4"
     elif d.Cout > 32 and blocks >= 1024:
         tile = "64,128,2,2"
     elif d.Cout > 32:
@@ -82,6 +84,9 @@ def cpu_baseline(batch, steps, dim):
     from oracle import nets as onets, samplers as osam, schedules as osched
     from oracle.detweights import det_params, det_tensor
     import safediffcon_amd as sdc
+    # the GPU box gives one GPU a 16-core CPU share: use exactly that many threads (oversubscribing the
+    # visible 128 logical CPUs makes the baseline slower, not faster)
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
     net = sdc.Unet2D(dim=dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
     spec = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
     P = det_params(spec, 0)

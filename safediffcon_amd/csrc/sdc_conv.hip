@@ -353,6 +353,8 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
     const int64_t blocks64x128 = (int64_t)((a.Ntot + 127) / 128) * ((d.Cout + 63) / 64);
     if (d.Cout > 64 && a.Ntot >= 128 * 256)
         launch<128, 128, 2, 2>(a, fast, s);
+    else if (d.Cout > 32 && d.Cout <= 64 && a.Ntot >= 256 * 1024)
+        launch<64, 256, 1, 4>(a, fast, s);     // wide tile: each wave owns 64x64 (2x2 MFMA tiles) like the 128x128 case
     else if (d.Cout > 32 && blocks64x128 >= 1024)
         launch<64, 128, 2, 2>(a, fast, s);
     else if (d.Cout > 32)

@@ -1,0 +1,43 @@
+"""Batch-of-trajectories sharding: trajectories are independent given the weights, so the
+batch axis is split in contiguous blocks over one process per GPU; weights are replicated; no collective runs
+during the 1000 denoising steps.  The only exchange is the conformal all-gather (safediffcon_amd.conformal)."""
+import os
+
+import torch
+
+
+def world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(n, rank=None, world_size=None):
+    """contiguous, equal-size block of [0, n) for this rank (n must divide evenly: the all-gather is unpadded)."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    if n % world_size:
+        raise ValueError(f"batch {n} does not split evenly over {world_size} ranks")
+    per = n // world_size
+    return rank * per, (rank + 1) * per
+
+
+def shard(t, dim=0):
+    lo, hi = shard_range(t.shape[dim])
+    return t.narrow(dim, lo, hi - lo)
+
+
+def init_from_env(backend=None):
+    """one process per GPU, launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    import torch.distributed as dist
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")     # "nccl" IS RCCL on ROCm
+        dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=ws)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return int(os.environ.get("RANK", "0")), ws, local

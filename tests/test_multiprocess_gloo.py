@@ -1,0 +1,64 @@
+"""N>1 path on CPU: world_size-2 gloo.  The sampler itself needs no collective (batch sharding); what is
+exchanged is the per-sample conformal (score, weight) pair -> all-gather -> identical Q on every rank, equal to
+the single-process reference arithmetic (oracle) on the un-sharded calibration set."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, alpha, smoke, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from safediffcon_amd import conformal
+    from safediffcon_amd.dist import shard, shard_range
+    g = torch.Generator().manual_seed(7)
+    scores = torch.rand(n, generator=g)
+    weights = torch.rand(n, generator=g) * 3
+    weights[3] = float("inf")
+    assert shard_range(n) == (rank * n // world, (rank + 1) * n // world)
+    Q, nw = conformal.weighted_quantile(shard(scores), shard(weights), alpha, smoke=smoke)
+    q.put((rank, float(Q), nw.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("smoke,alpha,n", [(False, 0.98, 1000), (False, 0.9, 64), (True, 0.04, 200)])
+def test_conformal_allgather_world2(smoke, alpha, n):
+    from oracle import samplers as osam
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, alpha, smoke, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(7)
+    scores = torch.rand(n, generator=g)
+    weights = torch.rand(n, generator=g) * 3
+    weights[3] = float("inf")
+    nw = osam.normalize_weights(weights, smoke=smoke)
+    want = (osam.quantile_smoke if smoke else osam.quantile_lucid)(nw * scores, alpha)
+    assert res[0][1] == res[1][1] == float(want)              # identical on every rank, equal to the oracle
+    assert res[0][2] == res[1][2] == nw.tolist()
+
+
+def test_shard_range_rejects_ragged():
+    from safediffcon_amd.dist import shard_range
+    assert shard_range(512, 3, 8) == (192, 256)
+    with pytest.raises(ValueError):
+        shard_range(10, 0, 4)
