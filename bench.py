@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- sampled control trajectories / second of the SafeDiffCon DDPM hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "C2"): 1D Burgers, Unet2D dim=64 (1,2,4,8), state (B,3,16,128), B=256
-per GPU, 1000-step DDPM, closed-form safety guidance on, conformal quantile on (Q comes from the HIP
-conformal-score kernel + all-gather + rank select on a synthetic calibration set, and feeds the guidance).
+Default workload (BASELINE.json configs[1], "C2"): 1D Burgers, Unet2D dim=64 (1,2,4,8), state (B,3,16,128),
+B=256 per GPU, 1000-step DDPM, closed-form safety guidance on, conformal quantile on (Q comes from the HIP
+conformal-score kernel + all-gather + rank select on a synthetic calibration set and feeds the guidance).
+`--workload c3` (tokamak Unet1D dim=256, B=128) and `--workload c4` (2D smoke Unet3D 64x64x32, B=64) run the
+other BASELINE configs through the same harness (parity cases / profiling; not the driver's bench line).
 
-A "step" is ONE denoising step of the whole batch: U-Net epsilon prediction (~190 kernels) + guidance
-reduction + fused posterior update + step counter, replayed from one captured hipGraph.  A trajectory costs
-exactly `timesteps`=1000 such steps, so  value = global_batch / (1000 * seconds_per_step).
-N>1: one process per GPU, the batch axis sharded (weak scaling: 256 trajectories per GPU), no data-path
+A "step" is ONE denoising step of the whole batch: U-Net epsilon prediction + guidance reduction + fused
+posterior update + step counter, replayed from one captured hipGraph.  A trajectory costs exactly
+`timesteps`=1000 such steps, so  value = global_batch / (1000 * seconds_per_step).
+N>1: one process per GPU, the batch axis sharded (weak scaling: fixed trajectories per GPU), no data-path
 collective; the only exchange is the conformal all-gather before the loop.
 
 Also reported: `roofline` for the dominant kernel (the fp32-MFMA implicit-GEMM conv), timed live with HIP
@@ -52,7 +54,7 @@ def conv_flops(d):
     return 2.0 * d.B * d.oD * d.oH * d.oW * d.Cout * (d.Cin0 + d.Cin1) * d.kD * d.kH * d.kW
 
 
-def time_conv_calls(plan, lib, stream, reps=5):
+def time_conv_calls(plan, lib, stream, reps=3):
     """HIP-event timing of every sdc_conv call of the plan, grouped by kernel template instance."""
     from safediffcon_amd._lib import check
     e0, e1 = C.c_void_p(), C.c_void_p()
@@ -79,28 +81,99 @@ def time_conv_calls(plan, lib, stream, reps=5):
     return groups
 
 
-def cpu_baseline(batch, steps, dim):
+# --------------------------------------------------------------------------- workloads
+def workload(name, dim, B, dev, rank, world):
+    """-> (description, sampler, prepare() -> _Loop, conformal_Q)"""
+    import safediffcon_amd as sdc
+    from safediffcon_amd import conformal
+    torch.manual_seed(0)                                   # weights: default nn-style init under seed 0
+    g1 = torch.Generator().manual_seed(1 + rank)           # conditions: seed 1 (+rank: every shard differs)
+    n_cal = max(8, 1000 // world) if name != "c4" else max(8, 200 // world)
+    if name == "c2":
+        dim = dim or 64
+        net = sdc.Unet2D(dim=dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1).to(dev)
+        gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=T_DDPM, temporal=True, use_conv2d=True,
+                                          is_condition_u0=True, is_condition_uT=True, condition_idx=10,
+                                          train_on_padded_locations=False).to(dev)
+        u0 = (0.1 * torch.randn(B, 128, generator=g1)).clamp(-0.1, 0.3).to(dev)
+        uT = (0.1 * torch.randn(B, 128, generator=g1)).clamp(-0.1, 0.3).to(dev)
+        # conformal quantile: synthetic calibration shard -> HIP score kernel -> all-gather -> rank select
+        pred = (0.1 * torch.randn(n_cal, 3, 16, 128, generator=g1)).to(dev)
+        truth = (0.1 * torch.randn(n_cal, 3, 16, 128, generator=g1)).to(dev)
+        s, w = conformal.scores_and_weights("burgers", pred, truth, [500.0, 0.8 ** 2, 0.0, 10.0])
+        Q = float(conformal.weighted_quantile(s, w, 0.98)[0].item())
+        guid = sdc.BurgersGuidance(Q, 500.0, 0.8, use_max_safety=True)     # 1D/configs/inference_config.py:122
+        prep = lambda: gd.sample(batch_size=B, clip_denoised=True, u_init=u0, u_final=uT, guidance_u0=True,   # noqa: E731
+                                 nablaJ=guid, J_scheduler=None, enable_grad=False, _prepare=True)
+        desc = f"C2: 1D Burgers Unet2D dim={dim} (1,2,4,8) state (B,3,16,128), guided 1000-step DDPM, conformal quantile on"
+    elif name == "c3":
+        dim = dim or 256
+        net = sdc.Unet1D(dim=dim, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1).to(dev)
+        gd = sdc.GaussianDiffusionTokamak(net, seq_length=128, nt=122, timesteps=T_DDPM).to(dev)
+        u0 = (0.4 + 0.4 * torch.rand(B, 3, generator=g1)).to(dev)
+        uT = (0.6 + 0.02 * torch.randn(B, 2, 122, generator=g1).cumsum(-1)).clamp(0.3, 0.9).to(dev)
+        target = (uT.new_zeros(B, 3, 122))
+        target[:, 0], target[:, 2] = uT[:, 0] * 2, uT[:, 1] * 2
+        pred = (0.5 + 0.3 * torch.randn(n_cal, 12, 128, generator=g1)).to(dev)
+        truth = (0.5 + 0.3 * torch.randn(n_cal, 12, 128, generator=g1)).to(dev)
+        tgt_cal = (1.0 + 0.3 * torch.randn(n_cal, 3, 122, generator=g1)).to(dev)
+        s, w = conformal.scores_and_weights("tokamak", pred, truth, [0.0, 1.0, 0.01, 4.98, 0.0], target=tgt_cal)
+        Q = float(conformal.weighted_quantile(s, w, 0.9)[0].item())
+        # tokamak/scripts/finetune.sh:13, configs/inference_config.py:25,107-111 (the pipeline always uses Q = 0.0)
+        guid = sdc.TokamakGuidance(target, 122, w_obj=0.0, w_safe=1.0, guidance_scaler=0.01, Q=0.0, safety_threshold=4.98)
+        prep = lambda: gd.sample(batch_size=B, clip_denoised=True, u_init=u0, u_final=uT, guidance_u0=True,   # noqa: E731
+                                 nablaJ=guid, J_scheduler=None, enable_grad=False, _prepare=True)
+        desc = f"C3: tokamak Unet1D dim={dim} (1,2,4,8) state (B,12,128), guided 1000-step DDPM"
+    elif name == "c4":
+        dim = dim or 64
+        net = sdc.Unet3D_with_Conv3D(dim=dim, dim_mults=(1, 2, 4), channels=7).to(dev)
+        gd = sdc.GaussianDiffusionSmoke(net, image_size=64, frames=32, timesteps=T_DDPM, loss_type="l2",
+                                        standard_fixed_ratio=100.0).to(dev)
+        init = (0.5 * torch.rand(B, 64, 64, generator=g1)).to(dev)
+        pred = (0.3 * torch.randn(n_cal, 32, 7, 64, 64, generator=g1)).to(dev)
+        truth = (0.3 * torch.randn(n_cal, 32, 7, 64, 64, generator=g1)).to(dev)
+        s, w = conformal.scores_and_weights("smoke", pred, truth, [0.9, 0.1, 0.0, 100.0])
+        Q = float(conformal.weighted_quantile(s, w, 0.04, smoke=True)[0].item())
+        del pred, truth
+        guid = sdc.SmokeGuidance(Q, w_safe=0.9, safe_bound=0.1)            # 2d/scripts/posttrain.sh:20-21
+        prep = lambda: gd.sample(batch_size=B, design_fn=guid, enable_grad=False, init=init, _prepare=True)  # noqa: E731
+        desc = f"C4: 2D smoke Unet3D_with_Conv3D dim={dim} (1,2,4) state (B,32,7,64,64), guided 1000-step DDPM"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return desc, gd, prep, Q
+
+
+def cpu_baseline(name, batch, steps, dim):
     """the CPU oracle's guided p_sample step (U-Net + autograd guidance + posterior update), torch fp32 on the host cores"""
     from oracle import nets as onets, samplers as osam, schedules as osched
     from oracle.detweights import det_params, det_tensor
     import safediffcon_amd as sdc
     # the GPU box gives one GPU a 16-core CPU share: use exactly that many threads (oversubscribing the
-    # visible 128 logical CPUs makes the baseline slower, not faster)
+    # visible logical CPUs makes the baseline slower, not faster)
     torch.set_num_threads(min(16, os.cpu_count() or 16))
-    net = sdc.Unet2D(dim=dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
-    spec = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    if name == "c2":
+        net, fwd, shape = sdc.Unet2D(dim=dim or 64, channels=3, resnet_block_groups=1), onets.unet_burgers, (3, 16, 128)
+        nablaJ, sched, k = osam.burgers_guidance(0.01, 500.0, 0.8), "cosine", 1.0
+    elif name == "c3":
+        net, fwd, shape = sdc.Unet1D(dim=dim or 256, channels=12, resnet_block_groups=1), onets.unet_tokamak, (12, 128)
+        nablaJ, sched, k = osam.tokamak_guidance(torch.ones(batch, 3, 122), 122, 0.0, 4.98, 0.0, 1.0, 0.01), "cosine", 1.0
+    else:
+        net, fwd, shape = sdc.Unet3D_with_Conv3D(dim=dim or 64, dim_mults=(1, 2, 4), channels=7), onets.unet_smoke, (32, 7, 64, 64)
+        nablaJ, sched, k = osam.smoke_guidance(0.01, 0.9, 0.1), "sigmoid", 100.0
+    dim = net.dim
+    kw = dict(dim=dim) if name != "c4" else dict(dim=dim, dim_mults=(1, 2, 4))
+    spec = [(kk, tuple(v.shape)) for kk, v in net.state_dict().items()]
     P = det_params(spec, 0)
-    tabs = osched.make_tables("cosine", T_DDPM)
-    nablaJ = osam.burgers_guidance(0.01, 500.0, 0.8)
-    x = det_tensor((batch, 3, 16, 128), 5)
+    tabs = osched.make_tables(sched, T_DDPM)
+    x = det_tensor((batch, *shape), 5)
     ts = []
     with torch.no_grad():
         for i in range(steps + 1):
             t = T_DDPM - 1 - i
             t0 = time.perf_counter()
-            eps = onets.unet_burgers(P, x, torch.full((batch,), t, dtype=torch.long), dim=dim)
+            eps = fwd(P, x, torch.full((batch,), t, dtype=torch.long), **kw)
             g = nablaJ(osam._x0_from_eps(tabs, x, t, eps))
-            x, _ = osam._posterior_step(tabs, x, t, eps, g, 1.0, True, torch.randn_like(x))
+            x, _ = osam._posterior_step(tabs, x, t, eps, g, k, True, torch.randn_like(x))
             ts.append(time.perf_counter() - t0)
     s_per_step = sum(ts[1:]) / steps
     return dict(value=batch / (T_DDPM * s_per_step), unit="trajectories/s", cores=torch.get_num_threads(), kind="port",
@@ -113,10 +186,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="trajectories per GPU")
-    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
+    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: 256 / 128 / 64 for c2 / c3 / c4)")
+    ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-batch", type=int, default=0)
     ap.add_argument("--cpu-steps", type=int, default=3)
     a = ap.parse_args()
 
@@ -131,40 +205,20 @@ def main():
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
-    import safediffcon_amd as sdc
-    from safediffcon_amd import _lib, conformal
+    from safediffcon_amd import _lib
     lib = _lib.get_lib()
+    B = a.batch or {"c2": 256, "c3": 128, "c4": 64}[a.workload]
+    desc, gd, prep, Q = workload(a.workload, a.dim, B, dev, rank, world)
 
-    torch.manual_seed(0)                                   # weights: default nn-style init under seed 0
-    net = sdc.Unet2D(dim=a.dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1).to(dev)
-    gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=T_DDPM, temporal=True, use_conv2d=True,
-                                      is_condition_u0=True, is_condition_uT=True, condition_idx=10,
-                                      train_on_padded_locations=False).to(dev)
-    B = a.batch
-    torch.manual_seed(1 + rank)                            # conditions: seed 1 (+rank: every shard differs)
-    u0 = (0.1 * torch.randn(B, 128)).clamp(-0.1, 0.3).to(dev)
-    uT = (0.1 * torch.randn(B, 128)).clamp(-0.1, 0.3).to(dev)
-
-    # ---- conformal quantile ("on"): synthetic calibration shard -> HIP score kernel -> all-gather -> rank select
-    n_cal = 1000 // world
-    pred = (0.1 * torch.randn(n_cal, 3, 16, 128)).to(dev)
-    truth = (0.1 * torch.randn(n_cal, 3, 16, 128)).to(dev)
-    gpar = [500.0, 0.8 ** 2, 0.0, 10.0]                    # w_score, u_bound^2, Q, SCALER (1D/configs/inference_config.py:122)
-    s, w = conformal.scores_and_weights("burgers", pred, truth, gpar)
-    Q, _ = conformal.weighted_quantile(s, w, 0.98)
-    Q = float(Q.item())
-
-    guid = sdc.BurgersGuidance(Q, 500.0, 0.8, use_max_safety=True)
     side = torch.cuda.Stream(device=dev)
     torch.manual_seed(2 + rank)                            # noise: seed 2
     with torch.cuda.stream(side), torch.no_grad():
-        S = gd._setup(B, (3, 16, 128, 1), noise=None, guide=guid, J_scheduler=None, k_const=1.0, cond=(u0, uT, None),
-                      flags=dict(clip=1, cond_idx=10, pad_zero=1, has_wgt=0, use_max=0), impose_last=False)
+        S = prep()
         S.init()
 
         def run(n):
             for _ in range(n):
-                if S.t_host <= 0:
+                if S.t_host < (0 if S.impose_last else 1):      # ran out of graph-able timesteps: restart at t = T-1
                     S.init()
                 S.step()
 
@@ -207,15 +261,14 @@ def main():
             "metric": "sampled control trajectories/sec (1000-step DDPM)", "value": round(value, 4), "unit": "trajectories/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: 1D Burgers Unet2D dim=%d (1,2,4,8) state (B,3,16,128), guided 1000-step DDPM, "
-                                   "conformal quantile on" % a.dim,
-                       "batch_per_gpu": B, "global_batch": world * B, "ddpm_timesteps": T_DDPM,
+            "config": {"workload": desc, "batch_per_gpu": B, "global_batch": world * B, "ddpm_timesteps": T_DDPM,
                        "step": "one denoising step of the whole batch (U-Net + guidance + posterior update), hipGraph replay",
                        "parallelism": f"batch-sharded x{world}, no data-path collective", "conformal_Q": round(Q, 6)},
             "roofline": roof,
         }
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_steps, a.dim)
+            cb = a.cpu_batch or {"c2": 32, "c3": 32, "c4": 1}[a.workload]
+            out["cpu_baseline"] = cpu_baseline(a.workload, cb, a.cpu_steps if a.workload != "c4" else 1, a.dim)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -114,54 +114,96 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const float* x, const floa
     }
 }
 
+// Short rows (S < 1024, e.g. the tokamak U-Net: 16..128 time steps per channel): one workgroup per (b, c)
+// row would leave most lanes idle, so threads walk a flat vector index and look the row constants up.
+__global__ __launch_bounds__(NT) void gn_apply_flat_kernel(const float* x, const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ ss, const int32_t* __restrict__ t_dev,
+                                                           int64_t ss_t_stride, int64_t ss_b_stride, int64_t ss_off,
+                                                           const float* res, float* y, int C, int G, int nv_row,
+                                                           int64_t nv_total) {
+    const int64_t trow = (ss && t_dev) ? (int64_t)(*t_dev) * ss_t_stride : 0;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* r4 = res ? reinterpret_cast<const float4*>(res) : nullptr;
+    float4* y4 = reinterpret_cast<float4*>(y);
+    for (int64_t v = (int64_t)blockIdx.x * NT + threadIdx.x; v < nv_total; v += (int64_t)gridDim.x * NT) {
+        const int bc = (int)(v / nv_row);
+        const int b = bc / C, c = bc - b * C;
+        const int g = c / (C / G);
+        const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+        float mul = rstd * gamma[c];
+        float add = beta[c] - mean * mul;
+        if (ss) {
+            const int64_t row = trow + (int64_t)b * ss_b_stride + ss_off;
+            const float sc = ss[row + c] + 1.0f, sh = ss[row + C + c];
+            mul *= sc;
+            add = add * sc + sh;
+        }
+        float4 q = x4[v];
+        q.x = sdc::silu_f(q.x * mul + add);
+        q.y = sdc::silu_f(q.y * mul + add);
+        q.z = sdc::silu_f(q.z * mul + add);
+        q.w = sdc::silu_f(q.w * mul + add);
+        if (r4) {
+            const float4 r = r4[v];
+            q.x += r.x; q.y += r.y; q.z += r.z; q.w += r.w;
+        }
+        y4[v] = q;
+    }
+}
+
 // ---------------------------------------------------------------- channel LayerNorm / RMSNorm
 // 64 positions x 4 channel slices per workgroup; positions are the contiguous axis so every
 // channel row is read in 256-byte wave-wide segments.  Two passes over C (second pass is L2-hot).
+template <int PL>      // PL position lanes x (NT/PL) channel slices per workgroup
 __global__ __launch_bounds__(NT) void chan_norm_kernel(const float* x, const float* __restrict__ g,
                                                        const float* res, float* y, int C,
                                                        int64_t S, int mode, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int slice = threadIdx.x >> 6;
+    constexpr int NSL = NT / PL;
+    const int lane = threadIdx.x % PL;
+    const int slice = threadIdx.x / PL;
     const int b = blockIdx.y;
-    const int64_t pos = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t pos = (int64_t)blockIdx.x * PL + lane;
     const bool ok = pos < S;
     const int64_t base = (int64_t)b * C * S + pos;
     float s = 0.f, q = 0.f;
     if (ok) {
-        for (int c = slice; c < C; c += 4) {
+        for (int c = slice; c < C; c += NSL) {
             const float v = x[base + (int64_t)c * S];
             s += v;
             q += v * v;
         }
     }
-    __shared__ float sh[2][4][64];
+    __shared__ float sh[2][NSL][PL];
     sh[0][slice][lane] = s;
     sh[1][slice][lane] = q;
     __syncthreads();
-    s = sh[0][0][lane] + sh[0][1][lane] + sh[0][2][lane] + sh[0][3][lane];
-    q = sh[1][0][lane] + sh[1][1][lane] + sh[1][2][lane] + sh[1][3][lane];
+    s = 0.f; q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) { s += sh[0][i][lane]; q += sh[1][i][lane]; }
     float mean, mul;
     if (mode == 0) {
         mean = s / C;
-        float var = q / C - mean * mean;
         // second, centred pass for the variance keeps LN exact when |mean| >> std
         float q2 = 0.f;
         if (ok)
-            for (int c = slice; c < C; c += 4) {
+            for (int c = slice; c < C; c += NSL) {
                 const float dv = x[base + (int64_t)c * S] - mean;
                 q2 += dv * dv;
             }
         __syncthreads();
         sh[1][slice][lane] = q2;
         __syncthreads();
-        var = (sh[1][0][lane] + sh[1][1][lane] + sh[1][2][lane] + sh[1][3][lane]) / C;
-        mul = 1.0f / sqrtf(var + eps);
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) var += sh[1][i][lane];
+        mul = 1.0f / sqrtf(var / C + eps);
     } else {
         mean = 0.f;
         mul = sqrtf((float)C) / fmaxf(sqrtf(q), 1e-12f);
     }
     if (!ok) return;
-    for (int c = slice; c < C; c += 4) {
+    for (int c = slice; c < C; c += NSL) {
         const int64_t o = base + (int64_t)c * S;
         float v = (x[o] - mean) * mul * g[c];
         if (res) v += res[o];
@@ -219,7 +261,13 @@ extern "C" int sdc_gn_apply(const float* x, const float* stats, const float* gam
     int gx = (int)((work + NT - 1) / NT);
     if (gx > 64) gx = 64;
     dim3 grid(B * C, gx);
-    if (vec)
+    if (vec && S < 1024) {
+        const int64_t nvt = (int64_t)B * C * (S / 4);
+        int64_t blocks = (nvt + NT - 1) / NT;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gn_apply_flat_kernel, dim3((unsigned)blocks), dim3(NT), 0, s, x, stats, gamma, beta, ss, t_dev,
+                           ss_t_stride, ss_b_stride, ss_off, residual, y, C, G, (int)(S / 4), nvt);
+    } else if (vec)
         hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(NT), 0, s, x, stats, gamma, beta, ss, t_dev, ss_t_stride,
                            ss_b_stride, ss_off, residual, y, C, G, S);
     else
@@ -233,8 +281,13 @@ extern "C" int sdc_chan_norm(const float* x, const float* g, const float* residu
     SDC_REQUIRE(x && g && y, SDC_ENULL, "sdc_chan_norm: null pointer");
     SDC_REQUIRE(B > 0 && C > 0 && S > 0 && (mode == 0 || mode == 1), SDC_EINVAL, "sdc_chan_norm: bad arguments");
     SDC_REQUIRE(B < 65536, SDC_EINVAL, "sdc_chan_norm: B too large for grid.y");
-    dim3 grid((unsigned)((S + 63) / 64), B);
-    hipLaunchKernelGGL(chan_norm_kernel, grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
+    if (S >= 64) {
+        dim3 grid((unsigned)((S + 63) / 64), B);
+        hipLaunchKernelGGL(chan_norm_kernel<64>, grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
+    } else {   // few positions, many channels (deep levels): 16 position lanes x 16 channel slices
+        dim3 grid((unsigned)((S + 15) / 16), B);
+        hipLaunchKernelGGL(chan_norm_kernel<16>, grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
+    }
     return sdc::check_launch("sdc_chan_norm");
 }
 

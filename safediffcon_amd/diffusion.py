@@ -252,6 +252,15 @@ class _SamplerBase(nn.Module):
             p._emit(lib.sdc_advance, ptr(st.t_dev), -1, ptr(st.draw_dev), 1 + d.skip_draws)
         return p
 
+    def _dispatch(self, prepare, B, dims, **kw):
+        """sample() runs the whole reverse process; sample(..., _prepare=True) only binds it and returns the _Loop
+        (init/step/final/close) -- used by bench.py to time single denoising steps; the caller owns the stream."""
+        if prepare:
+            kw.setdefault("target", None)
+            kw.setdefault("final_update", True)
+            return self._setup(B, dims, **kw)
+        return self._reverse_loop(B, dims, **kw)
+
     def _reverse_loop(self, B, dims, *, noise, guide, J_scheduler, k_const, cond, flags, impose_last, target=None,
                       final_update=True):
         """Shared DDPM loop.  `guide`: None | GuidanceSpec | callable.  `cond`: (c0, c1, c2) tensors or None.
@@ -476,9 +485,9 @@ class GaussianDiffusionBurgers(_SamplerBase):
                 raise NotImplementedError("guidance on x_t (guidance_u0=False with nablaJ) is unused by the reference pipelines")
             flags["skip_draws"] = 1          # calibration branch draws twice per step (:421-423)
             guide = None
-        return self._reverse_loop(batch_size, (C_, H, W, 1), noise=noise, guide=guide, J_scheduler=J_sched, k_const=1.0,
-                                  cond=(kwargs["u_init"], kwargs["u_final"], w_groundtruth), flags=flags,
-                                  impose_last=False, final_update=self.guidance_u0 or not enable_grad)
+        return self._dispatch(kwargs.get("_prepare", False), batch_size, (C_, H, W, 1), noise=noise, guide=guide,
+                              J_scheduler=J_sched, k_const=1.0, cond=(kwargs["u_init"], kwargs["u_final"], w_groundtruth),
+                              flags=flags, impose_last=False, final_update=self.guidance_u0 or not enable_grad)
 
 
 class GaussianDiffusionTokamak(_SamplerBase):
@@ -527,10 +536,10 @@ class GaussianDiffusionTokamak(_SamplerBase):
                 raise NotImplementedError("guidance on x_t (guidance_u0=False with nablaJ) is unused by the reference pipelines")
             flags["skip_draws"] = 1
             guide = None
-        return self._reverse_loop(batch_size, (self.channels, self.seq_length, 1, 1), noise=noise, guide=guide,
-                                  J_scheduler=J_sched, k_const=1.0, cond=(kwargs["u_init"], kwargs["u_final"], None),
-                                  flags=flags, impose_last=False, target=target,
-                                  final_update=self.guidance_u0 or not enable_grad)
+        return self._dispatch(kwargs.get("_prepare", False), batch_size, (self.channels, self.seq_length, 1, 1), noise=noise,
+                              guide=guide, J_scheduler=J_sched, k_const=1.0, cond=(kwargs["u_init"], kwargs["u_final"], None),
+                              flags=flags, impose_last=False, target=target,
+                              final_update=self.guidance_u0 or not enable_grad)
 
 
 class GaussianDiffusionSmoke(_SamplerBase):
@@ -550,16 +559,17 @@ class GaussianDiffusionSmoke(_SamplerBase):
         return (B, self.frames, self.channels, self.image_size, self.image_size)
 
     @torch.no_grad()
-    def sample(self, batch_size=16, design_fn=None, enable_grad=False, init=None, control=None, device=None, noise=None):
+    def sample(self, batch_size=16, design_fn=None, enable_grad=False, init=None, control=None, device=None, noise=None,
+               _prepare=False):
         """Reference signature (2d/ddpm/diffusion_2d.py:406-414)."""
         if self.is_ddim_sampling:
             raise NotImplementedError("DDIM sampling is a 'next' row (SURVEY 8f); use sampling_timesteps == timesteps")
         assert init is not None and batch_size == init.shape[0]
         flags = dict(clip=1, has_wgt=0 if control is None else 1)
         S = self.image_size
-        return self._reverse_loop(batch_size, (self.frames, self.channels, S, S), noise=noise, guide=design_fn,
-                                  J_scheduler=None, k_const=float(self.standard_fixed_ratio),
-                                  cond=(init, control, None), flags=flags, impose_last=True)
+        return self._dispatch(_prepare, batch_size, (self.frames, self.channels, S, S), noise=noise, guide=design_fn,
+                              J_scheduler=None, k_const=float(self.standard_fixed_ratio), cond=(init, control, None),
+                              flags=flags, impose_last=True)
 
 
 # reference-compatible alias: each reference tree calls its class ``GaussianDiffusion``
