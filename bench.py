@@ -47,6 +47,12 @@ def conv_instance(d):
         tile = "64,64,2,2"
     else:
         tile = "32,128,1,4"
+    bn = int(tile.split(",")[1])
+    rowhalo = (fast and not tile.startswith("32") and d.sW == 1 and d.uD == d.uH == d.uW == 1 and d.up_mode == 0
+               and d.kW == 3 and d.kD * d.kH <= 32 and d.Cout % 4 == 0
+               and (d.oW % bn == 0 or (bn % d.oW == 0 and d.oW >= 16)))
+    if rowhalo:
+        return f"conv_rh_kernel<{tile},3>"
     return f"conv_kernel<{tile},{'true' if fast else 'false'}>"
 
 

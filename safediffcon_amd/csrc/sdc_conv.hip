@@ -15,6 +15,7 @@
 // global loads for chunk c+1 are issued before the MFMAs of chunk c and written to the other LDS
 // buffer afterwards (one barrier per chunk).
 #include "sdc_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -55,7 +56,54 @@ struct ConvArgs {
     int Ktot;      // taps*Cin
     int Cin;
     int lgD, lgH, lgW;
+    int rowhalo;   // allow the row-halo kernel (env SDC_NO_ROWHALO=1 disables it for A/B timing)
 };
+
+// ---- epilogue: D rows (co) live in registers, columns (positions) on lanes -> coalesced along W.
+// Bias / residual loads are issued as a batch (clamped addresses, no per-element branches) so the
+// workgroup pays one memory round trip per 16 outputs instead of sixteen.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw, int lane) {
+    const SdcConvDesc& d = a.d;
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int cob = mw + i * 32 + 4 * lh;
+        float bv[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int co = cob + (rr & 3) + 8 * (rr >> 2);
+            bv[rr] = a.bias ? a.bias[co < d.Cout ? co : d.Cout - 1] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int pp = nw + j * 32 + l31;
+            const bool pok = pp < a.Ntot;
+            int r = pok ? pp : 0;
+            const int qw = r % d.oW; r /= d.oW;
+            const int qh = r % d.oH; r /= d.oH;
+            const int qd = r % d.oD; const int qb = r / d.oD;
+            const int64_t yoff = qb * d.ys[0] + qd * d.ys[2] + qh * d.ys[3] + qw * d.ys[4];
+            float rv[16];
+            if (a.res) {
+                const int64_t roff = qb * d.rs[0] + qd * d.rs[2] + qh * d.rs[3] + qw * d.rs[4];
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const int co = cob + (rr & 3) + 8 * (rr >> 2);
+                    rv[rr] = a.res[roff + (co < d.Cout ? co : d.Cout - 1) * d.rs[1]];
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) rv[rr] = 0.0f;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int co = cob + (rr & 3) + 8 * (rr >> 2);
+                if (pok && co < d.Cout) a.y[yoff + co * d.ys[1]] = acc[i][j][rr] + bv[rr] + rv[rr];
+            }
+        }
+    }
+}
 
 template <int BM, int BN, int WM, int WN, bool FAST>
 __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs a) {
@@ -264,46 +312,187 @@ __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs a) {
         if (SDC_EXP < 2 || SDC_EXP >= 4) __syncthreads();
     }
 
-    // ---- epilogue: D rows (co) live in registers, columns (positions) on lanes -> coalesced along W.
-    // Bias / residual loads are issued as a batch (clamped addresses, no per-element branches) so the
-    // workgroup pays one memory round trip per 16 outputs instead of sixteen.
+    conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-halo variant (stride-1 along W, no virtual upsampling, Cin % 16 == 0): the B tile of one
+// (kd, kh, channel-chunk) stage is the input ROW SEGMENT with its kW-1 halo columns, staged once and read
+// at kW shifted LDS offsets -- the "LDS-staged activation tile".  One stage feeds kW x 8 k-steps, so the
+// gather (the measured limiter of the plain kernel: VMEM issue, not latency) drops ~kW-fold, barriers
+// too; the weight tile of the stage comes in with 16-byte loads.
+// LDS: As[2][KW][BK][BM], Bs[2][BK][NSEG][seg + KW - 1] with seg = min(oW, BN), NSEG = BN / seg.
+template <int BM, int BN, int WM, int WN, int KW>
+__global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int KSMAX = BN + (BN / 16) * (KW - 1);            // LDS floats per k row, worst case (16-wide rows)
+    constexpr int NCOL = (KSMAX + 63) / 64;                     // 64-lane sweeps over one k row
+    constexpr int KROWS = BK / (NT / 64);                       // k rows per wave per stage
+    constexpr int NA4 = KW * BK * BM / 4 / NT;                  // float4 weight loads per thread per stage
+    static_assert(NA4 >= 1, "weight tile too small");
+
+    __shared__ __attribute__((aligned(16))) float As[2][KW][BK][BM];
+    __shared__ float Bs[2][BK * KSMAX];
+
+    const SdcConvDesc& d = a.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = SDC_UNIFORM(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * BM;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int seg = d.oW < BN ? d.oW : BN;
+    const int nseg = BN / seg;
+    const int rowlen = seg + KW - 1;
+    const int ks_stride = nseg * rowlen;          // LDS floats per k row
+    const bool two = d.Cin1 > 0;
+
+    // ---- gather state: this lane's columns of a k row (the same for every k row and every stage).  A wave
+    // loads whole k rows, so the channel part of the address is wave-uniform; only (segment, column) is per lane.
+    int v0[NCOL], v1[NCOL];
+    uint32_t smask[NCOL];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int cob = m0 + wm * (TM * 32) + i * 32 + 4 * lh;
-        float bv[16];
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            const int co = cob + (rr & 3) + 8 * (rr >> 2);
-            bv[rr] = a.bias ? a.bias[co < d.Cout ? co : d.Cout - 1] : 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int pp = n0 + wn * (TN * 32) + j * 32 + l31;
-            const bool pok = pp < a.Ntot;
-            int r = pok ? pp : 0;
-            const int qw = r % d.oW; r /= d.oW;
-            const int qh = r % d.oH; r /= d.oH;
-            const int qd = r % d.oD; const int qb = r / d.oD;
-            const int64_t yoff = qb * d.ys[0] + qd * d.ys[2] + qh * d.ys[3] + qw * d.ys[4];
-            float rv[16];
-            if (a.res) {
-                const int64_t roff = qb * d.rs[0] + qd * d.rs[2] + qh * d.rs[3] + qw * d.rs[4];
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) {
-                    const int co = cob + (rr & 3) + 8 * (rr >> 2);
-                    rv[rr] = a.res[roff + (co < d.Cout ? co : d.Cout - 1) * d.rs[1]];
+    for (int t = 0; t < NCOL; ++t) {
+        const int cidx = lane + 64 * t;
+        v0[t] = 0; v1[t] = 0; smask[t] = 0;
+        if (cidx < ks_stride) {
+            const int sg = cidx / rowlen;
+            const int cc = cidx - sg * rowlen;
+            const int pseg = n0 + sg * seg;
+            if (pseg < a.Ntot) {
+                int q = pseg;
+                const int ow0 = q % d.oW; q /= d.oW;
+                const int oh = q % d.oH; q /= d.oH;
+                const int od = q % d.oD; const int ob = q / d.oD;
+                const int col = ow0 + cc - d.pW;
+                const int id0 = od * d.sD - d.pD, ih0 = oh * d.sH - d.pH;
+                uint32_t m = 0;
+                if (col >= 0 && col < d.iW) {
+                    for (int kd = 0; kd < d.kD; ++kd)
+                        for (int kh = 0; kh < d.kH; ++kh)
+                            if (id0 + kd >= 0 && id0 + kd < d.iD && ih0 + kh >= 0 && ih0 + kh < d.iH)
+                                m |= 1u << (kd * d.kH + kh);
                 }
-            } else {
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) rv[rr] = 0.0f;
-            }
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                const int co = cob + (rr & 3) + 8 * (rr >> 2);
-                if (pok && co < d.Cout) a.y[yoff + co * d.ys[1]] = acc[i][j][rr] + bv[rr] + rv[rr];
+                smask[t] = m;
+                v0[t] = (int)(ob * d.x0s[0] + id0 * d.x0s[2] + ih0 * d.x0s[3] + col * d.x0s[4]);
+                if (two) v1[t] = (int)(ob * d.x1s[0] + id0 * d.x1s[2] + ih0 * d.x1s[3] + col * d.x1s[4]);
             }
         }
     }
+    // ---- per-lane B fragment offsets inside one k row
+    int boff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int pl = wn * (TN * 32) + j * 32 + l31;
+        const int sg = pl / seg;
+        boff[j] = sg * rowlen + (pl - sg * seg);
+    }
+    // ---- weight tile: float4 f = tid + NT*i  ->  row = f / (BM/4) in [0, KW*BK), 4 consecutive co
+    int a_col[NA4];
+    bool a_ok[NA4];
+#pragma unroll
+    for (int i = 0; i < NA4; ++i) {
+        const int c4 = ((tid + i * NT) % (BM / 4)) * 4;
+        a_ok[i] = (m0 + c4) < d.Cout;            // Cout % 4 == 0 (host check): a float4 is all-in or all-out
+        a_col[i] = a_ok[i] ? (m0 + c4) : 0;
+    }
+
+    float breg[KROWS][NCOL];
+    float4 areg[NA4];
+    uint32_t mbits = 0;                          // bit t: column sweep t of the stage in flight is valid for this lane
+    int s_kd = 0, s_kh = 0, s_ci = 0;            // stage walk: kd, kh outer; channel chunk inner
+
+    auto load_stage = [&]() {
+        const int tapbit = s_kd * d.kH + s_kh;
+        const int tap0 = tapbit * KW;
+#pragma unroll
+        for (int i = 0; i < NA4; ++i) {
+            const int row = (tid + i * NT) / (BM / 4);
+            const int kw = row / BK, kr = row % BK;
+            const int64_t wrow = (int64_t)(tap0 + kw) * a.Cin + s_ci + kr;
+            areg[i] = *reinterpret_cast<const float4*>(a.wp + wrow * d.Cout + a_col[i]);
+        }
+        const bool first = s_ci < d.Cin0;
+        const int64_t sc = first ? d.x0s[1] : d.x1s[1];
+        const int64_t toff = first ? s_kd * d.x0s[2] + s_kh * d.x0s[3] : s_kd * d.x1s[2] + s_kh * d.x1s[3];
+        const float* base = (first ? a.x0 + (int64_t)s_ci * sc : a.x1 + (int64_t)(s_ci - d.Cin0) * sc) +
+                            (int64_t)(wave * KROWS) * sc;                      // wave-uniform
+        mbits = 0;
+        int64_t off[NCOL];
+#pragma unroll
+        for (int t = 0; t < NCOL; ++t) {
+            const bool ok = (smask[t] >> tapbit) & 1u;
+            off[t] = ok ? (int64_t)(first ? v0[t] : v1[t]) + toff : 0;          // !ok: a safe in-bounds address
+            mbits |= (ok ? 1u : 0u) << t;
+        }
+#pragma unroll
+        for (int r = 0; r < KROWS; ++r)
+#pragma unroll
+            for (int t = 0; t < NCOL; ++t)
+                if (t * 64 < ks_stride) breg[r][t] = (base + r * sc)[off[t]];
+        s_ci += BK;
+        if (s_ci >= a.Cin) { s_ci = 0; if (++s_kh == d.kH) { s_kh = 0; ++s_kd; } }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA4; ++i) {
+            const int f = tid + i * NT;
+            const int row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
+            float4 v = areg[i];
+            if (!a_ok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&As[buf][row / BK][row % BK][c4]) = v;
+        }
+#pragma unroll
+        for (int r = 0; r < KROWS; ++r)
+#pragma unroll
+            for (int t = 0; t < NCOL; ++t) {
+                const int cidx = lane + 64 * t;
+                if (cidx < ks_stride) Bs[buf][(wave * KROWS + r) * ks_stride + cidx] = ((mbits >> t) & 1u) ? breg[r][t] : 0.0f;
+            }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nstages = d.kD * d.kH * (a.Cin / BK);
+    load_stage();
+    store_stage(0);
+    __syncthreads();
+    const int am = wm * (TM * 32) + l31;
+
+    for (int st = 0; st < nstages; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nstages) load_stage();
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+            float af[BK / 2][TM], bf[BK / 2][TN];
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[ks][i] = As[buf][kw][2 * ks + lh][am + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[ks][j] = Bs[buf][(2 * ks + lh) * ks_stride + boff[j] + kw];
+            }
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+        }
+        if (st + 1 < nstages) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
 }
 
 int ilog2_exact(int v) {
@@ -316,6 +505,16 @@ int ilog2_exact(int v) {
 template <int BM, int BN, int WM, int WN>
 void launch(const ConvArgs& a, bool fast, hipStream_t s) {
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
+    const SdcConvDesc& d = a.d;
+    // row-halo kernel: stride 1 along W, no virtual upsampling, kW == 3 (with kW == 1 there is no halo to share and
+    // the plain kernel measured faster), whole rows or whole row segments per tile
+    const bool rh = fast && a.rowhalo && d.sW == 1 && d.uD == 1 && d.uH == 1 && d.uW == 1 && d.up_mode == 0 &&
+                    d.kW == 3 && d.kD * d.kH <= 32 && d.Cout % 4 == 0 &&
+                    ((d.oW % BN == 0) || (BN % d.oW == 0 && d.oW >= 16)) &&
+                    (reinterpret_cast<uintptr_t>(a.wp) % 16 == 0);
+    if constexpr (BM >= 64) {
+        if (rh) { hipLaunchKernelGGL((conv_rh_kernel<BM, BN, WM, WN, 3>), grid, dim3(NT), 0, s, a); return; }
+    }
     if (fast)
         hipLaunchKernelGGL((conv_kernel<BM, BN, WM, WN, true>), grid, dim3(NT), 0, s, a);
     else
@@ -357,6 +556,8 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
     };
     const bool small = span(d.x0s, d.B, d.iD, d.iH, d.iW) < (1ll << 30) &&
                        (d.Cin1 == 0 || span(d.x1s, d.B, d.iD, d.iH, d.iW) < (1ll << 30));
+    static const int no_rh = getenv("SDC_NO_ROWHALO") ? atoi(getenv("SDC_NO_ROWHALO")) : 0;
+    a.rowhalo = !no_rh;
     const bool fast = (d.Cin0 % BK == 0) && (d.Cin1 % BK == 0) && small && d.Cout < (1 << 30);
     hipStream_t s = sdc::as_stream(stream);
     const int64_t blocks64x128 = (int64_t)((a.Ntot + 127) / 128) * ((d.Cout + 63) / 64);

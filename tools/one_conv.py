@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Launch one conv shape N times (for PMC / trace passes).  usage: one_conv.py Cin Cout k H W B [reps]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from safediffcon_amd.engine import Plan, as5
+cin, cout, k, H, W, B = (int(v) for v in sys.argv[1:7])
+reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5
+dev = "cuda:0"
+plan = Plan(dev)
+x = torch.randn(B, cin, H, W, device=dev)
+w = torch.randn(cout, cin, k, k, device=dev) * 0.05
+b = torch.randn(cout, device=dev)
+out = plan.conv(as5(x), plan.conv_weight(w), b, cout, (1, k, k), pad=(0, k // 2, k // 2))
+s = torch.cuda.current_stream().cuda_stream
+for _ in range(reps):
+    plan.run(s)
+torch.cuda.synchronize()
+print("done", out.shape)
