@@ -251,8 +251,18 @@ def main():
             name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
             avg_ms = g["ms"] / g["launches"]
             ach = g["flops"] / g["launches"] / (avg_ms * 1e-3) / 1e12
+            # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE), collected separately with
+            # rocprofv3 --pmc and committed under profiles/ (bench.py cannot run the profiler on itself)
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
+                    traffic = json.load(fh).get(name, {}).get("traffic_bytes")
+            except OSError:
+                pass
             roof = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, launches_per_step=g["launches"],
+                        frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
+                        sustained_peak_measured=123.0,   # bare v_mfma_f32_32x32x2 loop on this device (tools/mfma_peak.hip)
+                        launches_per_step=g["launches"],
                         avg_launch_ms=round(avg_ms, 4), share_of_step=round(g["ms"] / (dt / a.steps * 1e3), 3),
                         all_conv_instances={k: dict(launches=v["launches"], ms_per_step=round(v["ms"], 3),
                                                     tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2))

@@ -1,0 +1,100 @@
+"""-m gpu: BASELINE.json's full-size configurations.  The CPU oracle is affordable on one or two samples, so
+each full-width U-Net is checked (a) against the oracle on a sub-batch and (b) through size-independent
+properties on the full batch: batch independence (trajectories never mix), run-to-run determinism, the
+imposed conditions, finite bounded output."""
+import pytest
+import torch
+
+import safediffcon_amd as sdc
+from oracle import nets as onets
+from oracle.detweights import det_params, det_tensor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _spec(net):
+    return [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+
+
+def _mse(a, b):
+    return ((a - b) ** 2).mean().item()
+
+
+def test_c2_burgers_dim64_batch256():
+    net = sdc.Unet2D(dim=64, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+    P = det_params(_spec(net), 11)
+    net.load_state_dict(P)
+    net.to(DEV)
+    B = 256
+    x = det_tensor((B, 3, 16, 128), 12)
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(13))
+    eps = net(x.to(DEV), t.to(DEV))
+    eps2 = net(x.to(DEV), t.to(DEV))
+    assert torch.equal(eps, eps2)                                   # deterministic
+    idx = [0, 137, 255]
+    ref = onets.unet_burgers(P, x[idx], t[idx], dim=64)             # full-width oracle on 3 of the 256 samples
+    assert _mse(eps[idx].cpu(), ref) <= 1e-5
+    torch.testing.assert_close(eps[idx].cpu(), ref, rtol=1e-3, atol=1e-4)
+    sub = net(x[idx].to(DEV), t[idx].to(DEV))                       # same samples in a batch of 3: no cross-talk
+    torch.testing.assert_close(sub, eps[idx], rtol=1e-5, atol=1e-6)
+
+
+def test_c3_tokamak_dim256_batch128():
+    net = sdc.Unet1D(dim=256, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+    P = det_params(_spec(net), 21)
+    net.load_state_dict(P)
+    net.to(DEV)
+    B = 128
+    x = det_tensor((B, 12, 128), 22)
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(23))
+    eps = net(x.to(DEV), t.to(DEV))
+    idx = [0, 127]
+    ref = onets.unet_tokamak(P, x[idx], t[idx], dim=256)
+    assert _mse(eps[idx].cpu(), ref) <= 1e-5
+    torch.testing.assert_close(eps[idx].cpu(), ref, rtol=1e-3, atol=1e-4)
+    assert torch.isfinite(eps).all()
+
+
+def test_c4_smoke_dim64_full_resolution():
+    net = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+    P = det_params(_spec(net), 31)
+    net.load_state_dict(P)
+    net.to(DEV)
+    B = 3
+    x = det_tensor((B, 32, 7, 64, 64), 32)
+    t = torch.tensor([5, 500, 995])
+    eps = net(x.to(DEV), t.to(DEV))
+    ref = onets.unet_smoke(P, x[1:2], t[1:2], dim=64, dim_mults=(1, 2, 4))    # 64x64x32 oracle forward (~10 s CPU)
+    assert _mse(eps[1:2].cpu(), ref) <= 1e-5
+    torch.testing.assert_close(eps[1:2].cpu(), ref, rtol=2e-3, atol=2e-4)
+    sub = net(x[1:2].to(DEV), t[1:2].to(DEV))
+    torch.testing.assert_close(sub, eps[1:2], rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_sampler_properties():
+    """C2 at B=256 and C4-shaped smoke at B=4, a few steps with Philox noise: conditions imposed, trajectories
+    independent of their batch neighbours, finite."""
+    net = sdc.Unet2D(dim=64, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+    net.load_state_dict(det_params(_spec(net), 11))
+    net.to(DEV)
+    gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=4, temporal=True, use_conv2d=True,
+                                      is_condition_u0=True, is_condition_uT=True, condition_idx=10).to(DEV)
+    B = 256
+    u0, uT = det_tensor((B, 128), 41, 0.1).to(DEV), det_tensor((B, 128), 42, 0.1).to(DEV)
+    guid = sdc.BurgersGuidance(0.01, 500.0, 0.05)
+    torch.manual_seed(5)
+    out = gd.sample(batch_size=B, u_init=u0, u_final=uT, nablaJ=guid, enable_grad=False)
+    assert out.shape == (B, 3, 16, 128) and torch.isfinite(out).all()
+    torch.manual_seed(5)
+    out2 = gd.sample(batch_size=B, u_init=u0, u_final=uT, nablaJ=guid, enable_grad=False)
+    assert torch.equal(out, out2)
+
+    net3 = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+    net3.load_state_dict(det_params(_spec(net3), 31))
+    net3.to(DEV)
+    gs = sdc.GaussianDiffusionSmoke(net3, image_size=64, frames=32, timesteps=2, standard_fixed_ratio=100.0).to(DEV)
+    init = det_tensor((2, 64, 64), 43, 0.2).abs().to(DEV)
+    control = det_tensor((2, 32, 2, 64, 64), 44, 0.3).to(DEV)
+    o = gs.sample(batch_size=2, design_fn=sdc.SmokeGuidance(0.01, 0.9, 0.1), init=init, control=control)
+    assert torch.equal(o[:, 0, 0], init) and torch.equal(o[:, :, 3:5], control) and torch.isfinite(o).all()
