@@ -145,12 +145,15 @@ typedef struct SdcStepDesc {
     int32_t d0, d1, d2, d3;      /* per-sample dims: burgers (C,H,W,1) ; tokamak (C,L,1,1) ; smoke (F,C,H,W) */
     int32_t guide;               /* 0 none, 1 built-in closed form, 2 external g tensor */
     int32_t clip;                /* clip_denoised */
-    int32_t impose;              /* apply conditioning writes to the output */
+    int32_t impose;              /* 1: apply conditioning writes to the output; 2 (smoke): control channels only */
     int32_t cond_idx;            /* burgers: condition_idx (10); tokamak: nt (122) */
     int32_t pad_zero;            /* burgers/tokamak: !train_on_padded_locations */
     int32_t use_max;             /* burgers: 0 mean-mode (use_max_safety=True), 1 amax mode */
     int32_t has_wgt;             /* burgers: w_groundtruth given ; smoke: control given */
     int32_t skip_draws;          /* noise draws consumed per step beyond the one used (calibration branch: 1) */
+    int32_t ddim;                /* 1: DDIM update (ddim_sample, 1D/model/diffusion.py:451-555, 2d/...:324-404): x0 always
+                                    clipped, guidance on the clipped x0, eps re-derived, coef rows = {a, b, sqrt(a_next), c,
+                                    sigma, k, last} indexed by step number */
     uint64_t seed;
 } SdcStepDesc;
 
@@ -158,7 +161,7 @@ typedef struct SdcStepDesc {
  * conformal quantile Q):  burgers {w_score, u_bound^2, Q, 10}; tokamak {w_obj, w_safe, guidance_scaler,
  * safety_threshold, Q}; smoke {w_safe, safe_bound, Q, standard_fixed_ratio}.
  * sdc_guide_reduce: per-sample hinge-active flag + arg-extremum of the safety functional evaluated on
- * x0 = a x - b eps  -> gscal[2*B]   (1D/utils/guidance.py:58-77, tokamak/utils/guidance.py:32-56,
+ * x0 = a x - b eps  -> gscal[4*B] = {active, arg, extremum, 1/ties}   (1D/utils/guidance.py:58-77, tokamak/utils/guidance.py:32-56,
  * tokamak/utils/metrics.py:144-151, 2d/inference_2d.py:173-186). */
 int sdc_guide_reduce(const SdcStepDesc* d, const float* x, const float* eps, const float* coef, const int32_t* t_dev,
                      const float* gpar, float* gscal, void* stream);
@@ -174,6 +177,9 @@ int sdc_impose(const SdcStepDesc* d, float* x, const float* c0, const float* c1,
 int sdc_randn(float* x, int64_t n, uint64_t seed, const int32_t* draw_dev, void* stream);
 /* *t_dev += dt ; *draw_dev += ddraw   (one thread; keeps the step counter on the device for graph replay) */
 int sdc_advance(int32_t* t_dev, int dt, int32_t* draw_dev, int ddraw, void* stream);
+
+/* DDIM: ++*idx_dev ; *t_dev = ttab[*idx_dev] (the strided timestep list lives on the device) ; *draw_dev += ddraw */
+int sdc_advance_table(int32_t* idx_dev, int32_t* t_dev, const int32_t* ttab, int32_t* draw_dev, int ddraw, void* stream);
 
 /* ------------------------------------------------------------- conformal */
 /* per-sample conformal score |f(pred) - f(truth)| and weight exp(-J(truth)):

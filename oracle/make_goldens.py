@@ -212,6 +212,34 @@ def gen_burgers():
                                 enable_grad=False)
             save("burgers_traj_calib", out=out, u0=u0, uT=uT, w_gt=wgt, T=T, draws=st["i"], noise_seed=1000,
                  dim=dim, weight_seed=100)
+    if ref_guid:
+        _ddim_burgers(Unet2D, GaussianDiffusion, cfg, get_finetune_guidance, dim)
+
+
+def _ddim_burgers(Unet2D, GaussianDiffusion, cfg, get_finetune_guidance, dim):
+    T, S, B = 20, 5, 2
+    net = Unet2D(dim=dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+    load_det(net, seed=100)
+    gd = GaussianDiffusion(net, seq_length=(16, 128), timesteps=T, sampling_timesteps=S, ddim_sampling_eta=1.0,
+                           temporal=True, use_conv2d=True, is_condition_u0=True, is_condition_uT=True, condition_idx=10,
+                           train_on_padded_locations=False)
+    u0 = det_tensor((B, 128), 130, 0.1, -0.1, 0.3)
+    uT = det_tensor((B, 128), 131, 0.1, -0.1, 0.3)
+    noise = det_noise((B, 3, 16, 128), 1500)
+    Q = 0.01
+    cfg.use_max_safety, cfg.u_bound = True, 0.05
+    with injected_noise(noise) as st:
+        out = gd.sample(batch_size=B, clip_denoised=True, u_init=u0, u_final=uT, guidance_u0=True,
+                        nablaJ=lambda x: get_finetune_guidance(cfg, x, Q), J_scheduler=lambda t: 1.0, w_scheduler=None,
+                        enable_grad=False)
+    save("burgers_ddim_guided", out=out, u0=u0, uT=uT, Q=Q, w_score=500.0, u_bound=0.05, T=T, S=S, eta=1.0, draws=st["i"],
+         noise_seed=1500, dim=dim, weight_seed=100)
+    wgt = det_tensor((B, 16, 128), 132, 0.05)
+    with injected_noise(noise) as st:
+        out = gd.sample(batch_size=B, clip_denoised=True, guidance_u0=False, u_init=u0, u_final=uT, w_groundtruth=wgt,
+                        nablaJ=None, J_scheduler=None, w_scheduler=None, enable_grad=False)
+    save("burgers_ddim_calib", out=out, u0=u0, uT=uT, w_gt=wgt, T=T, S=S, eta=1.0, draws=st["i"], noise_seed=1500, dim=dim,
+         weight_seed=100)
 
 
 def gen_tokamak():
@@ -303,6 +331,24 @@ def gen_tokamak():
     except Exception as e:  # noqa: BLE001
         raised = type(e).__name__
     save("tokamak_wgt_bug", raised=raised)
+    # DDIM (eta = 1, 5 of 20 steps): guided, and calibration-style with w_groundtruth (works on this path)
+    T2, S2 = 20, 5
+    net = Unet1D(dim=dim, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+    load_det(net, seed=200)
+    gd2 = GaussianDiffusion(net, seq_length=128, nt=nt, timesteps=T2, sampling_timesteps=S2, ddim_sampling_eta=1.0,
+                            use_conv2d=False, temporal=False, guidance_u0=True, is_condition_u0=True, is_condition_uT=True)
+    noise2 = det_noise((B, 12, 128), 2500)
+    with injected_noise(noise2) as st:
+        out = gd2.sample(batch_size=B, clip_denoised=True, guidance_u0=True, u_init=u0, u_final=uT, nablaJ=nablaJ,
+                         J_scheduler=lambda t: 1.0, w_scheduler=None, enable_grad=False)
+    save("tokamak_ddim_guided", out=out, u0=u0, uT=uT, target=target2, T=T2, S=S2, eta=1.0, draws=st["i"], noise_seed=2500,
+         dim=dim, weight_seed=200, w_obj=0.0, w_safe=1.0, scaler=0.01, thr=4.98, Q=0.0)
+    wgt = det_tensor((B, 9, 128), 222, 0.2)
+    with injected_noise(noise2) as st:
+        out = gd2.sample(batch_size=B, clip_denoised=True, guidance_u0=False, u_init=u0, u_final=uT, w_groundtruth=wgt,
+                         nablaJ=None, J_scheduler=None, w_scheduler=None, enable_grad=False)
+    save("tokamak_ddim_calib", out=out, u0=u0, uT=uT, w_gt=wgt, T=T2, S=S2, eta=1.0, draws=st["i"], noise_seed=2500, dim=dim,
+         weight_seed=200)
 
 
 def gen_smoke():
@@ -402,6 +448,21 @@ def gen_smoke():
         out = gd.sample(batch_size=B, design_fn=None, init=init, control=control)
     save("smoke_traj_calib", out=out, init=init, control=control, T=T, draws=st["i"], noise_seed=3000, dim=dim,
          weight_seed=300)
+    T2, S2 = 20, 5
+    net = Unet3D_with_Conv3D(dim=dim, dim_mults=(1, 2, 4), channels=7)
+    load_det(net, seed=300)
+    gd2 = GaussianDiffusion(net, image_size=16, frames=8, timesteps=T2, sampling_timesteps=S2, ddim_sampling_eta=1.0,
+                            loss_type="l2", standard_fixed_ratio=100.0)
+    gd2.eval()
+    noise2 = det_noise((B, 8, 7, 16, 16), 3500)
+    with injected_noise(noise2) as st:
+        out = gd2.sample(batch_size=B, design_fn=design_fn, enable_grad=False, init=init)
+    save("smoke_ddim_guided", out=out, init=init, T=T2, S=S2, eta=1.0, draws=st["i"], noise_seed=3500, dim=dim,
+         weight_seed=300, Q=0.01, w_safe=0.9, safe_bound=-5.0, ratio=100.0)
+    with injected_noise(noise2) as st:
+        out = gd2.sample(batch_size=B, design_fn=None, init=init, control=control)
+    save("smoke_ddim_calib", out=out, init=init, control=control, T=T2, S=S2, eta=1.0, draws=st["i"], noise_seed=3500,
+         dim=dim, weight_seed=300)
 
 
 if __name__ == "__main__":

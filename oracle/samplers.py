@@ -257,3 +257,87 @@ def quantile_smoke(scores, alpha):
     _, idx = torch.sort(scores)
     q = int(min(np.ceil((n + 1) * (1 - alpha)), n - 1))
     return scores[idx[q - 1]]
+
+
+# ----------------------------------------------------------------------------
+# DDIM (SURVEY section 8f rank 1): what the reference's shipped scripts actually run
+# ----------------------------------------------------------------------------
+
+def ddim_pairs(T, S):
+    """[(time, time_next)] of ddim_sample: 1D/model/diffusion.py:460-462 (== tokamak, 2d)."""
+    times = torch.linspace(-1, T - 1, steps=S + 1)
+    times = list(reversed(times.int().tolist()))
+    return list(zip(times[:-1], times[1:]))
+
+
+def _ddim_loop(eps_fn, tabs, shape, noise, impose, finish, *, S, eta, guide, k_of_t):
+    """ddim_sample: 1D/model/diffusion.py:451-555, tokamak/...:374-496, 2d/ddpm/diffusion_2d.py:324-404.
+    model_predictions(clip_x_start=True, rederive_pred_noise=True): x0 clipped, guidance evaluated on the clipped x0,
+    eps re-derived from the clipped guided x0."""
+    T = tabs["betas"].shape[0]
+    ac = tabs["alphas_cumprod"]
+    draw = _Draws(noise)
+    img = draw().clone()
+    impose(img)
+    for time, time_next in ddim_pairs(T, S):
+        a, b = tabs["sqrt_recip_alphas_cumprod"][time], tabs["sqrt_recipm1_alphas_cumprod"][time]
+        eps = eps_fn(img, torch.full((shape[0],), time, dtype=torch.long))
+        x0 = (a * img - b * eps).clamp(-1.0, 1.0)
+        if guide is not None:
+            eps = eps + guide(x0) * k_of_t(time)
+        x0 = (a * img - b * eps).clamp(-1.0, 1.0)
+        eps = (a * img - x0) / b
+        if time_next < 0:
+            img = x0
+            continue
+        alpha, alpha_next = ac[time], ac[time_next]
+        sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+        c = (1 - alpha_next - sigma ** 2).sqrt()
+        img = x0 * alpha_next.sqrt() + c * eps + sigma * draw()
+        impose(img)
+    finish(img)
+    return img
+
+
+def ddim_burgers(eps_fn, tabs, batch, noise, *, S, eta, u_init, u_final, nablaJ=None, J_scheduler=None, guidance_u0=True,
+                 w_groundtruth=None, condition_idx=10, train_on_padded_locations=False, shape=(3, 16, 128)):
+    def impose(img):
+        img[:, 0, 0, :] = u_init
+        img[:, 0, condition_idx, :] = u_final
+        if w_groundtruth is not None:
+            img[:, 1, :, :] = w_groundtruth
+        if not train_on_padded_locations:
+            img[:, 0, condition_idx + 1:, :] = 0
+            img[:, 1, condition_idx:, :] = 0
+            img[:, 2, condition_idx:, :] = 0
+    k = (lambda t: J_scheduler(t)) if J_scheduler is not None else (lambda t: 1.0)
+    return _ddim_loop(eps_fn, tabs, (batch, *shape), noise, impose, lambda img: None, S=S, eta=eta,
+                      guide=nablaJ if guidance_u0 else None, k_of_t=k)
+
+
+def ddim_tokamak(eps_fn, tabs, batch, noise, *, S, eta, u_init, u_final, nablaJ=None, J_scheduler=None, guidance_u0=True,
+                 w_groundtruth=None, nt=122, train_on_padded_locations=True, shape=(12, 128)):
+    def impose(img):
+        img[:, :3, 0] = u_init
+        img[:, [0, 2], :nt] = u_final
+        if not train_on_padded_locations:
+            img[:, :3, nt:] = 0
+            img[:, 3:, nt - 1:] = 0
+        if w_groundtruth is not None:
+            img[:, 3:, :] = w_groundtruth                                 # the DDIM path indexes correctly (:411,:453)
+    k = (lambda t: J_scheduler(t)) if J_scheduler is not None else (lambda t: 1.0)
+    return _ddim_loop(eps_fn, tabs, (batch, *shape), noise, impose, lambda img: None, S=S, eta=eta,
+                      guide=nablaJ if guidance_u0 else None, k_of_t=k)
+
+
+def ddim_smoke(eps_fn, tabs, batch, noise, *, S, eta, init, control=None, design_fn=None, ratio=1.0, shape=(32, 7, 64, 64)):
+    def impose(x):
+        x[:, 0, 0] = init
+        if control is not None:
+            x[:, :, 3:5] = control
+
+    def finish(x):                                                        # 2d/ddpm/diffusion_2d.py:400-401
+        if control is not None:
+            x[:, :, 3:5] = control
+    return _ddim_loop(eps_fn, tabs, (batch, *shape), noise, impose, finish, S=S, eta=eta, guide=design_fn,
+                      k_of_t=lambda t: ratio)

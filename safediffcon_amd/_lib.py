@@ -27,7 +27,7 @@ class SdcConvDesc(C.Structure):
 class SdcStepDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "model", "B", "d0", "d1", "d2", "d3", "guide", "clip", "impose", "cond_idx", "pad_zero", "use_max",
-        "has_wgt", "skip_draws")] + [("seed", C.c_uint64)]
+        "has_wgt", "skip_draws", "ddim")] + [("_pad", C.c_int32), ("seed", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol include/sdc.h declares
@@ -51,6 +51,7 @@ SIGNATURES = {
     "sdc_impose": (C.c_int, [C.POINTER(SdcStepDesc), _f32p, _f32p, _f32p, _f32p, _stream]),
     "sdc_randn": (C.c_int, [_f32p, _i64, C.c_uint64, _i32p, _stream]),
     "sdc_advance": (C.c_int, [_i32p, C.c_int, _i32p, C.c_int, _stream]),
+    "sdc_advance_table": (C.c_int, [_i32p, _i32p, _i32p, _i32p, C.c_int, _stream]),
     "sdc_conformal_score": (C.c_int, [C.POINTER(SdcStepDesc), _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _stream]),
     "sdc_graph_begin": (C.c_int, [_stream]),
     "sdc_graph_end": (C.c_int, [_stream, C.POINTER(C.c_void_p)]),

@@ -8,7 +8,7 @@
 //   burgers: {w_score, u_bound^2, Q, SCALER=10}
 //   tokamak: {w_obj, w_safe, guidance_scaler, safety_threshold, Q}
 //   smoke  : {w_safe, safe_bound, Q, standard_fixed_ratio}
-// gscal (device float[2*B]) = {hinge-active flag, arg-extremum flat index} from sdc_guide_reduce.
+// gscal (device float[4*B]) = {hinge-active flag, arg-extremum flat index, extremum, 1/ties} from sdc_guide_reduce.
 #include "sdc_common.h"
 
 namespace {
@@ -78,19 +78,24 @@ __device__ void block_argext(float v, int idx, float sign, float* shv, int* shi,
     outv = bk * sign; outi = bi;
 }
 
-struct Coef { float a, b, c1, c2, sig, k; };
+// coefficient row of the current step.  DDPM (row index = t): {a, b, c1, c2, sigma, k}.
+// DDIM (row index = step number): {a, b, sqrt(alpha_next), c, sigma, k, last}: 1D/model/diffusion.py:500-510.
+struct Coef { float a, b, c1, c2, sig, k, last; };
 __device__ __forceinline__ Coef load_coef(const float* coef, const int32_t* t_dev) {
     const float* c = coef + (int64_t)(*t_dev) * 8;
-    return Coef{c[0], c[1], c[2], c[3], c[4], c[5]};
+    return Coef{c[0], c[1], c[2], c[3], c[4], c[5], c[6]};
 }
 
 // safety functional f(state) per sample, evaluated on v(idx) (a callable giving the element value)
 //   burgers: 10 * mean|amax over (c=2, h<11)      (1D/utils/guidance.py:66-70)
 //   tokamak: min_t<nt 7*x[1,t]                    (tokamak/utils/metrics.py:144-151)
 //   smoke  : mean_hw R6*x[F-1,6]                  (2d/inference_2d.py:183)
+// `ties` = how many elements attain the extremum (amax / amin modes): torch's amax/amin backward splits the
+// gradient evenly between tied elements, which happens for real once x0 is clipped to [-1, 1] (DDIM).
 template <typename V>
-__device__ void safety_functional(const SdcStepDesc& d, V v, float* shf, int* shi, float& val, int& arg) {
-    arg = 0;
+__device__ void safety_functional(const SdcStepDesc& d, V v, float* shf, int* shi, float& val, int& arg, int& ties,
+                                  float& raw) {
+    arg = 0; ties = 1; raw = 0.f;
     if (d.model == SDC_MODEL_BURGERS) {
         const int H = d.d1, W = d.d2;
         const int n = 11 * W;
@@ -106,6 +111,10 @@ __device__ void safety_functional(const SdcStepDesc& d, V v, float* shf, int* sh
                 if (x > m) { m = x; mi = base + i; }
             }
             block_argext(m, mi, 1.f, shf, shi, val, arg);
+            raw = val;
+            float cnt = 0.f;
+            for (int i = threadIdx.x; i < n; i += NT) cnt += (v(base + i) == raw) ? 1.f : 0.f;
+            ties = (int)(block_sum(cnt, shf) + 0.5f);
             val *= 10.0f;
         }
     } else if (d.model == SDC_MODEL_TOKAMAK) {
@@ -116,6 +125,10 @@ __device__ void safety_functional(const SdcStepDesc& d, V v, float* shf, int* sh
             if (x < m) { m = x; mi = L + i; }
         }
         block_argext(m, mi, -1.f, shf, shi, val, arg);
+        raw = val;
+        float cnt = 0.f;
+        for (int i = threadIdx.x; i < nt; i += NT) cnt += (v(L + i) == raw) ? 1.f : 0.f;
+        ties = (int)(block_sum(cnt, shf) + 0.5f);
         val *= TOK_SCALER[1];
     } else {
         const int F = d.d0, C = d.d1, HW = d.d2 * d.d3;
@@ -144,25 +157,34 @@ __global__ __launch_bounds__(NT) void guide_reduce_kernel(const SdcStepDesc d, c
     const Coef c = load_coef(coef, t_dev);
     const float* xb = x + b * per;
     const float* eb = eps + b * per;
-    float f; int arg;
-    safety_functional(d, [&](int i) { return c.a * xb[i] - c.b * eb[i]; }, shf, shi, f, arg);
+    float f, raw; int arg, ties;
+    const bool ddim = d.ddim != 0;
+    safety_functional(d, [&](int i) {
+        const float v = c.a * xb[i] - c.b * eb[i];
+        return ddim ? fminf(fmaxf(v, -1.0f), 1.0f) : v;
+    }, shf, shi, f, arg, ties, raw);
     if (threadIdx.x == 0) {
-        gscal[b * 2] = hinge_arg(d, gpar, f) > 0.f ? 1.0f : 0.0f;
-        gscal[b * 2 + 1] = __int_as_float(arg);
+        gscal[b * 4] = hinge_arg(d, gpar, f) > 0.f ? 1.0f : 0.0f;
+        gscal[b * 4 + 1] = __int_as_float(arg);
+        gscal[b * 4 + 2] = raw;                          // the extremum itself (for tie detection)
+        gscal[b * 4 + 3] = 1.0f / (float)ties;
     }
 }
 
 // closed-form dJ/dx0 for element `i` of sample b (i = flat per-sample index), given x0 there
 __device__ __forceinline__ float guide_grad(const SdcStepDesc& d, const float* gp, const float* gscal,
                                             const float* target, int b, int i, float x0) {
-    const float active = gscal[b * 2];
-    const int arg = __float_as_int(gscal[b * 2 + 1]);
+    const float active = gscal[b * 4];
+    const int arg = __float_as_int(gscal[b * 4 + 1]);
+    const float ext = gscal[b * 4 + 2], share = gscal[b * 4 + 3];
+    // unique extremum: the index decides (robust to re-computation); ties (clipped values): value equality is exact
+    const bool hit = share == 1.0f ? (i == arg) : (x0 == ext);
     if (d.model == SDC_MODEL_BURGERS) {
         const int H = d.d1, W = d.d2;
         const int c = i / (H * W), h = (i / W) % H;
         if (c != 2 || h >= 11) return 0.f;
         if (!d.use_max) return active * gp[0] * 10.0f / (float)(11 * W);
-        return (i == arg) ? active * gp[0] * 10.0f : 0.f;
+        return hit ? active * gp[0] * 10.0f * share : 0.f;
     }
     if (d.model == SDC_MODEL_TOKAMAK) {
         const int L = d.d1, nt = d.cond_idx;
@@ -173,7 +195,7 @@ __device__ __forceinline__ float guide_grad(const SdcStepDesc& d, const float* g
             const float tg = target[((int64_t)b * 3 + c) * nt + t];
             return gp[2] * gp[0] * 2.0f * (S * x0 - tg) * S / (float)nt;
         }
-        if (c == 1 && i == arg) return -gp[2] * gp[1] * TOK_SCALER[1] * active;
+        if (c == 1 && hit) return -gp[2] * gp[1] * TOK_SCALER[1] * active * share;
         return 0.f;
     }
     const int C = d.d1, HW = d.d2 * d.d3, F = d.d0;
@@ -198,6 +220,7 @@ __device__ __forceinline__ bool cond_value(const SdcStepDesc& d, const float* c0
     if (d.model == SDC_MODEL_TOKAMAK) {
         const int L = d.d1, nt = d.cond_idx;
         const int c = i / L, t = i % L;
+        if (d.has_wgt && c >= 3) { v = c2[((int64_t)b * 9 + (c - 3)) * L + t]; return true; }   // tokamak/...:411,453
         if (d.pad_zero && ((c < 3 && t >= nt) || (c >= 3 && t >= nt - 1))) { v = 0.f; return true; }
         if ((c == 0 || c == 2) && t < nt) { v = c1[((int64_t)b * 2 + (c >> 1)) * nt + t]; return true; }
         if (c < 3 && t == 0) { v = c0[b * 3 + c]; return true; }
@@ -206,6 +229,7 @@ __device__ __forceinline__ bool cond_value(const SdcStepDesc& d, const float* c0
     const int F = d.d0, C = d.d1, HW = d.d2 * d.d3;
     const int f = i / (C * HW), c = (i / HW) % C, p = i % HW;
     if (d.has_wgt && (c == 3 || c == 4)) { v = c1[(((int64_t)b * F + f) * 2 + (c - 3)) * HW + p]; return true; }
+    if (d.impose == 2) return false;          // control only (end of the smoke DDIM loop, 2d/ddpm/diffusion_2d.py:400-401)
     if (f == 0 && c == 0) { v = c0[(int64_t)b * HW + p]; return true; }
     return false;
 }
@@ -238,9 +262,14 @@ __global__ __launch_bounds__(NT) void step_update_kernel(const StepArgs a) {
             const float4 gv = *reinterpret_cast<const float4*>(a.gext + e0);
             gs[0] = gv.x; gs[1] = gv.y; gs[2] = gv.z; gs[3] = gv.w;
         }
-        if (d.guide == 3) {   // x0 only (caller evaluates an arbitrary nablaJ on it)
-            *reinterpret_cast<float4*>(a.x0out + e0) = make_float4(c.a * xs[0] - c.b * es[0], c.a * xs[1] - c.b * es[1],
-                                                                  c.a * xs[2] - c.b * es[2], c.a * xs[3] - c.b * es[3]);
+        if (d.guide == 3) {   // x0 only (caller evaluates an arbitrary nablaJ on it); DDIM hands over the clipped x0
+            float q[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                q[j] = c.a * xs[j] - c.b * es[j];
+                if (d.ddim) q[j] = fminf(fmaxf(q[j], -1.0f), 1.0f);
+            }
+            *reinterpret_cast<float4*>(a.x0out + e0) = make_float4(q[0], q[1], q[2], q[3]);
             continue;
         }
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -253,16 +282,26 @@ __global__ __launch_bounds__(NT) void step_update_kernel(const StepArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float e = es[j];
+            const bool ddim = d.ddim != 0;
             if (d.guide == 1) {
-                const float x0 = c.a * xs[j] - c.b * e;
+                float x0 = c.a * xs[j] - c.b * e;
+                if (ddim) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
                 e = e + guide_grad(d, a.gpar, a.gscal, a.target, b, i0 + j, x0) * c.k;
             } else if (d.guide == 2) {
                 e = e + gs[j] * c.k;
             }
             float x0 = c.a * xs[j] - c.b * e;
-            if (d.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            if (d.clip || ddim) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
             x0c[j] = x0;
-            float o = c.c1 * x0 + c.c2 * xs[j] + c.sig * zs[j];
+            float o;
+            if (!ddim) {
+                o = c.c1 * x0 + c.c2 * xs[j] + c.sig * zs[j];
+            } else if (c.last != 0.f) {
+                o = x0;                                              // time_next < 0: img = x_start
+            } else {
+                const float er = (c.a * xs[j] - x0) / c.b;           // rederive_pred_noise (:272-273)
+                o = x0 * c.c1 + c.c2 * er + c.sig * zs[j];           // x0 sqrt(a_next) + c eps + sigma z (:508-510)
+            }
             if (d.impose) {
                 float cv;
                 if (cond_value(d, a.c0, a.c1, a.c2, b, i0 + j, cv)) o = cv;
@@ -290,6 +329,15 @@ __global__ __launch_bounds__(NT) void randn_kernel(float* __restrict__ x, int64_
         *reinterpret_cast<float4*>(x + v * 4) = philox_normal4(seed, (uint32_t)draw, (uint64_t)v);
 }
 
+__global__ void advance_table_kernel(int32_t* idx_dev, int32_t* t_dev, const int32_t* ttab, int32_t* draw_dev, int ddraw) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int i = *idx_dev + 1;
+        *idx_dev = i;
+        *t_dev = ttab[i];
+        if (draw_dev) *draw_dev += ddraw;
+    }
+}
+
 __global__ void advance_kernel(int32_t* t_dev, int dt, int32_t* draw_dev, int ddraw) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (t_dev) *t_dev += dt;
@@ -308,9 +356,9 @@ __global__ __launch_bounds__(NT) void conformal_kernel(const SdcStepDesc d, cons
     const int64_t per = (int64_t)d.d0 * d.d1 * d.d2 * d.d3;
     const float* pb = pred + b * per;
     const float* tb = truth + b * per;
-    float fp, ft; int arg;
-    safety_functional(d, [&](int i) { return pb[i]; }, shf, shi, fp, arg);
-    safety_functional(d, [&](int i) { return tb[i]; }, shf, shi, ft, arg);
+    float fp, ft, raw; int arg, ties;
+    safety_functional(d, [&](int i) { return pb[i]; }, shf, shi, fp, arg, ties, raw);
+    safety_functional(d, [&](int i) { return tb[i]; }, shf, shi, ft, arg, ties, raw);
     float J, sc;
     if (d.model == SDC_MODEL_BURGERS) {
         sc = fabsf(fp - ft);
@@ -389,6 +437,7 @@ int sdc_step_update(const SdcStepDesc* d, const float* x, const float* eps, cons
         SDC_REQUIRE(c0, SDC_ENULL, "sdc_step_update: impose needs c0");
         SDC_REQUIRE(d->model == SDC_MODEL_SMOKE || c1, SDC_ENULL, "sdc_step_update: impose needs c1");
         SDC_REQUIRE(!d->has_wgt || (d->model == SDC_MODEL_SMOKE ? c1 : c2), SDC_ENULL, "sdc_step_update: has_wgt needs its tensor");
+        SDC_REQUIRE(d->impose != 2 || d->model == SDC_MODEL_SMOKE, SDC_EINVAL, "sdc_step_update: impose=2 is smoke-only");
     }
     const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(eps) | reinterpret_cast<uintptr_t>(xout) |
                          reinterpret_cast<uintptr_t>(x0out) | reinterpret_cast<uintptr_t>(gext) | reinterpret_cast<uintptr_t>(noise);
@@ -423,6 +472,13 @@ int sdc_randn(float* x, int64_t n, uint64_t seed, const int32_t* draw_dev, void*
 int sdc_advance(int32_t* t_dev, int dt, int32_t* draw_dev, int ddraw, void* stream) {
     hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, sdc::as_stream(stream), t_dev, dt, draw_dev, ddraw);
     return sdc::check_launch("sdc_advance");
+}
+
+int sdc_advance_table(int32_t* idx_dev, int32_t* t_dev, const int32_t* ttab, int32_t* draw_dev, int ddraw, void* stream) {
+    SDC_REQUIRE(idx_dev && t_dev && ttab, SDC_ENULL, "sdc_advance_table: null pointer");
+    hipLaunchKernelGGL(advance_table_kernel, dim3(1), dim3(64), 0, sdc::as_stream(stream), idx_dev, t_dev, ttab, draw_dev,
+                       ddraw);
+    return sdc::check_launch("sdc_advance_table");
 }
 
 int sdc_conformal_score(const SdcStepDesc* d, const float* pred, const float* truth, const float* target,

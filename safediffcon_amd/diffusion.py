@@ -157,9 +157,10 @@ class _State:
     def __init__(self, dev, B, per, T):
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)  # noqa: E731
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.idx_dev = torch.zeros(1, dtype=torch.int32, device=dev)     # DDIM: step number (row of coef / ttab)
         self.draw_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.gpar = z(8)
-        self.gscal = z(2 * B)
+        self.gscal = z(4 * B)
         self.noise = None            # single-slot injected-noise buffer
         self.x0 = None
         self.cond = {}               # name -> persistent device buffer
@@ -204,6 +205,30 @@ class _SamplerBase(nn.Module):
             c[:, 5] = torch.tensor([float(J_scheduler(t)) for t in range(T)]) * k_const
         return c.to(self.betas.device)
 
+    def _coef_ddim(self, J_scheduler, k_const=1.0):
+        """DDIM rows in step order, {a, b, sqrt(alpha_next), c, sigma, k, last, 0}, and the timestep of every step.
+        Scalars are formed with fp32 tensor arithmetic exactly like ddim_sample does (1D/model/diffusion.py:500-504)."""
+        T, S, eta = self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
+        times = torch.linspace(-1, T - 1, steps=S + 1)
+        times = list(reversed(times.int().tolist()))
+        pairs = list(zip(times[:-1], times[1:]))
+        ac = self.alphas_cumprod.cpu()
+        c = torch.zeros(len(pairs), 8, dtype=torch.float32)
+        for i, (time, nxt) in enumerate(pairs):
+            c[i, 0] = self.sqrt_recip_alphas_cumprod.cpu()[time]
+            c[i, 1] = self.sqrt_recipm1_alphas_cumprod.cpu()[time]
+            c[i, 5] = (float(J_scheduler(time)) if J_scheduler is not None else 1.0) * k_const
+            if nxt < 0:
+                c[i, 6] = 1.0
+                continue
+            alpha, alpha_next = ac[time], ac[nxt]
+            sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            c[i, 2] = alpha_next.sqrt()
+            c[i, 3] = (1 - alpha_next - sigma ** 2).sqrt()
+            c[i, 4] = sigma
+        ttab = torch.tensor([p[0] for p in pairs] + [0], dtype=torch.int32)
+        return c.to(self.betas.device), ttab.to(self.betas.device)
+
     def _state(self, B, per):
         key = (B, per, str(self.betas.device))
         if key not in self._states:
@@ -237,19 +262,23 @@ class _SamplerBase(nn.Module):
         buf.copy_(t)
         return buf
 
-    def _tail(self, st, ent, d, coef, guide_spec, target, c0, c1, c2, noise_buf, advance=True):
-        """Plan with the post-U-Net part of one step: [guide_reduce] -> step_update (x in place) -> advance."""
+    def _tail(self, st, ent, d, coef, guide_spec, target, c0, c1, c2, noise_buf, advance=True, ttab=None):
+        """Plan with the post-U-Net part of one step: [guide_reduce] -> step_update (x in place) -> advance.
+        DDPM: coefficient row = timestep (st.t_dev); DDIM (ttab given): row = step number (st.idx_dev)."""
         p = Plan(self.betas.device)
         lib = self._lib
         x, eps = ent["x"], ent["eps"]
         ptr = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
-        p.keep += [d, coef, x, eps, c0, c1, c2, target, noise_buf]
+        p.keep += [d, coef, x, eps, c0, c1, c2, target, noise_buf, ttab]
+        row = st.t_dev if ttab is None else st.idx_dev
         if d.guide == 1:
-            p._emit(lib.sdc_guide_reduce, C.byref(d), ptr(x), ptr(eps), ptr(coef), ptr(st.t_dev), ptr(st.gpar), ptr(st.gscal))
-        p._emit(lib.sdc_step_update, C.byref(d), ptr(x), ptr(eps), 0, ptr(coef), ptr(st.t_dev), ptr(st.draw_dev),
+            p._emit(lib.sdc_guide_reduce, C.byref(d), ptr(x), ptr(eps), ptr(coef), ptr(row), ptr(st.gpar), ptr(st.gscal))
+        p._emit(lib.sdc_step_update, C.byref(d), ptr(x), ptr(eps), 0, ptr(coef), ptr(row), ptr(st.draw_dev),
                 ptr(noise_buf), 0, ptr(st.gpar), ptr(st.gscal), ptr(target), ptr(c0), ptr(c1), ptr(c2), ptr(x), 0)
-        if advance:
+        if advance and ttab is None:
             p._emit(lib.sdc_advance, ptr(st.t_dev), -1, ptr(st.draw_dev), 1 + d.skip_draws)
+        elif advance:
+            p._emit(lib.sdc_advance_table, ptr(st.idx_dev), ptr(st.t_dev), ptr(ttab), ptr(st.draw_dev), 1)
         return p
 
     def _dispatch(self, prepare, B, dims, **kw):
@@ -262,7 +291,7 @@ class _SamplerBase(nn.Module):
         return self._reverse_loop(B, dims, **kw)
 
     def _reverse_loop(self, B, dims, *, noise, guide, J_scheduler, k_const, cond, flags, impose_last, target=None,
-                      final_update=True):
+                      final_update=True, ddim=False, control_at_end=False):
         """Shared DDPM loop.  `guide`: None | GuidanceSpec | callable.  `cond`: (c0, c1, c2) tensors or None.
         `noise`: None (Philox in-kernel) or callable i -> tensor (injected, parity runs)."""
         dev = self.betas.device
@@ -277,14 +306,15 @@ class _SamplerBase(nn.Module):
         with torch.cuda.stream(self._side):
             out = self._reverse_loop_on_stream(B, dims, noise=noise, guide=guide, J_scheduler=J_scheduler, k_const=k_const,
                                                cond=cond, flags=flags, impose_last=impose_last, target=target,
-                                               final_update=final_update)
+                                               final_update=final_update, ddim=ddim, control_at_end=control_at_end)
         cur.wait_stream(self._side)
         return out
 
     def _reverse_loop_on_stream(self, B, dims, *, noise, guide, J_scheduler, k_const, cond, flags, impose_last, target,
-                                final_update):
+                                final_update, ddim, control_at_end):
         S = self._setup(B, dims, noise=noise, guide=guide, J_scheduler=J_scheduler, k_const=k_const, cond=cond,
-                        flags=flags, impose_last=impose_last, target=target, final_update=final_update)
+                        flags=flags, impose_last=impose_last, target=target, final_update=final_update, ddim=ddim,
+                        control_at_end=control_at_end)
         try:
             S.init()
             for _ in range(S.n_main):
@@ -295,7 +325,7 @@ class _SamplerBase(nn.Module):
             S.close()
 
     def _setup(self, B, dims, *, noise, guide, J_scheduler, k_const, cond, flags, impose_last, target=None,
-               final_update=True):
+               final_update=True, ddim=False, control_at_end=False):
         """Bind everything one sample() needs and return a _Loop: init() draws x_T and imposes the conditions,
         step() runs one denoising step (a hipGraph launch when possible), final() the last, un-imposed step."""
         dev = self.betas.device
@@ -313,7 +343,14 @@ class _SamplerBase(nn.Module):
             net.bind_cond(ent, st.t_dev)
         L = _Loop()
         L.gd, L.st, L.ent, L.x, L.eps, L.T, L.B, L.shape = self, st, ent, ent["x"], ent["eps"], T, B, shape
-        L.coef = self._coef(J_scheduler, k_const)
+        L.ddim, L.ttab, L.control_at_end = ddim, None, control_at_end
+        if ddim:
+            L.coef, L.ttab = self._coef_ddim(J_scheduler, k_const)
+            flags = {**flags, "ddim": 1}
+            impose_last = False                      # the last DDIM step returns x_start un-imposed (:495-498)
+        else:
+            L.coef = self._coef(J_scheduler, k_const)
+        L.nsteps = int(L.coef.shape[0])
         L.c0 = self._persist(st, "c0", cond[0])
         L.c1 = self._persist(st, "c1", cond[1])
         L.c2 = self._persist(st, "c2", cond[2])
@@ -330,15 +367,16 @@ class _SamplerBase(nn.Module):
             st.noise = torch.empty(B * per, dtype=torch.float32, device=dev)
         L.nbuf = st.noise if noise is not None else None
         L.skip = flags.get("skip_draws", 0)
-        L.impose_last, L.final_update = impose_last, final_update
-        L.n_main = T if impose_last else T - 1
+        L.impose_last, L.final_update = impose_last, final_update or ddim
+        L.n_main = L.nsteps if impose_last else L.nsteps - 1
         L.mk = lambda **kw: self._desc(B, dims, **{**flags, "seed": L.seed, **kw})  # noqa: E731
         L.d_init = L.mk(impose=1)
         if not L.external:
             gmode = 1 if L.fused else 0
-            L.tail = self._tail(st, ent, L.mk(guide=gmode, impose=1), L.coef, guide, L.tgt, L.c0, L.c1, L.c2, L.nbuf)
+            L.tail = self._tail(st, ent, L.mk(guide=gmode, impose=1), L.coef, guide, L.tgt, L.c0, L.c1, L.c2, L.nbuf,
+                                ttab=L.ttab)
             L.tail_last = self._tail(st, ent, L.mk(guide=gmode, impose=1 if impose_last else 0), L.coef, guide, L.tgt,
-                                     L.c0, L.c1, L.c2, L.nbuf)
+                                     L.c0, L.c1, L.c2, L.nbuf, ttab=L.ttab)
         else:
             if st.x0 is None:
                 st.x0 = torch.empty_like(L.x)
@@ -365,9 +403,13 @@ class _Loop:
             st.draw_dev.zero_()
             check(lib.sdc_randn(x.data_ptr(), x.numel(), self.seed, st.draw_dev.data_ptr(), stream), "sdc_randn")
         check(lib.sdc_impose(C.byref(self.d_init), x.data_ptr(), p(self.c0), p(self.c1), p(self.c2), stream), "sdc_impose")
-        st.t_dev.fill_(self.T - 1)
+        if self.ddim:
+            st.idx_dev.zero_()
+            st.t_dev.copy_(self.ttab[:1])
+        else:
+            st.t_dev.fill_(self.T - 1)
         st.draw_dev.fill_(1)
-        self.draw_i, self.t_host = 1, self.T - 1
+        self.draw_i, self.t_host = 1, self.nsteps - 1            # t_host counts the steps still to run, minus one
         if self.use_graph and self.graph is None:
             # one capture per bound loop: the descriptors carry this call's Philox seed
             check(lib.sdc_graph_begin(stream), "sdc_graph_begin")
@@ -408,22 +450,31 @@ class _Loop:
         # arbitrary guidance callable: x0 kernel -> callable (torch, on device) -> update kernel
         lib, st, p, stream = self.gd._lib, self.st, self._ptr, self.gd._stream()
         x, eps = self.x, self.eps
+        row = st.idx_dev if self.ddim else st.t_dev
         self._feed_noise()
         self.ent["plan"].run(stream)
-        check(lib.sdc_step_update(C.byref(self.d_x0), p(x), p(eps), 0, p(self.coef), p(st.t_dev), p(st.draw_dev), 0, 0, 0,
+        check(lib.sdc_step_update(C.byref(self.d_x0), p(x), p(eps), 0, p(self.coef), p(row), p(st.draw_dev), 0, 0, 0,
                                   0, 0, 0, 0, 0, 0, p(st.x0), stream), "sdc_step_update[x0]")
         g = self.guide(st.x0.view(self.shape))
         gk = (g if isinstance(g, torch.Tensor) else torch.zeros_like(x) + g).to(torch.float32).contiguous()
         d_up = self.mk(guide=2, impose=(0 if (last and not self.impose_last) else 1))
-        check(lib.sdc_step_update(C.byref(d_up), p(x), p(eps), p(gk), p(self.coef), p(st.t_dev), p(st.draw_dev),
+        check(lib.sdc_step_update(C.byref(d_up), p(x), p(eps), p(gk), p(self.coef), p(row), p(st.draw_dev),
                                   p(self.nbuf), 0, 0, 0, 0, p(self.c0), p(self.c1), p(self.c2), p(x), 0, stream),
               "sdc_step_update[ext]")
-        check(lib.sdc_advance(p(st.t_dev), -1, p(st.draw_dev), 1 + self.skip, stream), "sdc_advance")
+        if self.ddim:
+            check(lib.sdc_advance_table(p(st.idx_dev), p(st.t_dev), p(self.ttab), p(st.draw_dev), 1, stream), "sdc_advance_table")
+        else:
+            check(lib.sdc_advance(p(st.t_dev), -1, p(st.draw_dev), 1 + self.skip, stream), "sdc_advance")
         self.t_host -= 1
 
     def final(self):
         if not self.impose_last:
             self.step(last=True)
+        if self.control_at_end and self.c1 is not None:
+            # smoke DDIM: after the loop only the control channels are written back (2d/ddpm/diffusion_2d.py:400-401)
+            d = self.mk(impose=2)
+            check(self.gd._lib.sdc_impose(C.byref(d), self.x.data_ptr(), self._ptr(self.c0), self._ptr(self.c1),
+                                          self._ptr(self.c2), self.gd._stream()), "sdc_impose[control]")
 
     def close(self):
         if self.graph is not None:
@@ -466,8 +517,7 @@ class GaussianDiffusionBurgers(_SamplerBase):
         """Reference signature (1D/model/diffusion.py:557-607) + ``noise`` (i -> tensor) for injected-noise parity."""
         if "guidance_u0" in kwargs:
             self.guidance_u0 = kwargs["guidance_u0"]
-        if self.is_ddim_sampling:
-            raise NotImplementedError("DDIM sampling is a 'next' row (SURVEY 8f); use sampling_timesteps == timesteps")
+        ddim = self.is_ddim_sampling        # ddim_sample (:451-555); the enable_grad tail returns the same numbers, no autograd graph
         if not (self.is_condition_u0 and self.is_condition_uT):
             raise NotImplementedError("built for is_condition_u0 = is_condition_uT = True (1D/configs/*)")
         assert kwargs.get("u_init") is not None and kwargs.get("u_final") is not None
@@ -481,13 +531,14 @@ class GaussianDiffusionBurgers(_SamplerBase):
         if isinstance(guide, BurgersGuidance):
             flags["use_max"] = 0 if guide.use_max_safety else 1
         if not self.guidance_u0:
-            if nablaJ is not None:
+            if nablaJ is not None and not ddim:
                 raise NotImplementedError("guidance on x_t (guidance_u0=False with nablaJ) is unused by the reference pipelines")
-            flags["skip_draws"] = 1          # calibration branch draws twice per step (:421-423)
+            if not ddim:
+                flags["skip_draws"] = 1      # DDPM calibration branch draws twice per step (:421-423)
             guide = None
         return self._dispatch(kwargs.get("_prepare", False), batch_size, (C_, H, W, 1), noise=noise, guide=guide,
                               J_scheduler=J_sched, k_const=1.0, cond=(kwargs["u_init"], kwargs["u_final"], w_groundtruth),
-                              flags=flags, impose_last=False, final_update=self.guidance_u0 or not enable_grad)
+                              flags=flags, impose_last=False, final_update=self.guidance_u0 or not enable_grad, ddim=ddim)
 
 
 class GaussianDiffusionTokamak(_SamplerBase):
@@ -517,29 +568,30 @@ class GaussianDiffusionTokamak(_SamplerBase):
         """Reference signature (tokamak/model/diffusion.py:498-539)."""
         if "guidance_u0" in kwargs:
             self.guidance_u0 = kwargs["guidance_u0"]
-        if self.is_ddim_sampling:
-            raise NotImplementedError("DDIM sampling is a 'next' row (SURVEY 8f); use sampling_timesteps == timesteps")
+        ddim = self.is_ddim_sampling
         if not (self.is_condition_u0 and self.is_condition_uT):
             raise NotImplementedError("built for is_condition_u0 = is_condition_uT = True")
         assert kwargs.get("u_init") is not None and kwargs.get("u_final") is not None
-        if w_groundtruth is not None:
+        if w_groundtruth is not None and not ddim:
             # the reference's DDPM path executes ``img[:,1,:,:] = w_groundtruth`` on a 3-D tensor (:335-336)
             raise IndexError("too many indices for tensor of dimension 3")
         nablaJ, J_sched = kwargs.get("nablaJ"), kwargs.get("J_scheduler")
-        flags = dict(clip=1 if clip_denoised else 0, cond_idx=self.nt, pad_zero=0 if self.train_on_padded_locations else 1)
+        flags = dict(clip=1 if clip_denoised else 0, cond_idx=self.nt, pad_zero=0 if self.train_on_padded_locations else 1,
+                     has_wgt=0 if w_groundtruth is None else 1)
         guide, target = nablaJ, None
         if isinstance(guide, TokamakGuidance):
             target = guide.target
             assert tuple(target.shape) == (batch_size, 3, self.nt), "target must be (B, 3, nt)"
         if not self.guidance_u0:
-            if nablaJ is not None:
+            if nablaJ is not None and not ddim:
                 raise NotImplementedError("guidance on x_t (guidance_u0=False with nablaJ) is unused by the reference pipelines")
-            flags["skip_draws"] = 1
+            if not ddim:
+                flags["skip_draws"] = 1
             guide = None
         return self._dispatch(kwargs.get("_prepare", False), batch_size, (self.channels, self.seq_length, 1, 1), noise=noise,
-                              guide=guide, J_scheduler=J_sched, k_const=1.0, cond=(kwargs["u_init"], kwargs["u_final"], None),
-                              flags=flags, impose_last=False, target=target,
-                              final_update=self.guidance_u0 or not enable_grad)
+                              guide=guide, J_scheduler=J_sched, k_const=1.0,
+                              cond=(kwargs["u_init"], kwargs["u_final"], w_groundtruth), flags=flags, impose_last=False,
+                              target=target, final_update=self.guidance_u0 or not enable_grad, ddim=ddim)
 
 
 class GaussianDiffusionSmoke(_SamplerBase):
@@ -562,14 +614,13 @@ class GaussianDiffusionSmoke(_SamplerBase):
     def sample(self, batch_size=16, design_fn=None, enable_grad=False, init=None, control=None, device=None, noise=None,
                _prepare=False):
         """Reference signature (2d/ddpm/diffusion_2d.py:406-414)."""
-        if self.is_ddim_sampling:
-            raise NotImplementedError("DDIM sampling is a 'next' row (SURVEY 8f); use sampling_timesteps == timesteps")
+        ddim = self.is_ddim_sampling                  # ddim_sample, 2d/ddpm/diffusion_2d.py:324-404
         assert init is not None and batch_size == init.shape[0]
         flags = dict(clip=1, has_wgt=0 if control is None else 1)
         S = self.image_size
         return self._dispatch(_prepare, batch_size, (self.frames, self.channels, S, S), noise=noise, guide=design_fn,
                               J_scheduler=None, k_const=float(self.standard_fixed_ratio), cond=(init, control, None),
-                              flags=flags, impose_last=True)
+                              flags=flags, impose_last=True, ddim=ddim, control_at_end=ddim)
 
 
 # reference-compatible alias: each reference tree calls its class ``GaussianDiffusion``

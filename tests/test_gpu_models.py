@@ -197,3 +197,59 @@ def test_graph_and_eager_paths_agree_and_conditions_hold(golden):
     init, control = det_tensor((2, 16, 16), 6, 0.2).abs().to(DEV), det_tensor((2, 8, 2, 16, 16), 7, 0.3).to(DEV)
     out = gs.sample(batch_size=2, init=init, control=control)
     assert torch.equal(out[:, 0, 0], init) and torch.equal(out[:, :, 3:5], control)
+
+
+# ------------------------------------------------------------------ DDIM (eta = 1, 5 of 20 steps) vs reference fixtures
+def test_ddim_trajectories_golden(golden):
+    g = golden("burgers_ddim_guided")
+    T, S, eta = int(g.scalar("T")), int(g.scalar("S")), g.scalar("eta")
+    net = _load(sdc.Unet2D(dim=8, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1), golden("burgers_unet").spec(), 100)
+    gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=T, sampling_timesteps=S, ddim_sampling_eta=eta,
+                                      temporal=True, use_conv2d=True, is_condition_u0=True, is_condition_uT=True,
+                                      condition_idx=10, train_on_padded_locations=False).to(DEV)
+    noise = det_noise((2, 3, 16, 128), int(g.scalar("noise_seed")))
+    guid = sdc.BurgersGuidance(g.scalar("Q"), g.scalar("w_score"), g.scalar("u_bound"))
+    out = gd.sample(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True, nablaJ=guid,
+                    J_scheduler=lambda t: 1.0, enable_grad=False, noise=noise).cpu()
+    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    out = gd.sample(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True,
+                    nablaJ=lambda x: guid(x), enable_grad=False, noise=noise).cpu()          # opaque-callable route
+    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    g = golden("burgers_ddim_calib")
+    out = gd.sample(batch_size=2, clip_denoised=True, guidance_u0=False, u_init=g["u0"], u_final=g["uT"],
+                    w_groundtruth=g["w_gt"], nablaJ=None, enable_grad=False, noise=noise).cpu()
+    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    # Philox + hipGraph route: bit-identical to the eager call list, finite
+    gd.guidance_u0 = True
+    outs = []
+    for use_graph in (True, False):
+        gd.use_graph = use_graph
+        torch.manual_seed(3)
+        outs.append(gd.sample(batch_size=2, u_init=g["u0"], u_final=g["uT"], guidance_u0=True, nablaJ=guid, enable_grad=False))
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
+
+    g = golden("tokamak_ddim_guided")
+    net = _load(sdc.Unet1D(dim=8, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1), golden("tokamak_unet").spec(), 200)
+    gt = sdc.GaussianDiffusionTokamak(net, seq_length=128, nt=122, timesteps=T, sampling_timesteps=S, ddim_sampling_eta=eta).to(DEV)
+    noise = det_noise((2, 12, 128), int(g.scalar("noise_seed")))
+    guid = sdc.TokamakGuidance(g["target"], 122, g.scalar("w_obj"), g.scalar("w_safe"), g.scalar("scaler"), g.scalar("Q"),
+                               g.scalar("thr"))
+    out = gt.sample(batch_size=2, guidance_u0=True, u_init=g["u0"], u_final=g["uT"], nablaJ=guid, enable_grad=False,
+                    noise=noise).cpu()
+    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    g = golden("tokamak_ddim_calib")
+    out = gt.sample(batch_size=2, guidance_u0=False, u_init=g["u0"], u_final=g["uT"], w_groundtruth=g["w_gt"], nablaJ=None,
+                    enable_grad=False, noise=noise).cpu()
+    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+
+    g = golden("smoke_ddim_guided")
+    net = _load(sdc.Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2, 4), channels=7), golden("smoke_unet").spec(), 300)
+    gs = sdc.GaussianDiffusionSmoke(net, image_size=16, frames=8, timesteps=T, sampling_timesteps=S, ddim_sampling_eta=eta,
+                                    loss_type="l2", standard_fixed_ratio=g.scalar("ratio")).to(DEV)
+    noise = det_noise((2, 8, 7, 16, 16), int(g.scalar("noise_seed")))
+    out = gs.sample(batch_size=2, design_fn=sdc.SmokeGuidance(g.scalar("Q"), g.scalar("w_safe"), g.scalar("safe_bound")),
+                    init=g["init"], noise=noise).cpu()
+    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    g = golden("smoke_ddim_calib")
+    out = gs.sample(batch_size=2, design_fn=None, init=g["init"], control=g["control"], noise=noise).cpu()
+    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)

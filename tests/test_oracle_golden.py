@@ -166,3 +166,47 @@ def test_smoke_trajectories(golden):
     g = golden("smoke_traj_calib")
     out = samplers.sample_smoke(eps, tabs, 2, noise, init=g["init"], control=g["control"], shape=(8, 7, 16, 16))
     torch.testing.assert_close(out, g["out"], rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------ DDIM
+def test_ddim_trajectories(golden):
+    g = golden("burgers_ddim_guided")
+    P = det_params(_spec(golden, "burgers_unet"), int(g.scalar("weight_seed")))
+    T, S, eta = int(g.scalar("T")), int(g.scalar("S")), g.scalar("eta")
+    tabs = schedules.make_tables("cosine", T)
+    noise = det_noise((2, 3, 16, 128), int(g.scalar("noise_seed")))
+    eps = _eps_fn(nets.unet_burgers, P, int(g.scalar("dim")))
+    out = samplers.ddim_burgers(eps, tabs, 2, noise, S=S, eta=eta, u_init=g["u0"], u_final=g["uT"],
+                                nablaJ=samplers.burgers_guidance(g.scalar("Q"), g.scalar("w_score"), g.scalar("u_bound")))
+    torch.testing.assert_close(out, g["out"], rtol=1e-4, atol=1e-5)
+    assert int(g.scalar("draws")) == S                       # x_T + one draw per non-final step
+    g = golden("burgers_ddim_calib")
+    out = samplers.ddim_burgers(eps, tabs, 2, noise, S=S, eta=eta, u_init=g["u0"], u_final=g["uT"], guidance_u0=False,
+                                w_groundtruth=g["w_gt"])
+    torch.testing.assert_close(out, g["out"], rtol=1e-4, atol=1e-5)
+
+    g = golden("tokamak_ddim_guided")
+    P = det_params(_spec(golden, "tokamak_unet"), int(g.scalar("weight_seed")))
+    noise = det_noise((2, 12, 128), int(g.scalar("noise_seed")))
+    eps = _eps_fn(nets.unet_tokamak, P, int(g.scalar("dim")))
+    nablaJ = samplers.tokamak_guidance(g["target"], 122, g.scalar("Q"), g.scalar("thr"), g.scalar("w_obj"),
+                                       g.scalar("w_safe"), g.scalar("scaler"))
+    out = samplers.ddim_tokamak(eps, tabs, 2, noise, S=S, eta=eta, u_init=g["u0"], u_final=g["uT"], nablaJ=nablaJ)
+    torch.testing.assert_close(out, g["out"], rtol=1e-4, atol=1e-5)
+    g = golden("tokamak_ddim_calib")
+    out = samplers.ddim_tokamak(eps, tabs, 2, noise, S=S, eta=eta, u_init=g["u0"], u_final=g["uT"], guidance_u0=False,
+                                w_groundtruth=g["w_gt"])
+    torch.testing.assert_close(out, g["out"], rtol=1e-4, atol=1e-5)
+
+    g = golden("smoke_ddim_guided")
+    P = det_params(_spec(golden, "smoke_unet"), int(g.scalar("weight_seed")))
+    tabs = schedules.make_tables("sigmoid", T)
+    noise = det_noise((2, 8, 7, 16, 16), int(g.scalar("noise_seed")))
+    eps = _eps_fn(nets.unet_smoke, P, int(g.scalar("dim")))
+    out = samplers.ddim_smoke(eps, tabs, 2, noise, S=S, eta=eta, init=g["init"], ratio=g.scalar("ratio"),
+                              design_fn=samplers.smoke_guidance(g.scalar("Q"), g.scalar("w_safe"), g.scalar("safe_bound")),
+                              shape=(8, 7, 16, 16))
+    torch.testing.assert_close(out, g["out"], rtol=1e-4, atol=1e-5)
+    g = golden("smoke_ddim_calib")
+    out = samplers.ddim_smoke(eps, tabs, 2, noise, S=S, eta=eta, init=g["init"], control=g["control"], shape=(8, 7, 16, 16))
+    torch.testing.assert_close(out, g["out"], rtol=1e-4, atol=1e-5)
