@@ -235,6 +235,156 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs a) {
     for (int d = 0; d < DH; ++d) a.out[og + (int64_t)d * a.osc] = o[d] * inv;
 }
 
+// ------------------------------------------------------------------ temporal attention on the matrix cores
+// 32 frames x dim_head 32 is exactly one v_mfma_f32_32x32x2_f32 tile per product:
+//   S^T[key][query] = K . Q^T   (16 k-steps over d)      -> scores of one query sit in ONE lane's registers
+//   O[query][d]     = P^T . V   (16 k-steps over keys)   -> the P registers are the A operand as they stand
+// A workgroup owns 8 adjacent pixels (32-byte runs of the channel-major tensor) of one head; Q and K are staged
+// through LDS transposed to [pixel][d][frame], V to [pixel][frame][d] (loaded early, kept in registers while
+// Q.K^T runs, written over the Q tile afterwards); rotary + rel-pos bias + softmax run on the accumulators; the
+// output goes back through LDS so that global stores are 32-byte runs again.  Workgroups are numbered so that the
+// 4 pixel groups sharing a 128-byte line land on the same XCD (speed only).
+constexpr int TA_NS = 8;                 // sequences (adjacent pixels) per workgroup
+constexpr int TA_SQ = 32 * 32 + 8;       // LDS floats per pixel, [d][f] image (+8: bank spread of the transposing store)
+constexpr int TA_SV = 32 * 33 + 8;       // LDS floats per pixel, [f][d] image with a 33-float frame pitch
+
+__global__ __launch_bounds__(NT) void tattn_kernel(const AttnArgs a) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    __shared__ float Ks[TA_NS * TA_SQ];
+    __shared__ float QVs[TA_NS * TA_SV];         // Q ([d][f], TA_SQ pitch) first, then V / O ([f][d], TA_SV pitch)
+    __shared__ float biasT[32][33];              // [key][query] of this head
+    __shared__ float rotc[32][16], rots[32][16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    // XCD-aware numbering: consecutive logical ids stay on one XCD
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int head = bid % a.heads;
+    const int grp = bid / a.heads;
+    const int seq0 = grp * TA_NS;
+    const int o = seq0 / a.inner, i0 = seq0 - o * a.inner;
+    const float* qb = a.qkv + o * a.so + i0 + (int64_t)(head * DH) * a.sc;
+    const float* kb = qb + (int64_t)(a.heads * DH) * a.sc;
+    const float* vb = kb + (int64_t)(a.heads * DH) * a.sc;
+    const float scale = 0.17677669529663687f;
+
+    // ---- stage Q (scaled) and K: element e = tid + 256*it -> (d = e>>8, f = (e>>3)&31, hw = e&7)
+    float vreg[32];
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+        const int e = tid + it * NT;
+        const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
+        const int64_t g = (int64_t)d * a.sc + (int64_t)f * a.st + hw;
+        Ks[hw * TA_SQ + d * 32 + f] = kb[g];
+        QVs[hw * TA_SQ + d * 32 + f] = qb[g] * scale;
+    }
+    // V is only needed after the softmax: issue its loads now, park them in registers
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+        const int e = tid + it * NT;
+        const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
+        vreg[it] = vb[(int64_t)d * a.sc + (int64_t)f * a.st + hw];
+    }
+    for (int e = tid; e < 32 * 32; e += NT) {
+        const int q = e >> 5, kk = e & 31;
+        biasT[kk][q] = a.bias ? a.bias[((int64_t)head * 32 + q) * 32 + kk] : 0.0f;
+    }
+    if (a.rot)
+        for (int e = tid; e < 32 * 16; e += NT) {
+            rotc[e >> 4][e & 15] = a.rot[e * 2];
+            rots[e >> 4][e & 15] = a.rot[e * 2 + 1];
+        }
+    __syncthreads();
+    if (a.rot) {
+        // rotate (d = 2m, 2m+1) pairs of Q and K in place; angle = frame * freq[m]
+        for (int e = tid; e < TA_NS * 16 * 32; e += NT) {
+            const int f = e & 31, m = (e >> 5) & 15, hw = e >> 9;
+            const float c = rotc[f][m], sn = rots[f][m];
+            const int l0 = hw * TA_SQ + (2 * m) * 32 + f, l1 = l0 + 32;
+            float x0 = Ks[l0], x1 = Ks[l1];
+            Ks[l0] = x0 * c - x1 * sn; Ks[l1] = x1 * c + x0 * sn;
+            x0 = QVs[l0]; x1 = QVs[l1];
+            QVs[l0] = x0 * c - x1 * sn; QVs[l1] = x1 * c + x0 * sn;
+        }
+        __syncthreads();
+    }
+
+    // ---- S^T = K . Q^T, softmax over keys; wave w owns pixels 2w and 2w+1
+    f32x16 p[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int hw = wave * 2 + u;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float af = Ks[hw * TA_SQ + (2 * s + lh) * 32 + l31];      // A[key][d]
+            const float bf = QVs[hw * TA_SQ + (2 * s + lh) * 32 + l31];     // B[d][query]
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+        }
+        // lane (query = l31, half lh) holds keys (r&3) + 8*(r>>2) + 4*lh
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[r] += biasT[(r & 3) + 8 * (r >> 2) + 4 * lh][l31];
+            mx = fmaxf(mx, acc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = expf(acc[r] - mx); sum += acc[r]; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] *= inv;
+        p[u] = acc;
+    }
+    __syncthreads();                              // every wave is done with the Q tile
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+        const int e = tid + it * NT;
+        const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
+        QVs[hw * TA_SV + f * 33 + d] = vreg[it];
+    }
+    __syncthreads();
+
+    // ---- O = P^T . V : k-step r pairs key (r&3)+8*(r>>2) [half 0] with that key + 4 [half 1] -- exactly register r
+    f32x16 oacc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int hw = wave * 2 + u;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float bf = QVs[hw * TA_SV + key * 33 + l31];              // B[key][d]
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p[u][r], bf, acc, 0, 0, 0);   // A[query][key] = P^T
+        }
+        oacc[u] = acc;
+    }
+    __syncthreads();                              // V no longer needed: reuse its tile for the output image
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int hw = wave * 2 + u;
+        // lane (d = l31, half lh) holds queries (r&3) + 8*(r>>2) + 4*lh
+#pragma unroll
+        for (int r = 0; r < 16; ++r) QVs[hw * TA_SV + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + l31] = oacc[u][r];
+    }
+    __syncthreads();
+    float* ob = a.out + o * a.oso + i0 + (int64_t)(head * DH) * a.osc;
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+        const int e = tid + it * NT;
+        const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
+        ob[(int64_t)d * a.osc + (int64_t)f * a.ost + hw] = QVs[hw * TA_SV + f * 33 + d];
+    }
+}
+
 }  // namespace
 
 extern "C" int sdc_linattn(const float* qkv, float* ctx, float* out, int outer, int inner, int heads, int64_t n,
@@ -264,6 +414,11 @@ extern "C" int sdc_attn(const float* qkv, float* out, const float* rot, const fl
     a.so = q_so; a.sc = q_sc; a.si = q_si; a.st = q_st;
     a.oso = o_so; a.osc = o_sc; a.osi = o_si; a.ost = o_st;
     a.tok_contig = (q_st == 1);
+    if (!a.tok_contig && ntok == 32 && inner % TA_NS == 0 && q_si == 1 && o_si == 1) {
+        const int nblk = (outer * inner / TA_NS) * heads;
+        hipLaunchKernelGGL(tattn_kernel, dim3((unsigned)nblk), dim3(NT), 0, sdc::as_stream(stream), a);
+        return sdc::check_launch("sdc_attn[mfma]");
+    }
     int nseq = NT / ntok;
     if (nseq < 1) nseq = 1;
     const int nseq_tot = outer * inner;
