@@ -36,6 +36,9 @@ def conv_instance(d):
     """mirror of the tile selection in csrc/sdc_conv.hip::sdc_conv"""
     ntot = d.B * d.oD * d.oH * d.oW
     fast = (d.Cin0 % 16 == 0) and (d.Cin1 % 16 == 0)
+    if (d.kW == 7 and d.sW == 1 and d.uD == d.uH == d.uW == 1 and d.up_mode == 0 and d.kD * d.kH <= 64 and d.Cout % 4 == 0
+            and d.Cout > 32 and (d.oW % 128 == 0 or (128 % d.oW == 0 and d.oW >= 16))):
+        return "conv_rh_kernel<64,128,2,2,7,true>"
     blocks = ((ntot + 127) // 128) * ((d.Cout + 63) // 64)
     if d.Cout > 64 and ntot >= 128 * 256:
         tile = "128,128,2,2"
@@ -52,7 +55,7 @@ def conv_instance(d):
                and d.kW == 3 and d.kD * d.kH <= 32 and d.Cout % 4 == 0
                and (d.oW % bn == 0 or (bn % d.oW == 0 and d.oW >= 16)))
     if rowhalo:
-        return f"conv_rh_kernel<{tile},3>"
+        return f"conv_rh_kernel<{tile},3,false>"
     return f"conv_kernel<{tile},{'true' if fast else 'false'}>"
 
 

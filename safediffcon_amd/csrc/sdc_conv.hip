@@ -322,7 +322,9 @@ __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs a) {
 // gather (the measured limiter of the plain kernel: VMEM issue, not latency) drops ~kW-fold, barriers
 // too; the weight tile of the stage comes in with 16-byte loads.
 // LDS: As[2][KW][BK][BM], Bs[2][BK][NSEG][seg + KW - 1] with seg = min(oW, BN), NSEG = BN / seg.
-template <int BM, int BN, int WM, int WN, int KW>
+// GEN: the 16 k rows of a stage are arbitrary (kd, kh, ci) triples (flattened kr = (kd*kH + kh)*Cin + ci), so
+// Cin need not be a multiple of 16: the 7x7x7 / 7x7 / k7 stem convs (Cin = 7, 3, 12) run here with KW = 7.
+template <int BM, int BN, int WM, int WN, int KW, bool GEN>
 __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
     // ---- gather state: this lane's columns of a k row (the same for every k row and every stage).  A wave
     // loads whole k rows, so the channel part of the address is wave-uniform; only (segment, column) is per lane.
     int v0[NCOL], v1[NCOL];
-    uint32_t smask[NCOL];
+    uint64_t smask[NCOL];
 #pragma unroll
     for (int t = 0; t < NCOL; ++t) {
         const int cidx = lane + 64 * t;
@@ -369,12 +371,12 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
                 const int od = q % d.oD; const int ob = q / d.oD;
                 const int col = ow0 + cc - d.pW;
                 const int id0 = od * d.sD - d.pD, ih0 = oh * d.sH - d.pH;
-                uint32_t m = 0;
+                uint64_t m = 0;
                 if (col >= 0 && col < d.iW) {
                     for (int kd = 0; kd < d.kD; ++kd)
                         for (int kh = 0; kh < d.kH; ++kh)
                             if (id0 + kd >= 0 && id0 + kd < d.iD && ih0 + kh >= 0 && ih0 + kh < d.iH)
-                                m |= 1u << (kd * d.kH + kh);
+                                m |= 1ull << (kd * d.kH + kh);
                 }
                 smask[t] = m;
                 v0[t] = (int)(ob * d.x0s[0] + id0 * d.x0s[2] + ih0 * d.x0s[3] + col * d.x0s[4]);
@@ -402,39 +404,82 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
 
     float breg[KROWS][NCOL];
     float4 areg[NA4];
-    uint32_t mbits = 0;                          // bit t: column sweep t of the stage in flight is valid for this lane
+    uint32_t mbits = 0;                          // bit r*NCOL+t: (k row r, column sweep t) of the stage in flight is valid
     int s_kd = 0, s_kh = 0, s_ci = 0;            // stage walk: kd, kh outer; channel chunk inner
 
+    int s_st = 0;                                // GEN: stage number (k rows 16*s_st ..)
+    const int KR = d.kD * d.kH * a.Cin;          // GEN: number of (kd, kh, ci) rows
+    bool a_rowok[NA4];
+
     auto load_stage = [&]() {
-        const int tapbit = s_kd * d.kH + s_kh;
-        const int tap0 = tapbit * KW;
+        if constexpr (!GEN) {
+            const int tapbit = s_kd * d.kH + s_kh;
+            const int tap0 = tapbit * KW;
 #pragma unroll
-        for (int i = 0; i < NA4; ++i) {
-            const int row = (tid + i * NT) / (BM / 4);
-            const int kw = row / BK, kr = row % BK;
-            const int64_t wrow = (int64_t)(tap0 + kw) * a.Cin + s_ci + kr;
-            areg[i] = *reinterpret_cast<const float4*>(a.wp + wrow * d.Cout + a_col[i]);
+            for (int i = 0; i < NA4; ++i) {
+                const int row = (tid + i * NT) / (BM / 4);
+                const int kw = row / BK, kr = row % BK;
+                const int64_t wrow = (int64_t)(tap0 + kw) * a.Cin + s_ci + kr;
+                areg[i] = *reinterpret_cast<const float4*>(a.wp + wrow * d.Cout + a_col[i]);
+                a_rowok[i] = true;
+            }
+            const bool first = s_ci < d.Cin0;
+            const int64_t sc = first ? d.x0s[1] : d.x1s[1];
+            const int64_t toff = first ? s_kd * d.x0s[2] + s_kh * d.x0s[3] : s_kd * d.x1s[2] + s_kh * d.x1s[3];
+            const float* base = (first ? a.x0 + (int64_t)s_ci * sc : a.x1 + (int64_t)(s_ci - d.Cin0) * sc) +
+                                (int64_t)(wave * KROWS) * sc;                      // wave-uniform
+            mbits = 0;
+            int64_t off[NCOL];
+#pragma unroll
+            for (int t = 0; t < NCOL; ++t) {
+                const bool ok = (smask[t] >> tapbit) & 1u;
+                off[t] = ok ? (int64_t)(first ? v0[t] : v1[t]) + toff : 0;          // !ok: a safe in-bounds address
+#pragma unroll
+                for (int r = 0; r < KROWS; ++r) mbits |= (ok ? 1u : 0u) << (r * NCOL + t);
+            }
+#pragma unroll
+            for (int r = 0; r < KROWS; ++r)
+#pragma unroll
+                for (int t = 0; t < NCOL; ++t)
+                    if (t * 64 < ks_stride) breg[r][t] = (base + r * sc)[off[t]];
+            s_ci += BK;
+            if (s_ci >= a.Cin) { s_ci = 0; if (++s_kh == d.kH) { s_kh = 0; ++s_kd; } }
+        } else {
+            // weights: LDS row (kw, krl) <- Wp[((kdkh * KW + kw) * Cin + ci)], kr = 16*s_st + krl = kdkh*Cin + ci
+#pragma unroll
+            for (int i = 0; i < NA4; ++i) {
+                const int row = (tid + i * NT) / (BM / 4);
+                const int kw = row / BK, kr = s_st * BK + row % BK;
+                const bool ok = kr < KR;
+                const int krc = ok ? kr : 0;
+                const int kdkh = krc / a.Cin, ci = krc - kdkh * a.Cin;
+                const int64_t wrow = (int64_t)(kdkh * KW + kw) * a.Cin + ci;
+                areg[i] = *reinterpret_cast<const float4*>(a.wp + wrow * d.Cout + a_col[i]);
+                a_rowok[i] = ok;
+            }
+            mbits = 0;
+#pragma unroll
+            for (int r = 0; r < KROWS; ++r) {
+                const int kr = SDC_UNIFORM(s_st * BK + wave * KROWS + r);
+                const bool rok = kr < KR;
+                const int krc = rok ? kr : 0;
+                const int kdkh = krc / a.Cin, ci = krc - kdkh * a.Cin;
+                const int kd = kdkh / d.kH, kh = kdkh - kd * d.kH;
+                const bool first = ci < d.Cin0;
+                const float* base = first ? a.x0 + ci * d.x0s[1] + kd * d.x0s[2] + kh * d.x0s[3]
+                                          : a.x1 + (ci - d.Cin0) * d.x1s[1] + kd * d.x1s[2] + kh * d.x1s[3];
+#pragma unroll
+                for (int t = 0; t < NCOL; ++t) {
+                    if (t * 64 < ks_stride) {
+                        const bool ok = rok && ((smask[t] >> kdkh) & 1ull);
+                        const int64_t off = ok ? (int64_t)(first ? v0[t] : v1[t]) : 0;
+                        breg[r][t] = ok ? base[off] : (first ? a.x0 : a.x1)[0];
+                        mbits |= (ok ? 1u : 0u) << (r * NCOL + t);
+                    }
+                }
+            }
+            ++s_st;
         }
-        const bool first = s_ci < d.Cin0;
-        const int64_t sc = first ? d.x0s[1] : d.x1s[1];
-        const int64_t toff = first ? s_kd * d.x0s[2] + s_kh * d.x0s[3] : s_kd * d.x1s[2] + s_kh * d.x1s[3];
-        const float* base = (first ? a.x0 + (int64_t)s_ci * sc : a.x1 + (int64_t)(s_ci - d.Cin0) * sc) +
-                            (int64_t)(wave * KROWS) * sc;                      // wave-uniform
-        mbits = 0;
-        int64_t off[NCOL];
-#pragma unroll
-        for (int t = 0; t < NCOL; ++t) {
-            const bool ok = (smask[t] >> tapbit) & 1u;
-            off[t] = ok ? (int64_t)(first ? v0[t] : v1[t]) + toff : 0;          // !ok: a safe in-bounds address
-            mbits |= (ok ? 1u : 0u) << t;
-        }
-#pragma unroll
-        for (int r = 0; r < KROWS; ++r)
-#pragma unroll
-            for (int t = 0; t < NCOL; ++t)
-                if (t * 64 < ks_stride) breg[r][t] = (base + r * sc)[off[t]];
-        s_ci += BK;
-        if (s_ci >= a.Cin) { s_ci = 0; if (++s_kh == d.kH) { s_kh = 0; ++s_kd; } }
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
@@ -442,7 +487,7 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
             const int f = tid + i * NT;
             const int row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
             float4 v = areg[i];
-            if (!a_ok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!a_ok[i] || !a_rowok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(&As[buf][row / BK][row % BK][c4]) = v;
         }
 #pragma unroll
@@ -450,7 +495,7 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
 #pragma unroll
             for (int t = 0; t < NCOL; ++t) {
                 const int cidx = lane + 64 * t;
-                if (cidx < ks_stride) Bs[buf][(wave * KROWS + r) * ks_stride + cidx] = ((mbits >> t) & 1u) ? breg[r][t] : 0.0f;
+                if (cidx < ks_stride) Bs[buf][(wave * KROWS + r) * ks_stride + cidx] = ((mbits >> (r * NCOL + t)) & 1u) ? breg[r][t] : 0.0f;
             }
     };
 
@@ -462,7 +507,7 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nstages = d.kD * d.kH * (a.Cin / BK);
+    const int nstages = GEN ? (KR + BK - 1) / BK : d.kD * d.kH * (a.Cin / BK);
     load_stage();
     store_stage(0);
     __syncthreads();
@@ -513,7 +558,7 @@ void launch(const ConvArgs& a, bool fast, hipStream_t s) {
                     ((d.oW % BN == 0) || (BN % d.oW == 0 && d.oW >= 16)) &&
                     (reinterpret_cast<uintptr_t>(a.wp) % 16 == 0);
     if constexpr (BM >= 64) {
-        if (rh) { hipLaunchKernelGGL((conv_rh_kernel<BM, BN, WM, WN, 3>), grid, dim3(NT), 0, s, a); return; }
+        if (rh) { hipLaunchKernelGGL((conv_rh_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(NT), 0, s, a); return; }
     }
     if (fast)
         hipLaunchKernelGGL((conv_kernel<BM, BN, WM, WN, true>), grid, dim3(NT), 0, s, a);
@@ -560,6 +605,14 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
     a.rowhalo = !no_rh;
     const bool fast = (d.Cin0 % BK == 0) && (d.Cin1 % BK == 0) && small && d.Cout < (1 << 30);
     hipStream_t s = sdc::as_stream(stream);
+    // stem convs (kW = 7, tiny Cin): row-halo kernel with generalized k rows
+    if (a.rowhalo && d.kW == 7 && d.sW == 1 && d.uD == 1 && d.uH == 1 && d.uW == 1 && d.up_mode == 0 && d.kD * d.kH <= 64 &&
+        d.Cout % 4 == 0 && d.Cout > 32 && small && ((d.oW % 128 == 0) || (128 % d.oW == 0 && d.oW >= 16)) &&
+        reinterpret_cast<uintptr_t>(wp) % 16 == 0) {
+        dim3 grid((a.Ntot + 127) / 128, (d.Cout + 63) / 64);
+        hipLaunchKernelGGL((conv_rh_kernel<64, 128, 2, 2, 7, true>), grid, dim3(NT), 0, s, a);
+        return sdc::check_launch("sdc_conv[stem]");
+    }
     const int64_t blocks64x128 = (int64_t)((a.Ntot + 127) / 128) * ((d.Cout + 63) / 64);
     if (d.Cout > 64 && a.Ntot >= 128 * 256)
         launch<128, 128, 2, 2>(a, fast, s);
