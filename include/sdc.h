@@ -188,6 +188,15 @@ int sdc_advance_table(int32_t* idx_dev, int32_t* t_dev, const int32_t* ttab, int
 int sdc_conformal_score(const SdcStepDesc* d, const float* pred, const float* truth, const float* target,
                         const float* gpar, float* score, float* weight, void* stream);
 
+/* --------------------------------------------------- evaluation rollout */
+/* Explicit finite-difference Burgers' solver used to score a sampled control:
+ * burgers_numeric_solve_free, 1D/data/generate_burgers.py:207-299, called by control_trajectories,
+ * 1D/utils/metrics.py:42-65.  u0 (N,s), f (N,Nt,s) -> traj (N,Nt+1,s); `steps` Euler steps of size dt, the force row
+ * advances and a snapshot is recorded every `record_every` steps; coef_transport = 1/(2 dx), d0..d2 = visc*[1,-2,1]/dx^2
+ * (all rounded to fp32 by the caller exactly as the reference's FloatTensor(...) does). */
+int sdc_burgers_rollout(const float* u0, const float* f, float* traj, int N, int s, int Nt, int steps, int record_every,
+                        float dt, float coef_transport, float d0, float d1, float d2, void* stream);
+
 /* ----------------------------------------------------------------- graphs */
 int sdc_graph_begin(void* stream);
 int sdc_graph_end(void* stream, void** graph_exec);

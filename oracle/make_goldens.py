@@ -214,6 +214,15 @@ def gen_burgers():
                  dim=dim, weight_seed=100)
     if ref_guid:
         _ddim_burgers(Unet2D, GaussianDiffusion, cfg, get_finetune_guidance, dim)
+    # evaluation rollout: the reference's finite-difference solver on seeded inputs
+    try:
+        from data.generate_burgers import burgers_numeric_solve_free
+        u0 = det_tensor((3, 128), 140, 0.5)
+        ff = det_tensor((3, 10, 128), 141, 1.0)
+        traj = burgers_numeric_solve_free(u0, ff, visc=0.01, T=1.0, dt=1e-4, num_t=10)
+        save("burgers_rollout", u0=u0, f=ff, traj=traj)
+    except Exception as e:  # noqa: BLE001
+        print("!! burgers solver import failed:", repr(e))
 
 
 def _ddim_burgers(Unet2D, GaussianDiffusion, cfg, get_finetune_guidance, dim):

@@ -53,6 +53,8 @@ SIGNATURES = {
     "sdc_advance": (C.c_int, [_i32p, C.c_int, _i32p, C.c_int, _stream]),
     "sdc_advance_table": (C.c_int, [_i32p, _i32p, _i32p, _i32p, C.c_int, _stream]),
     "sdc_conformal_score": (C.c_int, [C.POINTER(SdcStepDesc), _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _stream]),
+    "sdc_burgers_rollout": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                      C.c_float, C.c_float, C.c_float, _stream]),
     "sdc_graph_begin": (C.c_int, [_stream]),
     "sdc_graph_end": (C.c_int, [_stream, C.POINTER(C.c_void_p)]),
     "sdc_graph_launch": (C.c_int, [C.c_void_p, _stream]),

@@ -19,10 +19,7 @@
 
 namespace {
 
-#ifndef SDC_BK
-#define SDC_BK 16
-#endif
-constexpr int BK = SDC_BK;     // K chunk per LDS stage (experiment builds may override)
+constexpr int BK = 16;          // K chunk per LDS stage (BK = 32 measured no faster: the kernel is MFMA-issue bound)
 constexpr int NT = 256;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -278,20 +275,17 @@ __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs a) {
     const int bn = wn * (TN * 32) + l31;
 
     for (int kc = 0; kc < nchunks; ++kc) {
-#ifndef SDC_EXP
-#define SDC_EXP 0      // timing-only experiment builds (tools/): 1 no gather, 2 +no LDS store/barrier, 3 +no LDS reads
-#endif
-        const int buf = (SDC_EXP >= 2 && SDC_EXP < 4) ? 0 : (kc & 1);
-        if ((SDC_EXP < 1 || SDC_EXP == 4) && kc + 1 < nchunks) load_chunk(kc + 1);
+        const int buf = kc & 1;
+        if (kc + 1 < nchunks) load_chunk(kc + 1);
         // all fragments of the chunk are read into registers first (8 k-steps x (TM+TN) ds_read_b32), so the
         // MFMAs below issue back to back instead of stalling on an LDS round trip every k-step
         float af[BK / 2][TM], bf[BK / 2][TN];
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[ks][i] = (SDC_EXP == 3) ? (float)(kc + ks + i) : As[buf][2 * ks + lh][am + i * 32];
+            for (int i = 0; i < TM; ++i) af[ks][i] = As[buf][2 * ks + lh][am + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[ks][j] = (SDC_EXP == 3) ? (float)(kc - ks + j) : Bs[buf][2 * ks + lh][bn + j * 32];
+            for (int j = 0; j < TN; ++j) bf[ks][j] = Bs[buf][2 * ks + lh][bn + j * 32];
         }
         __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads ahead of the MFMA block
 #pragma unroll
@@ -302,14 +296,8 @@ __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs a) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
         }
-        if ((SDC_EXP < 1 || SDC_EXP == 5) && kc + 1 < nchunks) store_chunk(buf ^ 1);
-        if (SDC_EXP == 4) {
-#pragma unroll
-            for (int i = 0; i < BROWS; ++i) asm volatile("" ::"v"(breg[i]));
-#pragma unroll
-            for (int i = 0; i < AROWS; ++i) asm volatile("" ::"v"(areg[i]));
-        }
-        if (SDC_EXP < 2 || SDC_EXP >= 4) __syncthreads();
+        if (kc + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
     }
 
     conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);

@@ -164,8 +164,6 @@ class _State:
         self.noise = None            # single-slot injected-noise buffer
         self.x0 = None
         self.cond = {}               # name -> persistent device buffer
-        self.graphs = {}             # config key -> captured graph handle
-        self.tails = {}              # config key -> tail Plan
 
 
 class _SamplerBase(nn.Module):
@@ -257,8 +255,6 @@ class _SamplerBase(nn.Module):
         if buf is None or buf.shape != t.shape:
             buf = torch.empty_like(t)
             st.cond[name] = buf
-            st.graphs.clear()
-            st.tails.clear()
         buf.copy_(t)
         return buf
 

@@ -55,7 +55,7 @@ class Pool:
 
 
 class Plan:
-    """Recorded kernel calls.  `run(stream)` replays them; `capture(stream)` turns them into a hipGraph."""
+    """Recorded kernel calls; `run(stream)` replays them (the samplers capture that replay into a hipGraph)."""
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -64,7 +64,6 @@ class Plan:
         self.pool = Pool(self.device)
         self.keep = []           # descriptors / tensors that must outlive the plan
         self.repackers = []      # (dst tensor, fn() -> src tensor) to refresh repacked weights
-        self.graph = None
         self._stats = None
         self._ctx = None
 
@@ -74,28 +73,6 @@ class Plan:
             rc = fn(*args, stream)
             if rc:
                 check(rc, fn.__name__)
-
-    def capture(self, stream):
-        if self.graph is not None:
-            return
-        check(self.lib.sdc_graph_begin(stream), "sdc_graph_begin")
-        try:
-            self.run(stream)
-        finally:
-            g = C.c_void_p()
-            rc = self.lib.sdc_graph_end(stream, C.byref(g))
-        check(rc, "sdc_graph_end")
-        self.graph = g
-
-    def launch(self, stream):
-        check(self.lib.sdc_graph_launch(self.graph, stream), "sdc_graph_launch")
-
-    def __del__(self):
-        try:
-            if self.graph is not None:
-                self.lib.sdc_graph_destroy(self.graph)
-        except Exception:  # noqa: BLE001
-            pass
 
     def refresh_weights(self):
         """Re-run every weight repack (after an optimiser step / load_state_dict)."""

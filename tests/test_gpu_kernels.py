@@ -71,7 +71,12 @@ def _conv_case(plan_cls, nd, B, cin, cout, sp, k, stride=1, pad=0, up=1, cin1=0,
     dict(nd=2, B=2, cin=32, cout=16, sp=(4, 32), k=3, pad=1, up=2),         # Upsample2d
     dict(nd=3, B=1, cin=7, cout=8, sp=(8, 16, 16), k=7, pad=3),             # smoke init conv
     dict(nd=3, B=2, cin=16, cout=32, sp=(4, 8, 8), k=3, pad=1, cin1=16),    # Conv3d 3^3 with skip concat
-    dict(nd=3, B=36, cin=128, cout=160, sp=(4, 16, 16), k=3, pad=1),        # 128x128 tile path (Ntot >= 32768)
+    dict(nd=3, B=36, cin=128, cout=160, sp=(4, 16, 16), k=3, pad=1),        # 128x128 tile path (Ntot >= 32768), row-halo
+    dict(nd=2, B=3, cin=3, cout=64, sp=(16, 128), k=7, pad=3),              # stem conv path (generalized k rows, KW=7)
+    dict(nd=3, B=2, cin=7, cout=64, sp=(8, 32, 32), k=7, pad=3),            # smoke stem: 343 (kd,kh,ci) rows, ragged last stage
+    dict(nd=1, B=5, cin=12, cout=64, sp=(128,), k=7, pad=3),                # tokamak stem
+    dict(nd=2, B=130, cin=64, cout=64, sp=(16, 128), k=3, pad=1),           # 64x256 row-halo tile, ragged last tile rows
+    dict(nd=3, B=2, cin=32, cout=64, sp=(6, 16, 32), k=3, pad=1, cin1=32, residual=True),   # row-halo with concat + residual
 ])
 def test_conv_matches_torch(plan_cls, case):
     _conv_case(plan_cls, **case)

@@ -210,3 +210,12 @@ def test_ddim_trajectories(golden):
     g = golden("smoke_ddim_calib")
     out = samplers.ddim_smoke(eps, tabs, 2, noise, S=S, eta=eta, init=g["init"], control=g["control"], shape=(8, 7, 16, 16))
     torch.testing.assert_close(out, g["out"], rtol=1e-4, atol=1e-5)
+
+
+def test_burgers_rollout_oracle_vs_reference_solver(golden):
+    """evaluation rollout: oracle restatement == reference burgers_numeric_solve_free, bit for bit"""
+    from oracle import solvers
+    g = golden("burgers_rollout")
+    traj = solvers.burgers_rollout(g["u0"], g["f"])
+    assert traj.shape == (3, 11, 128)
+    assert torch.equal(traj, g["traj"])
