@@ -285,7 +285,7 @@ def main():
                        "parallelism": f"batch-sharded x{world}, no data-path collective", "conformal_Q": round(Q, 6)},
             "roofline": roof,
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:          # reported on rank 0 at N=1 only
             cb = a.cpu_batch or {"c2": 32, "c3": 32, "c4": 1}[a.workload]
             out["cpu_baseline"] = cpu_baseline(a.workload, cb, a.cpu_steps if a.workload != "c4" else 1, a.dim)
         print(json.dumps(out), flush=True)
