@@ -59,6 +59,9 @@ int sdc_last_error(char* buf, size_t cap);
  * (1D/model/unet.py:132-134,161-163,189-197,232-236,326,345,370,378;
  *  conv3d.py:159-163,192,218,239-240,291-292,395,471).
  * Wp is the caller-repacked weight [K = taps*Cin][Cout] (row-major, Cout fastest).
+ * precision 1 (opt-in, NOT the parity mode): split-bf16 3-pass MFMA (~16 mantissa bits); the wp buffer then holds
+ * the fp32 Wp followed by the pre-split weights as bf16 [Cout][K] hi and [Cout][K] lo (k contiguous); layers the
+ * split kernel does not cover (Cin % 32 != 0, Cout <= 32) silently run the exact fp32 kernel.
  */
 typedef struct SdcConvDesc {
     int32_t B, Cin0, Cin1, Cout;

@@ -57,9 +57,10 @@ class Pool:
 class Plan:
     """Recorded kernel calls; `run(stream)` replays them (the samplers capture that replay into a hipGraph)."""
 
-    def __init__(self, device):
+    def __init__(self, device, precision=0):
         self.device = torch.device(device)
         self.lib = _lib.get_lib()
+        self.precision = int(precision)   # 0 exact fp32 MFMA (parity mode) | 1 opt-in split-bf16 conv (include/sdc.h)
         self.calls = []          # (fn, args, keepalive)
         self.pool = Pool(self.device)
         self.keep = []           # descriptors / tensors that must outlive the plan
@@ -122,6 +123,18 @@ class Plan:
                 return t4.permute(2, 3, 1, 0).reshape(-1, co).contiguous()
             t5 = as5(t)                                       # (Cout, Cin, kD, kH, kW)
             return t5.permute(2, 3, 4, 1, 0).reshape(-1, t5.shape[0]).contiguous()
+        if self.precision == 1:
+            # fp32 Wp followed by the split weights, bf16 [Cout][K] hi then lo (x = hi + lo to ~2^-17)
+            def fn3():
+                wp = fn().to(torch.float32)
+                wt = wp.t().contiguous()
+                hi = wt.to(torch.bfloat16)
+                lo = (wt - hi.to(torch.float32)).to(torch.bfloat16)
+                n = wp.numel()
+                if n % 2:
+                    return wp.reshape(-1)
+                return torch.cat([wp.reshape(-1), hi.reshape(-1).view(torch.float32), lo.reshape(-1).view(torch.float32)])
+            return self.packed(fn3)
         return self.packed(fn)
 
     def vec(self, p):
@@ -142,7 +155,9 @@ class Plan:
         if out is None:
             out = self.pool.get((B, cout, *o))
         assert tuple(out.shape) == (B, cout, *o), (out.shape, (B, cout, *o))
-        assert wp.shape == (k[0] * k[1] * k[2] * (c0 + c1), cout), (wp.shape, k, c0, c1, cout)
+        nw = k[0] * k[1] * k[2] * (c0 + c1) * cout
+        split = wp.dim() == 1 and wp.numel() == 2 * nw
+        assert split or wp.numel() == nw, (wp.shape, k, c0, c1, cout)
         d = SdcConvDesc()
         d.B, d.Cin0, d.Cin1, d.Cout = B, c0, c1, cout
         d.iD, d.iH, d.iW = iD, iH, iW
@@ -151,7 +166,7 @@ class Plan:
         d.sD, d.sH, d.sW = stride
         d.pD, d.pH, d.pW = pad
         d.uD, d.uH, d.uW = up
-        d.up_mode, d.precision = up_mode, 0
+        d.up_mode, d.precision = up_mode, (1 if split else 0)
         d.x0s[:] = _s5(x)
         d.x1s[:] = _s5(x1) if x1 is not None else (0,) * 5
         d.ys[:] = _s5(out)

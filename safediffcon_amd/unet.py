@@ -246,6 +246,7 @@ class _HipUNet(nn.Module):
             _register(self, k, v)
         self._spec = spec
         self._plans = {}
+        self.precision = 0        # 0: exact fp32 convs (parity mode); 1: opt-in split-bf16 convs (set before first use)
         self.dim = dim
         self.self_condition = False
         # every time-conditioned ResnetBlock gets a slot [scale | shift] in the conditioning row
@@ -294,13 +295,13 @@ class _HipUNet(nn.Module):
     def entry(self, shape, rows, lut=False):
         """Plan for an input of `shape` whose conditioning table has `rows` rows: one row per sample
         (lut=False, forward(x, time)) or one row per timestep read through a device-side t (lut=True, samplers)."""
-        key = (tuple(shape), rows, bool(lut))
+        key = (tuple(shape), rows, bool(lut), int(self.precision))
         if key not in self._plans:
             dev = self.device()
             if dev.type != "cuda":
                 raise RuntimeError("safediffcon_amd runs on MI355X only: move the model to a cuda (HIP) device; "
                                    "there is no CPU fallback")
-            plan = Plan(dev)
+            plan = Plan(dev, precision=self.precision)
             x = torch.zeros(shape, dtype=torch.float32, device=dev)
             eps = torch.zeros(shape, dtype=torch.float32, device=dev)
             b = _Builder(self, plan)

@@ -98,3 +98,34 @@ def test_full_size_sampler_properties():
     control = det_tensor((2, 32, 2, 64, 64), 44, 0.3).to(DEV)
     o = gs.sample(batch_size=2, design_fn=sdc.SmokeGuidance(0.01, 0.9, 0.1), init=init, control=control)
     assert torch.equal(o[:, 0, 0], init) and torch.equal(o[:, :, 3:5], control) and torch.isfinite(o).all()
+
+
+def test_split_bf16_opt_in_meets_the_eps_mse_gate():
+    """precision=1 (split-bf16 convs) is opt-in and not bit-compatible with fp32, but it must stay far inside the
+    north-star gate eps-MSE <= 1e-5 at full width; the fp32 default must be unaffected by the switch."""
+    net = sdc.Unet2D(dim=64, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+    P = det_params(_spec(net), 11)
+    net.load_state_dict(P)
+    net.to(DEV)
+    x = det_tensor((8, 3, 16, 128), 12)
+    t = torch.tensor([0, 10, 100, 300, 500, 700, 900, 999])
+    ref = onets.unet_burgers(P, x[:3], t[:3], dim=64)
+    e32 = net(x.to(DEV), t.to(DEV))
+    net.precision = 1
+    e3 = net(x.to(DEV), t.to(DEV))
+    net.precision = 0
+    assert torch.equal(net(x.to(DEV), t.to(DEV)), e32)
+    m32, m3 = _mse(e32[:3].cpu(), ref), _mse(e3[:3].cpu(), ref)
+    print(f"eps-MSE fp32 {m32:.3e}  split-bf16 {m3:.3e}  max|d| {(e3 - e32).abs().max().item():.3e}")
+    assert m32 <= 1e-9 and m3 <= 1e-7 and not torch.equal(e3, e32)
+
+    net3 = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+    P3 = det_params(_spec(net3), 31)
+    net3.load_state_dict(P3)
+    net3.to(DEV)
+    x3, t3 = det_tensor((1, 32, 7, 64, 64), 32), torch.tensor([500])
+    ref3 = onets.unet_smoke(P3, x3, t3, dim=64, dim_mults=(1, 2, 4))
+    net3.precision = 1
+    m = _mse(net3(x3.to(DEV), t3.to(DEV)).cpu(), ref3)
+    print(f"smoke eps-MSE split-bf16 {m:.3e}")
+    assert m <= 1e-7
