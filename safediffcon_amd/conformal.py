@@ -142,3 +142,55 @@ class ConformalCalculator:
 
     def calculate_quantile(self, scores, weights, states, alpha):
         return calculate_quantile(scores, alpha)
+
+
+class SmokeConformal:
+    """2D smoke: drop-in for the conformal / weighting methods of InferencePipeline
+    (2d/inference_2d.py:83-165: get_weight, normalize_weights, get_weighted_score_set, get_quantile, guidance)."""
+
+    def __init__(self, model, args_general, RESCALER=None):
+        self.model, self.args_general = model, args_general
+        self.device = getattr(args_general, "device", "cuda")
+        self.Q = 0.0
+
+    def _gpar(self, Q, ratio):
+        a = self.args_general
+        return [a.w_safe, a.safe_bound, float(Q), float(ratio)]
+
+    def get_weight(self, state, mode="train"):
+        a = self.args_general
+        if mode == "train":
+            g = self._gpar(self.Q, a.standard_fixed_ratio)
+        else:   # the reference's guidance() adds self.Q even when a Q argument is passed (2d/inference_2d.py:183)
+            g = self._gpar(self.Q, a.finetune_standard_fixed_ratio)
+        return scores_and_weights("smoke", state, state, g)[1]
+
+    def normalize_weights(self, weights):
+        return normalize_weights(weights, smoke=True)
+
+    def get_weighted_score_set(self, cal_dataloader, group=None):
+        a = self.args_general
+        scores, weights, states = [], [], []
+        for _ in range(a.N_cal_batch):
+            state, _sim_id = next(cal_dataloader)
+            states.append(state)
+            state = state.to(self.device)
+            out = self.model.sample(batch_size=state.shape[0], design_fn=None, init=state[:, 0, 0], control=state[:, :, 3:5])
+            s, w = scores_and_weights("smoke", out, state, self._gpar(self.Q, a.standard_fixed_ratio))
+            if getattr(a, "finetune_set", "train") != "train":
+                w = w * self.get_weight(state, mode="test")
+            scores.append(s)
+            weights.append(w)
+        s = all_gather_1d(torch.cat(scores), group)
+        w = all_gather_1d(torch.cat(weights), group)
+        nw = normalize_weights(w, smoke=True)
+        return nw * s, nw, torch.cat(states)
+
+    def get_quantile(self, conformal_score_set, normalized_weights, ori_states, alpha):
+        return calculate_quantile(conformal_score_set, alpha, smoke=True)
+
+    def conformal_prediction(self, cal_dataloader):
+        with torch.no_grad():
+            s, nw, st = self.get_weighted_score_set(cal_dataloader)
+        self.Q = self.get_quantile(s, nw, st, self.args_general.alpha)
+        return self.Q

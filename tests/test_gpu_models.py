@@ -253,3 +253,35 @@ def test_ddim_trajectories_golden(golden):
     g = golden("smoke_ddim_calib")
     out = gs.sample(batch_size=2, design_fn=None, init=g["init"], control=g["control"], noise=noise).cpu()
     torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+
+
+def test_conformal_pipelines_end_to_end(golden):
+    """ConformalCalculator (1D) and SmokeConformal (2D) drop-ins: sample -> HIP scores/weights -> quantile, against the
+    oracle's arithmetic on the same sampled outputs."""
+    import types
+    from safediffcon_amd import conformal
+    spec = golden("burgers_unet").spec()
+    net = _load(sdc.Unet2D(dim=8, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1), spec, 100)
+    gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=3, temporal=True, use_conv2d=True,
+                                      is_condition_u0=True, is_condition_uT=True, condition_idx=10).to(DEV)
+    cfg = types.SimpleNamespace(device=DEV, num_cal_batch=2, nt=11, use_max_safety=True, u_bound=0.3, InfFT_Q=None,
+                                guidance_weights={"w_score": 50.0})
+    states = [det_tensor((4, 3, 16, 128), 900 + i, 0.1) for i in range(2)]
+    calc = conformal.ConformalCalculator(gd, cfg, kind="burgers")
+    torch.manual_seed(1)
+    ws, nw, st = calc.get_conformal_scores(iter(states), Q=0.02)
+    assert ws.shape == (8,) and torch.isfinite(ws).all() and abs(nw.sum().item() - 8) < 1e-3
+    want_w = osam.normalize_weights(osam.burgers_weight(torch.cat(states), 0.02, 50.0, 0.3))
+    torch.testing.assert_close(nw.cpu(), want_w, rtol=1e-4, atol=1e-6)
+    q = calc.calculate_quantile(ws, nw, st, 0.9)
+    assert q == osam.quantile_lucid(ws.cpu(), 0.9)
+
+    spec = golden("smoke_unet").spec()
+    net3 = _load(sdc.Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2, 4), channels=7), spec, 300)
+    gs = sdc.GaussianDiffusionSmoke(net3, image_size=16, frames=8, timesteps=2, standard_fixed_ratio=3.0).to(DEV)
+    args = types.SimpleNamespace(device=DEV, w_safe=0.9, safe_bound=0.1, standard_fixed_ratio=3.0, N_cal_batch=2, alpha=0.2,
+                                 finetune_set="train")
+    sc = conformal.SmokeConformal(gs, args)
+    data = [(det_tensor((3, 8, 7, 16, 16), 950 + i, 0.3), None) for i in range(2)]
+    Q = sc.conformal_prediction(iter(data))
+    assert torch.isfinite(Q) and Q >= 0
