@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "split-bf16"],
                     help="conv arithmetic: exact fp32 MFMA (parity mode, default) or the opt-in 3-pass split-bf16 MFMA")
     ap.add_argument("--no-extra", action="store_true", help="skip the additional split-bf16 measurement at N=1")
+    ap.add_argument("--full-sample", action="store_true",
+                    help="also time ONE complete 1000-step sample() call (validates value = B / (1000 * step time))")
     ap.add_argument("--cpu-batch", type=int, default=0)
     ap.add_argument("--cpu-steps", type=int, default=3)
     a = ap.parse_args()
@@ -295,6 +297,21 @@ def main():
                                     "note": "opt-in precision=1: convs as 3-pass split-bf16 MFMA (~16 mantissa bits); eps-MSE vs the "
                                             "fp32 oracle 6.7e-10 (C2) / 2.3e-10 (C4) at full width (tests/test_gpu_fullsize.py), "
                                             "gate 1e-5; NOT bit-compatible with fp32, so `value` above stays the fp32 number"}}
+        if a.full_sample and rank == 0:
+            S3 = prep()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            S3.init()
+            for _ in range(S3.n_main):
+                S3.step()
+            S3.final()
+            torch.cuda.synchronize()
+            full_s = time.perf_counter() - t0
+            S3.close()
+            extra = dict(extra or {})
+            extra["full_sample"] = {"seconds_for_one_1000_step_sample": round(full_s, 3),
+                                    "trajectories_per_s": round(B / full_s, 4),
+                                    "note": "includes x_T draw, conditioning, graph capture and the final eager step"}
     assert finite, "non-finite state after the timed steps"
 
     ms_per_step = dt / a.steps * 1e3
