@@ -56,6 +56,13 @@ struct ConvArgs {
     int rowhalo;   // allow the row-halo kernel (env SDC_NO_ROWHALO=1 disables it for A/B timing)
 };
 
+// Position-tile numbering: workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  Neighbouring
+// position tiles share their halo rows (kh / kd taps), so consecutive LOGICAL tiles are given to one XCD
+// (bijective when the tile count is a multiple of 8; speed / HBM traffic only, never correctness).
+__device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
+    return (ntiles & 7) == 0 ? (bid & 7) * (ntiles >> 3) + (bid >> 3) : bid;
+}
+
 // ---- epilogue: D rows (co) live in registers, columns (positions) on lanes -> coalesced along W.
 // Bias / residual loads are issued as a batch (clamped addresses, no per-element branches) so the
 // workgroup pays one memory round trip per 16 outputs instead of sixteen.
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs a) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int n0 = blockIdx.x * BN;
+    const int n0 = xcd_tile(blockIdx.x, gridDim.x) * BN;
     const int m0 = blockIdx.y * BM;
 
     // ---- B loader: this thread's output position
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
     const int lane = tid & 63;
     const int wave = SDC_UNIFORM(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int n0 = blockIdx.x * BN;
+    const int n0 = xcd_tile(blockIdx.x, gridDim.x) * BN;
     const int m0 = blockIdx.y * BM;
     const int l31 = lane & 31, lh = lane >> 5;
 
@@ -569,7 +576,7 @@ __global__ __launch_bounds__(NT) void conv_bf3_kernel(const ConvArgs a) {
     const SdcConvDesc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int n0 = xcd_tile(blockIdx.x, gridDim.x) * BN, m0 = blockIdx.y * BM;
     const int l31 = lane & 31, lh = lane >> 5;
 
     // ---- this thread's output position (B loader)
