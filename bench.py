@@ -215,8 +215,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" IS RCCL on ROCm.  SDC_DIST_BACKEND=gloo + SDC_FORCE_DEVICE=0 exist only to rehearse the multi-process
+        # path on a one-GPU box (RCCL refuses two ranks on one device).
+        dist.init_process_group(os.environ.get("SDC_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    local = int(os.environ.get("SDC_FORCE_DEVICE", local))
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
