@@ -715,6 +715,199 @@ __global__ __launch_bounds__(NT) void conv_bf3_kernel(const ConvArgs a) {
     conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
 }
 
+// Row-halo form of the split-bf16 kernel (3-wide taps along W, stride 1, Cin % 32 == 0): one stage = (kd, kh,
+// 32-channel chunk); the input row segment + halo is split and staged ONCE as [position][32 k] bf16 hi / lo and the
+// three kw taps read it at shifted position rows, so the gather + split work per MFMA drops 3-fold.
+// Single LDS buffer (hi + lo of three weight taps and the halo tile do not fit twice): the next stage is fetched
+// into registers while the MFMAs run and written behind a second barrier.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NT) void conv_rh_bf3_kernel(const ConvArgs a) {
+    constexpr int KW = 3;
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int KSMAX = BN + (BN / 16) * (KW - 1);
+    constexpr int NSLOT = (KSMAX * 4 + NT - 1) / NT;     // (position, octet) slots per thread per stage
+    constexpr int NAO = KW * 4 * BM / NT;                // weight octets per thread per stage (per hi / lo)
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds3[];
+    constexpr int ASZ = KW * BM * LDK, BSZ = KSMAX * LDK;
+    unsigned short* Ah = lds3;
+    unsigned short* Al = lds3 + ASZ;
+    unsigned short* Bh = lds3 + 2 * ASZ;
+    unsigned short* Bl = lds3 + 2 * ASZ + BSZ;
+
+    const SdcConvDesc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = xcd_tile(blockIdx.x, gridDim.x) * BN, m0 = blockIdx.y * BM;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int seg = d.oW < BN ? d.oW : BN;
+    const int nseg = BN / seg;
+    const int rowlen = seg + KW - 1;
+    const int ks_stride = nseg * rowlen;          // halo positions per stage
+    const int nslots = ks_stride * 4;
+    const bool two = d.Cin1 > 0;
+
+    // ---- per-slot gather state: slot e = tid + 256 i -> (octet = e / ks_stride, position = e % ks_stride)
+    int v0[NSLOT], v1[NSLOT], lofs[NSLOT];
+    uint32_t smask[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+        const int e = tid + i * NT;
+        v0[i] = 0; v1[i] = 0; smask[i] = 0; lofs[i] = -1;
+        if (e < nslots) {
+            const int oc = e / ks_stride, pos = e - oc * ks_stride;
+            lofs[i] = pos * LDK + oc * 8;
+            const int sg = pos / rowlen, cc = pos - sg * rowlen;
+            const int pseg = n0 + sg * seg;
+            if (pseg < a.Ntot) {
+                int q = pseg;
+                const int ow0 = q % d.oW; q /= d.oW;
+                const int oh = q % d.oH; q /= d.oH;
+                const int od = q % d.oD; const int ob = q / d.oD;
+                const int col = ow0 + cc - d.pW;
+                const int id0 = od * d.sD - d.pD, ih0 = oh * d.sH - d.pH;
+                uint32_t m = 0;
+                if (col >= 0 && col < d.iW)
+                    for (int kd = 0; kd < d.kD; ++kd)
+                        for (int kh = 0; kh < d.kH; ++kh)
+                            if (id0 + kd >= 0 && id0 + kd < d.iD && ih0 + kh >= 0 && ih0 + kh < d.iH)
+                                m |= 1u << (kd * d.kH + kh);
+                smask[i] = m;
+                v0[i] = (int)(ob * d.x0s[0] + (oc * 8) * d.x0s[1] + id0 * d.x0s[2] + ih0 * d.x0s[3] + col * d.x0s[4]);
+                if (two) v1[i] = (int)(ob * d.x1s[0] + (oc * 8) * d.x1s[1] + id0 * d.x1s[2] + ih0 * d.x1s[3] + col * d.x1s[4]);
+            }
+        }
+    }
+    int boff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int pl = wn * (TN * 32) + j * 32 + l31;
+        const int sg = pl / seg;
+        boff[j] = sg * rowlen + (pl - sg * seg);
+    }
+    const unsigned short* whi = reinterpret_cast<const unsigned short*>(a.wp + (int64_t)a.Ktot * d.Cout);
+    const unsigned short* wlo = whi + (int64_t)a.Ktot * d.Cout;
+
+    float breg[NSLOT][8];
+    uint4 ahreg[NAO], alreg[NAO];
+    uint32_t mbits = 0;
+    int s_kd = 0, s_kh = 0, s_ci = 0;
+
+    auto load_stage = [&]() {
+        const int tapbit = s_kd * d.kH + s_kh;
+        // weights: LDS row (kw, co) <- W[co][((tapbit*KW + kw) * Cin + s_ci) + 0..31]
+#pragma unroll
+        for (int i = 0; i < NAO; ++i) {
+            const int f = tid + i * NT;
+            const int oc = f & 3, row = f >> 2;          // row in [0, KW*BM)
+            const int kw = row / BM, co = row - kw * BM;
+            const bool ok = (m0 + co) < d.Cout;
+            const int64_t off = (int64_t)(ok ? m0 + co : 0) * a.Ktot + (int64_t)(tapbit * KW + kw) * a.Cin + s_ci + oc * 8;
+            ahreg[i] = ok ? *reinterpret_cast<const uint4*>(whi + off) : make_uint4(0, 0, 0, 0);
+            alreg[i] = ok ? *reinterpret_cast<const uint4*>(wlo + off) : make_uint4(0, 0, 0, 0);
+        }
+        const bool first = s_ci < d.Cin0;
+        const int sc = (int)(first ? d.x0s[1] : d.x1s[1]);
+        const int64_t toff = first ? s_kd * d.x0s[2] + s_kh * d.x0s[3] : s_kd * d.x1s[2] + s_kh * d.x1s[3];
+        const float* base = first ? a.x0 + (int64_t)s_ci * sc : a.x1 + (int64_t)(s_ci - d.Cin0) * sc;
+        mbits = 0;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const bool ok = (smask[i] >> tapbit) & 1u;
+            const float* src = ok ? base + ((int64_t)(first ? v0[i] : v1[i]) + toff) : (first ? a.x0 : a.x1);
+            const int st = ok ? sc : 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) breg[i][e] = src[e * st];
+            mbits |= (ok ? 1u : 0u) << i;
+        }
+        s_ci += BK3;
+        if (s_ci >= a.Cin) { s_ci = 0; if (++s_kh == d.kH) { s_kh = 0; ++s_kd; } }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NAO; ++i) {
+            const int f = tid + i * NT;
+            const int oc = f & 3, row = f >> 2;
+            *reinterpret_cast<uint4*>(Ah + row * LDK + oc * 8) = ahreg[i];
+            *reinterpret_cast<uint4*>(Al + row * LDK + oc * 8) = alreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            if (lofs[i] >= 0) {
+                const bool ok = (mbits >> i) & 1u;
+                uint4 h, l;
+                split2(ok ? breg[i][0] : 0.f, ok ? breg[i][1] : 0.f, h.x, l.x);
+                split2(ok ? breg[i][2] : 0.f, ok ? breg[i][3] : 0.f, h.y, l.y);
+                split2(ok ? breg[i][4] : 0.f, ok ? breg[i][5] : 0.f, h.z, l.z);
+                split2(ok ? breg[i][6] : 0.f, ok ? breg[i][7] : 0.f, h.w, l.w);
+                *reinterpret_cast<uint4*>(Bh + lofs[i]) = h;
+                *reinterpret_cast<uint4*>(Bl + lofs[i]) = l;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nstages = d.kD * d.kH * (a.Cin / BK3);
+    load_stage();
+    store_stage();
+    __syncthreads();
+    const int am = wm * (TM * 32) + l31;
+
+    for (int st = 0; st < nstages; ++st) {
+        if (st + 1 < nstages) load_stage();
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+#pragma unroll
+            for (int ks = 0; ks < BK3 / 16; ++ks) {
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8*>(Ah + (kw * BM + am + i * 32) * LDK + ks * 16 + lh * 8);
+                    al[i] = *reinterpret_cast<const bf16x8*>(Al + (kw * BM + am + i * 32) * LDK + ks * 16 + lh * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8*>(Bh + (boff[j] + kw) * LDK + ks * 16 + lh * 8);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(Bl + (boff[j] + kw) * LDK + ks * 16 + lh * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();                         // every wave is done reading this stage
+        if (st + 1 < nstages) store_stage();
+        __syncthreads();
+    }
+    conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_rh_bf3(const ConvArgs& a, hipStream_t s) {
+    dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
+    constexpr int KSMAX = BN + (BN / 16) * 2;
+    const size_t lds = (2u * 3u * BM * LDK + 2u * KSMAX * LDK) * sizeof(unsigned short);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rh_bf3_kernel<BM, BN, WM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv_rh_bf3_kernel<BM, BN, WM, WN>), grid, dim3(NT), lds, s, a);
+}
+
 template <int BM, int BN, int WM, int WN>
 void launch_bf3(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
@@ -796,8 +989,16 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
     // opt-in split-bf16: whole 32-channel chunks per tap, 32-bit offsets, 16-byte aligned pre-split weights
     if (d.precision == 1 && d.Cin0 % BK3 == 0 && d.Cin1 % BK3 == 0 && small && d.Cout > 32 &&
         reinterpret_cast<uintptr_t>(wp) % 16 == 0 && ((int64_t)a.Ktot * d.Cout) % 4 == 0) {
-        if (d.Cout > 64 && a.Ntot >= 128 * 256) launch_bf3<128, 128, 2, 2>(a, s);
-        else if (a.Ntot >= 128 * 512) launch_bf3<64, 256, 1, 4>(a, s);
+        const bool big = d.Cout > 64 && a.Ntot >= 128 * 256, wide = a.Ntot >= 128 * 512;
+        const int bn = big ? 128 : (wide ? 256 : 128);
+        const bool rh3 = a.rowhalo && d.kW == 3 && d.sW == 1 && d.uD == 1 && d.uH == 1 && d.uW == 1 && d.up_mode == 0 &&
+                         d.kD * d.kH <= 32 && ((d.oW % bn == 0) || (bn % d.oW == 0 && d.oW >= 16));
+        // (the 128x128 row-halo form needs 84 KB of LDS = one workgroup per CU and measured slower than the plain one)
+        if (rh3 && !big) {
+            if (wide) launch_rh_bf3<64, 256, 1, 4>(a, s);
+            else launch_rh_bf3<64, 128, 2, 2>(a, s);
+        } else if (big) launch_bf3<128, 128, 2, 2>(a, s);
+        else if (wide) launch_bf3<64, 256, 1, 4>(a, s);
         else launch_bf3<64, 128, 2, 2>(a, s);
         return sdc::check_launch("sdc_conv[bf16x3]");
     }
