@@ -24,23 +24,34 @@ __global__ __launch_bounds__(NT) void la_ctx_kernel(const float* __restrict__ qk
     __shared__ float rmax[DH], rinv[DH];
     __shared__ float pk[DH][65], vv[DH][65];
 
-    // row statistics: each wave owns 8 rows
-    for (int r = 0; r < 8; ++r) {
-        const int d = wave * 8 + r;
-        const float* row = kb + (int64_t)d * sc;
-        float m = -INFINITY;
-        for (int64_t j = lane; j < n; j += 64) m = fmaxf(m, row[j]);
-        m = sdc::wave_max(m);
-        float s = 0.f;
-        for (int64_t j = lane; j < n; j += 64) s += expf(row[j] - m);
-        s = sdc::wave_sum(s);
-        if (lane == 0) { rmax[d] = m; rinv[d] = 1.0f / s; }
+    // row maxima: each wave owns 8 rows and sweeps them together (8 independent loads in flight per step);
+    // the softmax denominators come for free from the tile pass below
+    {
+        float m[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) m[r] = -INFINITY;
+        for (int64_t j = lane; j < n; j += 64) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) m[r] = fmaxf(m[r], kb[(int64_t)(wave * 8 + r) * sc + j]);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float mm = sdc::wave_max(m[r]);
+            if (lane == 0) rmax[wave * 8 + r] = mm;
+        }
     }
     __syncthreads();
+    float psum[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) psum[it] = 0.f;
 
-    const int d = threadIdx.x >> 3;
-    const int e0 = (threadIdx.x & 7) * 4;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // ctx = P . V^T on the matrix cores: per 64-token tile every wave takes 16 tokens = 8 k-steps of
+    // v_mfma_f32_32x32x2_f32 (A[d][n] = exp(k - max), B[n][e] = v), partial tiles are summed through LDS at the end
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int l31 = lane & 31, lh = lane >> 5;
     for (int64_t t0 = 0; t0 < n; t0 += 64) {
         // stage exp(k - max) and v tiles: thread -> (row = wave + 4*it, col = lane)
 #pragma unroll
@@ -54,21 +65,40 @@ __global__ __launch_bounds__(NT) void la_ctx_kernel(const float* __restrict__ qk
             }
             pk[row][lane] = kvv;
             vv[row][lane] = vvv;
+            psum[it] += kvv;
         }
         __syncthreads();
-#pragma unroll 8
-        for (int j = 0; j < 64; ++j) {
-            const float p = pk[d][j];
-            acc[0] += p * vv[e0 + 0][j];
-            acc[1] += p * vv[e0 + 1][j];
-            acc[2] += p * vv[e0 + 2][j];
-            acc[3] += p * vv[e0 + 3][j];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            const int col = wave * 16 + 2 * s8 + lh;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pk[l31][col], vv[l31][col], acc, 0, 0, 0);
         }
         __syncthreads();
     }
-    float* out = ctx + (int64_t)blockIdx.x * DH * DH + d * DH + e0;
-    const float inv = rinv[d];
-    out[0] = acc[0] * inv; out[1] = acc[1] * inv; out[2] = acc[2] * inv; out[3] = acc[3] * inv;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {             // softmax denominators: row (wave + 4*it) was staged by this wave only
+        const float t = sdc::wave_sum(psum[it]);
+        if (lane == 0) rinv[wave + 4 * it] = 1.0f / t;
+    }
+    // lane (e = l31, half lh) holds d = (r&3) + 8*(r>>2) + 4*lh; reduce the four waves' partial contexts
+    float* red = &pk[0][0];                      // 32 x 65 floats are enough for one 32x32 partial per pass
+    float tot[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + l31] = acc[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = threadIdx.x * 4 + i;   // o = d*32 + e
+            tot[i] += red[(o >> 5) * 33 + (o & 31)];
+        }
+        __syncthreads();
+    }
+    float* out = ctx + (int64_t)blockIdx.x * DH * DH + threadIdx.x * 4;
+    const float inv = rinv[threadIdx.x >> 3];
+    out[0] = tot[0] * inv; out[1] = tot[1] * inv; out[2] = tot[2] * inv; out[3] = tot[3] * inv;
 }
 
 // ------------------------------------------------------------------ linear attention: output

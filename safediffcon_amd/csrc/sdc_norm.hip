@@ -155,19 +155,31 @@ __global__ __launch_bounds__(NT) void gn_apply_flat_kernel(const float* x, const
 // ---------------------------------------------------------------- channel LayerNorm / RMSNorm
 // 64 positions x 4 channel slices per workgroup; positions are the contiguous axis so every
 // channel row is read in 256-byte wave-wide segments.  Two passes over C (second pass is L2-hot).
-template <int PL>      // PL position lanes x (NT/PL) channel slices per workgroup
+// PL position lanes x (NT/PL) channel slices per workgroup.  CACHE: C <= CPT*NSL, every thread keeps its channel
+// values in registers, so x is read from HBM exactly once (otherwise the later passes re-read it L2-hot).
+template <int PL, bool CACHE>
 __global__ __launch_bounds__(NT) void chan_norm_kernel(const float* x, const float* __restrict__ g,
                                                        const float* res, float* y, int C,
                                                        int64_t S, int mode, float eps) {
     constexpr int NSL = NT / PL;
+    constexpr int CPT = 32;
     const int lane = threadIdx.x % PL;
     const int slice = threadIdx.x / PL;
     const int b = blockIdx.y;
     const int64_t pos = (int64_t)blockIdx.x * PL + lane;
     const bool ok = pos < S;
     const int64_t base = (int64_t)b * C * S + pos;
+    float vc[CACHE ? CPT : 1];
     float s = 0.f, q = 0.f;
-    if (ok) {
+    if constexpr (CACHE) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = slice + i * NSL;
+            vc[i] = (ok && c < C) ? x[base + (int64_t)c * S] : 0.f;
+            s += vc[i];
+            q += vc[i] * vc[i];
+        }
+    } else if (ok) {
         for (int c = slice; c < C; c += NSL) {
             const float v = x[base + (int64_t)c * S];
             s += v;
@@ -186,11 +198,18 @@ __global__ __launch_bounds__(NT) void chan_norm_kernel(const float* x, const flo
         mean = s / C;
         // second, centred pass for the variance keeps LN exact when |mean| >> std
         float q2 = 0.f;
-        if (ok)
+        if constexpr (CACHE) {
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const float dv = (slice + i * NSL < C) ? vc[i] - mean : 0.f;
+                q2 += dv * dv;
+            }
+        } else if (ok) {
             for (int c = slice; c < C; c += NSL) {
                 const float dv = x[base + (int64_t)c * S] - mean;
                 q2 += dv * dv;
             }
+        }
         __syncthreads();
         sh[1][slice][lane] = q2;
         __syncthreads();
@@ -203,11 +222,24 @@ __global__ __launch_bounds__(NT) void chan_norm_kernel(const float* x, const flo
         mul = sqrtf((float)C) / fmaxf(sqrtf(q), 1e-12f);
     }
     if (!ok) return;
-    for (int c = slice; c < C; c += NSL) {
-        const int64_t o = base + (int64_t)c * S;
-        float v = (x[o] - mean) * mul * g[c];
-        if (res) v += res[o];
-        y[o] = v;
+    if constexpr (CACHE) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = slice + i * NSL;
+            if (c < C) {
+                const int64_t o = base + (int64_t)c * S;
+                float v = (vc[i] - mean) * mul * g[c];
+                if (res) v += res[o];
+                y[o] = v;
+            }
+        }
+    } else {
+        for (int c = slice; c < C; c += NSL) {
+            const int64_t o = base + (int64_t)c * S;
+            float v = (x[o] - mean) * mul * g[c];
+            if (res) v += res[o];
+            y[o] = v;
+        }
     }
 }
 
@@ -283,10 +315,16 @@ extern "C" int sdc_chan_norm(const float* x, const float* g, const float* residu
     SDC_REQUIRE(B < 65536, SDC_EINVAL, "sdc_chan_norm: B too large for grid.y");
     if (S >= 64) {
         dim3 grid((unsigned)((S + 63) / 64), B);
-        hipLaunchKernelGGL(chan_norm_kernel<64>, grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
+        if (C <= 128)
+            hipLaunchKernelGGL((chan_norm_kernel<64, true>), grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
+        else
+            hipLaunchKernelGGL((chan_norm_kernel<64, false>), grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
     } else {   // few positions, many channels (deep levels): 16 position lanes x 16 channel slices
         dim3 grid((unsigned)((S + 15) / 16), B);
-        hipLaunchKernelGGL(chan_norm_kernel<16>, grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
+        if (C <= 512)
+            hipLaunchKernelGGL((chan_norm_kernel<16, true>), grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
+        else
+            hipLaunchKernelGGL((chan_norm_kernel<16, false>), grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
     }
     return sdc::check_launch("sdc_chan_norm");
 }
