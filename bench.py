@@ -36,6 +36,14 @@ def conv_instance(d):
     """mirror of the tile selection in csrc/sdc_conv.hip::sdc_conv"""
     ntot = d.B * d.oD * d.oH * d.oW
     fast = (d.Cin0 % 16 == 0) and (d.Cin1 % 16 == 0)
+    if (d.precision == 2 and fast and d.kW == 3 and d.sW == 1 and d.uD == d.uH == d.uW == 1 and d.up_mode == 0
+            and d.kD * d.kH <= 32 and d.Cout % 4 == 0 and d.Cout > 32 and d.oW % 2 == 0 and d.oW >= 16
+            and (d.oW % 128 == 0 or 128 % d.oW == 0)):
+        if d.Cout > 64 and ((ntot + 127) // 128) * ((d.Cout + 127) // 128) >= 256:
+            return "conv_wg_kernel<128,128,4,2,16,512>"
+        if d.Cout <= 64 and ntot >= 64 * 1024 and (d.oW % 256 == 0 or 256 % d.oW == 0):
+            return "conv_wg_kernel<64,256,2,4,16,512>"
+        return "conv_wg_kernel<64,128,2,2,16,256>"
     if (d.kW == 7 and d.sW == 1 and d.uD == d.uH == d.uW == 1 and d.up_mode == 0 and d.kD * d.kH <= 64 and d.Cout % 4 == 0
             and d.Cout > 32 and (d.oW % 128 == 0 or (128 % d.oW == 0 and d.oW >= 16))):
         return "conv_rh_kernel<64,128,2,2,7,true>"
@@ -200,8 +208,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: 256 / 128 / 64 for c2 / c3 / c4)")
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "split-bf16"],
-                    help="conv arithmetic: exact fp32 MFMA (parity mode, default) or the opt-in 3-pass split-bf16 MFMA")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-direct", "split-bf16"],
+                    help="conv arithmetic: fp32 MFMA with Winograd F(2,3) along W on the 3-tap convs (default), fp32 direct "
+                         "form everywhere, or the opt-in 3-pass split-bf16 MFMA")
     ap.add_argument("--no-extra", action="store_true", help="skip the additional split-bf16 measurement at N=1")
     ap.add_argument("--full-sample", action="store_true",
                     help="also time ONE complete 1000-step sample() call (validates value = B / (1000 * step time))")
@@ -226,7 +235,7 @@ def main():
     from safediffcon_amd import _lib
     lib = _lib.get_lib()
     B = a.batch or {"c2": 256, "c3": 128, "c4": 64}[a.workload]
-    prec = 1 if a.precision == "split-bf16" else 0
+    prec = {"fp32": 2, "fp32-direct": 0, "split-bf16": 1}[a.precision]
     desc, gd, prep, Q = workload(a.workload, a.dim, B, dev, rank, world, prec)
 
     side = torch.cuda.Stream(device=dev)
@@ -280,22 +289,31 @@ def main():
             roof = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
                         sustained_peak_measured=123.0,   # bare v_mfma_f32_32x32x2 loop on this device (tools/mfma_peak.hip)
+                        flops="algorithmic (direct-form) conv FLOPs per launch; a conv_wg_kernel (Winograd F(2,3) along W) "
+                              "issues 2/3 of them as MFMA work" if "conv_wg" in name else "algorithmic conv FLOPs per launch",
                         launches_per_step=g["launches"],
                         avg_launch_ms=round(avg_ms, 4), share_of_step=round(g["ms"] / (dt / a.steps * 1e3), 3),
                         all_conv_instances={k: dict(launches=v["launches"], ms_per_step=round(v["ms"], 3),
                                                     tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2))
                                             for k, v in groups.items()})
         S.close()
-        if world == 1 and prec == 0 and not a.no_extra:
-            # opt-in split-bf16 convs (not the parity mode): same workload, same harness, reported beside the headline
-            gd.model.precision = 1
-            S2 = prep()
-            S2.init()
-            dt2 = timed(S2, a.warmup, a.steps)
-            ok2 = bool(torch.isfinite(S2.x).all().item())
-            S2.close()
-            gd.model.precision = 0
-            extra = {"split_bf16": {"value": round(B / (T_DDPM * dt2 / a.steps), 4), "unit": "trajectories/s",
+        if world == 1 and prec == 2 and not a.no_extra:
+            # the other two conv modes on the same workload and harness, reported beside the headline
+            def other(mode):
+                gd.model.precision = mode
+                S2 = prep()
+                S2.init()
+                dt_ = timed(S2, a.warmup, a.steps)
+                ok_ = bool(torch.isfinite(S2.x).all().item())
+                S2.close()
+                gd.model.precision = 2
+                return dt_, ok_
+            dt0, ok0 = other(0)
+            dt2, ok2 = other(1)
+            extra = {"fp32_direct": {"value": round(B / (T_DDPM * dt0 / a.steps), 4), "unit": "trajectories/s",
+                                     "ms_per_step": round(dt0 / a.steps * 1e3, 4), "finite": ok0,
+                                     "note": "precision=0: every conv in the direct implicit-GEMM form (k-ordered fp32 FMA chains)"},
+                     "split_bf16": {"value": round(B / (T_DDPM * dt2 / a.steps), 4), "unit": "trajectories/s",
                                     "ms_per_step": round(dt2 / a.steps * 1e3, 4), "finite": ok2,
                                     "note": "opt-in precision=1: convs as 3-pass split-bf16 MFMA (~16 mantissa bits); eps-MSE vs the "
                                             "fp32 oracle 6.7e-10 (C2) / 2.3e-10 (C4) at full width (tests/test_gpu_fullsize.py), "
@@ -323,7 +341,7 @@ def main():
         out = {
             "metric": "sampled control trajectories/sec (1000-step DDPM)", "value": round(value, 4), "unit": "trajectories/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if prec == 0 else "f32 (split-bf16 conv operands, fp32 accumulate)", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if prec != 1 else "f32 (split-bf16 conv operands, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": desc, "batch_per_gpu": B, "global_batch": world * B, "ddpm_timesteps": T_DDPM,
                        "step": "one denoising step of the whole batch (U-Net + guidance + posterior update), hipGraph replay",
                        "parallelism": f"batch-sharded x{world}, no data-path collective", "conformal_Q": round(Q, 6)},

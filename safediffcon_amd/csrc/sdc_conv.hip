@@ -54,6 +54,7 @@ struct ConvArgs {
     int Cin;
     int lgD, lgH, lgW;
     int rowhalo;   // allow the row-halo kernel (env SDC_NO_ROWHALO=1 disables it for A/B timing)
+    int vec2;      // Winograd epilogue: y (and residual) rows allow 8-byte accesses at even positions
 };
 
 // Position-tile numbering: workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  Neighbouring
@@ -894,6 +895,302 @@ __global__ __launch_bounds__(NT) void conv_rh_bf3_kernel(const ConvArgs a) {
     conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
 }
 
+// ------------------------------------------------------------------------------------------------
+// precision = 2: fp32 Winograd F(2,3) along W on top of the row-halo staging (3-wide taps, stride 1).  For an
+// output pair (2j, 2j+1) of a row and the four inputs d0..d3 under it, with the taps g0..g2:
+//     m0 = (d0-d2) g0,  m1 = (d1+d2)(g0+g1+g2)/2,  m2 = (d2-d1)(g0-g1+g2)/2,  m3 = (d1-d3) g2
+//     y[2j] = m0 + m1 + m2,   y[2j+1] = m1 - m2 - m3
+// i.e. four GEMMs over K = kD*kH*Cin with N = positions/2 instead of three with N = positions: 2/3 of the fp32
+// MFMA work of the direct form.  The caller stores the transformed taps Wg[(kdkh*4 + xi)*Cin + ci][Cout] behind
+// Wp; the input transform is two adds on the B fragment while it is read from the staged row (ds_read_b64 of
+// (d0,d1) and (d2,d3)), the output transform runs on the accumulators in the epilogue.  Still fp32 end to end
+// (differences to the direct kernel are rounding-order only, ~1e-7 relative), but not bit-identical to it.
+template <int TM, int TP>
+__device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[4][TM][TP], int mw, int pw, int lane) {
+    const SdcConvDesc& d = a.d;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const bool v2 = a.vec2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int cob = mw + i * 32 + 4 * lh;
+        float bv[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int co = cob + (rr & 3) + 8 * (rr >> 2);
+            bv[rr] = a.bias ? a.bias[co < d.Cout ? co : d.Cout - 1] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int pp = 2 * (pw + j * 32 + l31);          // even position; pp + 1 is in the same row (oW even)
+            const bool pok = pp < a.Ntot;
+            int r = pok ? pp : 0;
+            const int qw = r % d.oW; r /= d.oW;
+            const int qh = r % d.oH; r /= d.oH;
+            const int qd = r % d.oD; const int qb = r / d.oD;
+            const int64_t yoff = qb * d.ys[0] + qd * d.ys[2] + qh * d.ys[3] + qw * d.ys[4];
+            float r0[16], r1[16];
+            if (a.res) {
+                const int64_t roff = qb * d.rs[0] + qd * d.rs[2] + qh * d.rs[3] + qw * d.rs[4];
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const int co = cob + (rr & 3) + 8 * (rr >> 2);
+                    const float* rp = a.res + roff + (co < d.Cout ? co : d.Cout - 1) * d.rs[1];
+                    if (v2) { const float2 t = *reinterpret_cast<const float2*>(rp); r0[rr] = t.x; r1[rr] = t.y; }
+                    else { r0[rr] = rp[0]; r1[rr] = rp[d.rs[4]]; }
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) { r0[rr] = 0.0f; r1[rr] = 0.0f; }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int co = cob + (rr & 3) + 8 * (rr >> 2);
+                const float m0 = acc[0][i][j][rr], m1 = acc[1][i][j][rr], m2 = acc[2][i][j][rr], m3 = acc[3][i][j][rr];
+                const float y0 = ((m0 + m1) + m2) + bv[rr] + r0[rr];
+                const float y1 = ((m1 - m2) - m3) + bv[rr] + r1[rr];
+                if (pok && co < d.Cout) {
+                    float* yp = a.y + yoff + co * d.ys[1];
+                    if (v2) *reinterpret_cast<float2*>(yp) = make_float2(y0, y1);
+                    else { yp[0] = y0; yp[d.ys[4]] = y1; }
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int SK, int NTH>
+__global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
+    constexpr int TM = BM / WM / 32;
+    constexpr int TP = BN / 2 / WN / 32;                        // 32-pair column tiles per wave
+    constexpr int KSMAX = BN + (BN / 16) * 2;                   // LDS floats per k row, worst case (16-wide rows)
+    constexpr int NCOL = (KSMAX + 63) / 64;
+    constexpr int KROWS = SK / (NTH / 64);
+    constexpr int NA4 = 4 * SK * BM / 4 / NTH;                  // float4 weight loads per thread per stage
+    static_assert(TM >= 1 && TP >= 1 && KROWS >= 1 && NA4 >= 1 && WM * WN * 64 == NTH, "bad tile");
+    extern __shared__ __attribute__((aligned(16))) float ldsw[];
+    constexpr int ASZ = 4 * SK * BM, BSZ = SK * KSMAX;          // floats per buffer
+    float* const As = ldsw;                                     // [2][4][SK][BM]
+    float* const Bs = ldsw + 2 * ASZ;                           // [2][SK * ks_stride]
+
+    const SdcConvDesc& d = a.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = SDC_UNIFORM(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = xcd_tile(blockIdx.x, gridDim.x) * BN;
+    const int m0 = blockIdx.y * BM;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int seg = d.oW < BN ? d.oW : BN;
+    const int nseg = BN / seg;
+    const int rowlen = seg + 2;
+    const int ks_stride = nseg * rowlen;          // even: seg is even
+    const bool two = d.Cin1 > 0;
+
+    int v0[NCOL], v1[NCOL];
+    uint64_t smask[NCOL];
+#pragma unroll
+    for (int t = 0; t < NCOL; ++t) {
+        const int cidx = lane + 64 * t;
+        v0[t] = 0; v1[t] = 0; smask[t] = 0;
+        if (cidx < ks_stride) {
+            const int sg = cidx / rowlen;
+            const int cc = cidx - sg * rowlen;
+            const int pseg = n0 + sg * seg;
+            if (pseg < a.Ntot) {
+                int q = pseg;
+                const int ow0 = q % d.oW; q /= d.oW;
+                const int oh = q % d.oH; q /= d.oH;
+                const int od = q % d.oD; const int ob = q / d.oD;
+                const int col = ow0 + cc - d.pW;
+                const int id0 = od * d.sD - d.pD, ih0 = oh * d.sH - d.pH;
+                uint64_t m = 0;
+                if (col >= 0 && col < d.iW) {
+                    for (int kd = 0; kd < d.kD; ++kd)
+                        for (int kh = 0; kh < d.kH; ++kh)
+                            if (id0 + kd >= 0 && id0 + kd < d.iD && ih0 + kh >= 0 && ih0 + kh < d.iH)
+                                m |= 1ull << (kd * d.kH + kh);
+                }
+                smask[t] = m;
+                v0[t] = (int)(ob * d.x0s[0] + id0 * d.x0s[2] + ih0 * d.x0s[3] + col * d.x0s[4]);
+                if (two) v1[t] = (int)(ob * d.x1s[0] + id0 * d.x1s[2] + ih0 * d.x1s[3] + col * d.x1s[4]);
+            }
+        }
+    }
+    // per-lane offset of (d0, d1) of this lane's output pair inside one staged k row (even -> 8-byte aligned)
+    int boff[TP];
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const int pos = 2 * (wn * (TP * 32) + j * 32 + l31);
+        const int sg = pos / seg;
+        boff[j] = sg * rowlen + (pos - sg * seg);
+    }
+    int a_col[NA4];
+    bool a_ok[NA4];
+#pragma unroll
+    for (int i = 0; i < NA4; ++i) {
+        const int c4 = ((tid + i * NTH) % (BM / 4)) * 4;
+        a_ok[i] = (m0 + c4) < d.Cout;
+        a_col[i] = a_ok[i] ? (m0 + c4) : 0;
+    }
+    const float* wg = a.wp + (int64_t)a.Ktot * d.Cout;          // transformed taps, 4 per (kd, kh)
+
+    float breg[KROWS][NCOL];
+    float4 areg[NA4];
+    uint32_t mbits = 0;
+    int s_kd = 0, s_kh = 0, s_ci = 0;
+
+    // The fetch of a stage is cut into NSL pieces that are issued BETWEEN the MFMA groups of the main loop (a
+    // workgroup's loads all at once keep the CU's one vector-memory pipe -- 64 B/clk -- busy for hundreds of cycles
+    // with the matrix cores idle behind it).  Stage st+2 is fetched to registers during the second half of
+    // stage st and written to the other LDS buffer during the first half of stage st+1.
+    constexpr int NSL = SK / 4;                                  // pieces (= half of the k-steps of a stage)
+    int l_tap = 0, l_ci = 0;
+    const float* l_base = a.x0;
+    int64_t l_sc = 0;
+    int64_t l_off[NCOL];
+    auto load_begin = [&]() {
+        l_tap = s_kd * d.kH + s_kh;
+        l_ci = s_ci;
+        const bool first = s_ci < d.Cin0;
+        l_sc = first ? d.x0s[1] : d.x1s[1];
+        const int64_t toff = first ? s_kd * d.x0s[2] + s_kh * d.x0s[3] : s_kd * d.x1s[2] + s_kh * d.x1s[3];
+        l_base = (first ? a.x0 + (int64_t)s_ci * l_sc : a.x1 + (int64_t)(s_ci - d.Cin0) * l_sc) + (int64_t)(wave * KROWS) * l_sc;
+        mbits = 0;
+#pragma unroll
+        for (int t = 0; t < NCOL; ++t) {
+            const bool ok = (smask[t] >> l_tap) & 1u;
+            l_off[t] = ok ? (int64_t)(first ? v0[t] : v1[t]) + toff : 0;
+            mbits |= (ok ? 1u : 0u) << t;
+        }
+        s_ci += SK;
+        // (past the last stage the walk wraps to the first one: the two extra fetches of the pipeline tail stay in
+        // bounds and are never consumed -- keeping them unconditional keeps the loop free of load-skipping branches)
+        if (s_ci >= a.Cin) { s_ci = 0; if (++s_kh == d.kH) { s_kh = 0; if (++s_kd == d.kD) s_kd = 0; } }
+    };
+    auto load_piece = [&](int p) {
+#pragma unroll
+        for (int i = 0; i < NA4; ++i) {
+            if (i % NSL != p) continue;
+            const int row = (tid + i * NTH) / (BM / 4);           // [0, 4*SK): (xi, k row)
+            const int xi = row / SK, kr = row % SK;
+            const int64_t wrow = (int64_t)(l_tap * 4 + xi) * a.Cin + l_ci + kr;
+            areg[i] = *reinterpret_cast<const float4*>(wg + wrow * d.Cout + a_col[i]);
+        }
+#pragma unroll
+        for (int r = 0; r < KROWS; ++r)
+#pragma unroll
+            for (int t = 0; t < NCOL; ++t)
+                if ((NA4 + r * NCOL + t) % NSL == p) breg[r][t] = (l_base + r * l_sc)[l_off[t]];   // ks_stride > 64*(NCOL-1)
+    };
+    auto store_piece = [&](int buf, int p) {
+#pragma unroll
+        for (int i = 0; i < NA4; ++i) {
+            if (i % NSL != p) continue;
+            const int f = tid + i * NTH;
+            const int row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
+            float4 v = areg[i];
+            if (!a_ok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(As + buf * ASZ + row * BM + c4) = v;
+        }
+#pragma unroll
+        for (int r = 0; r < KROWS; ++r)
+#pragma unroll
+            for (int t = 0; t < NCOL; ++t) {
+                const int cidx = lane + 64 * t;
+                if ((NA4 + r * NCOL + t) % NSL == p && cidx < ks_stride)
+                    Bs[buf * BSZ + (wave * KROWS + r) * ks_stride + cidx] = ((mbits >> t) & 1u) ? breg[r][t] : 0.0f;
+            }
+    };
+
+    f32x16 acc[4][TM][TP];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][i][j][r] = 0.0f;
+
+    const int nstages = d.kD * d.kH * (a.Cin / SK);
+    load_begin();
+#pragma unroll
+    for (int p = 0; p < NSL; ++p) load_piece(p);
+#pragma unroll
+    for (int p = 0; p < NSL; ++p) store_piece(0, p);
+    load_begin();
+#pragma unroll
+    for (int p = 0; p < NSL; ++p) load_piece(p);
+    __syncthreads();
+    const int am = wm * (TM * 32) + l31;
+
+    for (int st = 0; st < nstages; ++st) {
+        const int buf = st & 1;
+        const float* Ab = As + buf * ASZ;
+        const float* Bb = Bs + buf * BSZ;
+        float fa[2][4][TM];
+        float2 fb[2][TP][2];
+        auto read_frag = [&](int ks, int set) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[set][x][i] = Ab[(x * SK + 2 * ks + lh) * BM + am + i * 32];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const float2* bp = reinterpret_cast<const float2*>(Bb + (2 * ks + lh) * ks_stride + boff[j]);
+                fb[set][j][0] = bp[0];
+                fb[set][j][1] = bp[1];
+            }
+        };
+        read_frag(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < SK / 2; ++ks) {
+            const int set = ks & 1;
+            if (ks + 1 < SK / 2) read_frag(ks + 1, set ^ 1);
+            if (ks < NSL) {
+                store_piece(buf ^ 1, ks);
+            } else {
+                if (ks == NSL) load_begin();
+                load_piece(ks - NSL);
+            }
+            float bt[TP][4];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const float2 p0 = fb[set][j][0], p1 = fb[set][j][1];
+                bt[j][0] = p0.x - p1.x;
+                bt[j][1] = p0.y + p1.x;
+                bt[j][2] = p1.x - p0.y;
+                bt[j][3] = p0.y - p1.y;
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j)
+                        acc[x][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][x][i], bt[j][x], acc[x][i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    wg_epilogue<TM, TP>(a, acc, m0 + wm * (TM * 32), n0 / 2 + wn * (TP * 32), lane);
+}
+
+template <int BM, int BN, int WM, int WN, int SK, int NTH = 256>
+void launch_wg(const ConvArgs& a, hipStream_t s) {
+    dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
+    constexpr int KSMAX = BN + (BN / 16) * 2;
+    const size_t lds = (2u * 4u * SK * BM + 2u * SK * KSMAX) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wg_kernel<BM, BN, WM, WN, SK, NTH>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv_wg_kernel<BM, BN, WM, WN, SK, NTH>), grid, dim3(NTH), lds, s, a);
+}
+
 template <int BM, int BN, int WM, int WN>
 void launch_rh_bf3(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
@@ -957,7 +1254,7 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
     SDC_REQUIRE(d.Cin1 == 0 || x1, SDC_ENULL, "sdc_conv: Cin1 > 0 but x1 is null");
     SDC_REQUIRE(d.kD > 0 && d.kH > 0 && d.kW > 0 && d.sD > 0 && d.sH > 0 && d.sW > 0, SDC_EINVAL,
                 "sdc_conv: bad kernel/stride");
-    SDC_REQUIRE(d.precision == 0 || d.precision == 1, SDC_EINVAL, "sdc_conv: precision must be 0 (fp32 MFMA) or 1 (split-bf16)");
+    SDC_REQUIRE(d.precision >= 0 && d.precision <= 2, SDC_EINVAL, "sdc_conv: precision must be 0 (fp32 MFMA), 1 (split-bf16) or 2 (fp32 Winograd)");
     ConvArgs a;
     a.d = d;
     a.lgD = ilog2_exact(d.uD); a.lgH = ilog2_exact(d.uH); a.lgW = ilog2_exact(d.uW);
@@ -984,6 +1281,7 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
                        (d.Cin1 == 0 || span(d.x1s, d.B, d.iD, d.iH, d.iW) < (1ll << 30));
     static const int no_rh = getenv("SDC_NO_ROWHALO") ? atoi(getenv("SDC_NO_ROWHALO")) : 0;
     a.rowhalo = !no_rh;
+    a.vec2 = 0;
     const bool fast = (d.Cin0 % BK == 0) && (d.Cin1 % BK == 0) && small && d.Cout < (1 << 30);
     hipStream_t s = sdc::as_stream(stream);
     // opt-in split-bf16: whole 32-channel chunks per tap, 32-bit offsets, 16-byte aligned pre-split weights
@@ -1002,6 +1300,27 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
         else launch_bf3<64, 128, 2, 2>(a, s);
         return sdc::check_launch("sdc_conv[bf16x3]");
     }
+    // opt-in fp32 Winograd F(2,3) along W: 3-wide stride-1 taps, whole 16-channel chunks, even rows
+    if (d.precision == 2 && a.rowhalo && d.kW == 3 && d.sW == 1 && d.uD == 1 && d.uH == 1 && d.uW == 1 && d.up_mode == 0 &&
+        d.kD * d.kH <= 32 && d.Cin0 % 16 == 0 && d.Cin1 % 16 == 0 && small && d.Cout % 4 == 0 && d.Cout > 32 &&
+        d.oW % 2 == 0 && d.oW >= 16 && reinterpret_cast<uintptr_t>(wp) % 16 == 0 && ((int64_t)a.Ktot * d.Cout) % 4 == 0) {
+        auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
+        a.vec2 = even(d.ys) && reinterpret_cast<uintptr_t>(y) % 8 == 0 &&
+                 (!residual || (even(d.rs) && reinterpret_cast<uintptr_t>(residual) % 8 == 0));
+        auto fits = [&](int bn) { return (d.oW % bn == 0) || (bn % d.oW == 0); };
+        static const int wg_tile = getenv("SDC_WG_TILE") ? atoi(getenv("SDC_WG_TILE")) : 0;   // tuning knob
+        // 8-wave workgroups (two waves per SIMD, 64 accumulator registers each) share one staged weight tile:
+        // 128 x 128 outputs for wide layers, 64 x 256 for Cout <= 64; 4-wave 64 x 128 for short rows / small N
+        const int64_t b128 = (int64_t)((a.Ntot + 127) / 128) * ((d.Cout + 127) / 128);
+        int pick = wg_tile ? wg_tile : (d.Cout > 64 && b128 >= 256 ? 6 : (d.Cout <= 64 && a.Ntot >= 64 * 1024 ? 7 : 3));
+        if (pick == 7 && !fits(256)) pick = 3;
+        if (fits(128)) {
+            if (pick == 6) launch_wg<128, 128, 4, 2, 16, 512>(a, s);
+            else if (pick == 7) launch_wg<64, 256, 2, 4, 16, 512>(a, s);
+            else launch_wg<64, 128, 2, 2, 16>(a, s);
+            return sdc::check_launch("sdc_conv[winograd]");
+        }
+    }
     // stem convs (kW = 7, tiny Cin): row-halo kernel with generalized k rows
     if (a.rowhalo && d.kW == 7 && d.sW == 1 && d.uD == 1 && d.uH == 1 && d.uW == 1 && d.up_mode == 0 && d.kD * d.kH <= 64 &&
         d.Cout % 4 == 0 && d.Cout > 32 && small && ((d.oW % 128 == 0) || (128 % d.oW == 0 && d.oW >= 16)) &&
@@ -1011,6 +1330,17 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
         return sdc::check_launch("sdc_conv[stem]");
     }
     const int64_t blocks64x128 = (int64_t)((a.Ntot + 127) / 128) * ((d.Cout + 63) / 64);
+    static const int force_tile = getenv("SDC_TILE") ? atoi(getenv("SDC_TILE")) : 0;   // tuning knob: 1..5 picks a tile
+    if (force_tile && d.Cout > 32) {
+        switch (force_tile) {
+            case 1: launch<128, 128, 2, 2>(a, fast, s); break;
+            case 2: launch<64, 256, 1, 4>(a, fast, s); break;
+            case 3: launch<64, 128, 2, 2>(a, fast, s); break;
+            case 4: launch<64, 64, 2, 2>(a, fast, s); break;
+            default: launch<32, 128, 1, 4>(a, fast, s); break;
+        }
+        return sdc::check_launch("sdc_conv");
+    }
     if (d.Cout > 64 && a.Ntot >= 128 * 256)
         launch<128, 128, 2, 2>(a, fast, s);
     else if (d.Cout > 32 && d.Cout <= 64 && a.Ntot >= 256 * 1024)

@@ -246,7 +246,9 @@ class _HipUNet(nn.Module):
             _register(self, k, v)
         self._spec = spec
         self._plans = {}
-        self.precision = 0        # 0: exact fp32 convs (parity mode); 1: opt-in split-bf16 convs (set before first use)
+        # conv algorithm (include/sdc.h): 2 = fp32, Winograd F(2,3) along W for the 3-tap stride-1 convs (default; same
+        # fp32 accuracy as the direct form, 2/3 of its MFMA work); 0 = fp32 direct everywhere; 1 = opt-in split-bf16
+        self.precision = 2
         self.dim = dim
         self.self_condition = False
         # every time-conditioned ResnetBlock gets a slot [scale | shift] in the conditioning row

@@ -310,3 +310,45 @@ def test_conv_split_bf16_opt_in(plan_cls, case):
     e1 = (outs[1] - ref).abs().max().item() / scale
     assert e0 < 2e-6 and e1 < 2e-4, (e0, e1)
     assert e1 > 0            # it really is the other kernel
+
+
+@pytest.mark.parametrize("case", [
+    dict(nd=2, B=4, cin=64, cout=64, sp=(16, 128), k=3, pad=1),                                 # whole rows per tile
+    dict(nd=2, B=40, cin=128, cout=192, sp=(8, 64), k=3, pad=1, cin1=64, residual=True),        # 128-row tile, concat, ragged Cout tile
+    dict(nd=2, B=6, cin=32, cout=128, sp=(2, 16), k=3, pad=1),                                  # 16-wide rows: 8 segments per tile
+    dict(nd=2, B=300, cin=64, cout=64, sp=(16, 128), k=3, pad=1, residual=True),                # 64x256 tile
+    dict(nd=2, B=1, cin=16, cout=36, sp=(5, 256), k=3, pad=1),                                  # rows longer than a tile, ragged N
+    dict(nd=3, B=2, cin=32, cout=96, sp=(4, 16, 16), k=3, pad=1),                               # 3x3x3
+    dict(nd=1, B=3, cin=48, cout=64, sp=(128,), k=3, pad=1),                                    # Conv1d k3
+    dict(nd=2, B=2, cin=64, cout=384, sp=(16, 128), k=1),                                       # not covered -> direct kernel
+    dict(nd=2, B=2, cin=24, cout=64, sp=(8, 30), k=3, pad=1),                                   # Cin % 16 != 0 -> direct kernel
+])
+def test_conv_winograd_mode(plan_cls, case):
+    """precision=2: fp32 Winograd F(2,3) along W.  Same fp32 arithmetic in a different summation order: error stays
+    within a few fp32 ulps of the output scale (direct kernel: <= 2e-6, Winograd: <= 6e-6)."""
+    from safediffcon_amd.engine import as5
+    nd, B, cin, cout, sp, k = case["nd"], case["B"], case["cin"], case["cout"], case["sp"], case["k"]
+    pad, cin1 = case.get("pad", 0), case.get("cin1", 0)
+    x, x1 = det_tensor((B, cin, *sp), 91), (det_tensor((B, cin1, *sp), 92) if cin1 else None)
+    w, b = det_tensor((cout, cin + cin1, *([k] * nd)), 93, 0.2), det_tensor((cout,), 94, 0.1)
+    xin = x if x1 is None else torch.cat((x, x1), 1)
+    ref = (F.conv1d, F.conv2d, F.conv3d)[nd - 1](xin.double(), w.double(), b.double(), padding=pad)
+    res = det_tensor(tuple(ref.shape), 95) if case.get("residual") else None
+    if res is not None:
+        ref = ref + res.double()
+    outs = {}
+    for prec in (0, 2):
+        plan = plan_cls(DEV, precision=prec)
+        k3, p3 = (1,) * (3 - nd) + (k,) * nd, (0,) * (3 - nd) + (pad,) * nd
+        out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, k3,
+                        x1=None if x1 is None else as5(x1.to(DEV)), pad=p3,
+                        residual=None if res is None else as5(res.to(DEV)))
+        _run(plan)
+        outs[prec] = out.cpu().reshape(ref.shape).double()
+    scale = ref.abs().max().item()
+    e0 = (outs[0] - ref).abs().max().item() / scale
+    e2 = (outs[2] - ref).abs().max().item() / scale
+    print(f"rel err direct {e0:.2e} winograd {e2:.2e}")
+    assert e0 < 2e-6 and e2 < 6e-6, (e0, e2)
+    covered = k == 3 and cin % 16 == 0 and cin1 % 16 == 0 and cout > 32
+    assert torch.equal(outs[0], outs[2]) != covered       # Winograd where eligible, the direct kernel elsewhere

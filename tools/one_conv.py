@@ -7,13 +7,18 @@ from safediffcon_amd.engine import Plan, as5
 cin, cout, k, H, W, B = (int(v) for v in sys.argv[1:7])
 reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5
 dev = "cuda:0"
-plan = Plan(dev)
+plan = Plan(dev, precision=int(os.environ.get('SDC_PRECISION', '0')))
 x = torch.randn(B, cin, H, W, device=dev)
 w = torch.randn(cout, cin, k, k, device=dev) * 0.05
 b = torch.randn(cout, device=dev)
 out = plan.conv(as5(x), plan.conv_weight(w), b, cout, (1, k, k), pad=(0, k // 2, k // 2))
 s = torch.cuda.current_stream().cuda_stream
+plan.run(s)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
 for _ in range(reps):
     plan.run(s)
+e1.record()
 torch.cuda.synchronize()
-print("done", out.shape)
+ms = e0.elapsed_time(e1) / reps
+print(f"done {tuple(out.shape)} {ms:.4f} ms {2.0 * B * H * W * cout * cin * k * k / ms / 1e9:.1f} TF/s")
