@@ -39,9 +39,15 @@ def conv_instance(d):
     if (d.precision == 2 and fast and d.kW == 3 and d.sW == 1 and d.uD == d.uH == d.uW == 1 and d.up_mode == 0
             and d.kD * d.kH <= 32 and d.Cout % 4 == 0 and d.Cout > 32 and d.oW % 2 == 0 and d.oW >= 16
             and (d.oW % 128 == 0 or 128 % d.oW == 0)):
-        if d.Cout > 64 and ((ntot + 127) // 128) * ((d.Cout + 127) // 128) >= 256:
-            return "conv_wg_kernel<128,128,4,2,16,512>"
-        if d.Cout <= 64 and ntot >= 64 * 1024 and (d.oW % 256 == 0 or 256 % d.oW == 0):
+        fits = lambda bn: d.oW % bn == 0 or bn % d.oW == 0
+        nblk = lambda bm, bn: ((ntot + bn - 1) // bn) * ((d.Cout + bm - 1) // bm)
+        if d.Cout > 64:
+            if fits(256) and nblk(128, 256) >= 256:
+                return "conv_wg_kernel<128,256,4,2,16,512>"
+            return "conv_wg_kernel<128,128,4,2,16,512>" if nblk(128, 128) >= 256 else "conv_wg_kernel<64,128,2,2,16,256>"
+        if fits(512) and nblk(64, 512) >= 512:
+            return "conv_wg_kernel<64,512,2,4,16,512>"
+        if fits(256) and nblk(64, 256) >= 256:
             return "conv_wg_kernel<64,256,2,4,16,512>"
         return "conv_wg_kernel<64,128,2,2,16,256>"
     if (d.kW == 7 and d.sW == 1 and d.uD == d.uH == d.uW == 1 and d.up_mode == 0 and d.kD * d.kH <= 64 and d.Cout % 4 == 0

@@ -1309,14 +1309,22 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
                  (!residual || (even(d.rs) && reinterpret_cast<uintptr_t>(residual) % 8 == 0));
         auto fits = [&](int bn) { return (d.oW % bn == 0) || (bn % d.oW == 0); };
         static const int wg_tile = getenv("SDC_WG_TILE") ? atoi(getenv("SDC_WG_TILE")) : 0;   // tuning knob
-        // 8-wave workgroups (two waves per SIMD, 64 accumulator registers each) share one staged weight tile:
-        // 128 x 128 outputs for wide layers, 64 x 256 for Cout <= 64; 4-wave 64 x 128 for short rows / small N
-        const int64_t b128 = (int64_t)((a.Ntot + 127) / 128) * ((d.Cout + 127) / 128);
-        int pick = wg_tile ? wg_tile : (d.Cout > 64 && b128 >= 256 ? 6 : (d.Cout <= 64 && a.Ntot >= 64 * 1024 ? 7 : 3));
-        if (pick == 7 && !fits(256)) pick = 3;
+        // 8-wave workgroups (two waves per SIMD) share one staged weight tile; the bigger the tile the fewer L2->LDS
+        // bytes per MFMA: 128 x 256 (128 accumulator registers per lane) / 128 x 128 for wide layers, 64 x 512 /
+        // 64 x 256 for Cout <= 64, 4-wave 64 x 128 for small grids
+        auto nblk = [&](int bm, int bn) { return (int64_t)((a.Ntot + bn - 1) / bn) * ((d.Cout + bm - 1) / bm); };
+        int pick = wg_tile;
+        if (!pick) {
+            if (d.Cout > 64) pick = (fits(256) && nblk(128, 256) >= 256) ? 9 : (nblk(128, 128) >= 256 ? 6 : 3);
+            else pick = (fits(512) && nblk(64, 512) >= 512) ? 10 : (fits(256) && nblk(64, 256) >= 256 ? 7 : 3);
+        }
+        if ((pick == 7 || pick == 9) && !fits(256)) pick = 3;
+        if (pick == 10 && !fits(512)) pick = 3;
         if (fits(128)) {
             if (pick == 6) launch_wg<128, 128, 4, 2, 16, 512>(a, s);
             else if (pick == 7) launch_wg<64, 256, 2, 4, 16, 512>(a, s);
+            else if (pick == 9) launch_wg<128, 256, 4, 2, 16, 512>(a, s);
+            else if (pick == 10) launch_wg<64, 512, 2, 4, 16, 512>(a, s);
             else launch_wg<64, 128, 2, 2, 16>(a, s);
             return sdc::check_launch("sdc_conv[winograd]");
         }

@@ -316,7 +316,10 @@ def test_conv_split_bf16_opt_in(plan_cls, case):
     dict(nd=2, B=4, cin=64, cout=64, sp=(16, 128), k=3, pad=1),                                 # whole rows per tile
     dict(nd=2, B=40, cin=128, cout=192, sp=(8, 64), k=3, pad=1, cin1=64, residual=True),        # 128-row tile, concat, ragged Cout tile
     dict(nd=2, B=6, cin=32, cout=128, sp=(2, 16), k=3, pad=1),                                  # 16-wide rows: 8 segments per tile
-    dict(nd=2, B=300, cin=64, cout=64, sp=(16, 128), k=3, pad=1, residual=True),                # 64x256 tile
+    dict(nd=2, B=300, cin=64, cout=64, sp=(16, 128), k=3, pad=1, residual=True),                # 64x512 tile
+    dict(nd=2, B=40, cin=32, cout=48, sp=(16, 128), k=3, pad=1),                                # 64x256 tile, ragged Cout
+    dict(nd=2, B=64, cin=32, cout=128, sp=(16, 64), k=3, pad=1, residual=True),                 # 128x256 tile
+    dict(nd=2, B=260, cin=16, cout=160, sp=(16, 16), k=3, pad=1),                               # 128x256 tile, 16-wide rows, ragged
     dict(nd=2, B=1, cin=16, cout=36, sp=(5, 256), k=3, pad=1),                                  # rows longer than a tile, ragged N
     dict(nd=3, B=2, cin=32, cout=96, sp=(4, 16, 16), k=3, pad=1),                               # 3x3x3
     dict(nd=1, B=3, cin=48, cout=64, sp=(128,), k=3, pad=1),                                    # Conv1d k3
