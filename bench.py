@@ -36,11 +36,19 @@ def conv_instance(d):
     """mirror of the tile selection in csrc/sdc_conv.hip::sdc_conv"""
     ntot = d.B * d.oD * d.oH * d.oW
     fast = (d.Cin0 % 16 == 0) and (d.Cin1 % 16 == 0)
-    if (d.precision == 2 and fast and d.kW == 3 and d.sW == 1 and d.uD == d.uH == d.uW == 1 and d.up_mode == 0
+    ups = d.uH > 1 or d.uW > 1
+    if (d.precision == 2 and fast and d.kW == 3 and d.sW == 1 and d.uD == 1 and d.up_mode == 0
+            and (not ups or (d.uH <= 2 and d.uW <= 2 and d.kD == 1 and d.kH <= 3 and d.sH == 1 and d.Cin1 == 0))
             and d.kD * d.kH <= 32 and d.Cout % 4 == 0 and d.Cout > 32 and d.oW % 2 == 0 and d.oW >= 16
             and (d.oW % 128 == 0 or 128 % d.oW == 0)):
         fits = lambda bn: d.oW % bn == 0 or bn % d.oW == 0
         nblk = lambda bm, bn: ((ntot + bn - 1) // bn) * ((d.Cout + bm - 1) // bm)
+        if ups:
+            if d.Cout > 64 and nblk(128, 128) >= 256:
+                return "conv_wg_kernel<128,128,4,2,16,512,ups>"
+            if d.Cout <= 64 and fits(256) and nblk(64, 256) >= 256:
+                return "conv_wg_kernel<64,256,2,4,16,512,ups>"
+            return "conv_wg_kernel<64,128,2,2,16,256,ups>"
         if d.Cout > 64:
             if fits(256) and nblk(128, 256) >= 256:
                 return "conv_wg_kernel<128,256,4,2,16,512>"

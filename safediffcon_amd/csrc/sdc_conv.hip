@@ -958,7 +958,10 @@ __device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[4][
     }
 }
 
-template <int BM, int BN, int WM, int WN, int SK, int NTH>
+// UPS: the input is read through a virtual nearest-neighbour x2 upsampling along H and/or W (Upsample + conv,
+// 1D/model/unet.py:24-37): the staged row is the upsampled one (column >> 1), and the source row of tap kh,
+// (oh - pH + kh) >> 1, differs per output row, so its offset is kept per lane for the (<= 3) kh taps; kD = 1, one input.
+template <int BM, int BN, int WM, int WN, int SK, int NTH, bool UPS>
 __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TP = BN / 2 / WN / 32;                        // 32-pair column tiles per wave
@@ -988,11 +991,13 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
     const bool two = d.Cin1 > 0;
 
     int v0[NCOL], v1[NCOL];
+    int hoff[UPS ? NCOL : 1][3];
     uint64_t smask[NCOL];
 #pragma unroll
     for (int t = 0; t < NCOL; ++t) {
         const int cidx = lane + 64 * t;
         v0[t] = 0; v1[t] = 0; smask[t] = 0;
+        if constexpr (UPS) { hoff[t][0] = 0; hoff[t][1] = 0; hoff[t][2] = 0; }
         if (cidx < ks_stride) {
             const int sg = cidx / rowlen;
             const int cc = cidx - sg * rowlen;
@@ -1005,15 +1010,27 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
                 const int col = ow0 + cc - d.pW;
                 const int id0 = od * d.sD - d.pD, ih0 = oh * d.sH - d.pH;
                 uint64_t m = 0;
-                if (col >= 0 && col < d.iW) {
-                    for (int kd = 0; kd < d.kD; ++kd)
+                if constexpr (UPS) {
+                    if (col >= 0 && col < (d.iW << a.lgW)) {
                         for (int kh = 0; kh < d.kH; ++kh)
-                            if (id0 + kd >= 0 && id0 + kd < d.iD && ih0 + kh >= 0 && ih0 + kh < d.iH)
-                                m |= 1ull << (kd * d.kH + kh);
+                            if (ih0 + kh >= 0 && ih0 + kh < (d.iH << a.lgH)) {
+                                m |= 1ull << kh;
+                                hoff[t][kh] = (int)(((ih0 + kh) >> a.lgH) * d.x0s[3]);
+                            }
+                    }
+                    smask[t] = m;
+                    v0[t] = (int)(ob * d.x0s[0] + id0 * d.x0s[2] + (col >> a.lgW) * d.x0s[4]);
+                } else {
+                    if (col >= 0 && col < d.iW) {
+                        for (int kd = 0; kd < d.kD; ++kd)
+                            for (int kh = 0; kh < d.kH; ++kh)
+                                if (id0 + kd >= 0 && id0 + kd < d.iD && ih0 + kh >= 0 && ih0 + kh < d.iH)
+                                    m |= 1ull << (kd * d.kH + kh);
+                    }
+                    smask[t] = m;
+                    v0[t] = (int)(ob * d.x0s[0] + id0 * d.x0s[2] + ih0 * d.x0s[3] + col * d.x0s[4]);
+                    if (two) v1[t] = (int)(ob * d.x1s[0] + id0 * d.x1s[2] + ih0 * d.x1s[3] + col * d.x1s[4]);
                 }
-                smask[t] = m;
-                v0[t] = (int)(ob * d.x0s[0] + id0 * d.x0s[2] + ih0 * d.x0s[3] + col * d.x0s[4]);
-                if (two) v1[t] = (int)(ob * d.x1s[0] + id0 * d.x1s[2] + ih0 * d.x1s[3] + col * d.x1s[4]);
             }
         }
     }
@@ -1054,13 +1071,16 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
         l_ci = s_ci;
         const bool first = s_ci < d.Cin0;
         l_sc = first ? d.x0s[1] : d.x1s[1];
-        const int64_t toff = first ? s_kd * d.x0s[2] + s_kh * d.x0s[3] : s_kd * d.x1s[2] + s_kh * d.x1s[3];
+        const int64_t toff = UPS ? 0 : (first ? s_kd * d.x0s[2] + s_kh * d.x0s[3] : s_kd * d.x1s[2] + s_kh * d.x1s[3]);
         l_base = (first ? a.x0 + (int64_t)s_ci * l_sc : a.x1 + (int64_t)(s_ci - d.Cin0) * l_sc) + (int64_t)(wave * KROWS) * l_sc;
         mbits = 0;
 #pragma unroll
         for (int t = 0; t < NCOL; ++t) {
             const bool ok = (smask[t] >> l_tap) & 1u;
-            l_off[t] = ok ? (int64_t)(first ? v0[t] : v1[t]) + toff : 0;
+            if constexpr (UPS)
+                l_off[t] = ok ? (int64_t)v0[t] + (s_kh == 0 ? hoff[t][0] : (s_kh == 1 ? hoff[t][1] : hoff[t][2])) : 0;
+            else
+                l_off[t] = ok ? (int64_t)(first ? v0[t] : v1[t]) + toff : 0;
             mbits |= (ok ? 1u : 0u) << t;
         }
         s_ci += SK;
@@ -1177,18 +1197,18 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
     wg_epilogue<TM, TP>(a, acc, m0 + wm * (TM * 32), n0 / 2 + wn * (TP * 32), lane);
 }
 
-template <int BM, int BN, int WM, int WN, int SK, int NTH = 256>
+template <int BM, int BN, int WM, int WN, int SK, int NTH = 256, bool UPS = false>
 void launch_wg(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
     constexpr int KSMAX = BN + (BN / 16) * 2;
     const size_t lds = (2u * 4u * SK * BM + 2u * SK * KSMAX) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wg_kernel<BM, BN, WM, WN, SK, NTH>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((conv_wg_kernel<BM, BN, WM, WN, SK, NTH>), grid, dim3(NTH), lds, s, a);
+    hipLaunchKernelGGL((conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS>), grid, dim3(NTH), lds, s, a);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -1301,7 +1321,9 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
         return sdc::check_launch("sdc_conv[bf16x3]");
     }
     // opt-in fp32 Winograd F(2,3) along W: 3-wide stride-1 taps, whole 16-channel chunks, even rows
-    if (d.precision == 2 && a.rowhalo && d.kW == 3 && d.sW == 1 && d.uD == 1 && d.uH == 1 && d.uW == 1 && d.up_mode == 0 &&
+    const bool wg_ups = (d.uH > 1 || d.uW > 1);      // nearest x2 upsampling folded into the gather: one input, kD = 1, kH <= 3
+    if (d.precision == 2 && a.rowhalo && d.kW == 3 && d.sW == 1 && d.uD == 1 && d.up_mode == 0 &&
+        (!wg_ups || (d.uH <= 2 && d.uW <= 2 && d.kD == 1 && d.kH <= 3 && d.sH == 1 && d.Cin1 == 0)) &&
         d.kD * d.kH <= 32 && d.Cin0 % 16 == 0 && d.Cin1 % 16 == 0 && small && d.Cout % 4 == 0 && d.Cout > 32 &&
         d.oW % 2 == 0 && d.oW >= 16 && reinterpret_cast<uintptr_t>(wp) % 16 == 0 && ((int64_t)a.Ktot * d.Cout) % 4 == 0) {
         auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
@@ -1320,6 +1342,12 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
         }
         if ((pick == 7 || pick == 9) && !fits(256)) pick = 3;
         if (pick == 10 && !fits(512)) pick = 3;
+        if (wg_ups && fits(128)) {
+            if (d.Cout > 64 && nblk(128, 128) >= 256) launch_wg<128, 128, 4, 2, 16, 512, true>(a, s);
+            else if (d.Cout <= 64 && fits(256) && nblk(64, 256) >= 256) launch_wg<64, 256, 2, 4, 16, 512, true>(a, s);
+            else launch_wg<64, 128, 2, 2, 16, 256, true>(a, s);
+            return sdc::check_launch("sdc_conv[winograd,upsample]");
+        }
         if (fits(128)) {
             if (pick == 6) launch_wg<128, 128, 4, 2, 16, 512>(a, s);
             else if (pick == 7) launch_wg<64, 256, 2, 4, 16, 512>(a, s);

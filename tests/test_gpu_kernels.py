@@ -355,3 +355,32 @@ def test_conv_winograd_mode(plan_cls, case):
     assert e0 < 2e-6 and e2 < 6e-6, (e0, e2)
     covered = k == 3 and cin % 16 == 0 and cin1 % 16 == 0 and cout > 32
     assert torch.equal(outs[0], outs[2]) != covered       # Winograd where eligible, the direct kernel elsewhere
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=6, cin=128, cout=64, sp=(8, 64), up=(2, 2)),        # Upsample2d: 16x128 out, Cout 64
+    dict(B=40, cin=256, cout=128, sp=(4, 32), up=(2, 2)),      # 128-row tile
+    dict(B=3, cin=64, cout=96, sp=(1, 64), up=(1, 2)),         # tokamak Upsample (1-D): kH = 1
+    dict(B=2, cin=32, cout=40, sp=(5, 8), up=(2, 2)),          # 16-wide upsampled rows, odd row count, ragged Cout
+])
+def test_conv_winograd_nearest_upsample(plan_cls, case):
+    """nn.Upsample(scale 2, nearest) + conv k3 p1 folded into one launch, direct (precision 0) and Winograd (2)."""
+    from safediffcon_amd.engine import as5
+    B, cin, cout, sp, up = case["B"], case["cin"], case["cout"], case["sp"], case["up"]
+    x = det_tensor((B, cin, *sp), 101)
+    kh = 3 if up[0] == 2 else 1
+    w, b = det_tensor((cout, cin, kh, 3), 102, 0.2), det_tensor((cout,), 103, 0.1)
+    xu = x.double().repeat_interleave(up[0], 2).repeat_interleave(up[1], 3)
+    ref = F.conv2d(xu, w.double(), b.double(), padding=(kh // 2, 1))
+    outs = {}
+    for prec in (0, 2):
+        plan = plan_cls(DEV, precision=prec)
+        out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, (1, kh, 3), pad=(0, kh // 2, 1),
+                        up=(1, *up))
+        _run(plan)
+        outs[prec] = out.cpu().reshape(ref.shape).double()
+    scale = ref.abs().max().item()
+    e0 = (outs[0] - ref).abs().max().item() / scale
+    e2 = (outs[2] - ref).abs().max().item() / scale
+    assert e0 < 6e-6 and e2 < 6e-6, (e0, e2)        # K up to 2304: a few fp32 ulps of the output scale
+    assert not torch.equal(outs[0], outs[2])
