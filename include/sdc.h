@@ -114,6 +114,19 @@ int sdc_chan_norm(const float* x, const float* g, const float* residual, float* 
 int sdc_linattn(const float* qkv, float* ctx, float* out, int outer, int inner, int heads, int64_t n,
                 int64_t q_so, int64_t q_sc, int64_t q_si, int64_t o_so, int64_t o_sc, int64_t o_si, void* stream);
 
+/* Fused LinearAttention block, dim C in {64, 128}, heads 4 x 32, tokens contiguous, n % 64 == 0:
+ *   y = x + post( Wo . LA(pre(x)) + bo )
+ * i.e. Residual(PreNorm(dim, LinearAttention(dim))) in one call: 1D/model/unet.py:64-71,182-222,341-342;
+ * tokamak/model/unet.py:186-222; conv3d.py:176-184,232-258 (SpatialLinearAttention, post_mode -1).
+ * pre_mode / post_mode: 0 channel LayerNorm (gain only), 1 RMSNorm, post_mode -1 = none.
+ * wqkv = packed 1x1 weight [C][384] (q | k | v), wo = packed [128][C], bo = [C] or null.
+ * x and y share the layout element(o, c, i, tok) at o*so + c*sc + i*si + tok.  `work` holds
+ * sdc_linattn_block_bytes(...) bytes of scratch.  Three launches: x is read three times, y written once. */
+size_t sdc_linattn_block_bytes(int outer, int inner, int C, int64_t n);
+int sdc_linattn_block(const float* x, const float* g_pre, const float* wqkv, const float* wo, const float* bo,
+                      const float* g_post, float* work, float* y, int outer, int inner, int C, int64_t n,
+                      int64_t so, int64_t sc, int64_t si, int pre_mode, int post_mode, float eps, void* stream);
+
 /* ------------------------------------------------------- softmax attention */
 /* Attention core (heads x 32): out = softmax(q*scale . k^T + bias) v, optional rotary on q,k.
  * 1D/model/unet.py:247-251 ; conv3d.py:313-353 (focus_present_mask all-False).

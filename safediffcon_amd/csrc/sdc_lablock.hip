@@ -1,0 +1,434 @@
+// Fused LinearAttention block (Residual(PreNorm(dim, LinearAttention(dim))), heads 4 x dim_head 32, dim C in {64,128}):
+//
+//   y = x + post( Wo . LA(pre(x)) + bo ),   LA: q = softmax_d(Wq xn) * 32^-0.5, k = softmax_n(Wk xn), v = Wv xn,
+//                                               ctx = k v^T (32x32 per head), out = ctx^T q
+// 1D/model/unet.py:182-222 (+ PreNorm :64-71, LayerNorm :53-63), tokamak/model/unet.py:186-222 (RMSNorm :45-51),
+// conv3d.py:232-258 (SpatialLinearAttention, PreNorm :176-184).
+//
+// The unfused chain writes xn, q/k/v (3 x 128 channels), out (128 channels) and the projected y to HBM and reads them
+// back -- ~27 x the bytes of x per block at C = 64.  Here x is read three times and y written once:
+//   pass 1  la_blk_ctx : x tile -> channel norm -> K = Wk xn on the matrix cores -> online softmax over tokens
+//                        (running row max, rescaled accumulators) -> M[d][c] += sum_tok p[d][tok] xn[c][tok]
+//                        (ctx = M Wv^T / rowsum: V is never formed per token)
+//   mid     la_blk_mid : merge the token splits (log-sum-exp), ctx = M Wv^T / sum, T[co][h,d] = sum_e Wo[co][h,e] ctx_h[d][e]
+//   pass 2  la_blk_out : x tile -> channel norm -> Q = Wq xn -> softmax over d, * scale -> y = T q + bo -> channel
+//                        norm (LayerNorm / RMSNorm / none) -> + x -> store
+// All products are v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate).  Tokens contiguous, n % 64 == 0.
+#include "sdc_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int TT = 64;            // tokens per tile
+constexpr int XP = TT + 1;        // LDS pitch of a token row (odd: conflict-free when lanes walk channels)
+constexpr int HID = 128;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct LaArgs {
+    const float* x;
+    const float* g_pre;
+    const float* wqkv;      // packed [C][384]  (q | k | v, each heads*32)
+    const float* wo;        // packed [128][C]
+    const float* bo;        // [C] or null
+    const float* g_post;    // [C] or null
+    float* part;            // [nseq][nsplit][4][32*(C+2)]
+    float* tt;              // [nseq][128][C]
+    float* y;
+    int inner, nsplit, tiles_per_split, ntiles, tiles_per_blk;
+    int pre_mode, post_mode;
+    float eps;
+    int64_t so, sc, si;
+};
+
+__device__ __forceinline__ float half_max(float v) {      // max over the 32 lanes of this lane's half-wave
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// x tile (C channels x 64 tokens) -> channel norm over C per token -> xs[c][tok].  Thread (tok = tid & 63, group =
+// tid >> 6) owns C/4 channels of one token; the per-token statistics are combined across the 4 groups through `red`.
+// mode 0: (x - mean) * rsqrt(var + eps) * g (two-pass variance); mode 1: x / max(||x||, 1e-12) * g * sqrt(C).
+// fetch_tile only issues the loads (the next tile's are issued while the current one is on the matrix cores);
+// norm_tile consumes them; `xr`, when given, keeps the raw tile for the residual add.
+template <int C>
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ xb, int64_t sc, int tid, float (&v)[C / 4]) {
+    constexpr int CG = C / 4;
+    const int tok = tid & 63, grp = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < CG; ++k) v[k] = xb[(int64_t)(grp * CG + k) * sc + tok];
+}
+
+template <int C>
+__device__ __forceinline__ void norm_tile(float (&v)[C / 4], const float* __restrict__ g, int mode, float eps,
+                                          float* __restrict__ xs, float* __restrict__ xr, float* __restrict__ red, int tid) {
+    constexpr int CG = C / 4;
+    const int tok = tid & 63, grp = tid >> 6;
+    if (xr) {
+#pragma unroll
+        for (int k = 0; k < CG; ++k) xr[(grp * CG + k) * XP + tok] = v[k];
+    }
+    float s = 0.f;
+    if (mode == 0) {
+#pragma unroll
+        for (int k = 0; k < CG; ++k) s += v[k];
+        red[grp * TT + tok] = s;
+        __syncthreads();
+        const float mean = (red[tok] + red[TT + tok] + red[2 * TT + tok] + red[3 * TT + tok]) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < CG; ++k) { v[k] -= mean; q += v[k] * v[k]; }
+        red[(4 + grp) * TT + tok] = q;
+        __syncthreads();
+        const float var = (red[4 * TT + tok] + red[5 * TT + tok] + red[6 * TT + tok] + red[7 * TT + tok]) * (1.0f / C);
+        const float rstd = rsqrtf(var + eps);
+#pragma unroll
+        for (int k = 0; k < CG; ++k) xs[(grp * CG + k) * XP + tok] = v[k] * rstd * g[grp * CG + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < CG; ++k) s += v[k] * v[k];
+        red[grp * TT + tok] = s;
+        __syncthreads();
+        const float nrm = sqrtf(red[tok] + red[TT + tok] + red[2 * TT + tok] + red[3 * TT + tok]);
+        const float f = sqrtf((float)C) / fmaxf(nrm, 1e-12f);
+#pragma unroll
+        for (int k = 0; k < CG; ++k) xs[(grp * CG + k) * XP + tok] = v[k] * f * g[grp * CG + k];
+    }
+    __syncthreads();
+}
+
+// 32 x 64 projection tile of one head: acc[j][r] = (W_h xn)[row(r, lh)][j*32 + l31], W fragments in registers
+template <int C>
+__device__ __forceinline__ void project(const float (&wreg)[C / 2], const float* __restrict__ xs, int l31, int lh, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < C / 2; ++ks) {
+        const float b0 = xs[(2 * ks + lh) * XP + l31], b1 = xs[(2 * ks + lh) * XP + 32 + l31];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[ks], b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[ks], b1, acc[1], 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------ pass 1: per (split, sequence); wave = head
+template <int C>
+__global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) void la_blk_ctx(const LaArgs a) {
+    constexpr int NCT = C / 32;                     // column tiles of M (channels)
+    extern __shared__ float lds[];                  // C = 128 needs 67 KB: dynamic
+    float* const xs = lds;                          // [C][XP]
+    float* const ps = lds + C * XP;                 // [4][32][XP]
+    float* const red = ps + HID * XP;               // [8][TT]
+    const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int split = blockIdx.x, seq = blockIdx.y;
+    const int o = seq / a.inner, i = seq - o * a.inner;
+    const float* xseq = a.x + o * a.so + i * a.si;
+
+    float wreg[C / 2];                              // Wk_h[d = l31][c = 2ks + lh]
+#pragma unroll
+    for (int ks = 0; ks < C / 2; ++ks) wreg[ks] = a.wqkv[(int64_t)(2 * ks + lh) * (3 * HID) + HID + head * 32 + l31];
+
+    f32x16 macc[NCT];
+    float mrun[16], psum[16];
+#pragma unroll
+    for (int t = 0; t < NCT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) macc[t][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { mrun[r] = -INFINITY; psum[r] = 0.f; }
+    float* psh = ps + head * 32 * XP;
+
+    const int t0 = split * a.tiles_per_split;
+    const int t1 = min(t0 + a.tiles_per_split, a.ntiles);
+    float xv[C / 4];
+    if (t0 < t1) fetch_tile<C>(xseq + (int64_t)t0 * TT, a.sc, tid, xv);
+    for (int tile = t0; tile < t1; ++tile) {
+        norm_tile<C>(xv, a.g_pre, a.pre_mode, a.eps, xs, nullptr, red, tid);
+        if (tile + 1 < t1) fetch_tile<C>(xseq + (int64_t)(tile + 1) * TT, a.sc, tid, xv);
+        f32x16 kacc[2];
+        project<C>(wreg, xs, l31, lh, kacc);
+        // online softmax over tokens: row d = (r&3) + 8*(r>>2) + 4*lh lives in register r of this half-wave
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float tmax = half_max(fmaxf(kacc[0][r], kacc[1][r]));
+            const float mnew = fmaxf(mrun[r], tmax);
+            const float f = __expf(mrun[r] - mnew);
+            mrun[r] = mnew;
+            const float p0 = __expf(kacc[0][r] - mnew), p1 = __expf(kacc[1][r] - mnew);
+            psum[r] = psum[r] * f + p0 + p1;
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) macc[t][r] *= f;
+            const int d = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            psh[d * XP + l31] = p0;
+            psh[d * XP + 32 + l31] = p1;
+        }
+        // M[d][c] += sum_tok p[d][tok] * xn[c][tok]   (A = p from this wave's own LDS rows, B = xn^T)
+#pragma unroll 8
+        for (int ks = 0; ks < TT / 2; ++ks) {
+            const float av = psh[l31 * XP + 2 * ks + lh];
+#pragma unroll
+            for (int t = 0; t < NCT; ++t)
+                macc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xs[(t * 32 + l31) * XP + 2 * ks + lh], macc[t], 0, 0, 0);
+        }
+        __syncthreads();                             // xs is rewritten by the next tile
+    }
+    // partial result of this split: M[32][C], m[32], s[32]
+    float* pp = a.part + (((int64_t)seq * a.nsplit + split) * 4 + head) * (32 * (C + 2));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float s = half_sum(psum[r]);
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) pp[d * C + t * 32 + l31] = macc[t][r];
+        if (l31 == 0) { pp[32 * C + d] = mrun[r]; pp[32 * C + 32 + d] = s; }
+    }
+}
+
+// ------------------------------------------------------------------ mid: per (sequence, head)
+template <int C>
+__global__ __launch_bounds__(NT) void la_blk_mid(const LaArgs a) {
+    __shared__ float Ms[32][C + 1];
+    __shared__ float cs[32][33];
+    __shared__ float fsp[8][32];                    // per split: exp(m_s - m) ; nsplit <= 8
+    __shared__ float rs[32];
+    const int tid = threadIdx.x;
+    const int head = blockIdx.x, seq = blockIdx.y;
+    const float* pb = a.part + ((int64_t)seq * a.nsplit * 4 + head) * (32 * (C + 2));
+    const int64_t sstride = (int64_t)4 * 32 * (C + 2);
+    if (tid < 32) {
+        float m = -INFINITY;
+        for (int s = 0; s < a.nsplit; ++s) m = fmaxf(m, pb[s * sstride + 32 * C + tid]);
+        float tot = 0.f;
+        for (int s = 0; s < a.nsplit; ++s) {
+            const float f = __expf(pb[s * sstride + 32 * C + tid] - m);
+            fsp[s][tid] = f;
+            tot += f * pb[s * sstride + 32 * C + 32 + tid];
+        }
+        rs[tid] = 1.0f / tot;
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * C; e += NT) {
+        const int d = e / C, c = e - d * C;
+        float v = 0.f;
+        for (int s = 0; s < a.nsplit; ++s) v += fsp[s][d] * pb[s * sstride + e];
+        Ms[d][c] = v;
+    }
+    __syncthreads();
+    // ctx[d][e] = sum_c M[d][c] Wv[e][c] / rowsum[d]
+    for (int q = tid; q < 32 * 32; q += NT) {
+        const int d = q >> 5, e = q & 31;
+        float v = 0.f;
+        for (int c = 0; c < C; ++c) v += Ms[d][c] * a.wqkv[(int64_t)c * (3 * HID) + 2 * HID + head * 32 + e];
+        cs[d][e] = v * rs[d];
+    }
+    __syncthreads();
+    // Tt[h*32 + d][co] = sum_e Wo[(h*32 + e)][co] ctx[d][e]
+    float* tb = a.tt + (int64_t)seq * HID * C + (int64_t)head * 32 * C;
+    for (int q = tid; q < 32 * C; q += NT) {
+        const int d = q / C, co = q - d * C;
+        float v = 0.f;
+#pragma unroll 8
+        for (int e = 0; e < 32; ++e) v += a.wo[(int64_t)(head * 32 + e) * C + co] * cs[d][e];
+        tb[d * C + co] = v;
+    }
+}
+
+// ------------------------------------------------------------------ pass 2: per (tile group, sequence)
+template <int C>
+__global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) void la_blk_out(const LaArgs a) {
+    constexpr int NRT = C / 32;                     // row tiles of y (channels)
+    constexpr int TPW = NRT / 2;                    // y tiles per wave (one row tile, TPW column tiles)
+    extern __shared__ float lds[];
+    float* const xs = lds;                          // [C][XP]
+    float* const qs = lds + C * XP;                 // [128][XP]
+    float* const red = qs + HID * XP;               // [8][TT]
+    float* const xr = red + 8 * TT;                 // [C][XP] raw x tile (residual)
+    float* const bg = xr + C * XP;                  // [2][C] bias | post gain
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int seq = blockIdx.y;
+    const int o = seq / a.inner, i = seq - o * a.inner;
+    const float* xseq = a.x + o * a.so + i * a.si;
+    float* yseq = a.y + o * a.so + i * a.si;
+    const int rt = (NRT == 2) ? (wave & 1) : wave;  // this wave's row tile of y
+    const int ct0 = (NRT == 2) ? (wave >> 1) : 0;   // its first column tile
+
+    float wreg[C / 2];                              // Wq_h[d = l31][c = 2ks + lh], head = wave
+#pragma unroll
+    for (int ks = 0; ks < C / 2; ++ks) wreg[ks] = a.wqkv[(int64_t)(2 * ks + lh) * (3 * HID) + wave * 32 + l31];
+    float treg[HID / 2];                            // T[co = rt*32 + l31][hd = 2ks + lh]
+    const float* tb = a.tt + (int64_t)seq * HID * C;
+#pragma unroll
+    for (int ks = 0; ks < HID / 2; ++ks) treg[ks] = tb[(2 * ks + lh) * C + rt * 32 + l31];
+    for (int c = tid; c < C; c += NT) {
+        bg[c] = a.bo ? a.bo[c] : 0.f;
+        bg[C + c] = a.g_post ? a.g_post[c] : 1.f;
+    }
+
+    const int t0 = blockIdx.x * a.tiles_per_blk;
+    const int t1 = min(t0 + a.tiles_per_blk, a.ntiles);
+    float xv[C / 4];
+    if (t0 < t1) fetch_tile<C>(xseq + (int64_t)t0 * TT, a.sc, tid, xv);
+    for (int tile = t0; tile < t1; ++tile) {
+        norm_tile<C>(xv, a.g_pre, a.pre_mode, a.eps, xs, xr, red, tid);
+        if (tile + 1 < t1) fetch_tile<C>(xseq + (int64_t)(tile + 1) * TT, a.sc, tid, xv);
+        f32x16 qacc[2];
+        project<C>(wreg, xs, l31, lh, qacc);
+        // softmax over d (the 32 rows of the head) per token, times dim_head^-0.5
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float m = qacc[j][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, qacc[j][r]);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { qacc[j][r] = __expf(qacc[j][r] - m); s += qacc[j][r]; }
+            s += __shfl_xor(s, 32, 64);
+            const float f = 0.17677669529663687f / s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                qs[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XP + j * 32 + l31] = qacc[j][r] * f;
+        }
+        __syncthreads();
+        // y[co][tok] = sum_hd T[co][hd] q[hd][tok]
+        f32x16 yacc[TPW];
+#pragma unroll
+        for (int u = 0; u < TPW; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yacc[u][r] = bg[rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+        for (int ks = 0; ks < HID / 2; ++ks)
+#pragma unroll
+            for (int u = 0; u < TPW; ++u)
+                yacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(treg[ks], qs[(2 * ks + lh) * XP + (ct0 + u) * 32 + l31], yacc[u], 0, 0, 0);
+        // channel norm over the C rows of each token column: 16 registers x 2 half-waves x NRT row tiles (waves)
+        if (a.post_mode >= 0) {
+            float st[TPW];
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += (a.post_mode == 0) ? yacc[u][r] : yacc[u][r] * yacc[u][r];
+                s += __shfl_xor(s, 32, 64);
+                if (lh == 0) red[rt * TT + (ct0 + u) * 32 + l31] = s;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < NRT; ++q) s += red[q * TT + (ct0 + u) * 32 + l31];
+                st[u] = s;
+            }
+            if (a.post_mode == 0) {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    const float mean = st[u] * (1.0f / C);
+                    float q = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { yacc[u][r] -= mean; q += yacc[u][r] * yacc[u][r]; }
+                    q += __shfl_xor(q, 32, 64);
+                    if (lh == 0) red[(4 + rt) * TT + (ct0 + u) * 32 + l31] = q;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    float q = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NRT; ++w) q += red[(4 + w) * TT + (ct0 + u) * 32 + l31];
+                    const float rstd = rsqrtf(q * (1.0f / C) + a.eps);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) yacc[u][r] = yacc[u][r] * rstd * bg[C + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    const float f = sqrtf((float)C) / fmaxf(sqrtf(st[u]), 1e-12f);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) yacc[u][r] = yacc[u][r] * f * bg[C + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+                }
+            }
+        }
+        // + x, store (tokens on lanes: coalesced rows)
+#pragma unroll
+        for (int u = 0; u < TPW; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int col = (ct0 + u) * 32 + l31;
+                yseq[(int64_t)co * a.sc + (int64_t)tile * TT + col] = yacc[u][r] + xr[co * XP + col];
+            }
+        __syncthreads();                             // xs / qs / red are rewritten by the next tile
+    }
+}
+
+// token splits of pass 1: a function of the sequence length only, so a trajectory's result does not depend on how
+// many others share the launch (batch-invariant summation order)
+int pick_nsplit(int64_t /*nseq*/, int ntiles) {
+    int ns = ntiles / 8;
+    if (ns > 8) ns = 8;
+    return ns < 1 ? 1 : ns;
+}
+
+}  // namespace
+
+extern "C" size_t sdc_linattn_block_bytes(int outer, int inner, int C, int64_t n) {
+    if (outer <= 0 || inner <= 0 || n <= 0 || (C != 64 && C != 128)) return 0;
+    const int64_t nseq = (int64_t)outer * inner;
+    const int ns = pick_nsplit(nseq, (int)(n / TT));
+    return sizeof(float) * (size_t)(nseq * ns * 4 * 32 * (C + 2) + nseq * HID * C);
+}
+
+extern "C" int sdc_linattn_block(const float* x, const float* g_pre, const float* wqkv, const float* wo, const float* bo,
+                                 const float* g_post, float* work, float* y, int outer, int inner, int C, int64_t n,
+                                 int64_t so, int64_t sc, int64_t si, int pre_mode, int post_mode, float eps, void* stream) {
+    SDC_REQUIRE(x && g_pre && wqkv && wo && work && y, SDC_ENULL, "sdc_linattn_block: null pointer");
+    SDC_REQUIRE(C == 64 || C == 128, SDC_EINVAL, "sdc_linattn_block: dim must be 64 or 128 (got %d)", C);
+    SDC_REQUIRE(outer > 0 && inner > 0 && n > 0 && n % TT == 0, SDC_EINVAL, "sdc_linattn_block: tokens must be a multiple of 64");
+    SDC_REQUIRE((pre_mode == 0 || pre_mode == 1) && post_mode >= -1 && post_mode <= 1, SDC_EINVAL, "sdc_linattn_block: bad norm mode");
+    SDC_REQUIRE(post_mode < 0 || g_post, SDC_ENULL, "sdc_linattn_block: post norm needs its gain");
+    const int64_t nseq = (int64_t)outer * inner;
+    SDC_REQUIRE(nseq < 65536, SDC_EINVAL, "sdc_linattn_block: outer*inner must be < 65536");
+    LaArgs a;
+    a.x = x; a.g_pre = g_pre; a.wqkv = wqkv; a.wo = wo; a.bo = bo; a.g_post = g_post; a.y = y;
+    a.inner = inner; a.ntiles = (int)(n / TT);
+    a.nsplit = pick_nsplit(nseq, a.ntiles);
+    a.tiles_per_split = (a.ntiles + a.nsplit - 1) / a.nsplit;
+    a.nsplit = (a.ntiles + a.tiles_per_split - 1) / a.tiles_per_split;     // no empty splits
+    {
+        // keep the layout sdc_linattn_block_bytes promised: partials first (sized for the unclamped split count)
+        const int ns0 = pick_nsplit(nseq, a.ntiles);
+        a.part = work;
+        a.tt = work + nseq * ns0 * 4 * 32 * (C + 2);
+    }
+    int tpb = (int)((nseq * a.ntiles + 1023) / 1024);
+    a.tiles_per_blk = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+    a.pre_mode = pre_mode; a.post_mode = post_mode; a.eps = eps;
+    a.so = so; a.sc = sc; a.si = si;
+    hipStream_t s = sdc::as_stream(stream);
+    const dim3 g1((unsigned)a.nsplit, (unsigned)nseq), gm(4, (unsigned)nseq),
+        g2((unsigned)((a.ntiles + a.tiles_per_blk - 1) / a.tiles_per_blk), (unsigned)nseq);
+    const size_t ldsb = sizeof(float) * (size_t)((C + HID) * XP + 8 * TT);          // pass 1
+    const size_t ldsb2 = ldsb + sizeof(float) * (size_t)(C * XP + 2 * C);          // pass 2: + raw tile, bias, gain
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(la_blk_ctx<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(la_blk_out<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(la_blk_out<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr = true;
+    }
+    if (C == 64) {
+        hipLaunchKernelGGL(la_blk_ctx<64>, g1, dim3(NT), ldsb, s, a);
+        hipLaunchKernelGGL(la_blk_mid<64>, gm, dim3(NT), 0, s, a);
+        hipLaunchKernelGGL(la_blk_out<64>, g2, dim3(NT), ldsb2, s, a);
+    } else {
+        hipLaunchKernelGGL(la_blk_ctx<128>, g1, dim3(NT), ldsb, s, a);
+        hipLaunchKernelGGL(la_blk_mid<128>, gm, dim3(NT), 0, s, a);
+        hipLaunchKernelGGL(la_blk_out<128>, g2, dim3(NT), ldsb2, s, a);
+    }
+    return sdc::check_launch("sdc_linattn_block");
+}

@@ -227,6 +227,16 @@ class Plan:
         self._emit(self.lib.sdc_linattn, _ptr(qkv), _ptr(ctx), _ptr(out), outer, inner, heads, n, *q_strides, *o_strides)
         return out
 
+    def linattn_block(self, x, g_pre, wqkv, wo, bo, g_post, outer, inner, n, strides, pre_mode, post_mode, eps=1e-5):
+        """Residual(PreNorm(LinearAttention)) in one call (dim 64 / 128, n % 64 == 0); returns y shaped like x."""
+        Cc = x.shape[1]
+        y = self.pool.get(tuple(x.shape))
+        work = torch.empty(int(self.lib.sdc_linattn_block_bytes(outer, inner, Cc, n)) // 4, dtype=torch.float32, device=self.device)
+        self.keep += [x, g_pre, wqkv, wo, bo, g_post, work, y]
+        self._emit(self.lib.sdc_linattn_block, _ptr(x), _ptr(g_pre), _ptr(wqkv), _ptr(wo), _ptr(bo), _ptr(g_post), _ptr(work),
+                   _ptr(y), outer, inner, Cc, n, *strides, pre_mode, post_mode, eps)
+        return y
+
     def attn(self, qkv, out, heads, outer, inner, ntok, q_strides, o_strides, rot=None, bias=None):
         self.keep += [qkv, out, rot, bias]
         self._emit(self.lib.sdc_attn, _ptr(qkv), _ptr(out), _ptr(rot), _ptr(bias), outer, inner, heads, ntok,

@@ -11,6 +11,7 @@ is no torch.nn op and no CPU path.  Weights live in ordinary ``nn.Parameter``s, 
 into kernel layouts when a plan is built (``refresh()`` after weights change).
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -249,6 +250,9 @@ class _HipUNet(nn.Module):
         # conv algorithm (include/sdc.h): 2 = fp32, Winograd F(2,3) along W for the 3-tap stride-1 convs (default; same
         # fp32 accuracy as the direct form, 2/3 of its MFMA work); 0 = fp32 direct everywhere; 1 = opt-in split-bf16
         self.precision = 2
+        # LinearAttention blocks of width 64 / 128 as the fused 3-launch form (csrc/sdc_lablock.hip); False = the
+        # unfused chain norm -> 1x1 -> attention core -> 1x1 -> norm (kept for wider layers and for A/B checks)
+        self.fuse_linattn = os.environ.get("SDC_NO_LABLOCK", "0") != "1"
         self.dim = dim
         self.self_condition = False
         # every time-conditioned ResnetBlock gets a slot [scale | shift] in the conditioning row
@@ -297,7 +301,7 @@ class _HipUNet(nn.Module):
     def entry(self, shape, rows, lut=False):
         """Plan for an input of `shape` whose conditioning table has `rows` rows: one row per sample
         (lut=False, forward(x, time)) or one row per timestep read through a device-side t (lut=True, samplers)."""
-        key = (tuple(shape), rows, bool(lut), int(self.precision))
+        key = (tuple(shape), rows, bool(lut), int(self.precision), bool(self.fuse_linattn))
         if key not in self._plans:
             dev = self.device()
             if dev.type != "cuda":
@@ -388,6 +392,10 @@ class _LucidUNet(_HipUNet):
         plan, pool = b.plan, b.plan.pool
         B, C = x.shape[0], x.shape[1]
         n = x.numel() // (B * C)
+        if self.fuse_linattn and C in (64, 128) and n % 64 == 0:
+            return plan.linattn_block(x, b.V(f"{prefix}.fn.norm.g"), b.W(f"{prefix}.fn.fn.to_qkv.weight"),
+                                      b.W(f"{prefix}.fn.fn.to_out.0.weight"), b.V(f"{prefix}.fn.fn.to_out.0.bias"),
+                                      b.V(f"{prefix}.fn.fn.to_out.1.g"), B, 1, n, (C * n, n, 0), self.NORM_MODE, self.NORM_MODE)
         xn = plan.chan_norm(x, b.V(f"{prefix}.fn.norm.g"), self.NORM_MODE)
         qkv = b.conv(xn, f"{prefix}.fn.fn.to_qkv", bias=False)
         pool.put(xn)
@@ -559,6 +567,10 @@ class Unet3D_with_Conv3D(_HipUNet):
         plan, pool = b.plan, b.plan.pool
         B, C, F, H, W = x.shape
         hw = H * W
+        if self.fuse_linattn and C in (64, 128) and hw % 64 == 0 and B * F < 65536:
+            return plan.linattn_block(x, b.V(f"{prefix}.fn.norm.gamma"), b.W(f"{prefix}.fn.fn.to_qkv.weight"),
+                                      b.W(f"{prefix}.fn.fn.to_out.weight"), b.V(f"{prefix}.fn.fn.to_out.bias"), None,
+                                      B, F, hw, (C * F * hw, F * hw, hw), 0, -1)
         xn = plan.chan_norm(x, b.V(f"{prefix}.fn.norm.gamma"), 0)
         qkv = b.conv(xn, f"{prefix}.fn.fn.to_qkv", bias=False)
         pool.put(xn)

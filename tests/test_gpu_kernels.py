@@ -384,3 +384,44 @@ def test_conv_winograd_nearest_upsample(plan_cls, case):
     e2 = (outs[2] - ref).abs().max().item() / scale
     assert e0 < 6e-6 and e2 < 6e-6, (e0, e2)        # K up to 2304: a few fp32 ulps of the output scale
     assert not torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=3, F=1, C=64, n=2048, pre=0, post=0),       # Burgers top level: LayerNorm in and out, 32 token tiles, splits
+    dict(B=5, F=1, C=128, n=128, pre=0, post=0),       # Burgers level 2
+    dict(B=2, F=1, C=64, n=128, pre=1, post=1),        # tokamak-style RMSNorm (dim 64 configuration)
+    dict(B=2, F=3, C=64, n=256, pre=0, post=-1),       # smoke SpatialLinearAttention: per-frame sequences, no post norm
+    dict(B=300, F=1, C=64, n=64, pre=0, post=0),       # one tile per sequence, many sequences
+])
+def test_linear_attention_block_fused(plan_cls, case):
+    """sdc_linattn_block == x + post(Wo LA(pre(x)) + bo) in fp64 torch (1D/model/unet.py:182-222, conv3d.py:232-258)."""
+    B, Fr, Cc, n, pre, post = case["B"], case["F"], case["C"], case["n"], case["pre"], case["post"]
+    x = det_tensor((B, Cc, Fr, n), 111)
+    g1, g2 = det_tensor((Cc,), 112, 0.3) + 1.0, det_tensor((Cc,), 113, 0.3) + 1.0
+    wqkv, wo, bo = det_tensor((384, Cc), 114, 0.4), det_tensor((Cc, 128), 115, 0.3), det_tensor((Cc,), 116, 0.1)
+
+    def norm(t, g, mode):          # over the channel axis (dim 1)
+        if mode == 0:
+            return (t - t.mean(1, keepdim=True)) * (t.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt() * g.view(1, -1, 1, 1)
+        return F.normalize(t, dim=1) * g.view(1, -1, 1, 1) * Cc ** 0.5
+
+    xd = x.double()
+    xn = norm(xd, g1.double(), pre)
+    qkv = torch.einsum("oc,bcfn->bofn", wqkv.double(), xn)
+    q, k, v = (t.reshape(B, 4, 32, Fr, n) for t in qkv.chunk(3, 1))
+    q = q.softmax(2) * 32 ** -0.5
+    k = k.softmax(-1)
+    ctx = torch.einsum("bhdfn,bhefn->bhfde", k, v)
+    out = torch.einsum("bhfde,bhdfn->bhefn", ctx, q).reshape(B, 128, Fr, n)
+    y = torch.einsum("oc,bcfn->bofn", wo.double(), out) + bo.double().view(1, -1, 1, 1)
+    if post >= 0:
+        y = norm(y, g2.double(), post)
+    ref = y + xd
+
+    plan = plan_cls(DEV)
+    xg = x.to(DEV)
+    got = plan.linattn_block(xg, g1.to(DEV), plan.conv_weight(wqkv.view(384, Cc, 1).to(DEV)),
+                             plan.conv_weight(wo.view(Cc, 128, 1).to(DEV)), bo.to(DEV), g2.to(DEV) if post >= 0 else None,
+                             B, Fr, n, (Cc * Fr * n, Fr * n, n), pre, post)
+    _run(plan)
+    torch.testing.assert_close(got.cpu().double(), ref, rtol=2e-4, atol=2e-5)
