@@ -41,13 +41,13 @@ def sinusoidal_embedding(t, dim, theta=10000.0):
     """1D/model/unet.py:81-107 (even dim branch), conv3d.py:139-151."""
     half = dim // 2
     if dim % 2 == 0:
-        f = torch.exp(torch.arange(half) * -(math.log(theta) / (half - 1)))
+        f = torch.exp(torch.arange(half, device=t.device) * -(math.log(theta) / (half - 1)))
         a = t[:, None] * f[None, :]
         return torch.cat((a.sin(), a.cos()), dim=-1)
-    f = torch.exp(torch.arange(half) * -(math.log(theta) / (half - 1)))
+    f = torch.exp(torch.arange(half, device=t.device) * -(math.log(theta) / (half - 1)))
     a = t[:, None] * f[None, :]
     half1 = (dim + 1) // 2
-    f1 = torch.exp(torch.arange(half1) * -(math.log(theta) / (half1 - 1)))
+    f1 = torch.exp(torch.arange(half1, device=t.device) * -(math.log(theta) / (half1 - 1)))
     a1 = t[:, None] * f1[None, :]
     return torch.cat((a.sin(), a1.cos()), dim=-1)
 
@@ -229,7 +229,7 @@ def unet_tokamak(P, x, t, *, dim, dim_mults=(1, 2, 4, 8), groups=1):
 def rel_pos_bias(emb_weight, n, num_buckets=32, max_distance=32):
     """T5-style bucketed bias, conv3d.py:74-112.  emb_weight (num_buckets, heads)
     -> (heads, n, n)."""
-    q = torch.arange(n)
+    q = torch.arange(n, device=emb_weight.device)
     rel = q[None, :] - q[:, None]                       # k_pos - q_pos
     m = -rel
     nb = num_buckets // 2
@@ -252,7 +252,7 @@ def rotary(x, freqs):
     width is 2*len(freqs) (= d here).  Call sites: conv3d.py:320-322.
     Third-party, unpinned (requirements.txt) -> "parity unpinned" here."""
     n = x.shape[-2]
-    ang = torch.arange(n, dtype=freqs.dtype)[:, None] * freqs[None, :]
+    ang = torch.arange(n, dtype=freqs.dtype, device=freqs.device)[:, None] * freqs[None, :]
     ang = ang.repeat_interleave(2, dim=-1)               # (n, rot)
     rot = ang.shape[-1]
     xr, xp = x[..., :rot], x[..., rot:]

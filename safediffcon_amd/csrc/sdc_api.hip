@@ -45,7 +45,7 @@ int sdc_graph_end(void* stream, void** graph_exec) {
     HIP_TRY(hipStreamEndCapture(sdc::as_stream(stream), &g));
     hipGraphExec_t ge = nullptr;
     hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     if (e != hipSuccess) {
         sdc::set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
         return SDC_EHIP;

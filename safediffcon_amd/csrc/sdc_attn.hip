@@ -468,7 +468,7 @@ extern "C" int sdc_attn(const float* qkv, float* out, const float* rot, const fl
     const int ngrp = (nseq_tot + nseq - 1) / nseq;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
         attr_done = true;
     }

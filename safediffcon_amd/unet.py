@@ -10,12 +10,14 @@ is no torch.nn op and no CPU path.  Weights live in ordinary ``nn.Parameter``s, 
 ``load_state_dict`` of a reference checkpoint works unchanged; they are repacked
 into kernel layouts when a plan is built (``refresh()`` after weights change).
 """
+import ctypes as C
 import math
 import os
 
 import torch
 from torch import nn
 
+from ._lib import check
 from .engine import Plan, as5
 
 HEADS, DIM_HEAD = 4, 32
@@ -169,14 +171,18 @@ def _default_init(spec, gen):
 def sinusoid_table(times, dim, theta=10000.0):
     """SinusoidalPosEmb rows for the given timesteps, evaluated on the host exactly like the reference
     does on CPU (1D/model/unet.py:81-107, conv3d.py:139-151): fp32 exp / sin / cos of t * freq."""
-    t = times.detach().cpu()
+    return _sinusoid(times.detach().cpu(), dim, theta)
+
+
+def _sinusoid(t, dim, theta=10000.0):
+    """rows on t's device; the frequency vector is always formed on the host (fp32 exp), like the LUT's"""
     half = dim // 2
-    f = torch.exp(torch.arange(half) * -(math.log(theta) / (half - 1)))
+    f = torch.exp(torch.arange(half) * -(math.log(theta) / (half - 1))).to(t.device)
     a = t[:, None] * f[None, :]
     if dim % 2 == 0:
         return torch.cat((a.sin(), a.cos()), dim=-1)
     half1 = (dim + 1) // 2
-    f1 = torch.exp(torch.arange(half1) * -(math.log(theta) / (half1 - 1)))
+    f1 = torch.exp(torch.arange(half1) * -(math.log(theta) / (half1 - 1))).to(t.device)
     return torch.cat((a.sin(), (t[:, None] * f1[None, :]).cos()), dim=-1)
 
 
@@ -253,6 +259,8 @@ class _HipUNet(nn.Module):
         # LinearAttention blocks of width 64 / 128 as the fused 3-launch form (csrc/sdc_lablock.hip); False = the
         # unfused chain norm -> 1x1 -> attention core -> 1x1 -> norm (kept for wider layers and for A/B checks)
         self.fuse_linattn = os.environ.get("SDC_NO_LABLOCK", "0") != "1"
+        self.forward_graph = True    # model(x, t) replays a captured hipGraph; False = launch the call list every time
+        self._side = None
         self.dim = dim
         self.self_condition = False
         # every time-conditioned ResnetBlock gets a slot [scale | shift] in the conditioning row
@@ -361,8 +369,33 @@ class _HipUNet(nn.Module):
                 self.bind_cond(ent, None)
                 ent["bound"] = True
             ent["x"].copy_(x)
-            self.fill_cond(ent, time, stream)
-            ent["plan"].run(stream)
+            # sin / cos of the embedding on the device (no host round trip, no sync; host timesteps are shipped first)
+            emb = _sinusoid(time.detach().to(x.device), self.dim)
+            ent["emb"].copy_(emb.reshape(ent["emb"].shape))
+            if not self.forward_graph:
+                ent["cond"].run(stream)
+                ent["plan"].run(stream)
+                return ent["eps"].clone()
+            # ~330 launches per forward: replayed as one hipGraph (captured once per input shape on a private stream;
+            # the repacked weights, the conditioning table and x / eps live in buffers the graph keeps pointing at)
+            cur = torch.cuda.current_stream(x.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(x.device)
+            side = self._side
+            side.wait_stream(cur)
+            lib = ent["plan"].lib
+            if ent.get("graph") is None:
+                check(lib.sdc_graph_begin(side.cuda_stream), "sdc_graph_begin")
+                try:
+                    ent["cond"].run(side.cuda_stream)
+                    ent["plan"].run(side.cuda_stream)
+                finally:
+                    g = C.c_void_p()
+                    rc = lib.sdc_graph_end(side.cuda_stream, C.byref(g))
+                check(rc, "sdc_graph_end")
+                ent["graph"] = g
+            check(lib.sdc_graph_launch(ent["graph"], side.cuda_stream), "sdc_graph_launch")
+            cur.wait_stream(side)
             return ent["eps"].clone()
 
 

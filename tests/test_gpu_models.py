@@ -68,6 +68,30 @@ def test_unet_burgers_wider_vs_oracle():
     torch.testing.assert_close(eps, ref, **EPS_TOL)
 
 
+def test_forward_graph_replay_equals_call_list(golden):
+    """model(x, t) replays a hipGraph captured on first use; it must give the bits of the plain call list, follow new
+    inputs / timesteps on every call, and survive a weight refresh (the graph points at the repacked buffers)."""
+    spec = golden("burgers_unet").spec()
+    net = _load(sdc.Unet2D(dim=8, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1), spec, 100)
+    outs = {}
+    for mode in (True, False):
+        net.forward_graph = mode
+        res = []
+        for seed, tt in ((1, [3, 500]), (2, [999, 0]), (1, [3, 500])):
+            x = det_tensor((2, 3, 16, 128), seed).to(DEV)
+            res.append(net(x, torch.tensor(tt, device=DEV)))
+        outs[mode] = res
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[True][0], outs[True][2]) and not torch.equal(outs[True][0], outs[True][1])
+    net.forward_graph = True
+    with torch.no_grad():
+        net.final_conv.bias.add_(1.0)
+    net.refresh()
+    x = det_tensor((2, 3, 16, 128), 1).to(DEV)
+    torch.testing.assert_close(net(x, torch.tensor([3, 500], device=DEV)), outs[True][0] + 1.0, rtol=0, atol=1e-6)
+
+
 def test_refresh_after_weight_update(golden):
     g = golden("tokamak_unet")
     net = _load(sdc.Unet1D(dim=8, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1), g.spec(), 200)
