@@ -297,7 +297,9 @@ def main():
             traffic = None
             try:
                 with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
-                    traffic = json.load(fh).get(name, {}).get("traffic_bytes")
+                    ent = json.load(fh).get(name, {})
+                    if ent.get("workload", "c2") == a.workload:      # counters were collected on this workload's shape only
+                        traffic = ent.get("traffic_bytes")
             except OSError:
                 pass
             roof = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",

@@ -42,6 +42,8 @@ def work(fn, a):
         nin = d.B * cin * d.iD * d.iH * d.iW
         by = 4.0 * (nin + P * d.Cout * (2 if a[5] else 1) + taps * cin * d.Cout)
         kind = f"conv {d.kD}x{d.kH}x{d.kW}" + (" (up/transposed)" if d.uH > 1 else "") + (" s2" if d.sH > 1 else "")
+        if d.precision == 2 and d.kW == 3 and d.sW == 1:
+            kind += " [Winograd F(2,3) along W; FLOPs = direct-form]"
         return kind, 2.0 * P * d.Cout * cin * taps, by
     if fn is lib.sdc_gn_stats:
         Bb, Cc, S = a[2], a[3], a[5]
@@ -56,6 +58,12 @@ def work(fn, a):
         outer, inner, heads, nn = a[3], a[4], a[5], a[6]
         seqs = outer * inner * heads
         return "linear attention core", seqs * nn * (2 * 2 * 32 * 32 + 10 * 32), 4.0 * seqs * nn * 32 * 4
+    if fn is lib.sdc_linattn_block:
+        outer, inner, Cc, nn = a[8], a[9], a[10], a[11]
+        toks = outer * inner * nn
+        # reference-equivalent work: qkv 1x1 (C -> 384), attention core (4 heads x two 32x32 products), out 1x1 (128 -> C),
+        # two channel norms; bytes: x read once, y written once (what the fused block is priced against)
+        return "fused LinearAttention block (norm+qkv+core+out+norm+res)", toks * (2.0 * Cc * 384 + 4 * 2 * 2 * 32 * 32 + 2.0 * 128 * Cc + 16 * Cc), 8.0 * toks * Cc
     if fn is lib.sdc_attn:
         outer, inner, heads, nt = a[4], a[5], a[6], a[7]
         seqs = outer * inner * heads
