@@ -127,6 +127,16 @@ int sdc_linattn_block(const float* x, const float* g_pre, const float* wqkv, con
                       const float* g_post, float* work, float* y, int outer, int inner, int C, int64_t n,
                       int64_t so, int64_t sc, int64_t si, int pre_mode, int post_mode, float eps, void* stream);
 
+/* Fused temporal-attention block of the smoke U-Net, dim 64, 32 frames, heads 4 x 32:
+ *   y = x + Wo . softmax( rot(s Wq xn) rot(Wk xn)^T + relpos ) (Wv xn),  xn = channel LayerNorm(x) * gamma
+ * Residual(PreNorm(dim, EinopsToAndFrom(Attention))): conv3d.py:165-184,262-275,277-353,383,402-405.
+ * wqkv = packed [64][384] (bias-free Linear), wo = packed [128][64]; rot = [32][16][2] (cos, sin) or null,
+ * bias = [heads][query][key] or null.  Element (o, c, pixel i, frame f) of x and y at o*so + c*sc + f*st + i;
+ * inner = pixels per outer index, a multiple of 8. */
+int sdc_tattn_block(const float* x, const float* g_pre, const float* wqkv, const float* wo, const float* rot,
+                    const float* bias, float* y, int outer, int inner, int C, int ntok, int64_t so, int64_t sc,
+                    int64_t st, float eps, void* stream);
+
 /* ------------------------------------------------------- softmax attention */
 /* Attention core (heads x 32): out = softmax(q*scale . k^T + bias) v, optional rotary on q,k.
  * 1D/model/unet.py:247-251 ; conv3d.py:313-353 (focus_present_mask all-False).

@@ -1,0 +1,234 @@
+// Fused temporal-attention block of the smoke U-Net at width 64 (Residual(PreNorm(dim, EinopsToAndFrom(Attention)))):
+//
+//   y = x + Wo . softmax( rot(s Wq xn) rot(Wk xn)^T + relpos ) (Wv xn),   xn = channel LayerNorm(x) * gamma
+//
+// conv3d.py:262-275 (EinopsToAndFrom 'b c f h w' <-> 'b (h w) f c'), :277-353 (Attention: bias-free qkv / out Linear,
+// heads 4 x 32, q*scale, rotary on q and k, relative-position bias, softmax over keys), :165-184 (PreNorm, LayerNorm),
+// :383,:402-405 (the wrapping).  A sequence is the 32 frames of one pixel; tokens are strided by H*W.
+//
+// The unfused chain (norm -> 1x1 C->384 -> attention core -> 1x1 128->C + residual) writes xn, q/k/v and the 128-
+// channel attention output to HBM and reads them back: 14 x the bytes of x on top of x itself.  Here one workgroup
+// owns 8 adjacent pixels (32-byte runs of the channel-major tensor, all 32 frames, all 4 heads):
+//   1. x tile (64 ch x 256 tokens) -> per-token LayerNorm (two threads per token) -> LDS
+//   2. per head, per wave (one pixel each, 8 waves = two per SIMD): q, k, v = W_h xn on the matrix cores (K = 64, weight
+//      fragments fetched one 32-step chain ahead into rotating register sets), q scaled, rotary on the
+//      accumulators, S^T = K Q^T (+ bias), softmax in registers, O = P^T V, y += Wo_h O  -- all wave-local: a wave
+//      only touches the LDS images of its own pixel, so there is no workgroup barrier inside the head loop
+//   3. y (64 ch x 32 frames per wave) through LDS -> + x -> stores in 32-byte runs.
+// x is read twice (the second time for the residual, L2/MALL-warm), y written once.  fp32 MFMA throughout.
+#include "sdc_common.h"
+
+namespace {
+
+constexpr int NT = 512;                  // 8 waves: one pixel each, two waves per SIMD
+constexpr int C = 64;
+constexpr int NS = 8;                    // pixels per workgroup
+constexpr int XP = NS * 33;              // LDS pitch of one channel row: [pixel][33 frames]
+constexpr int SQ = 32 * 32 + 8;          // per-pixel [d][f] image (K)
+constexpr int SV = 32 * 33 + 8;          // per-pixel slot: Q as [d][f], then V / O as [f][d] with a 33-float frame pitch
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct TaArgs {
+    const float* x; const float* g; const float* wqkv; const float* wo; const float* rot; const float* bias;
+    float* y;
+    int inner;               // pixels per outer index (H*W)
+    float eps;
+    int64_t so, sc, st;      // element (o, c, pixel i, frame f) at o*so + c*sc + f*st + i
+};
+
+__device__ __forceinline__ int crow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+__global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
+    extern __shared__ float lds[];
+    float* const xs = lds;                        // [64][XP]   xn, later the y image
+    float* const Ks = xs + C * XP;                // [8][SQ]
+    float* const QVs = Ks + NS * SQ;              // [8][SV]
+    float* const biasT = QVs + NS * SV;           // [4][32][33]  [head][key][query]
+    float* const rotc = biasT + 4 * 32 * 33;      // [32][16]
+    float* const rots = rotc + 32 * 16;           // [32][16]
+    float* const red = Ks;                        // [2][2][256] LayerNorm partials (before the K images exist)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    // XCD-aware numbering: the 4 pixel groups sharing a 128-byte line stay on one XCD (speed only)
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int seq0 = bid * NS;
+    const int o = seq0 / a.inner, i0 = seq0 - o * a.inner;
+    const float* xb = a.x + o * a.so + i0;
+    float* yb = a.y + o * a.so + i0;
+
+    // ---- 1. x tile + LayerNorm over the 64 channels of a token (pixel hw, frame f): two threads per token, 32 channels each
+    {
+        const int tok = tid & 255, half = tid >> 8, hw = tok & 7, f = tok >> 3;
+        const float* xt = xb + (int64_t)f * a.st + hw + (int64_t)(half * 32) * a.sc;
+        float v[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) v[c] = xt[(int64_t)c * a.sc];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) s += v[c];
+        red[half * 256 + tok] = s;
+        __syncthreads();
+        const float mean = (red[tok] + red[256 + tok]) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) { v[c] -= mean; q += v[c] * v[c]; }
+        red[512 + half * 256 + tok] = q;
+        __syncthreads();
+        const float rstd = rsqrtf((red[512 + tok] + red[768 + tok]) * (1.0f / C) + a.eps);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) xs[(half * 32 + c) * XP + hw * 33 + f] = v[c] * rstd * a.g[half * 32 + c];
+    }
+    for (int e = tid; e < 4 * 32 * 32; e += NT) {
+        const int h = e >> 10, q = (e >> 5) & 31, kk = e & 31;
+        biasT[(h * 32 + kk) * 33 + q] = a.bias ? a.bias[e] : 0.0f;
+    }
+    for (int e = tid; e < 32 * 16; e += NT) {
+        rotc[e] = a.rot ? a.rot[e * 2] : 1.0f;
+        rots[e] = a.rot ? a.rot[e * 2 + 1] : 0.0f;
+    }
+    __syncthreads();
+
+    // ---- 2. heads; this wave owns pixel `wave`
+    const int hw = wave;
+    f32x16 yacc[2];                                // row tiles of y (32 channels each)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yacc[i][r] = 0.f;
+    const float scale = 0.17677669529663687f;
+    float* const Kp = Ks + hw * SQ;
+    float* const Qp = QVs + hw * SV;
+
+    // Weight fragments (A operands) are fetched a whole 32-step chain ahead into two rotating register sets: a load
+    // consumed a few instructions after its issue exposed the L1/L2 latency on every matrix instruction.
+    float w0[32], w1[32];
+    auto fetch_w = [&](float (&w)[32], int head, int part) {
+        const float* wp = a.wqkv + part * 128 + head * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) w[ks] = wp[(int64_t)(2 * ks + lh) * 384];
+    };
+    auto project = [&](const float (&w)[32], f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ks], xs[(2 * ks + lh) * XP + hw * 33 + l31], acc, 0, 0, 0);
+    };
+    fetch_w(w0, 0, 0);
+    for (int head = 0; head < 4; ++head) {
+        // q, k, v [32 d][32 f]: A = W[(part, head)][d = l31][c], B = xn[c][f]
+        f32x16 pr[3];
+        fetch_w(w1, head, 1);
+        __builtin_amdgcn_sched_barrier(0);         // keep the whole fetch ahead of the chain it overlaps with
+        project(w0, pr[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_w(w0, head, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        project(w1, pr[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        {   // output-projection fragments of this head: Wo_p[(head*32 + d)][co], co = l31 and 32 + l31
+            const float* woh = a.wo + (int64_t)(head * 32) * C + l31;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) { w1[2 * s2] = woh[(2 * s2 + lh) * C]; w1[2 * s2 + 1] = woh[(2 * s2 + lh) * C + 32]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        project(w0, pr[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (head < 3) fetch_w(w0, head + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // q * scale, rotary on (d = 2m, 2m+1) pairs = registers (r, r+1) for even r; frame = l31
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const int m = crow(r, lh) >> 1;
+            const float cs = rotc[l31 * 16 + m], sn = rots[l31 * 16 + m];
+            const float q0 = pr[0][r] * scale, q1 = pr[0][r + 1] * scale;
+            pr[0][r] = q0 * cs - q1 * sn; pr[0][r + 1] = q1 * cs + q0 * sn;
+            const float k0 = pr[1][r], k1 = pr[1][r + 1];
+            pr[1][r] = k0 * cs - k1 * sn; pr[1][r + 1] = k1 * cs + k0 * sn;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            Qp[crow(r, lh) * 32 + l31] = pr[0][r];
+            Kp[crow(r, lh) * 32 + l31] = pr[1][r];
+        }
+        // S^T[key][query] = K . Q^T
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Kp[(2 * s + lh) * 32 + l31], Qp[(2 * s + lh) * 32 + l31], acc, 0, 0, 0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[r] += biasT[(head * 32 + crow(r, lh)) * 33 + l31];
+            mx = fmaxf(mx, acc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = expf(acc[r] - mx); sum += acc[r]; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] *= inv;
+        // V image [f][d] over the Q image (this wave is done with its Q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Qp[l31 * 33 + crow(r, lh)] = pr[2][r];
+        // O[query][d] = P^T . V : k-step r pairs key crow(r, 0) [half 0] with crow(r, 1) [half 1] = register r of P
+        f32x16 oacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], Qp[crow(r, lh) * 33 + l31], oacc, 0, 0, 0);
+        // O back over the V image as [f = query][d]: lane (d = l31) holds queries crow(r, lh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Qp[crow(r, lh) * 33 + l31] = oacc[r];
+        // y[co][f] += sum_d Wo[co][head*32 + d] O[f][d]:  A = Wo fragments (w1), B[k = d][col = f] = O image
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const float bv = Qp[l31 * 33 + 2 * s2 + lh];
+            yacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2 * s2], bv, yacc[0], 0, 0, 0);
+            yacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2 * s2 + 1], bv, yacc[1], 0, 0, 0);
+        }
+    }
+    __syncthreads();                               // every wave is done reading xn
+    // ---- 3. y image [co][pixel][f] over xn, then + x and 32-byte-run stores
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xs[(i * 32 + crow(r, lh)) * XP + hw * 33 + l31] = yacc[i][r];
+    __syncthreads();
+    {
+        const int tok = tid & 255, half = tid >> 8, pw = tok & 7, f = tok >> 3;
+        const int64_t off = (int64_t)f * a.st + pw + (int64_t)(half * 32) * a.sc;
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) yb[off + (int64_t)c * a.sc] = xs[(half * 32 + c) * XP + pw * 33 + f] + xb[off + (int64_t)c * a.sc];
+    }
+}
+
+}  // namespace
+
+extern "C" int sdc_tattn_block(const float* x, const float* g_pre, const float* wqkv, const float* wo, const float* rot,
+                               const float* bias, float* y, int outer, int inner, int Cc, int ntok, int64_t so, int64_t sc,
+                               int64_t st, float eps, void* stream) {
+    SDC_REQUIRE(x && g_pre && wqkv && wo && y, SDC_ENULL, "sdc_tattn_block: null pointer");
+    SDC_REQUIRE(Cc == 64 && ntok == 32, SDC_EINVAL, "sdc_tattn_block: dim 64 and 32 frames only (got %d, %d)", Cc, ntok);
+    SDC_REQUIRE(outer > 0 && inner > 0 && inner % NS == 0, SDC_EINVAL, "sdc_tattn_block: pixels per image must be a multiple of 8");
+    const int64_t nblk = (int64_t)outer * inner / NS;
+    SDC_REQUIRE(nblk < (1ll << 31), SDC_EINVAL, "sdc_tattn_block: too many sequences");
+    TaArgs a;
+    a.x = x; a.g = g_pre; a.wqkv = wqkv; a.wo = wo; a.rot = rot; a.bias = bias; a.y = y;
+    a.inner = inner; a.eps = eps; a.so = so; a.sc = sc; a.st = st;
+    const size_t ldsb = sizeof(float) * (size_t)(C * XP + NS * SQ + NS * SV + 4 * 32 * 33 + 2 * 32 * 16);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ta_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(ta_block_kernel, dim3((unsigned)nblk), dim3(NT), ldsb, sdc::as_stream(stream), a);
+    return sdc::check_launch("sdc_tattn_block");
+}

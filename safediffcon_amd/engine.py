@@ -237,6 +237,16 @@ class Plan:
                    _ptr(y), outer, inner, Cc, n, *strides, pre_mode, post_mode, eps)
         return y
 
+    def tattn_block(self, x, g_pre, wqkv, wo, rot, bias, eps=1e-5):
+        """Residual(PreNorm(temporal Attention)) of the smoke net in one launch: x (B, 64, 32, H, W) contiguous."""
+        B, Cc, Fr, H, W = x.shape
+        assert x.is_contiguous()
+        y = self.pool.get(tuple(x.shape))
+        self.keep += [x, g_pre, wqkv, wo, rot, bias, y]
+        self._emit(self.lib.sdc_tattn_block, _ptr(x), _ptr(g_pre), _ptr(wqkv), _ptr(wo), _ptr(rot), _ptr(bias), _ptr(y),
+                   B, H * W, Cc, Fr, Cc * Fr * H * W, Fr * H * W, H * W, eps)
+        return y
+
     def attn(self, qkv, out, heads, outer, inner, ntok, q_strides, o_strides, rot=None, bias=None):
         self.keep += [qkv, out, rot, bias]
         self._emit(self.lib.sdc_attn, _ptr(qkv), _ptr(out), _ptr(rot), _ptr(bias), outer, inner, heads, ntok,

@@ -586,6 +586,9 @@ class Unet3D_with_Conv3D(_HipUNet):
         B, C, F, H, W = x.shape
         hw = H * W
         rot, bias = self._attn_tables(b, F)
+        if self.fuse_linattn and C == 64 and F == 32 and hw % 8 == 0 and x.is_contiguous():
+            return plan.tattn_block(x, b.V(f"{prefix}.fn.norm.gamma"), b.W(f"{prefix}.fn.fn.fn.to_qkv.weight"),
+                                    b.W(f"{prefix}.fn.fn.fn.to_out.weight"), rot, bias)
         xn = plan.chan_norm(x, b.V(f"{prefix}.fn.norm.gamma"), 0)
         qkv = b.conv(xn, f"{prefix}.fn.fn.fn.to_qkv", bias=False)
         pool.put(xn)

@@ -425,3 +425,35 @@ def test_linear_attention_block_fused(plan_cls, case):
                              B, Fr, n, (Cc * Fr * n, Fr * n, n), pre, post)
     _run(plan)
     torch.testing.assert_close(got.cpu().double(), ref, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 4, 8), (1, 16, 16), (3, 2, 4)])
+def test_temporal_attention_block_fused(plan_cls, B, H, W):
+    """sdc_tattn_block == x + Wo softmax(rot(s q) rot(k)^T + relpos) v over the 32 frames of every pixel, q/k/v from the
+    channel-LayerNormed input (conv3d.py:165-184, 277-353), in fp64 torch."""
+    from oracle import nets as onets
+    Cc, Fr = 64, 32
+    x = det_tensor((B, Cc, Fr, H, W), 121)
+    g = det_tensor((Cc,), 122, 0.3) + 1.0
+    wqkv, wo = det_tensor((384, Cc), 123, 0.3), det_tensor((Cc, 128), 124, 0.3)
+    freqs = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)))
+    relw = det_tensor((32, 4), 125, 0.5)                       # (num_buckets, heads) embedding
+    bias = onets.rel_pos_bias(relw, Fr).double()               # (heads, query, key)
+    xd = x.double()
+    xn = (xd - xd.mean(1, keepdim=True)) * (xd.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt() * g.double().view(1, -1, 1, 1, 1)
+    tok = xn.permute(0, 3, 4, 2, 1).reshape(B * H * W, Fr, Cc)                      # b (h w) f c
+    q, k, v = (tok @ wqkv.double().t()).chunk(3, -1)
+    sp = lambda t: t.reshape(-1, Fr, 4, 32).permute(0, 2, 1, 3)                     # n heads f d
+    q, k, v = sp(q) * 32 ** -0.5, sp(k), sp(v)
+    q, k = onets.rotary(q, freqs.double()), onets.rotary(k, freqs.double())
+    att = (q @ k.transpose(-1, -2) + bias[None]).softmax(-1)
+    out = (att @ v).permute(0, 2, 1, 3).reshape(-1, Fr, 128) @ wo.double().t()
+    ref = xd + out.reshape(B, H, W, Fr, Cc).permute(0, 4, 3, 1, 2)
+
+    plan = plan_cls(DEV)
+    ang = torch.arange(Fr, dtype=torch.float32)[:, None] * freqs[None, :]
+    rot = torch.stack((ang.cos(), ang.sin()), dim=-1).reshape(-1).to(DEV)
+    got = plan.tattn_block(x.to(DEV), g.to(DEV), plan.conv_weight(wqkv.view(384, Cc, 1).to(DEV)),
+                           plan.conv_weight(wo.view(Cc, 128, 1).to(DEV)), rot, bias.float().reshape(-1).to(DEV))
+    _run(plan)
+    torch.testing.assert_close(got.cpu().double(), ref, rtol=2e-4, atol=1e-4)       # |y| up to ~10 here
