@@ -10,10 +10,10 @@
 // channel attention output to HBM and reads them back: 14 x the bytes of x on top of x itself.  Here one workgroup
 // owns 8 adjacent pixels (32-byte runs of the channel-major tensor, all 32 frames, all 4 heads):
 //   1. x tile (64 ch x 256 tokens) -> per-token LayerNorm (two threads per token) -> LDS
-//   2. per head, per wave (one pixel each, 8 waves = two per SIMD): q, k, v = W_h xn on the matrix cores (K = 64, weight
+//   2. per head, per wave (one pixel each, 8 waves = two per SIMD): q, k, v^T = W_h xn on the matrix cores (K = 64, weight
 //      fragments fetched one 32-step chain ahead into rotating register sets), q scaled, rotary on the
-//      accumulators, S^T = K Q^T (+ bias), softmax in registers, O = P^T V, y += Wo_h O  -- all wave-local: a wave
-//      only touches the LDS images of its own pixel, so there is no workgroup barrier inside the head loop
+//      accumulators, S^T = K Q^T (+ bias), softmax, O^T = V P, y += Wo_h O^T -- every product's accumulator registers
+//      are the next product's operand fragments, so nothing but xn is read from LDS and there is no barrier in the loop
 //   3. y (64 ch x 32 frames per wave) through LDS -> + x -> stores in 32-byte runs.
 // x is read twice (the second time for the residual, L2/MALL-warm), y written once.  fp32 MFMA throughout.
 #include "sdc_common.h"
@@ -24,8 +24,6 @@ constexpr int NT = 512;                  // 8 waves: one pixel each, two waves p
 constexpr int C = 64;
 constexpr int NS = 8;                    // pixels per workgroup
 constexpr int XP = NS * 33;              // LDS pitch of one channel row: [pixel][33 frames]
-constexpr int SQ = 32 * 32 + 8;          // per-pixel [d][f] image (K)
-constexpr int SV = 32 * 33 + 8;          // per-pixel slot: Q as [d][f], then V / O as [f][d] with a 33-float frame pitch
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct TaArgs {
@@ -41,12 +39,10 @@ __device__ __forceinline__ int crow(int r, int lh) { return (r & 3) + 8 * (r >> 
 __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
     extern __shared__ float lds[];
     float* const xs = lds;                        // [64][XP]   xn, later the y image
-    float* const Ks = xs + C * XP;                // [8][SQ]
-    float* const QVs = Ks + NS * SQ;              // [8][SV]
-    float* const biasT = QVs + NS * SV;           // [4][32][33]  [head][key][query]
+    float* const biasT = xs + C * XP;             // [4][32][33]  [head][key][query]
     float* const rotc = biasT + 4 * 32 * 33;      // [32][16]
     float* const rots = rotc + 32 * 16;           // [32][16]
-    float* const red = Ks;                        // [2][2][256] LayerNorm partials (before the K images exist)
+    float* const red = rots + 32 * 16;            // [2][2][256] LayerNorm partials
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     // XCD-aware numbering: the 4 pixel groups sharing a 128-byte line stay on one XCD (speed only)
@@ -98,8 +94,6 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) yacc[i][r] = 0.f;
     const float scale = 0.17677669529663687f;
-    float* const Kp = Ks + hw * SQ;
-    float* const Qp = QVs + hw * SV;
 
     // Weight fragments (A operands) are fetched a whole 32-step chain ahead into two rotating register sets: a load
     // consumed a few instructions after its issue exposed the L1/L2 latency on every matrix instruction.
@@ -116,6 +110,15 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
         for (int ks = 0; ks < 32; ++ks)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ks], xs[(2 * ks + lh) * XP + hw * 33 + l31], acc, 0, 0, 0);
     };
+    // V is formed transposed (operands swapped: [frame rows][d columns]) so that its accumulator registers are the A
+    // fragments of O^T = V P as they stand
+    auto project_t = [&](const float (&w)[32], f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[(2 * ks + lh) * XP + hw * 33 + l31], w[ks], acc, 0, 0, 0);
+    };
     fetch_w(w0, 0, 0);
     for (int head = 0; head < 4; ++head) {
         // q, k, v [32 d][32 f]: A = W[(part, head)][d = l31][c], B = xn[c][f]
@@ -131,10 +134,10 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
         {   // output-projection fragments of this head: Wo_p[(head*32 + d)][co], co = l31 and 32 + l31
             const float* woh = a.wo + (int64_t)(head * 32) * C + l31;
 #pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) { w1[2 * s2] = woh[(2 * s2 + lh) * C]; w1[2 * s2 + 1] = woh[(2 * s2 + lh) * C + 32]; }
+            for (int r = 0; r < 16; ++r) { w1[2 * r] = woh[crow(r, lh) * C]; w1[2 * r + 1] = woh[crow(r, lh) * C + 32]; }   // d in accumulator-row order
         }
         __builtin_amdgcn_sched_barrier(0);
-        project(w0, pr[2]);
+        project_t(w0, pr[2]);
         __builtin_amdgcn_sched_barrier(0);
         if (head < 3) fetch_w(w0, head + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -148,22 +151,22 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
             const float k0 = pr[1][r], k1 = pr[1][r + 1];
             pr[1][r] = k0 * cs - k1 * sn; pr[1][r + 1] = k1 * cs + k0 * sn;
         }
+        // The products chain through registers: with the contraction index walked in accumulator-row order (step r covers
+        // rows crow(r, 0) | crow(r, 1) on the two half-waves), register r of one product's accumulator IS the operand
+        // fragment of the next -- K, Q, V^T, S^T and O^T never visit LDS.
+        // S^T[key][query] = sum_d K[d][key] Q[d][query]: A = K registers, B = Q registers (two half chains)
+        f32x16 acc, acc2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            Qp[crow(r, lh) * 32 + l31] = pr[0][r];
-            Kp[crow(r, lh) * 32 + l31] = pr[1][r];
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[1][r], pr[0][r], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[1][r + 1], pr[0][r + 1], acc2, 0, 0, 0);
         }
-        // S^T[key][query] = K . Q^T
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Kp[(2 * s + lh) * 32 + l31], Qp[(2 * s + lh) * 32 + l31], acc, 0, 0, 0);
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            acc[r] += biasT[(head * 32 + crow(r, lh)) * 33 + l31];
+            acc[r] += acc2[r] + biasT[(head * 32 + crow(r, lh)) * 33 + l31];
             mx = fmaxf(mx, acc[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -174,25 +177,22 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
         const float inv = 1.0f / sum;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] *= inv;
-        // V image [f][d] over the Q image (this wave is done with its Q)
+        // O^T[d][query] = sum_key V^T[key][d] P[key][query]: A = V^T registers, B = P registers
+        f32x16 oacc, oacc2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Qp[l31 * 33 + crow(r, lh)] = pr[2][r];
-        // O[query][d] = P^T . V : k-step r pairs key crow(r, 0) [half 0] with crow(r, 1) [half 1] = register r of P
-        f32x16 oacc;
+        for (int r = 0; r < 16; ++r) { oacc[r] = 0.f; oacc2[r] = 0.f; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+        for (int r = 0; r < 16; r += 2) {
+            oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[2][r], acc[r], oacc, 0, 0, 0);
+            oacc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[2][r + 1], acc[r + 1], oacc2, 0, 0, 0);
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], Qp[crow(r, lh) * 33 + l31], oacc, 0, 0, 0);
-        // O back over the V image as [f = query][d]: lane (d = l31) holds queries crow(r, lh)
+        for (int r = 0; r < 16; ++r) oacc[r] += oacc2[r];
+        // y[co][f] += sum_d Wo[co][head*32 + d] O^T[d][f]:  A = Wo fragments (w1, d in accumulator-row order), B = O^T registers
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Qp[crow(r, lh) * 33 + l31] = oacc[r];
-        // y[co][f] += sum_d Wo[co][head*32 + d] O[f][d]:  A = Wo fragments (w1), B[k = d][col = f] = O image
-#pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-            const float bv = Qp[l31 * 33 + 2 * s2 + lh];
-            yacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2 * s2], bv, yacc[0], 0, 0, 0);
-            yacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2 * s2 + 1], bv, yacc[1], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+            yacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2 * r], oacc[r], yacc[0], 0, 0, 0);
+            yacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2 * r + 1], oacc[r], yacc[1], 0, 0, 0);
         }
     }
     __syncthreads();                               // every wave is done reading xn
@@ -223,7 +223,7 @@ extern "C" int sdc_tattn_block(const float* x, const float* g_pre, const float* 
     TaArgs a;
     a.x = x; a.g = g_pre; a.wqkv = wqkv; a.wo = wo; a.rot = rot; a.bias = bias; a.y = y;
     a.inner = inner; a.eps = eps; a.so = so; a.sc = sc; a.st = st;
-    const size_t ldsb = sizeof(float) * (size_t)(C * XP + NS * SQ + NS * SV + 4 * 32 * 33 + 2 * 32 * 16);
+    const size_t ldsb = sizeof(float) * (size_t)(C * XP + 4 * 32 * 33 + 2 * 32 * 16 + 1024);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ta_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
