@@ -79,6 +79,16 @@ typedef struct SdcConvDesc {
 int sdc_conv(const SdcConvDesc* d, const float* x0, const float* x1, const float* wp, const float* bias,
              const float* residual, float* y, void* stream);
 
+/* Conv + GroupNorm statistics of its output in one pass (the Block.proj -> Block.norm pair, 1D/model/unet.py:132-141,
+ * conv3d.py:192-198): the conv epilogue leaves fp64 (sum, sum of squares) pairs per (sample, group, part) in `parts`
+ * (B * G * nparts pairs) and sdc_gn_finalize turns them into the {mean, rstd} table sdc_gn_apply reads -- y is not read
+ * again for the statistics.  sdc_conv_gnparts is a host-side query: nparts for this descriptor, or 0 when the fused form
+ * does not cover it (then run sdc_conv + sdc_gn_stats).  Covered: the precision-2 Winograd convs whose tile grid
+ * lines up with the samples and groups. */
+int sdc_conv_gnparts(const SdcConvDesc* d, int G);
+int sdc_conv_gn(const SdcConvDesc* d, const float* x0, const float* x1, const float* wp, const float* bias,
+                const float* residual, float* y, double* parts, int G, void* stream);
+
 /* ------------------------------------------------------------- group norm */
 /* nn.GroupNorm(G, C, eps=1e-5) statistics over contiguous (B, C, S) data:
  * stats[(b*G+g)*2 + {0,1}] = {mean, rstd}, accumulated in fp64.
@@ -86,6 +96,8 @@ int sdc_conv(const SdcConvDesc* d, const float* x0, const float* x1, const float
 int sdc_gn_stats(const float* x, float* stats, int B, int C, int G, int64_t S, float eps, void* stream);
 /* bytes the caller must allocate for `stats` (mean/rstd pairs + fp64 partial-sum scratch) */
 size_t sdc_gn_stats_bytes(int B, int G);
+/* stats from the partial sums of sdc_conv_gn: n_per_group = (C / G) * S elements per (sample, group) */
+int sdc_gn_finalize(const double* parts, float* stats, int B, int G, int nparts, int64_t n_per_group, float eps, void* stream);
 
 /* y = SiLU( ((x-mean)*rstd*gamma[c]+beta[c]) * (scale+1) + shift ) (+ residual)
  * Block.forward + the ResnetBlock residual add: 1D/model/unet.py:138-147,180 ; conv3d.py:196-204,230.

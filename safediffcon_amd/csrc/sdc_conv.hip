@@ -55,6 +55,9 @@ struct ConvArgs {
     int lgD, lgH, lgW;
     int rowhalo;   // allow the row-halo kernel (env SDC_NO_ROWHALO=1 disables it for A/B timing)
     int vec2;      // Winograd epilogue: y (and residual) rows allow 8-byte accesses at even positions
+    // GroupNorm partial sums of the output (sdc_conv_gn): fp64 (sum, sum of squares) per (sample, group, part)
+    double* gn_part;
+    int gn_G, gn_cpg, gn_nparts, gn_S;
 };
 
 // Position-tile numbering: workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  Neighbouring
@@ -905,11 +908,24 @@ __global__ __launch_bounds__(NT) void conv_rh_bf3_kernel(const ConvArgs a) {
 // Wp; the input transform is two adds on the B fragment while it is read from the staged row (ds_read_b64 of
 // (d0,d1) and (d2,d3)), the output transform runs on the accumulators in the epilogue.  Still fp32 end to end
 // (differences to the direct kernel are rounding-order only, ~1e-7 relative), but not bit-identical to it.
-template <int TM, int TP>
-__device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[4][TM][TP], int mw, int pw, int lane) {
+// GN (sdc_conv_gn): the GroupNorm statistics of the output are summed here, on the values as they are stored, instead
+// of in a second pass over y: per lane for every 8-row block (i, rr >> 2) of its rows, reduced over the wave, then over
+// the waves of the workgroup through `scratch` (the dead staging LDS) in a fixed order -> one fp64 (sum, sum of
+// squares) pair per (sample, group, part), summed by sdc_gn_finalize.  Deterministic: no atomics.
+template <int TM, int TP, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[4][TM][TP], int mw, int pw, int lane,
+                                            float* scratch, int wave, int m0, int n0) {
     const SdcConvDesc& d = a.d;
     const int l31 = lane & 31, lh = lane >> 5;
     const bool v2 = a.vec2;
+    const bool gn = a.gn_part != nullptr;
+    // fp64 from the first add on: the sums are then independent of how the tile grid cuts the sample (1e-16), so a
+    // trajectory's statistics do not depend on the batch it is launched with
+    double gs[TM][4], gq[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4) { gs[i][b4] = 0.0; gq[i][b4] = 0.0; }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int cob = mw + i * 32 + 4 * lh;
@@ -952,7 +968,40 @@ __device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[4][
                     float* yp = a.y + yoff + co * d.ys[1];
                     if (v2) *reinterpret_cast<float2*>(yp) = make_float2(y0, y1);
                     else { yp[0] = y0; yp[d.ys[4]] = y1; }
+                    if (gn) { gs[i][rr >> 2] += (double)y0 + (double)y1; gq[i][rr >> 2] += (double)y0 * y0 + (double)y1 * y1; }
                 }
+            }
+        }
+    }
+    if (gn) {
+        double* scr = reinterpret_cast<double*>(scratch);
+        // scr[wave][TM*4][2]; 8-row block t of the workgroup's rows = (wm = t / (TM*4), k = t % (TM*4)), summed over wn
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int b4 = 0; b4 < 4; ++b4) {
+                const double s1 = sdc::wave_sum(gs[i][b4]), q1 = sdc::wave_sum(gq[i][b4]);
+                if (lane == 0) { scr[(wave * TM * 4 + i * 4 + b4) * 2] = s1; scr[(wave * TM * 4 + i * 4 + b4) * 2 + 1] = q1; }
+            }
+        __syncthreads();
+        const int ngl = a.gn_cpg >= BM ? 1 : BM / a.gn_cpg;       // groups inside this workgroup's rows
+        const int t = threadIdx.x;
+        if (t < ngl) {
+            const int r0 = a.gn_cpg >= BM ? 0 : t * a.gn_cpg, r1 = a.gn_cpg >= BM ? BM : r0 + a.gn_cpg;   // local rows
+            double s = 0.0, q = 0.0;
+            for (int blk = r0 / 8; blk < r1 / 8; ++blk) {
+                const int wmi = blk / (TM * 4), k = blk - wmi * (TM * 4);
+                for (int wni = 0; wni < WN; ++wni) {
+                    s += scr[((wmi * WN + wni) * TM * 4 + k) * 2];
+                    q += scr[((wmi * WN + wni) * TM * 4 + k) * 2 + 1];
+                }
+            }
+            if (m0 + r0 < d.Cout) {
+                const int g = (m0 + r0) / a.gn_cpg;
+                const int b = n0 / a.gn_S, ntl = (n0 - b * a.gn_S) / BN;
+                const int idx = a.gn_cpg >= BM ? ntl * (a.gn_cpg / BM) + (m0 - g * a.gn_cpg) / BM : ntl;
+                double* pp = a.gn_part + (((int64_t)b * a.gn_G + g) * a.gn_nparts + idx) * 2;
+                pp[0] = s; pp[1] = q;
             }
         }
     }
@@ -1194,7 +1243,7 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
         }
         __syncthreads();
     }
-    wg_epilogue<TM, TP>(a, acc, m0 + wm * (TM * 32), n0 / 2 + wn * (TP * 32), lane);
+    wg_epilogue<TM, TP, BM, BN, WM, WN>(a, acc, m0 + wm * (TM * 32), n0 / 2 + wn * (TP * 32), lane, ldsw, wave, m0, n0);
 }
 
 template <int BM, int BN, int WM, int WN, int SK, int NTH = 256, bool UPS = false>
@@ -1264,10 +1313,84 @@ void launch(const ConvArgs& a, bool fast, hipStream_t s) {
         hipLaunchKernelGGL((conv_kernel<BM, BN, WM, WN, false>), grid, dim3(NT), 0, s, a);
 }
 
+// Winograd (precision 2) coverage and tile choice, shared by the dispatch and by sdc_conv_gnparts.
+// 8-wave workgroups (two waves per SIMD) share one staged weight tile; the bigger the tile the fewer L2->LDS bytes
+// per MFMA: 128 x 256 / 128 x 128 outputs for wide layers, 64 x 512 / 64 x 256 for Cout <= 64, 4-wave 64 x 128 for
+// small grids.  pick: 3 = 64x128, 6 = 128x128, 7 = 64x256, 9 = 128x256, 10 = 64x512; 0 = not covered.
+struct WgPick { int pick, bm, bn; bool ups; };
+WgPick wg_pick(const SdcConvDesc& d, int64_t ntot, bool small, bool rowhalo) {
+    WgPick w{0, 0, 0, false};
+    w.ups = (d.uH > 1 || d.uW > 1);      // nearest x2 upsampling folded into the gather: one input, kD = 1, kH <= 3
+    if (!(d.precision == 2 && rowhalo && d.kW == 3 && d.sW == 1 && d.uD == 1 && d.up_mode == 0 &&
+          (!w.ups || (d.uH <= 2 && d.uW <= 2 && d.kD == 1 && d.kH <= 3 && d.sH == 1 && d.Cin1 == 0)) &&
+          d.kD * d.kH <= 32 && d.Cin0 % 16 == 0 && d.Cin1 % 16 == 0 && small && d.Cout % 4 == 0 && d.Cout > 32 &&
+          d.oW % 2 == 0 && d.oW >= 16 && ((int64_t)d.kD * d.kH * d.kW * (d.Cin0 + d.Cin1) * d.Cout) % 4 == 0))
+        return w;
+    auto fits = [&](int bn) { return (d.oW % bn == 0) || (bn % d.oW == 0); };
+    if (!fits(128)) return w;
+    auto nblk = [&](int bm, int bn) { return ((ntot + bn - 1) / bn) * ((d.Cout + bm - 1) / bm); };
+    static const int wg_tile = getenv("SDC_WG_TILE") ? atoi(getenv("SDC_WG_TILE")) : 0;   // tuning knob
+    int pick = wg_tile;
+    if (w.ups) {
+        pick = (d.Cout > 64 && nblk(128, 128) >= 256) ? 6 : ((d.Cout <= 64 && fits(256) && nblk(64, 256) >= 256) ? 7 : 3);
+    } else {
+        if (!pick) {
+            if (d.Cout > 64) pick = (fits(256) && nblk(128, 256) >= 256) ? 9 : (nblk(128, 128) >= 256 ? 6 : 3);
+            else pick = (fits(512) && nblk(64, 512) >= 512) ? 10 : (fits(256) && nblk(64, 256) >= 256 ? 7 : 3);
+        }
+        if ((pick == 7 || pick == 9) && !fits(256)) pick = 3;
+        if (pick == 10 && !fits(512)) pick = 3;
+        if (pick != 6 && pick != 7 && pick != 9 && pick != 10) pick = 3;
+    }
+    w.pick = pick;
+    w.bm = (pick == 6 || pick == 9) ? 128 : 64;
+    w.bn = pick == 3 ? 128 : (pick == 6 ? 128 : (pick == 10 ? 512 : 256));
+    return w;
+}
+
+// GroupNorm partial sums in the Winograd epilogue: pairs per (sample, group), 0 if the tile grid does not line up
+int gn_parts_for(const SdcConvDesc& d, const WgPick& w, int G) {
+    if (!w.pick || G <= 0 || d.Cout % G) return 0;
+    const int cpg = d.Cout / G;
+    const int64_t S = (int64_t)d.oD * d.oH * d.oW;
+    if (cpg % 8 || S % w.bn || !(cpg % w.bm == 0 || w.bm % cpg == 0)) return 0;
+    return (int)(S / w.bn) * (cpg >= w.bm ? cpg / w.bm : 1);
+}
+
+bool conv_small(const SdcConvDesc& d) {
+    auto span = [](const int64_t* st, int b, int dd, int h, int w) {
+        return (int64_t)(b - 1) * st[0] + (int64_t)(dd - 1) * st[2] + (int64_t)(h - 1) * st[3] + (int64_t)(w - 1) * st[4];
+    };
+    return span(d.x0s, d.B, d.iD, d.iH, d.iW) < (1ll << 30) && (d.Cin1 == 0 || span(d.x1s, d.B, d.iD, d.iH, d.iW) < (1ll << 30));
+}
+
+int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const float* wp, const float* bias,
+              const float* residual, float* y, double* gn_part, int gn_G, void* stream);
+
 }  // namespace
 
 extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1, const float* wp, const float* bias,
                         const float* residual, float* y, void* stream) {
+    return conv_impl(dp, x0, x1, wp, bias, residual, y, nullptr, 0, stream);
+}
+
+extern "C" int sdc_conv_gnparts(const SdcConvDesc* dp, int G) {
+    if (!dp) return 0;
+    static const int no_rh = getenv("SDC_NO_ROWHALO") ? atoi(getenv("SDC_NO_ROWHALO")) : 0;
+    const int64_t ntot = (int64_t)dp->B * dp->oD * dp->oH * dp->oW;
+    return gn_parts_for(*dp, wg_pick(*dp, ntot, conv_small(*dp), !no_rh), G);
+}
+
+extern "C" int sdc_conv_gn(const SdcConvDesc* dp, const float* x0, const float* x1, const float* wp, const float* bias,
+                           const float* residual, float* y, double* parts, int G, void* stream) {
+    SDC_REQUIRE(parts && G > 0, SDC_EINVAL, "sdc_conv_gn: parts buffer and a positive group count are required");
+    return conv_impl(dp, x0, x1, wp, bias, residual, y, parts, G, stream);
+}
+
+namespace {
+
+int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const float* wp, const float* bias,
+              const float* residual, float* y, double* gn_part, int gn_G, void* stream) {
     SDC_REQUIRE(dp && x0 && wp && y, SDC_ENULL, "sdc_conv: null pointer");
     const SdcConvDesc& d = *dp;
     SDC_REQUIRE(d.B > 0 && d.Cin0 > 0 && d.Cin1 >= 0 && d.Cout > 0, SDC_EINVAL, "sdc_conv: bad channel/batch counts");
@@ -1275,6 +1398,7 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
     SDC_REQUIRE(d.kD > 0 && d.kH > 0 && d.kW > 0 && d.sD > 0 && d.sH > 0 && d.sW > 0, SDC_EINVAL,
                 "sdc_conv: bad kernel/stride");
     SDC_REQUIRE(d.precision >= 0 && d.precision <= 2, SDC_EINVAL, "sdc_conv: precision must be 0 (fp32 MFMA), 1 (split-bf16) or 2 (fp32 Winograd)");
+    SDC_REQUIRE(!gn_part || d.precision == 2, SDC_EINVAL, "sdc_conv_gn: fused GroupNorm statistics need precision 2 (sdc_conv_gnparts returned 0)");
     ConvArgs a;
     a.d = d;
     a.lgD = ilog2_exact(d.uD); a.lgH = ilog2_exact(d.uH); a.lgW = ilog2_exact(d.uW);
@@ -1294,14 +1418,11 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
     a.Cin = d.Cin0 + d.Cin1;
     a.Ktot = d.kD * d.kH * d.kW * a.Cin;
     // FAST: whole K chunks share a tap, and every per-thread offset fits the 32-bit voffset of the saddr load form
-    auto span = [](const int64_t* st, int b, int dd, int h, int w) {
-        return (int64_t)(b - 1) * st[0] + (int64_t)(dd - 1) * st[2] + (int64_t)(h - 1) * st[3] + (int64_t)(w - 1) * st[4];
-    };
-    const bool small = span(d.x0s, d.B, d.iD, d.iH, d.iW) < (1ll << 30) &&
-                       (d.Cin1 == 0 || span(d.x1s, d.B, d.iD, d.iH, d.iW) < (1ll << 30));
+    const bool small = conv_small(d);
     static const int no_rh = getenv("SDC_NO_ROWHALO") ? atoi(getenv("SDC_NO_ROWHALO")) : 0;
     a.rowhalo = !no_rh;
     a.vec2 = 0;
+    a.gn_part = nullptr; a.gn_G = a.gn_cpg = a.gn_nparts = a.gn_S = 0;
     const bool fast = (d.Cin0 % BK == 0) && (d.Cin1 % BK == 0) && small && d.Cout < (1 << 30);
     hipStream_t s = sdc::as_stream(stream);
     // opt-in split-bf16: whole 32-channel chunks per tap, 32-bit offsets, 16-byte aligned pre-split weights
@@ -1320,43 +1441,31 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
         else launch_bf3<64, 128, 2, 2>(a, s);
         return sdc::check_launch("sdc_conv[bf16x3]");
     }
-    // opt-in fp32 Winograd F(2,3) along W: 3-wide stride-1 taps, whole 16-channel chunks, even rows
-    const bool wg_ups = (d.uH > 1 || d.uW > 1);      // nearest x2 upsampling folded into the gather: one input, kD = 1, kH <= 3
-    if (d.precision == 2 && a.rowhalo && d.kW == 3 && d.sW == 1 && d.uD == 1 && d.up_mode == 0 &&
-        (!wg_ups || (d.uH <= 2 && d.uW <= 2 && d.kD == 1 && d.kH <= 3 && d.sH == 1 && d.Cin1 == 0)) &&
-        d.kD * d.kH <= 32 && d.Cin0 % 16 == 0 && d.Cin1 % 16 == 0 && small && d.Cout % 4 == 0 && d.Cout > 32 &&
-        d.oW % 2 == 0 && d.oW >= 16 && reinterpret_cast<uintptr_t>(wp) % 16 == 0 && ((int64_t)a.Ktot * d.Cout) % 4 == 0) {
+    // fp32 Winograd F(2,3) along W: 3-wide stride-1 taps, whole 16-channel chunks, even rows
+    const WgPick wgp = wg_pick(d, ntot, small, a.rowhalo != 0);
+    if (wgp.pick && reinterpret_cast<uintptr_t>(wp) % 16 == 0) {
         auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
         a.vec2 = even(d.ys) && reinterpret_cast<uintptr_t>(y) % 8 == 0 &&
                  (!residual || (even(d.rs) && reinterpret_cast<uintptr_t>(residual) % 8 == 0));
-        auto fits = [&](int bn) { return (d.oW % bn == 0) || (bn % d.oW == 0); };
-        static const int wg_tile = getenv("SDC_WG_TILE") ? atoi(getenv("SDC_WG_TILE")) : 0;   // tuning knob
-        // 8-wave workgroups (two waves per SIMD) share one staged weight tile; the bigger the tile the fewer L2->LDS
-        // bytes per MFMA: 128 x 256 (128 accumulator registers per lane) / 128 x 128 for wide layers, 64 x 512 /
-        // 64 x 256 for Cout <= 64, 4-wave 64 x 128 for small grids
-        auto nblk = [&](int bm, int bn) { return (int64_t)((a.Ntot + bn - 1) / bn) * ((d.Cout + bm - 1) / bm); };
-        int pick = wg_tile;
-        if (!pick) {
-            if (d.Cout > 64) pick = (fits(256) && nblk(128, 256) >= 256) ? 9 : (nblk(128, 128) >= 256 ? 6 : 3);
-            else pick = (fits(512) && nblk(64, 512) >= 512) ? 10 : (fits(256) && nblk(64, 256) >= 256 ? 7 : 3);
+        if (gn_part) {
+            a.gn_nparts = gn_parts_for(d, wgp, gn_G);
+            SDC_REQUIRE(a.gn_nparts > 0, SDC_EINVAL, "sdc_conv_gn: shape not covered by the fused statistics (sdc_conv_gnparts returned 0)");
+            a.gn_part = gn_part; a.gn_G = gn_G; a.gn_cpg = d.Cout / gn_G; a.gn_S = d.oD * d.oH * d.oW;
         }
-        if ((pick == 7 || pick == 9) && !fits(256)) pick = 3;
-        if (pick == 10 && !fits(512)) pick = 3;
-        if (wg_ups && fits(128)) {
-            if (d.Cout > 64 && nblk(128, 128) >= 256) launch_wg<128, 128, 4, 2, 16, 512, true>(a, s);
-            else if (d.Cout <= 64 && fits(256) && nblk(64, 256) >= 256) launch_wg<64, 256, 2, 4, 16, 512, true>(a, s);
+        if (wgp.ups) {
+            if (wgp.pick == 6) launch_wg<128, 128, 4, 2, 16, 512, true>(a, s);
+            else if (wgp.pick == 7) launch_wg<64, 256, 2, 4, 16, 512, true>(a, s);
             else launch_wg<64, 128, 2, 2, 16, 256, true>(a, s);
             return sdc::check_launch("sdc_conv[winograd,upsample]");
         }
-        if (fits(128)) {
-            if (pick == 6) launch_wg<128, 128, 4, 2, 16, 512>(a, s);
-            else if (pick == 7) launch_wg<64, 256, 2, 4, 16, 512>(a, s);
-            else if (pick == 9) launch_wg<128, 256, 4, 2, 16, 512>(a, s);
-            else if (pick == 10) launch_wg<64, 512, 2, 4, 16, 512>(a, s);
-            else launch_wg<64, 128, 2, 2, 16>(a, s);
-            return sdc::check_launch("sdc_conv[winograd]");
-        }
+        if (wgp.pick == 6) launch_wg<128, 128, 4, 2, 16, 512>(a, s);
+        else if (wgp.pick == 7) launch_wg<64, 256, 2, 4, 16, 512>(a, s);
+        else if (wgp.pick == 9) launch_wg<128, 256, 4, 2, 16, 512>(a, s);
+        else if (wgp.pick == 10) launch_wg<64, 512, 2, 4, 16, 512>(a, s);
+        else launch_wg<64, 128, 2, 2, 16>(a, s);
+        return sdc::check_launch("sdc_conv[winograd]");
     }
+    SDC_REQUIRE(!gn_part, SDC_EINVAL, "sdc_conv_gn: shape not covered by the fused statistics (sdc_conv_gnparts returned 0)");
     // stem convs (kW = 7, tiny Cin): row-halo kernel with generalized k rows
     if (a.rowhalo && d.kW == 7 && d.sW == 1 && d.uD == 1 && d.uH == 1 && d.uW == 1 && d.up_mode == 0 && d.kD * d.kH <= 64 &&
         d.Cout % 4 == 0 && d.Cout > 32 && small && ((d.oW % 128 == 0) || (128 % d.oW == 0 && d.oW >= 16)) &&
@@ -1389,3 +1498,5 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
         launch<32, 128, 1, 4>(a, fast, s);
     return sdc::check_launch("sdc_conv");
 }
+
+}  // namespace

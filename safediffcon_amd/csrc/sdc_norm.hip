@@ -281,6 +281,16 @@ extern "C" int sdc_gn_stats(const float* x, float* stats, int B, int C, int G, i
     return sdc::check_launch("sdc_gn_stats");
 }
 
+extern "C" int sdc_gn_finalize(const double* parts, float* stats, int B, int G, int nparts, int64_t n_per_group, float eps,
+                               void* stream) {
+    SDC_REQUIRE(parts && stats, SDC_ENULL, "sdc_gn_finalize: null pointer");
+    SDC_REQUIRE(B > 0 && G > 0 && nparts > 0 && n_per_group > 0, SDC_EINVAL, "sdc_gn_finalize: bad shape");
+    const int ngroups = B * G;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((ngroups + 63) / 64), dim3(64), 0, sdc::as_stream(stream), parts, stats, ngroups,
+                       nparts, 1.0 / (double)n_per_group, eps);
+    return sdc::check_launch("sdc_gn_finalize");
+}
+
 extern "C" int sdc_gn_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* ss,
                             const int32_t* t_dev, int64_t ss_t_stride, int64_t ss_b_stride, int64_t ss_off,
                             const float* residual, float* y, int B, int C, int G, int64_t S, void* stream) {

@@ -7,6 +7,7 @@ call list is either replayed from Python or captured into one hipGraph.
 Nothing in this file computes on the CPU or through torch ops on the hot path.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -67,6 +68,8 @@ class Plan:
         self.repackers = []      # (dst tensor, fn() -> src tensor) to refresh repacked weights
         self._stats = None
         self._ctx = None
+        self._gn_parts = {}      # out.data_ptr() -> (partial-sum buffer, parts per (sample, group), groups) left by sdc_conv_gn
+        self.fuse_gn_stats = os.environ.get("SDC_NO_GNFUSE", "0") != "1"
 
     # ------------------------------------------------------------------ execution
     def run(self, stream):
@@ -155,8 +158,10 @@ class Plan:
 
     # ------------------------------------------------------------------ stages
     def conv(self, x, wp, bias, cout, k, *, x1=None, stride=(1, 1, 1), pad=(0, 0, 0), up=(1, 1, 1), up_mode=0,
-             residual=None, out=None):
-        """x (and optional x1, channel-concatenated) are 5-D views; returns out (B,cout,oD,oH,oW)."""
+             residual=None, out=None, gn_groups=0):
+        """x (and optional x1, channel-concatenated) are 5-D views; returns out (B,cout,oD,oH,oW).
+        gn_groups > 0: a GroupNorm over `out` follows -- where the conv epilogue can sum its statistics (sdc_conv_gn) the
+        partial sums are kept for the gn_silu call on `out`, which then skips its own pass over the tensor."""
         B, c0, iD, iH, iW = x.shape
         c1 = 0 if x1 is None else x1.shape[1]
 
@@ -188,6 +193,14 @@ class Plan:
         if residual is not None:
             assert tuple(residual.shape) == tuple(out.shape)
         self.keep += [d, x, x1, wp, bias, residual, out]     # the call list holds raw pointers only
+        nparts = int(self.lib.sdc_conv_gnparts(C.byref(d), gn_groups)) if (gn_groups and self.fuse_gn_stats) else 0
+        if nparts > 0:
+            parts = torch.empty(B * gn_groups * nparts * 2, dtype=torch.float64, device=self.device)
+            self.keep.append(parts)
+            self._gn_parts[out.data_ptr()] = (parts, nparts, gn_groups)
+            self._emit(self.lib.sdc_conv_gn, C.byref(d), _ptr(x), _ptr(x1), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(out),
+                       _ptr(parts), gn_groups)
+            return out
         self._emit(self.lib.sdc_conv, C.byref(d), _ptr(x), _ptr(x1), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(out))
         return out
 
@@ -200,7 +213,11 @@ class Plan:
         st = self._stats_buf(B, groups)
         out = x if out is None else out
         self.keep += [x, gamma, beta, ss, t_dev, residual, out]
-        self._emit(self.lib.sdc_gn_stats, _ptr(x), _ptr(st), B, Cc, groups, S, eps)
+        fused = self._gn_parts.pop(x.data_ptr(), None)
+        if fused is not None and fused[2] == groups:
+            self._emit(self.lib.sdc_gn_finalize, _ptr(fused[0]), _ptr(st), B, groups, fused[1], (Cc // groups) * S, eps)
+        else:
+            self._emit(self.lib.sdc_gn_stats, _ptr(x), _ptr(st), B, Cc, groups, S, eps)
         self._emit(self.lib.sdc_gn_apply, _ptr(x), _ptr(st), _ptr(gamma), _ptr(beta), _ptr(ss), _ptr(t_dev),
                    ss_t_stride, ss_b_stride, ss_off, _ptr(residual), _ptr(out), B, Cc, groups, S)
         return out

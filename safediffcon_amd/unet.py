@@ -204,7 +204,7 @@ class _Builder:
         return (1,) * (3 - len(shp)) + shp
 
     def conv(self, x, prefix, *, x1=None, stride=1, pad=None, up=(1, 1, 1), residual=None, out=None, kind="conv",
-             bias=True):
+             bias=True, gn_groups=0):
         wkey = f"{prefix}.weight"
         w = self.net.P(wkey)
         if kind == "convT":
@@ -219,7 +219,7 @@ class _Builder:
             pad = tuple(kk // 2 for kk in k)
         b = self.V(f"{prefix}.bias") if bias else None
         return self.plan.conv(x, self.W(wkey, kind), b, cout, k, x1=x1, stride=stride, pad=pad, up=up,
-                              up_mode=1 if kind == "convT" else 0, residual=residual, out=out)
+                              up_mode=1 if kind == "convT" else 0, residual=residual, out=out, gn_groups=gn_groups)
 
     def gn(self, x, prefix, groups, residual=None, cond_off=None):
         self.plan.gn_silu(x, self.V(f"{prefix}.weight"), self.V(f"{prefix}.bias"), groups, residual=residual)
@@ -228,9 +228,9 @@ class _Builder:
 
     def resnet(self, prefix, x, groups, *, x1=None):
         net, pool = self.net, self.plan.pool
-        h = self.conv(x, f"{prefix}.block1.proj", x1=x1)
+        h = self.conv(x, f"{prefix}.block1.proj", x1=x1, gn_groups=groups)
         self.gn(h, f"{prefix}.block1.norm", groups, cond_off=net.cond_offsets.get(prefix))
-        g = self.conv(h, f"{prefix}.block2.proj")
+        g = self.conv(h, f"{prefix}.block2.proj", gn_groups=groups)
         pool.put(h)
         if net.has(f"{prefix}.res_conv.weight"):
             r = self.conv(x, f"{prefix}.res_conv", x1=x1)

@@ -457,3 +457,36 @@ def test_temporal_attention_block_fused(plan_cls, B, H, W):
                            plan.conv_weight(wo.view(Cc, 128, 1).to(DEV)), rot, bias.float().reshape(-1).to(DEV))
     _run(plan)
     torch.testing.assert_close(got.cpu().double(), ref, rtol=2e-4, atol=1e-4)       # |y| up to ~10 here
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=300, cin=64, cout=64, sp=(16, 128), G=1),           # 64x512 tiles, one group spanning the row tile
+    dict(B=40, cin=32, cout=64, sp=(16, 128), G=8),            # 64x256 tiles, 8 groups of 8 channels inside the row tile
+    dict(B=64, cin=32, cout=128, sp=(16, 64), G=1),            # 128x256 tiles
+    dict(B=260, cin=16, cout=256, sp=(16, 16), G=8),           # 128x256 tiles, groups of 32 channels, 16-wide rows
+    dict(B=40, cin=32, cout=256, sp=(8, 64), G=1),             # 128x128 tiles, the group spans two row tiles
+    dict(B=6, cin=32, cout=128, sp=(8, 32), G=8),              # 64x128 tiles (4 waves)
+    dict(B=40, cin=32, cout=192, sp=(8, 64), G=1, fused=False),   # 192 rows do not line up with 128-row tiles -> plain pass
+    dict(B=3, cin=32, cout=64, sp=(2, 16), G=1, fused=False),     # sample smaller than a tile -> plain statistics pass
+])
+def test_conv_groupnorm_statistics_in_the_epilogue(plan_cls, case):
+    """conv -> GroupNorm+SiLU with the statistics summed in the conv epilogue (sdc_conv_gn + sdc_gn_finalize) against the
+    two-pass form (sdc_conv + sdc_gn_stats) and against torch in fp64."""
+    from safediffcon_amd.engine import as5
+    B, cin, cout, sp, G = case["B"], case["cin"], case["cout"], case["sp"], case["G"]
+    x = det_tensor((B, cin, *sp), 131)
+    w, b = det_tensor((cout, cin, 3, 3), 132, 0.2), det_tensor((cout,), 133, 0.3)
+    gam, bet = det_tensor((cout,), 134, 0.3) + 1.0, det_tensor((cout,), 135, 0.2)
+    ref = F.silu(F.group_norm(F.conv2d(x.double(), w.double(), b.double(), padding=1), G, gam.double(), bet.double(), 1e-5))
+    outs = []
+    for fuse in (True, False):
+        plan = plan_cls(DEV, precision=2)
+        plan.fuse_gn_stats = fuse
+        h = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, (1, 3, 3), pad=(0, 1, 1), gn_groups=G)
+        plan.gn_silu(h, gam.to(DEV), bet.to(DEV), G)
+        used = any(fn is plan.lib.sdc_conv_gn for fn, _ in plan.calls)
+        assert used == (fuse and case.get("fused", True))
+        _run(plan)
+        outs.append(h.cpu().reshape(ref.shape).double())
+    torch.testing.assert_close(outs[0], ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-5, atol=2e-6)
