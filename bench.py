@@ -93,7 +93,7 @@ def time_conv_calls(plan, lib, stream, reps=3):
     check(lib.sdc_event_create(C.byref(e1)))
     groups = {}
     for fn, args in plan.calls:
-        if fn is not lib.sdc_conv:
+        if fn is not lib.sdc_conv and fn is not lib.sdc_conv_gn:      # (conv_gn = the same kernels + statistics epilogue)
             continue
         d = args[0]._obj
         fn(*args, stream)                                    # warm

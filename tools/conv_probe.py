@@ -46,7 +46,7 @@ for fn, args in ent["plan"].calls:
     lib.sdc_event_elapsed_ms(e0, e1, C.byref(ms))
     t = ms.value / reps
     tot[name] = tot.get(name, 0.0) + t
-    if fn is lib.sdc_conv:
+    if fn is lib.sdc_conv or fn is lib.sdc_conv_gn:
         d = args[0]._obj
         print(f"{conv_instance(d):34s} {d.Cin0 + d.Cin1:5d} {d.Cout:5d} {d.kD}x{d.kH}x{d.kW:<3d} "
               f"{d.oD}x{d.oH}x{d.oW:<6d} {t:8.4f} {conv_flops(d) / t / 1e9:7.1f}")

@@ -35,16 +35,21 @@ lib.sdc_event_create(C.byref(e0)); lib.sdc_event_create(C.byref(e1))
 def work(fn, a):
     """(stage name, flops, bytes)"""
     n = fn.__name__
-    if fn is lib.sdc_conv:
+    if fn is lib.sdc_conv or fn is lib.sdc_conv_gn:
         d = a[0]._obj
         P = d.B * d.oD * d.oH * d.oW
         cin, taps = d.Cin0 + d.Cin1, d.kD * d.kH * d.kW
         nin = d.B * cin * d.iD * d.iH * d.iW
         by = 4.0 * (nin + P * d.Cout * (2 if a[5] else 1) + taps * cin * d.Cout)
+
         kind = f"conv {d.kD}x{d.kH}x{d.kW}" + (" (up/transposed)" if d.uH > 1 else "") + (" s2" if d.sH > 1 else "")
         if d.precision == 2 and d.kW == 3 and d.sW == 1:
             kind += " [Winograd F(2,3) along W; FLOPs = direct-form]"
+        if fn is lib.sdc_conv_gn:
+            kind += " + GroupNorm statistics in the epilogue"
         return kind, 2.0 * P * d.Cout * cin * taps, by
+    if fn is lib.sdc_gn_finalize:
+        return "groupnorm stats (finalize of the conv-epilogue sums)", 0.0, 0.0
     if fn is lib.sdc_gn_stats:
         Bb, Cc, S = a[2], a[3], a[5]
         return "groupnorm stats", 3.0 * Bb * Cc * S, 4.0 * Bb * Cc * S
