@@ -69,6 +69,11 @@ def work(fn, a):
         # reference-equivalent work: qkv 1x1 (C -> 384), attention core (4 heads x two 32x32 products), out 1x1 (128 -> C),
         # two channel norms; bytes: x read once, y written once (what the fused block is priced against)
         return "fused LinearAttention block (norm+qkv+core+out+norm+res)", toks * (2.0 * Cc * 384 + 4 * 2 * 2 * 32 * 32 + 2.0 * 128 * Cc + 16 * Cc), 8.0 * toks * Cc
+    if fn is lib.sdc_tattn_block:
+        outer, inner, Cc, ntok = a[7], a[8], a[9], a[10]
+        toks = outer * inner * ntok
+        return ("fused temporal-attention block (norm+qkv+rotary/bias attention+out+res)",
+                toks * (2.0 * Cc * 384 + 4 * 2 * 2 * ntok * 32 + 2.0 * 128 * Cc + 8 * Cc), 8.0 * toks * Cc)
     if fn is lib.sdc_attn:
         outer, inner, heads, nt = a[4], a[5], a[6], a[7]
         seqs = outer * inner * heads
