@@ -309,3 +309,37 @@ def test_conformal_pipelines_end_to_end(golden):
     data = [(det_tensor((3, 8, 7, 16, 16), 950 + i, 0.3), None) for i in range(2)]
     Q = sc.conformal_prediction(iter(data))
     assert torch.isfinite(Q) and Q >= 0
+
+
+# ------------------------------------------------------------------ production-kernel widths at odd batch sizes
+@pytest.mark.parametrize("B", [1, 3])
+def test_mid_width_nets_odd_batches_vs_oracle(B):
+    """Widths 32 / 64 are the smallest that run the production kernels (Winograd tiles, GroupNorm sums in the conv
+    epilogue, fused LinearAttention / temporal-attention blocks) next to their fallbacks for ragged shapes (token
+    counts that are not multiples of 64, widths above 128); odd batch sizes leave partial tiles everywhere."""
+    net = sdc.Unet2D(dim=32, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+    spec = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    P = det_params(spec, 400)
+    net.load_state_dict(P)
+    net.to(DEV)
+    x, t = det_tensor((B, 3, 16, 128), 401), torch.arange(B) * 333 + 5
+    torch.testing.assert_close(net(x.to(DEV), t.to(DEV)).cpu(), onets.unet_burgers(P, x, t, dim=32), **EPS_TOL)
+
+    net1 = sdc.Unet1D(dim=64, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+    spec1 = [(k, tuple(v.shape)) for k, v in net1.state_dict().items()]
+    P1 = det_params(spec1, 410)
+    net1.load_state_dict(P1)
+    net1.to(DEV)
+    x1 = det_tensor((B, 12, 128), 411)
+    torch.testing.assert_close(net1(x1.to(DEV), t.to(DEV)).cpu(), onets.unet_tokamak(P1, x1, t, dim=64), **EPS_TOL)
+
+    net3 = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+    spec3 = [(k, tuple(v.shape)) for k, v in net3.state_dict().items()]
+    P3 = det_params(spec3, 420)
+    net3.load_state_dict(P3)
+    net3.to(DEV)
+    x3 = det_tensor((B, 32, 7, 16, 16), 421)
+    torch.testing.assert_close(net3(x3.to(DEV), t.to(DEV)).cpu(),
+                               onets.unet_smoke(P3, x3, t, dim=64, dim_mults=(1, 2, 4)), rtol=2e-3, atol=2e-4)
+    used = {fn.__name__ for fn, _ in net3.entry(tuple(x3.shape), B)["plan"].calls}
+    assert {"sdc_tattn_block", "sdc_linattn_block", "sdc_conv_gn"} <= used
