@@ -1020,7 +1020,9 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
     constexpr int NA4 = 4 * SK * BM / 4 / NTH;                  // float4 weight loads per thread per stage
     static_assert(TM >= 1 && TP >= 1 && KROWS >= 1 && NA4 >= 1 && WM * WN * 64 == NTH, "bad tile");
     extern __shared__ __attribute__((aligned(16))) float ldsw[];
-    constexpr int ASZ = 4 * SK * BM, BSZ = SK * KSMAX;          // floats per buffer
+    constexpr int PITCH = NCOL * 64 + 8;                        // LDS floats per staged k row: every (lane, sweep) slot exists, so the
+                                                                // staging stores need no per-lane predicate (+8: bank spread of the two half-waves)
+    constexpr int ASZ = 4 * SK * BM, BSZ = SK * PITCH;          // floats per buffer
     float* const As = ldsw;                                     // [2][4][SK][BM]
     float* const Bs = ldsw + 2 * ASZ;                           // [2][SK * ks_stride]
 
@@ -1091,13 +1093,17 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
         const int sg = pos / seg;
         boff[j] = sg * rowlen + (pos - sg * seg);
     }
-    int a_col[NA4];
+    // weight fetch: lane part of the address fixed for the whole kernel (row (xi, k row) and 4 output channels), the
+    // (tap, channel chunk) part wave-uniform -> `global_load_dwordx4 v, voff, s[base]`, no address arithmetic per load
+    uint32_t a_voff[NA4];
     bool a_ok[NA4];
 #pragma unroll
     for (int i = 0; i < NA4; ++i) {
-        const int c4 = ((tid + i * NTH) % (BM / 4)) * 4;
+        const int f = tid + i * NTH;
+        const int c4 = (f % (BM / 4)) * 4, row = f / (BM / 4);
+        const int xi = row / SK, kr = row % SK;
         a_ok[i] = (m0 + c4) < d.Cout;
-        a_col[i] = a_ok[i] ? (m0 + c4) : 0;
+        a_voff[i] = (uint32_t)(((int64_t)(xi * a.Cin + kr) * d.Cout + (a_ok[i] ? (m0 + c4) : 0)) * 4);
     }
     const float* wg = a.wp + (int64_t)a.Ktot * d.Cout;          // transformed taps, 4 per (kd, kh)
 
@@ -1114,7 +1120,7 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
     int l_tap = 0, l_ci = 0;
     const float* l_base = a.x0;
     int64_t l_sc = 0;
-    int64_t l_off[NCOL];
+    uint32_t l_off[NCOL];                         // byte offsets (every operand spans < 2^30 elements: host check `small`)
     auto load_begin = [&]() {
         l_tap = s_kd * d.kH + s_kh;
         l_ci = s_ci;
@@ -1127,9 +1133,9 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
         for (int t = 0; t < NCOL; ++t) {
             const bool ok = (smask[t] >> l_tap) & 1u;
             if constexpr (UPS)
-                l_off[t] = ok ? (int64_t)v0[t] + (s_kh == 0 ? hoff[t][0] : (s_kh == 1 ? hoff[t][1] : hoff[t][2])) : 0;
+                l_off[t] = ok ? (uint32_t)(v0[t] + (s_kh == 0 ? hoff[t][0] : (s_kh == 1 ? hoff[t][1] : hoff[t][2]))) * 4u : 0u;
             else
-                l_off[t] = ok ? (int64_t)(first ? v0[t] : v1[t]) + toff : 0;
+                l_off[t] = ok ? (uint32_t)((first ? v0[t] : v1[t]) + (int)toff) * 4u : 0u;
             mbits |= (ok ? 1u : 0u) << t;
         }
         s_ci += SK;
@@ -1138,19 +1144,23 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
         if (s_ci >= a.Cin) { s_ci = 0; if (++s_kh == d.kH) { s_kh = 0; if (++s_kd == d.kD) s_kd = 0; } }
     };
     auto load_piece = [&](int p) {
+        typedef const __attribute__((address_space(1))) char* gchar_p;
+        typedef float nfloat4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) nfloat4* gfloat4_p;
+        const gfloat_p wbase = uniform_ptr(wg + ((int64_t)(l_tap * 4) * a.Cin + l_ci) * d.Cout);
 #pragma unroll
         for (int i = 0; i < NA4; ++i) {
             if (i % NSL != p) continue;
-            const int row = (tid + i * NTH) / (BM / 4);           // [0, 4*SK): (xi, k row)
-            const int xi = row / SK, kr = row % SK;
-            const int64_t wrow = (int64_t)(l_tap * 4 + xi) * a.Cin + l_ci + kr;
-            areg[i] = *reinterpret_cast<const float4*>(wg + wrow * d.Cout + a_col[i]);
+            const nfloat4 wv = *(gfloat4_p)((gchar_p)wbase + a_voff[i]);
+            areg[i] = make_float4(wv.x, wv.y, wv.z, wv.w);
         }
 #pragma unroll
-        for (int r = 0; r < KROWS; ++r)
+        for (int r = 0; r < KROWS; ++r) {
+            const gfloat_p rb = uniform_ptr(l_base + r * l_sc);
 #pragma unroll
             for (int t = 0; t < NCOL; ++t)
-                if ((NA4 + r * NCOL + t) % NSL == p) breg[r][t] = (l_base + r * l_sc)[l_off[t]];   // ks_stride > 64*(NCOL-1)
+                if ((NA4 + r * NCOL + t) % NSL == p) breg[r][t] = ld_sv(rb, l_off[t]);   // ks_stride > 64*(NCOL-1)
+        }
     };
     auto store_piece = [&](int buf, int p) {
 #pragma unroll
@@ -1166,9 +1176,8 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
         for (int r = 0; r < KROWS; ++r)
 #pragma unroll
             for (int t = 0; t < NCOL; ++t) {
-                const int cidx = lane + 64 * t;
-                if ((NA4 + r * NCOL + t) % NSL == p && cidx < ks_stride)
-                    Bs[buf * BSZ + (wave * KROWS + r) * ks_stride + cidx] = ((mbits >> t) & 1u) ? breg[r][t] : 0.0f;
+                if ((NA4 + r * NCOL + t) % NSL == p)
+                    Bs[buf * BSZ + (wave * KROWS + r) * PITCH + lane + 64 * t] = ((mbits >> t) & 1u) ? breg[r][t] : 0.0f;
             }
     };
 
@@ -1207,12 +1216,28 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
                 for (int i = 0; i < TM; ++i) fa[set][x][i] = Ab[(x * SK + 2 * ks + lh) * BM + am + i * 32];
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                const float2* bp = reinterpret_cast<const float2*>(Bb + (2 * ks + lh) * ks_stride + boff[j]);
+                const float2* bp = reinterpret_cast<const float2*>(Bb + (2 * ks + lh) * PITCH + boff[j]);
                 fb[set][j][0] = bp[0];
                 fb[set][j][1] = bp[1];
             }
         };
+        // Input transform of a k-step's B fragments is done one step ahead, and the LDS reads, the staging piece and
+        // that transform are spread over the shadows of the step's MFMAs (sched_group_barrier): a wave that issues its
+        // MFMAs back to back and only then its other instructions leaves the matrix pipe idle while it catches up --
+        // the two waves of a SIMD drift into running one after the other, so nobody else fills those gaps.
+        float bt[2][TP][4];
+        auto transform = [&](int set) {
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const float2 p0 = fb[set][j][0], p1 = fb[set][j][1];
+                bt[set][j][0] = p0.x - p1.x;
+                bt[set][j][1] = p0.y + p1.x;
+                bt[set][j][2] = p1.x - p0.y;
+                bt[set][j][3] = p0.y - p1.y;
+            }
+        };
         read_frag(0, 0);
+        transform(0);
 #pragma unroll
         for (int ks = 0; ks < SK / 2; ++ks) {
             const int set = ks & 1;
@@ -1223,22 +1248,24 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
                 if (ks == NSL) load_begin();
                 load_piece(ks - NSL);
             }
-            float bt[TP][4];
-#pragma unroll
-            for (int j = 0; j < TP; ++j) {
-                const float2 p0 = fb[set][j][0], p1 = fb[set][j][1];
-                bt[j][0] = p0.x - p1.x;
-                bt[j][1] = p0.y + p1.x;
-                bt[j][2] = p1.x - p0.y;
-                bt[j][3] = p0.y - p1.y;
-            }
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TP; ++j)
-                        acc[x][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][x][i], bt[j][x], acc[x][i][j], 0, 0, 0);
+                        acc[x][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][x][i], bt[set][j][x], acc[x][i][j], 0, 0, 0);
+            if (ks + 1 < SK / 2) transform(set ^ 1);
+            // interleave: the next fragments' LDS reads behind the first MFMA, then per MFMA a few VALU and one staging
+            // access (LDS write / global load)
+#pragma unroll
+            for (int m = 0; m < 4 * TM * TP; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (m == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4 * TM + 4 * TP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x220, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -1250,7 +1277,8 @@ template <int BM, int BN, int WM, int WN, int SK, int NTH = 256, bool UPS = fals
 void launch_wg(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
     constexpr int KSMAX = BN + (BN / 16) * 2;
-    const size_t lds = (2u * 4u * SK * BM + 2u * SK * KSMAX) * sizeof(float);
+    constexpr int NCOLH = (KSMAX + 63) / 64;
+    const size_t lds = (2u * 4u * SK * BM + 2u * SK * (NCOLH * 64 + 8)) * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS>),
