@@ -1044,20 +1044,37 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
     int v0[NCOL], v1[NCOL];
     int hoff[UPS ? NCOL : 1][3];
     uint64_t smask[NCOL];
+    // Gather state.  n0 is decomposed once (wave-uniform); a segment adds whole output rows to it (nseg > 1 only when a
+    // segment IS a row), and the small per-lane quotients (segment of a column, (b, od, oh) of a row number) are exact
+    // float-reciprocal divisions -- runtime integer divisions here cost ~10K cycles per tile before the first MFMA.
+    int q0 = n0;
+    const int ow_b = q0 % d.oW; q0 /= d.oW;
+    const int row_b = q0;                                       // flattened (b, od, oh) of the tile's first position
+    const bool fdiv = (int64_t)d.B * d.oD * d.oH < (1 << 20);   // quotients below 2^20: the float form is exact
+    const float r_rowlen = 1.0f / (float)rowlen, r_oH = 1.0f / (float)d.oH, r_oD = 1.0f / (float)d.oD;
 #pragma unroll
     for (int t = 0; t < NCOL; ++t) {
         const int cidx = lane + 64 * t;
         v0[t] = 0; v1[t] = 0; smask[t] = 0;
         if constexpr (UPS) { hoff[t][0] = 0; hoff[t][1] = 0; hoff[t][2] = 0; }
         if (cidx < ks_stride) {
-            const int sg = cidx / rowlen;
+            const int sg = (int)(((float)cidx + 0.5f) * r_rowlen);
             const int cc = cidx - sg * rowlen;
             const int pseg = n0 + sg * seg;
             if (pseg < a.Ntot) {
-                int q = pseg;
-                const int ow0 = q % d.oW; q /= d.oW;
-                const int oh = q % d.oH; q /= d.oH;
-                const int od = q % d.oD; const int ob = q / d.oD;
+                const int ow0 = ow_b;                           // n0 + sg*seg starts a row whenever sg > 0
+                const int row = row_b + (nseg > 1 ? sg : 0);
+                int oh, od, ob;
+                if (fdiv) {
+                    const int t2 = (int)(((float)row + 0.5f) * r_oH);
+                    oh = row - t2 * d.oH;
+                    ob = (int)(((float)t2 + 0.5f) * r_oD);
+                    od = t2 - ob * d.oD;
+                } else {
+                    int q = row;
+                    oh = q % d.oH; q /= d.oH;
+                    od = q % d.oD; ob = q / d.oD;
+                }
                 const int col = ow0 + cc - d.pW;
                 const int id0 = od * d.sD - d.pD, ih0 = oh * d.sH - d.pH;
                 uint64_t m = 0;
@@ -1073,10 +1090,13 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
                     v0[t] = (int)(ob * d.x0s[0] + id0 * d.x0s[2] + (col >> a.lgW) * d.x0s[4]);
                 } else {
                     if (col >= 0 && col < d.iW) {
-                        for (int kd = 0; kd < d.kD; ++kd)
-                            for (int kh = 0; kh < d.kH; ++kh)
-                                if (id0 + kd >= 0 && id0 + kd < d.iD && ih0 + kh >= 0 && ih0 + kh < d.iH)
-                                    m |= 1ull << (kd * d.kH + kh);
+                        // taps (kd, kh) inside the input: a range of kh per kd, as bit fields
+                        const int h_lo = ih0 < 0 ? -ih0 : 0, h_hi = (d.iH - ih0) < d.kH ? (d.iH - ih0) : d.kH;
+                        const int d_lo = id0 < 0 ? -id0 : 0, d_hi = (d.iD - id0) < d.kD ? (d.iD - id0) : d.kD;
+                        if (h_hi > h_lo) {
+                            const uint64_t mh = ((1ull << h_hi) - 1) & ~((1ull << h_lo) - 1);
+                            for (int kd = d_lo; kd < d_hi; ++kd) m |= mh << (kd * d.kH);
+                        }
                     }
                     smask[t] = m;
                     v0[t] = (int)(ob * d.x0s[0] + id0 * d.x0s[2] + ih0 * d.x0s[3] + col * d.x0s[4]);
