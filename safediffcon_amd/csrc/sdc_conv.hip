@@ -1222,6 +1222,8 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
     for (int p = 0; p < NSL; ++p) load_piece(p);
     __syncthreads();
     const int am = wm * (TM * 32) + l31;
+    // the later-dispatched half of an 8-wave workgroup loses every arbitration against its SIMD partner: static priority
+    if (NTH == 512 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     for (int st = 0; st < nstages; ++st) {
         const int buf = st & 1;

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[(2 * ks + lh) * XP + hw * 33 + l31], w[ks], acc, 0, 0, 0);
     };
     fetch_w(w0, 0, 0);
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every arbitration against its SIMD partner otherwise
     for (int head = 0; head < 4; ++head) {
         // q, k, v [32 d][32 f]: A = W[(part, head)][d = l31][c], B = xn[c][f]
         f32x16 pr[3];
