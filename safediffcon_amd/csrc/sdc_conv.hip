@@ -298,7 +298,6 @@ __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[ks][j] = Bs[buf][2 * ks + lh][bn + j * 32];
         }
-        __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads ahead of the MFMA block
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
 #pragma unroll
@@ -307,6 +306,16 @@ __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs a) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
         }
+        // the chunk's global loads, address arithmetic and LDS fragment reads go into the shadows of its MFMAs (a wave that
+        // issues them in one block first leaves the matrix pipe idle meanwhile)
+#pragma unroll
+        for (int m = 0; m < (BK / 2) * TM * TN; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (kc + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
     }
