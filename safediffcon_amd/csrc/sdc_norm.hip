@@ -318,12 +318,72 @@ extern "C" int sdc_gn_apply(const float* x, const float* stats, const float* gam
     return sdc::check_launch("sdc_gn_apply");
 }
 
+// Wide-channel form (C too large for the register cache): the (C x PL) tile of PL positions is parked in LDS by the
+// statistics pass, so x is read from HBM once and the deep, short levels (tokamak: C up to 2048 at 16 positions) do not
+// pay two or three latency-bound sweeps over global memory.  Same thread layout: PL position lanes x NT/PL channel slices.
+template <int PL>
+__global__ __launch_bounds__(NT) void chan_norm_lds_kernel(const float* x, const float* __restrict__ g, const float* res, float* y,
+                                                           int C, int64_t S, int mode, float eps) {
+    constexpr int NSL = NT / PL;
+    extern __shared__ float tile[];                 // [C][PL] then [2][NSL][PL] reduction scratch
+    float* sh = tile + (size_t)C * PL;
+    const int lane = threadIdx.x % PL, slice = threadIdx.x / PL;
+    const int b = blockIdx.y;
+    const int64_t pos = (int64_t)blockIdx.x * PL + lane;
+    const bool ok = pos < S;
+    const int64_t base = (int64_t)b * C * S + pos;
+    float s = 0.f, q = 0.f;
+    for (int c = slice; c < C; c += NSL) {
+        const float v = ok ? x[base + (int64_t)c * S] : 0.f;
+        tile[c * PL + lane] = v;
+        s += v;
+        q += v * v;
+    }
+    sh[slice * PL + lane] = s;
+    sh[(NSL + slice) * PL + lane] = q;
+    __syncthreads();
+    s = 0.f; q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) { s += sh[i * PL + lane]; q += sh[(NSL + i) * PL + lane]; }
+    float mean, mul;
+    if (mode == 0) {
+        mean = s / C;
+        float q2 = 0.f;
+        for (int c = slice; c < C; c += NSL) { const float dv = tile[c * PL + lane] - mean; q2 += dv * dv; }
+        __syncthreads();
+        sh[(NSL + slice) * PL + lane] = q2;
+        __syncthreads();
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) var += sh[(NSL + i) * PL + lane];
+        mul = 1.0f / sqrtf(var / C + eps);
+    } else {
+        mean = 0.f;
+        mul = sqrtf((float)C) / fmaxf(sqrtf(q), 1e-12f);
+    }
+    if (!ok) return;
+    for (int c = slice; c < C; c += NSL) {
+        const int64_t o = base + (int64_t)c * S;
+        float v = (tile[c * PL + lane] - mean) * mul * g[c];
+        if (res) v += res[o];
+        y[o] = v;
+    }
+}
+
 extern "C" int sdc_chan_norm(const float* x, const float* g, const float* residual, float* y, int B, int C, int64_t S,
                              int mode, float eps, void* stream) {
     SDC_REQUIRE(x && g && y, SDC_ENULL, "sdc_chan_norm: null pointer");
     SDC_REQUIRE(B > 0 && C > 0 && S > 0 && (mode == 0 || mode == 1), SDC_EINVAL, "sdc_chan_norm: bad arguments");
     SDC_REQUIRE(B < 65536, SDC_EINVAL, "sdc_chan_norm: B too large for grid.y");
-    if (S >= 64) {
+    auto lds_bytes = [&](int pl) { return sizeof(float) * ((size_t)C * pl + 2 * (NT / pl) * pl); };
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chan_norm_lds_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        attr = true;
+    }
+    // 64-position tiles only when they still make >= 1024 workgroups; shorter rows take the 16-lane form (more, smaller
+    // workgroups: these launches are latency-bound, not bandwidth-bound)
+    if (S >= 64 && ((S + 63) / 64) * (int64_t)B >= 1024) {
         dim3 grid((unsigned)((S + 63) / 64), B);
         if (C <= 128)
             hipLaunchKernelGGL((chan_norm_kernel<64, true>), grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
@@ -333,6 +393,8 @@ extern "C" int sdc_chan_norm(const float* x, const float* g, const float* residu
         dim3 grid((unsigned)((S + 15) / 16), B);
         if (C <= 512)
             hipLaunchKernelGGL((chan_norm_kernel<16, true>), grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
+        else if (C <= 2048)
+            hipLaunchKernelGGL((chan_norm_lds_kernel<16>), grid, dim3(NT), lds_bytes(16), sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
         else
             hipLaunchKernelGGL((chan_norm_kernel<16, false>), grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
     }

@@ -163,7 +163,8 @@ def test_groupnorm_silu(plan_cls, B, Cc, G, sp):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("B,Cc,S", [(2, 8, 2048), (3, 64, 100), (2, 2048, 16), (1, 5, 3)])
+@pytest.mark.parametrize("B,Cc,S", [(2, 8, 2048), (3, 64, 100), (2, 2048, 16), (1, 5, 3), (3, 256, 128), (2, 1024, 20), (2, 512, 32),
+                                    (2, 4096, 16), (2, 448, 70)])
 def test_channel_norms(plan_cls, mode, B, Cc, S):
     x = det_tensor((B, Cc, S), 30) * 2 + 0.7
     g = det_tensor((1, Cc, 1), 31) * 0.3 + 1
