@@ -7,8 +7,8 @@
 //
 // The unfused chain writes xn, q/k/v (3 x 128 channels), out (128 channels) and the projected y to HBM and reads them
 // back -- ~27 x the bytes of x per block at C = 64.  Here x is read three times and y written once:
-//   pass 1  la_blk_ctx : x tile -> channel norm -> K = Wk xn on the matrix cores -> online softmax over tokens
-//                        (running row max, rescaled accumulators) -> M[d][c] += sum_tok p[d][tok] xn[c][tok]
+//   pass 1  la_blk_ctx : x tile -> channel norm -> K^T = xn^T Wk^T on the matrix cores -> online softmax over tokens
+//                        (running max per d, rescaled accumulators) -> M^T[c][d] += sum_tok xn[c][tok] p[tok][d]
 //                        (ctx = M Wv^T / rowsum: V is never formed per token)
 //   mid     la_blk_mid : merge the token splits (log-sum-exp), ctx = M Wv^T / sum, T[co][h,d] = sum_e Wo[co][h,e] ctx_h[d][e]
 //   pass 2  la_blk_out : x tile -> channel norm -> Q = Wq xn -> softmax over d, * scale -> y = T q + bo -> channel
@@ -39,17 +39,6 @@ struct LaArgs {
     float eps;
     int64_t so, sc, si;
 };
-
-__device__ __forceinline__ float half_max(float v) {      // max over the 32 lanes of this lane's half-wave
-#pragma unroll
-    for (int m = 1; m < 32; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-    return v;
-}
-__device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
 
 // x tile (C channels x 64 tokens) -> channel norm over C per token -> xs[c][tok].  Thread (tok = tid & 63, group =
 // tid >> 6) owns C/4 channels of one token; the per-token statistics are combined across the 4 groups through `red`.
@@ -116,13 +105,17 @@ __device__ __forceinline__ void project(const float (&wreg)[C / 2], const float*
 }
 
 // ------------------------------------------------------------------ pass 1: per (split, sequence); wave = head
+// Everything is kept transposed so that the reductions run over registers and the products chain without LDS:
+//   K^T[tok][d] = xn^T Wk^T        (operands swapped: rows = tokens on registers, columns = d on lanes)
+//   softmax statistics per d       = per lane: max / sum over the 32 accumulator registers + one cross-half shuffle
+//   M^T[c][d] += sum_tok xn[c][tok] p[tok][d]:  A = xn from LDS, B = the P registers as they stand (the contraction
+//   index tok is walked in accumulator-row order); the online rescale factor is per d = per lane, one multiply per register.
 template <int C>
 __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) void la_blk_ctx(const LaArgs a) {
-    constexpr int NCT = C / 32;                     // column tiles of M (channels)
+    constexpr int NCT = C / 32;                     // row tiles of M^T (channels)
     extern __shared__ float lds[];                  // C = 128 needs 67 KB: dynamic
     float* const xs = lds;                          // [C][XP]
-    float* const ps = lds + C * XP;                 // [4][32][XP]
-    float* const red = ps + HID * XP;               // [8][TT]
+    float* const red = lds + (C + HID) * XP;        // [8][TT]  (same offsets as pass 2's layout)
     const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int split = blockIdx.x, seq = blockIdx.y;
     const int o = seq / a.inner, i = seq - o * a.inner;
@@ -132,15 +125,12 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) void la_blk_ctx(const LaArgs
 #pragma unroll
     for (int ks = 0; ks < C / 2; ++ks) wreg[ks] = a.wqkv[(int64_t)(2 * ks + lh) * (3 * HID) + HID + head * 32 + l31];
 
-    f32x16 macc[NCT];
-    float mrun[16], psum[16];
+    f32x16 macc[NCT];                               // M^T tile t: rows c = t*32 + crow, columns d = l31
 #pragma unroll
     for (int t = 0; t < NCT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) macc[t][r] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { mrun[r] = -INFINITY; psum[r] = 0.f; }
-    float* psh = ps + head * 32 * XP;
+    float mrun = -INFINITY, psum = 0.f;             // per d (this lane; the two half-waves hold different token rows)
 
     const int t0 = split * a.tiles_per_split;
     const int t1 = min(t0 + a.tiles_per_split, a.ntiles);
@@ -149,43 +139,56 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) void la_blk_ctx(const LaArgs
     for (int tile = t0; tile < t1; ++tile) {
         norm_tile<C>(xv, a.g_pre, a.pre_mode, a.eps, xs, nullptr, red, tid);
         if (tile + 1 < t1) fetch_tile<C>(xseq + (int64_t)(tile + 1) * TT, a.sc, tid, xv);
+        // K^T tiles j = 0, 1: rows tok = j*32 + crow(r, lh), columns d = l31
         f32x16 kacc[2];
-        project<C>(wreg, xs, l31, lh, kacc);
-        // online softmax over tokens: row d = (r&3) + 8*(r>>2) + 4*lh lives in register r of this half-wave
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { kacc[0][r] = 0.f; kacc[1][r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < C / 2; ++ks) {
+            const float a0 = xs[(2 * ks + lh) * XP + l31], a1 = xs[(2 * ks + lh) * XP + 32 + l31];
+            kacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wreg[ks], kacc[0], 0, 0, 0);
+            kacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wreg[ks], kacc[1], 0, 0, 0);
+        }
+        // online softmax over tokens, per d
+        float tmax = kacc[0][0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(kacc[0][r], kacc[1][r]));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mrun, tmax);
+        const float f = __expf(mrun - mnew);
+        mrun = mnew;
+        float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float tmax = half_max(fmaxf(kacc[0][r], kacc[1][r]));
-            const float mnew = fmaxf(mrun[r], tmax);
-            const float f = __expf(mrun[r] - mnew);
-            mrun[r] = mnew;
-            const float p0 = __expf(kacc[0][r] - mnew), p1 = __expf(kacc[1][r] - mnew);
-            psum[r] = psum[r] * f + p0 + p1;
-#pragma unroll
-            for (int t = 0; t < NCT; ++t) macc[t][r] *= f;
-            const int d = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            psh[d * XP + l31] = p0;
-            psh[d * XP + 32 + l31] = p1;
+            kacc[0][r] = __expf(kacc[0][r] - mnew);
+            kacc[1][r] = __expf(kacc[1][r] - mnew);
+            ps += kacc[0][r] + kacc[1][r];
         }
-        // M[d][c] += sum_tok p[d][tok] * xn[c][tok]   (A = p from this wave's own LDS rows, B = xn^T)
-#pragma unroll 8
-        for (int ks = 0; ks < TT / 2; ++ks) {
-            const float av = psh[l31 * XP + 2 * ks + lh];
+        psum = psum * f + ps;
 #pragma unroll
-            for (int t = 0; t < NCT; ++t)
-                macc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xs[(t * 32 + l31) * XP + 2 * ks + lh], macc[t], 0, 0, 0);
-        }
+        for (int t = 0; t < NCT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) macc[t][r] *= f;
+        // M^T[c][d] += sum_tok xn[c][tok] p[tok][d]; step (j, r) covers tokens j*32 + crow(r, 0) | crow(r, 1)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tok = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+                for (int t = 0; t < NCT; ++t)
+                    macc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[(t * 32 + l31) * XP + tok], kacc[j][r], macc[t], 0, 0, 0);
+            }
         __syncthreads();                             // xs is rewritten by the next tile
     }
     // partial result of this split: M[32][C], m[32], s[32]
     float* pp = a.part + (((int64_t)seq * a.nsplit + split) * 4 + head) * (32 * (C + 2));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int d = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float s = half_sum(psum[r]);
+    for (int t = 0; t < NCT; ++t)
 #pragma unroll
-        for (int t = 0; t < NCT; ++t) pp[d * C + t * 32 + l31] = macc[t][r];
-        if (l31 == 0) { pp[32 * C + d] = mrun[r]; pp[32 * C + 32 + d] = s; }
-    }
+        for (int r = 0; r < 16; ++r) pp[l31 * C + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = macc[t][r];
+    const float stot = psum + __shfl_xor(psum, 32, 64);
+    if (lh == 0) { pp[32 * C + l31] = mrun; pp[32 * C + 32 + l31] = stot; }
 }
 
 // ------------------------------------------------------------------ mid: per (sequence, head)
