@@ -381,9 +381,10 @@ extern "C" int sdc_chan_norm(const float* x, const float* g, const float* residu
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chan_norm_lds_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         attr = true;
     }
-    // 64-position tiles only when they still make >= 1024 workgroups; shorter rows take the 16-lane form (more, smaller
-    // workgroups: these launches are latency-bound, not bandwidth-bound)
-    if (S >= 64 && ((S + 63) / 64) * (int64_t)B >= 1024) {
+    // 64-position tiles for long rows only; shorter rows take the 16-lane form (more, smaller workgroups: those launches
+    // are latency-bound, not bandwidth-bound).  The choice depends on the row length alone, never on the batch, so a
+    // trajectory's rounding does not depend on how many others share the launch.
+    if (S >= 1024) {
         dim3 grid((unsigned)((S + 63) / 64), B);
         if (C <= 128)
             hipLaunchKernelGGL((chan_norm_kernel<64, true>), grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
