@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
         // bounds and are never consumed -- keeping them unconditional keeps the loop free of load-skipping branches)
         if (s_ci >= a.Cin) { s_ci = 0; if (++s_kh == d.kH) { s_kh = 0; if (++s_kd == d.kD) s_kd = 0; } }
     };
-    auto load_piece = [&](int p) {
+    auto load_piece_to = [&](int p, float (&breg)[KROWS][NCOL], float4 (&areg)[NA4]) {
         typedef const __attribute__((address_space(1))) char* gchar_p;
         typedef float nfloat4 __attribute__((ext_vector_type(4)));
         typedef const __attribute__((address_space(1))) nfloat4* gfloat4_p;
@@ -1191,7 +1191,8 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
                 if ((NA4 + r * NCOL + t) % NSL == p) breg[r][t] = ld_sv(rb, l_off[t]);   // ks_stride > 64*(NCOL-1)
         }
     };
-    auto store_piece = [&](int buf, int p) {
+    auto load_piece = [&](int p) { load_piece_to(p, breg, areg); };
+    auto store_piece_from = [&](int buf, int p, const float (&breg)[KROWS][NCOL], const float4 (&areg)[NA4], uint32_t mbits) {
 #pragma unroll
         for (int i = 0; i < NA4; ++i) {
             if (i % NSL != p) continue;
@@ -1209,6 +1210,7 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
                     Bs[buf * BSZ + (wave * KROWS + r) * PITCH + lane + 64 * t] = ((mbits >> t) & 1u) ? breg[r][t] : 0.0f;
             }
     };
+    auto store_piece = [&](int buf, int p) { store_piece_from(buf, p, breg, areg, mbits); };
 
     f32x16 acc[4][TM][TP];
 #pragma unroll
@@ -1221,14 +1223,20 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
                 for (int r = 0; r < 16; ++r) acc[x][i][j][r] = 0.0f;
 
     const int nstages = d.kD * d.kH * (a.Cin / SK);
-    load_begin();
+    {   // prologue: the fetches of the first two stages travel together (stage 0 in a register set that dies here, before
+        // the accumulators come alive) -- one memory round trip before the first MFMA instead of two
+        float breg0[KROWS][NCOL];
+        float4 areg0[NA4];
+        load_begin();
+        const uint32_t mbits0 = mbits;
 #pragma unroll
-    for (int p = 0; p < NSL; ++p) load_piece(p);
+        for (int p = 0; p < NSL; ++p) load_piece_to(p, breg0, areg0);
+        load_begin();
 #pragma unroll
-    for (int p = 0; p < NSL; ++p) store_piece(0, p);
-    load_begin();
+        for (int p = 0; p < NSL; ++p) load_piece(p);
 #pragma unroll
-    for (int p = 0; p < NSL; ++p) load_piece(p);
+        for (int p = 0; p < NSL; ++p) store_piece_from(0, p, breg0, areg0, mbits0);
+    }
     __syncthreads();
     const int am = wm * (TM * 32) + l31;
     // the later-dispatched half of an 8-wave workgroup loses every arbitration against its SIMD partner: static priority
