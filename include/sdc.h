@@ -58,6 +58,8 @@ int sdc_last_error(char* buf, size_t cap);
  * Replaces: every nn.Conv1d/2d/3d, nn.Linear and nn.ConvTranspose3d on the path
  * (1D/model/unet.py:132-134,161-163,189-197,232-236,326,345,370,378;
  *  conv3d.py:159-163,192,218,239-240,291-292,395,471).
+ * Output size per axis: (i*u + 2p - k)/s + 1 (i -> (i-1)*u+1 for zero insertion); up to k-1 more positions are
+ * accepted and read implicit zeros past the far edge (one-sided padding), fewer compute a prefix.
  * Wp is the caller-repacked weight [K = taps*Cin][Cout] (row-major, Cout fastest).
  * precision 1 (opt-in, NOT the parity mode): split-bf16 3-pass MFMA (~16 mantissa bits); the wp buffer then holds
  * the fp32 Wp followed by the pre-split weights as bf16 [Cout][K] hi and [Cout][K] lo (k contiguous); layers the

@@ -1475,8 +1475,10 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
         const int v = mode ? (i - 1) * u + 1 : i * u;
         return (v + 2 * p - k) / s + 1;
     };
-    SDC_REQUIRE(d.oD == osz(d.iD, d.uD, d.up_mode, d.kD, d.sD, d.pD) && d.oH == osz(d.iH, d.uH, d.up_mode, d.kH, d.sH, d.pH) &&
-                    d.oW == osz(d.iW, d.uW, d.up_mode, d.kW, d.sW, d.pW),
+    // (up to k-1 extra positions per axis are allowed: they read the implicit zeros past the far edge -- one-sided padding,
+    // used by the sub-pixel form of the stride-2 transposed conv; a shorter axis computes a prefix)
+    auto fits = [&](int o, int i, int u, int k, int st, int p) { return o >= 1 && o <= osz(i, u, d.up_mode, k, st, p) + (k - 1); };
+    SDC_REQUIRE(fits(d.oD, d.iD, d.uD, d.kD, d.sD, d.pD) && fits(d.oH, d.iH, d.uH, d.kH, d.sH, d.pH) && fits(d.oW, d.iW, d.uW, d.kW, d.sW, d.pW),
                 SDC_EINVAL, "sdc_conv: output size (%d,%d,%d) inconsistent with input/kernel/stride/pad", d.oD, d.oH, d.oW);
     const int64_t ntot = (int64_t)d.B * d.oD * d.oH * d.oW;
     SDC_REQUIRE(ntot < (1ll << 31), SDC_EINVAL, "sdc_conv: too many output positions");

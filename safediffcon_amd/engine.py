@@ -120,6 +120,15 @@ class Plan:
                 t5 = as5(t)                                   # (Cin, Cout, kD, kH, kW)
                 t5 = t5.flip(2, 3, 4).permute(2, 3, 4, 0, 1)  # (kD,kH,kW,Cin,Cout)
                 return t5.reshape(-1, t5.shape[-1]).contiguous()
+            if isinstance(kind, tuple) and kind[0] == "convT_sub":
+                # sub-pixel form of ConvTranspose (1,4,4)/(1,2,2)/(0,1,1): output parity (ph, pw) is a 2x2 conv of the
+                # input with taps kh in (3,1) [ph=0] / (2,0) [ph=1] (same along W): out[2j+ph] = sum_t x[j+t-(1-ph)] W[kh_t]
+                _, ph, pw = kind
+                t5 = as5(t)                                   # (Cin, Cout, 1, 4, 4)
+                kh = (3, 1) if ph == 0 else (2, 0)
+                kw = (3, 1) if pw == 0 else (2, 0)
+                sub = t5[:, :, 0][:, :, list(kh)][:, :, :, list(kw)]       # (Cin, Cout, 2, 2)
+                return sub.permute(2, 3, 0, 1).reshape(-1, sub.shape[1]).contiguous()
             if kind == "unshuffle":
                 co, c4 = t.shape[0], t.shape[1]
                 t4 = t.reshape(co, c4 // 4, 2, 2)             # (Cout, C, p1, p2)
@@ -172,7 +181,11 @@ class Plan:
         o = tuple(osz(i, u, kk, s, p) for i, u, kk, s, p in zip((iD, iH, iW), up, k, stride, pad))
         if out is None:
             out = self.pool.get((B, cout, *o))
-        assert tuple(out.shape) == (B, cout, *o), (out.shape, (B, cout, *o))
+        else:
+            # a caller-sized output may differ from the symmetric-padding size by a one-sided margin (include/sdc.h); the
+            # library validates it
+            assert tuple(out.shape[:2]) == (B, cout) and out.dim() == 5, (out.shape, (B, cout, *o))
+            o = tuple(out.shape[2:])
         nw = k[0] * k[1] * k[2] * (c0 + c1) * cout
         split = wp.dim() == 1 and wp.numel() == 2 * nw
         wino = wp.dim() == 1 and k[2] == 3 and wp.numel() == nw + nw // 3 * 4
@@ -202,6 +215,18 @@ class Plan:
                        _ptr(parts), gn_groups)
             return out
         self._emit(self.lib.sdc_conv, C.byref(d), _ptr(x), _ptr(x1), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(out))
+        return out
+
+    def conv_transpose_422(self, x, w, bias, cout):
+        """nn.ConvTranspose3d(C, cout, (1,4,4), (1,2,2), (0,1,1)) as four 2x2 stride-1 convs, one per output parity,
+        each writing its quarter of the output through strides (conv3d.py:159-160).  The zero-stuffed form spends
+        3/4 of its MFMA work on inserted zeros."""
+        B, c0, iD, iH, iW = x.shape
+        out = self.pool.get((B, cout, iD, 2 * iH, 2 * iW))
+        for ph in (0, 1):
+            for pw in (0, 1):
+                wp = self.conv_weight(w, ("convT_sub", ph, pw))
+                self.conv(x, wp, bias, cout, (1, 2, 2), pad=(0, 1 - ph, 1 - pw), out=out[:, :, :, ph::2, pw::2])
         return out
 
     def gn_silu(self, x, gamma, beta, groups, *, ss=None, t_dev=None, ss_t_stride=0, ss_b_stride=0, ss_off=0,

@@ -676,7 +676,10 @@ class Unet3D_with_Conv3D(_HipUNet):
             pool.put(u3)
             h = u4
             if i < nres - 1:
-                h = b.conv(u4, f"{p}.4", kind="convT", up=(1, 2, 2), pad=(0, 2, 2))   # ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1)
+                # ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1): four 2x2 sub-pixel convs (the zero-stuffed single conv,
+                # kind="convT", does 4x the MFMA work)
+                h = b.plan.conv_transpose_422(u4, lambda p=p: self.P(f"{p}.4.weight"), b.V(f"{p}.4.bias"),
+                                              self.P(f"{p}.4.weight").shape[1])
                 pool.put(u4)
         f = b.resnet("final_conv.0", h, G, x1=r)
         pool.put(h), pool.put(r)

@@ -491,3 +491,17 @@ def test_conv_groupnorm_statistics_in_the_epilogue(plan_cls, case):
         outs.append(h.cpu().reshape(ref.shape).double())
     torch.testing.assert_close(outs[0], ref, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(outs[0], outs[1], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,Cc,Co,sp", [(2, 16, 32, (3, 8, 8)), (1, 64, 48, (2, 5, 7)), (3, 32, 32, (1, 16, 16))])
+def test_conv_transpose_subpixel(plan_cls, B, Cc, Co, sp):
+    """ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1) as four 2x2 sub-pixel convs == F.conv_transpose3d == the zero-stuffed form."""
+    x = det_tensor((B, Cc, *sp), 141)
+    w, b = det_tensor((Cc, Co, 1, 4, 4), 142, 0.2), det_tensor((Co,), 143, 0.1)
+    ref = F.conv_transpose3d(x.double(), w.double(), b.double(), stride=(1, 2, 2), padding=(0, 1, 1))
+    plan = plan_cls(DEV)
+    out = plan.conv_transpose_422(x.to(DEV), w.to(DEV), b.to(DEV), Co)
+    old = plan.conv(x.to(DEV), plan.conv_weight(w.to(DEV), "convT"), b.to(DEV), Co, (1, 4, 4), up=(1, 2, 2), up_mode=1, pad=(0, 2, 2))
+    _run(plan)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(old.cpu().double(), ref, rtol=1e-5, atol=1e-5)
