@@ -129,6 +129,16 @@ class Plan:
                 kw = (3, 1) if pw == 0 else (2, 0)
                 sub = t5[:, :, 0][:, :, list(kh)][:, :, :, list(kw)]       # (Cin, Cout, 2, 2)
                 return sub.permute(2, 3, 0, 1).reshape(-1, sub.shape[1]).contiguous()
+            if isinstance(kind, tuple) and kind[0] == "up2_sub":
+                # nearest x2 upsampling + 3x3 conv (pad 1), output parity (ph, pw): rows 2i+ph of the upsampled image see
+                # x[i-1], x[i], x[i] (ph = 0) or x[i], x[i], x[i+1] (ph = 1) -> a 2-tap kernel with merged weights
+                # (W0, W1+W2) on rows (i-1, i)  /  (W0+W1, W2) on rows (i, i+1); same along W.  9 taps -> 4.
+                _, ph, pw = kind
+                t5 = as5(t).to(torch.float64)                 # (Cout, Cin, 1, 3, 3)
+                mh = torch.tensor([[1, 0, 0], [0, 1, 1]] if ph == 0 else [[1, 1, 0], [0, 0, 1]], dtype=torch.float64, device=t5.device)
+                mw = torch.tensor([[1, 0, 0], [0, 1, 1]] if pw == 0 else [[1, 1, 0], [0, 0, 1]], dtype=torch.float64, device=t5.device)
+                sub = torch.einsum("ah,bw,oihw->oiab", mh, mw, t5[:, :, 0])                 # (Cout, Cin, 2, 2)
+                return sub.permute(2, 3, 1, 0).reshape(-1, sub.shape[0]).to(torch.float32).contiguous()
             if kind == "unshuffle":
                 co, c4 = t.shape[0], t.shape[1]
                 t4 = t.reshape(co, c4 // 4, 2, 2)             # (Cout, C, p1, p2)
@@ -226,6 +236,17 @@ class Plan:
         for ph in (0, 1):
             for pw in (0, 1):
                 wp = self.conv_weight(w, ("convT_sub", ph, pw))
+                self.conv(x, wp, bias, cout, (1, 2, 2), pad=(0, 1 - ph, 1 - pw), out=out[:, :, :, ph::2, pw::2])
+        return out
+
+    def upsample2_conv3(self, x, w, bias, cout):
+        """nn.Upsample(scale_factor=2, mode='nearest') + Conv2d(3x3, pad 1) (1D/model/unet.py:33-37) as four 2x2 convs of the
+        low-resolution input, one per output parity, with the taps that land on the same source pixel merged."""
+        B, c0, iD, iH, iW = x.shape
+        out = self.pool.get((B, cout, iD, 2 * iH, 2 * iW))
+        for ph in (0, 1):
+            for pw in (0, 1):
+                wp = self.conv_weight(w, ("up2_sub", ph, pw))
                 self.conv(x, wp, bias, cout, (1, 2, 2), pad=(0, 1 - ph, 1 - pw), out=out[:, :, :, ph::2, pw::2])
         return out
 

@@ -259,6 +259,9 @@ class _HipUNet(nn.Module):
         # LinearAttention blocks of width 64 / 128 as the fused 3-launch form (csrc/sdc_lablock.hip); False = the
         # unfused chain norm -> 1x1 -> attention core -> 1x1 -> norm (kept for wider layers and for A/B checks)
         self.fuse_linattn = os.environ.get("SDC_NO_LABLOCK", "0") != "1"
+        # nearest-x2 upsample + 3x3 conv as four sub-pixel 2x2 convs with merged taps (4/9 of the multiply-adds; the merged
+        # weights change the summation order by ~1e-7 relative); False = one conv with the upsampling folded into its gather
+        self.subpixel_upsample = os.environ.get("SDC_NO_SUBPIXEL", "0") != "1"
         self.forward_graph = True    # model(x, t) replays a captured hipGraph; False = launch the call list every time
         self._side = None
         self.dim = dim
@@ -309,7 +312,7 @@ class _HipUNet(nn.Module):
     def entry(self, shape, rows, lut=False):
         """Plan for an input of `shape` whose conditioning table has `rows` rows: one row per sample
         (lut=False, forward(x, time)) or one row per timestep read through a device-side t (lut=True, samplers)."""
-        key = (tuple(shape), rows, bool(lut), int(self.precision), bool(self.fuse_linattn))
+        key = (tuple(shape), rows, bool(lut), int(self.precision), bool(self.fuse_linattn), bool(self.subpixel_upsample))
         if key not in self._plans:
             dev = self.device()
             if dev.type != "cuda":
@@ -508,7 +511,9 @@ class Unet2D(_LucidUNet):
     def _up(self, b, p, x, last):
         if last:
             return b.conv(x, p)
-        return b.conv(x, f"{p}.1", up=(1, 2, 2))                                          # Upsample2d :33-37
+        if self.subpixel_upsample:                                                      # Upsample2d :33-37
+            return b.plan.upsample2_conv3(x, lambda p=p: self.P(f"{p}.1.weight"), b.V(f"{p}.1.bias"), self.P(f"{p}.1.weight").shape[0])
+        return b.conv(x, f"{p}.1", up=(1, 2, 2))
 
 
 class Unet1D(_LucidUNet):

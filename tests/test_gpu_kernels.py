@@ -505,3 +505,16 @@ def test_conv_transpose_subpixel(plan_cls, B, Cc, Co, sp):
     _run(plan)
     torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(old.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,Cc,Co,sp", [(2, 16, 32, (8, 16)), (1, 64, 48, (5, 7)), (3, 128, 64, (4, 32))])
+def test_upsample_conv_subpixel(plan_cls, B, Cc, Co, sp):
+    """nearest x2 + 3x3 conv as four merged-tap 2x2 convs == F.interpolate + F.conv2d."""
+    from safediffcon_amd.engine import as5
+    x = det_tensor((B, Cc, *sp), 151)
+    w, b = det_tensor((Co, Cc, 3, 3), 152, 0.2), det_tensor((Co,), 153, 0.1)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+    plan = plan_cls(DEV)
+    out = plan.upsample2_conv3(as5(x.to(DEV)), w.to(DEV), b.to(DEV), Co)
+    _run(plan)
+    torch.testing.assert_close(out.cpu().reshape(ref.shape).double(), ref, rtol=1e-5, atol=1e-5)
