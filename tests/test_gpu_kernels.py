@@ -518,3 +518,38 @@ def test_upsample_conv_subpixel(plan_cls, B, Cc, Co, sp):
     out = plan.upsample2_conv3(as5(x.to(DEV)), w.to(DEV), b.to(DEV), Co)
     _run(plan)
     torch.testing.assert_close(out.cpu().reshape(ref.shape).double(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=300, cin=64, cout=64, sp=(16, 128), k=1),                            # widest tile
+    dict(B=300, cin=128, cout=64, sp=(16, 128), k=1, cin1=64, residual=True),   # concat + residual
+    dict(B=64, cin=64, cout=384, sp=(16, 64), k=1),                             # 128x256 tiles
+    dict(B=40, cin=32, cout=192, sp=(8, 64), k=1),                              # 128x128 tiles, ragged Cout tile
+    dict(B=48, cin=32, cout=48, sp=(16, 128), k=1),                             # 64x256 tiles, ragged Cout
+    dict(B=260, cin=16, cout=160, sp=(16, 16), k=1),                            # 16-wide rows, 128x256 tiles
+    dict(B=300, cin=64, cout=64, sp=(16, 128), k=3, prec=0),                    # 3 taps, direct (precision 0)
+    dict(B=64, cin=32, cout=128, sp=(16, 64), k=3, prec=0, residual=True),
+    dict(B=2, cin=32, cout=96, sp=(8, 16, 16), k=3, prec=0, nd=3),              # 3x3x3 direct, small grid
+    dict(B=6, cin=32, cout=96, sp=(16, 32, 32), k=3, prec=0, nd=3),             # 3x3x3 direct, large grid
+])
+def test_conv_direct_big_grids(plan_cls, case):
+    """direct-form convs (1x1, and 3-tap in precision 0) on grids large enough for the biggest tiles, against fp64 torch"""
+    from safediffcon_amd.engine import as5
+    nd = case.get("nd", 2)
+    B, cin, cout, sp, k = case["B"], case["cin"], case["cout"], case["sp"], case["k"]
+    cin1, prec = case.get("cin1", 0), case.get("prec", 2)
+    x, x1 = det_tensor((B, cin, *sp), 161), (det_tensor((B, cin1, *sp), 162) if cin1 else None)
+    w, b = det_tensor((cout, cin + cin1, *([k] * nd)), 163, 0.2), det_tensor((cout,), 164, 0.1)
+    xin = x if x1 is None else torch.cat((x, x1), 1)
+    ref = (F.conv2d, F.conv3d)[nd - 2](xin.double(), w.double(), b.double(), padding=k // 2)
+    res = det_tensor(tuple(ref.shape), 165) if case.get("residual") else None
+    if res is not None:
+        ref = ref + res.double()
+    plan = plan_cls(DEV, precision=prec)
+    k3, p3 = (1,) * (3 - nd) + (k,) * nd, (0,) * (3 - nd) + (k // 2,) * nd
+    out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, k3,
+                    x1=None if x1 is None else as5(x1.to(DEV)), pad=p3, residual=None if res is None else as5(res.to(DEV)))
+    _run(plan)
+    got = out.cpu().reshape(ref.shape).double()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() / scale < 3e-6
