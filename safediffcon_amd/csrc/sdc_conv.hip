@@ -1300,10 +1300,10 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < 4 * TM * TP; ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (m == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4 * TM + 4 * TP, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                if (m < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM + 2 * TP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x220, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
