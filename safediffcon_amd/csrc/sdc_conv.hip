@@ -324,6 +324,129 @@ __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pointwise (1x1x1, stride 1) form over a dense spatial layout (positions of a sample contiguous, S % 4 == 0): both the
+// weight tile and the activation tile of a 16-channel chunk come in with 16-byte loads (4 consecutive output channels /
+// 4 consecutive positions per lane) in scalar-base form and go to LDS with ds_write_b128 -- 4 loads per thread per chunk
+// instead of 16.  These layers have K = Cin <= 768: few chunks per tile, so the load issue and its latency, not the
+// MFMA stream, decide.  Same k-ordered fp32 FMA chains as conv_kernel.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NT) void conv_pw_kernel(const ConvArgs a) {
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int NB4 = BK * BN / 4 / NT;      // float4 activation loads per thread per chunk
+    constexpr int NA4 = BK * BM / 4 / NT;      // float4 weight loads per thread per chunk
+    static_assert(NB4 >= 1 && NA4 >= 1, "tile too small");
+    typedef float nfloat4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) nfloat4* gfloat4_p;
+    typedef const __attribute__((address_space(1))) char* gchar_p;
+
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+    const SdcConvDesc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = xcd_tile(blockIdx.x, gridDim.x) * BN;
+    const int m0 = blockIdx.y * BM;
+    const int64_t S = (int64_t)d.oD * d.oH * d.oW;
+
+    // per-thread constant parts of the addresses (bytes): (row of the chunk) * channel stride + position offset
+    uint32_t bv0[NB4], bv1[NB4], av[NA4];
+    bool bok[NB4], aok[NA4];
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+        const int f = tid + i * NT;
+        const int row = f / (BN / 4), c4 = (f % (BN / 4)) * 4;
+        const int p = n0 + c4;
+        bok[i] = p < a.Ntot;
+        const int pp = bok[i] ? p : 0;
+        const int b = (int)(pp / S);
+        const int64_t sp = pp - (int64_t)b * S;
+        bv0[i] = (uint32_t)((b * d.x0s[0] + row * d.x0s[1] + sp) * 4);
+        bv1[i] = d.Cin1 > 0 ? (uint32_t)((b * d.x1s[0] + row * d.x1s[1] + sp) * 4) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < NA4; ++i) {
+        const int f = tid + i * NT;
+        const int row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
+        aok[i] = (m0 + c4) < d.Cout;
+        av[i] = (uint32_t)(((int64_t)row * d.Cout + (aok[i] ? m0 + c4 : 0)) * 4);
+    }
+    nfloat4 breg[NB4], areg[NA4];
+    auto load_chunk = [&](int kc) {
+        const int ci = kc * BK;
+        const gfloat_p wb = uniform_ptr(a.wp + (int64_t)ci * d.Cout);
+#pragma unroll
+        for (int i = 0; i < NA4; ++i) areg[i] = *(gfloat4_p)((gchar_p)wb + av[i]);
+        const bool first = ci < d.Cin0;
+        const gfloat_p xb = uniform_ptr(first ? a.x0 + (int64_t)ci * d.x0s[1] : a.x1 + (int64_t)(ci - d.Cin0) * d.x1s[1]);
+#pragma unroll
+        for (int i = 0; i < NB4; ++i) breg[i] = *(gfloat4_p)((gchar_p)xb + (first ? bv0[i] : bv1[i]));
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA4; ++i) {
+            const int f = tid + i * NT;
+            nfloat4 v = areg[i];
+            if (!aok[i]) v = nfloat4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<nfloat4*>(&As[buf][f / (BM / 4)][(f % (BM / 4)) * 4]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB4; ++i) {
+            const int f = tid + i * NT;
+            nfloat4 v = breg[i];
+            if (!bok[i]) v = nfloat4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<nfloat4*>(&Bs[buf][f / (BN / 4)][(f % (BN / 4)) * 4]) = v;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nchunks = a.Cin / BK;
+    load_chunk(0);
+    store_chunk(0);
+    if (nchunks > 1) load_chunk(1);
+    __syncthreads();
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int am = wm * (TM * 32) + l31, bn = wn * (TN * 32) + l31;
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int buf = kc & 1;
+        float af[BK / 2][TM], bf[BK / 2][TN];
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[ks][i] = As[buf][2 * ks + lh][am + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[ks][j] = Bs[buf][2 * ks + lh][bn + j * 32];
+        }
+        // chunk kc+1 is in registers (fetched during chunk kc-1): park it in the other LDS buffer first, then fetch kc+2
+        if (kc + 1 < nchunks) store_chunk(buf ^ 1);
+        if (kc + 2 < nchunks) load_chunk(kc + 2);
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+    conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_pw(const ConvArgs& a, hipStream_t s) {
+    dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
+    hipLaunchKernelGGL((conv_pw_kernel<BM, BN, WM, WN>), grid, dim3(NT), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row-halo variant (stride-1 along W, no virtual upsampling, Cin % 16 == 0): the B tile of one
 // (kd, kh, channel-chunk) stage is the input ROW SEGMENT with its kW-1 halo columns, staged once and read
 // at kW shifted LDS offsets -- the "LDS-staged activation tile".  One stage feeds kW x 8 k-steps, so the
@@ -1535,6 +1658,24 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
         return sdc::check_launch("sdc_conv[winograd]");
     }
     SDC_REQUIRE(!gn_part, SDC_EINVAL, "sdc_conv_gn: shape not covered by the fused statistics (sdc_conv_gnparts returned 0)");
+    // pointwise convs over a dense layout: 16-byte loads of weights and activations
+    static const int no_pw = getenv("SDC_NO_PW") ? atoi(getenv("SDC_NO_PW")) : 0;
+    {
+        const int64_t S = (int64_t)d.oD * d.oH * d.oW;
+        auto dense = [&](const int64_t* st) { return st[4] == 1 && st[3] == d.iW && st[2] == (int64_t)d.iH * d.iW && st[0] % 4 == 0 && st[1] % 4 == 0; };
+        if (!no_pw && d.precision != 1 && fast && d.kD * d.kH * d.kW == 1 && d.sD == 1 && d.sH == 1 && d.sW == 1 && d.uD == 1 && d.uH == 1 &&
+            d.uW == 1 && d.up_mode == 0 && d.pD == 0 && d.pH == 0 && d.pW == 0 && d.oD == d.iD && d.oH == d.iH && d.oW == d.iW &&
+            S % 4 == 0 && d.Cout % 4 == 0 && d.Cout > 32 && dense(d.x0s) && (d.Cin1 == 0 || dense(d.x1s)) &&
+            reinterpret_cast<uintptr_t>(x0) % 16 == 0 && (d.Cin1 == 0 || reinterpret_cast<uintptr_t>(x1) % 16 == 0) &&
+            reinterpret_cast<uintptr_t>(wp) % 16 == 0) {
+            const int64_t b64x128 = (int64_t)((a.Ntot + 127) / 128) * ((d.Cout + 63) / 64);
+            if (d.Cout > 64 && a.Ntot >= 128 * 256) launch_pw<128, 128, 2, 2>(a, s);
+            else if (d.Cout <= 64 && a.Ntot >= 256 * 1024) launch_pw<64, 256, 1, 4>(a, s);
+            else if (b64x128 >= 1024) launch_pw<64, 128, 2, 2>(a, s);
+            else launch_pw<64, 64, 2, 2>(a, s);
+            return sdc::check_launch("sdc_conv[pointwise]");
+        }
+    }
     // stem convs (kW = 7, tiny Cin): row-halo kernel with generalized k rows
     if (a.rowhalo && d.kW == 7 && d.sW == 1 && d.uD == 1 && d.uH == 1 && d.uW == 1 && d.up_mode == 0 && d.kD * d.kH <= 64 &&
         d.Cout % 4 == 0 && d.Cout > 32 && small && ((d.oW % 128 == 0) || (128 % d.oW == 0 && d.oW >= 16)) &&
