@@ -73,6 +73,11 @@ def conv_instance(d):
     else:
         tile = "32,128,1,4"
     bn = int(tile.split(",")[1])
+    dense = lambda st: st[4] == 1 and st[3] == d.iW and st[2] == d.iH * d.iW and st[0] % 4 == 0 and st[1] % 4 == 0
+    if (d.precision != 1 and fast and d.kD * d.kH * d.kW == 1 and d.sD == d.sH == d.sW == 1 and d.uD == d.uH == d.uW == 1
+            and d.up_mode == 0 and (d.oD * d.oH * d.oW) % 4 == 0 and d.Cout % 4 == 0 and d.Cout > 32
+            and dense(d.x0s) and (d.Cin1 == 0 or dense(d.x1s))):
+        return f"conv_pw_kernel<{tile}>"
     rowhalo = (fast and not tile.startswith("32") and d.sW == 1 and d.uD == d.uH == d.uW == 1 and d.up_mode == 0
                and d.kW == 3 and d.kD * d.kH <= 32 and d.Cout % 4 == 0
                and (d.oW % bn == 0 or (bn % d.oW == 0 and d.oW >= 16)))
