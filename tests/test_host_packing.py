@@ -1,0 +1,78 @@
+"""-m "not gpu": the host-side weight repacking (engine.Plan.conv_weight) checked against torch CPU convolutions --
+the sub-pixel forms of ConvTranspose3d (1,4,4)/(1,2,2) and Upsample(x2)+Conv2d 3x3, and the Winograd F(2,3) taps.
+Only the packing arithmetic runs here (no kernel is launched); the kernels that consume these layouts are covered by
+the -m gpu tests."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from safediffcon_amd.engine import Plan
+
+
+@pytest.fixture(scope="module")
+def plan():
+    try:
+        return Plan("cpu", precision=2)
+    except Exception as e:          # the library must load even without a GPU (tests/test_abi_and_host.py checks that)
+        pytest.skip(f"libsdc_hip.so not loadable here: {e}")
+
+
+def _unpack(wp, taps_h, taps_w, cin, cout):
+    """[K = (kh, kw, ci)][Cout] -> (Cout, Cin, kh, kw)"""
+    return wp.reshape(taps_h, taps_w, cin, cout).permute(3, 2, 0, 1).contiguous()
+
+
+def test_subpixel_transposed_conv_weights(plan):
+    g = torch.Generator().manual_seed(0)
+    cin, cout, H, W = 6, 5, 7, 9
+    x = torch.randn(2, cin, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(cin, cout, 1, 4, 4, generator=g, dtype=torch.float64)
+    ref = F.conv_transpose2d(x, w[:, :, 0], stride=2, padding=1)
+    out = torch.zeros_like(ref)
+    for ph in (0, 1):
+        for pw in (0, 1):
+            wp = plan.conv_weight(w.float(), ("convT_sub", ph, pw)).double()
+            k = _unpack(wp, 2, 2, cin, cout)
+            # pad (1 - ph) rows before / ph rows after (the kernel's one-sided margin), same along W
+            xp = F.pad(x, (1 - pw, pw, 1 - ph, ph))
+            out[:, :, ph::2, pw::2] = F.conv2d(xp, k)
+    torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-6)
+
+
+def test_subpixel_upsample_conv_weights(plan):
+    g = torch.Generator().manual_seed(1)
+    cin, cout, H, W = 5, 4, 6, 8
+    x = torch.randn(2, cin, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, padding=1)
+    out = torch.zeros_like(ref)
+    for ph in (0, 1):
+        for pw in (0, 1):
+            wp = plan.conv_weight(w.float(), ("up2_sub", ph, pw)).double()
+            k = _unpack(wp, 2, 2, cin, cout)
+            xp = F.pad(x, (1 - pw, pw, 1 - ph, ph))
+            out[:, :, ph::2, pw::2] = F.conv2d(xp, k)
+    torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-6)
+
+
+def test_winograd_taps(plan):
+    """[Wp | Wg]: y(2j), y(2j+1) from the four transformed taps == the direct 3-tap correlation, for every (kh, ci, co)."""
+    g = torch.Generator().manual_seed(2)
+    cin, cout = 3, 4
+    w = torch.randn(cout, cin, 1, 3, 3, generator=g)
+    buf = plan.conv_weight(w)
+    nw = 9 * cin * cout
+    assert buf.numel() == nw + nw // 3 * 4
+    wg = buf[nw:].double().reshape(1, 3, 4, cin, cout)            # (kd, kh, xi, ci, co)
+    d = torch.randn(4, generator=g, dtype=torch.float64)           # four inputs under one output pair
+    for kh in range(3):
+        for ci in range(cin):
+            for co in range(cout):
+                t = wg[0, kh, :, ci, co]
+                m = torch.stack([(d[0] - d[2]) * t[0], (d[1] + d[2]) * t[1], (d[2] - d[1]) * t[2], (d[1] - d[3]) * t[3]])
+                y0, y1 = m[0] + m[1] + m[2], m[1] - m[2] - m[3]
+                gk = w[co, ci, 0, kh].double()
+                torch.testing.assert_close(y0, (d[0:3] * gk).sum(), rtol=1e-5, atol=1e-6)
+                torch.testing.assert_close(y1, (d[1:4] * gk).sum(), rtol=1e-5, atol=1e-6)
+    # 1x1 weights carry no Winograd taps
+    assert plan.conv_weight(torch.randn(4, 3, 1, 1, 1)).numel() == 12
