@@ -54,7 +54,7 @@ def conv_instance(d):
                 return "conv_wg_kernel<128,256,4,2,16,512>"
             return "conv_wg_kernel<128,128,4,2,16,512>" if nblk(128, 128) >= 256 else "conv_wg_kernel<64,128,2,2,16,256>"
         if fits(512) and nblk(64, 512) >= 512:
-            return "conv_wg_kernel<64,512,2,4,16,512>"
+            return "conv_wg_kernel<64,512,1,8,16,512>"
         if fits(256) and nblk(64, 256) >= 256:
             return "conv_wg_kernel<64,256,2,4,16,512>"
         return "conv_wg_kernel<64,128,2,2,16,256>"
