@@ -1,130 +1,89 @@
 #!/usr/bin/env python3
 """bench.py -- sampled control trajectories / second of the SafeDiffCon DDPM hot path on MI355X.
 
-Default workload (BASELINE.json configs[1], "C2"): 1D Burgers, Unet2D dim=64 (1,2,4,8), state (B,3,16,128),
-B=256 per GPU, 1000-step DDPM, closed-form safety guidance on, conformal quantile on (Q comes from the HIP
-conformal-score kernel + all-gather + rank select on a synthetic calibration set and feeds the guidance).
-`--workload c3` (tokamak Unet1D dim=256, B=128) and `--workload c4` (2D smoke Unet3D 64x64x32, B=64) run the
-other BASELINE configs through the same harness (parity cases / profiling; not the driver's bench line).
+Default workload = the configuration BASELINE.json's north star quotes its targets on ("C4", configs[3]): 2D smoke,
+Unet3D_with_Conv3D dim=64 (1,2,4), state (B,32,7,64,64), B=64 per GPU, 1000-step DDPM, closed-form safety guidance on,
+conformal quantile on (Q comes from the HIP conformal-score kernel on a calibration shard + all-gather + rank select and
+feeds the guidance).  At N GPUs the batch axis is sharded, 64 trajectories per GPU (N=8 is BASELINE configs[4], "C5":
+B=512, calibration n=8x25, alpha=0.04).  `--workload c2` (1D Burgers Unet2D dim 64, B=256) and `--workload c3` (tokamak
+Unet1D dim 256, B=128) run the other single-GPU configs through the same harness; at N=1 a few steps of each are also
+reported under `extra`.
 
-A "step" is ONE denoising step of the whole batch: U-Net epsilon prediction + guidance reduction + fused
-posterior update + step counter, replayed from one captured hipGraph.  A trajectory costs exactly
-`timesteps`=1000 such steps, so  value = global_batch / (1000 * seconds_per_step).
-N>1: one process per GPU, the batch axis sharded (weak scaling: fixed trajectories per GPU), no data-path
-collective; the only exchange is the conformal all-gather before the loop.
+A "step" is ONE denoising step of the whole batch: U-Net epsilon prediction + guidance reduction + fused posterior
+update + step counter, replayed from one captured hipGraph.  A trajectory costs exactly `timesteps`=1000 such steps, so
+value = global_batch / (1000 * seconds_per_step).
 
-Also reported: `roofline` for the dominant kernel (the fp32-MFMA implicit-GEMM conv), timed live with HIP
-events on the launch stream, and `cpu_baseline` = the CPU oracle (oracle/, kind "port") on a bounded sample.
+`python bench.py --gpus N` with N > 1 launches itself: the parent touches no GPU and starts N fresh worker processes
+through `python -m torch.distributed.run` (one rank per GPU, RCCL); under an external torch.distributed.run (WORLD_SIZE
+set) it is a worker directly.  Rank 0 prints the one JSON line.
+
+`roofline`: the dominant kernel (the fp32-MFMA Winograd conv), HIP events on the launch stream.  `achieved` / `frac` are
+the MFMA FLOPs the kernel actually issues / second against the 157.3 TFLOP/s fp32 matrix peak (never above 1);
+`effective_tflops` is the direct-form (algorithmic) rate the same launch stands for.  `roofline.stages` carries the
+stage fractions the north star names: GroupNorm-apply GB/s against 8 TB/s, the Conv3d+GN+SiLU block as a whole, and the
+temporal-attention kernels' TFLOP/s against the fp32 matrix peak.  `cpu_baseline` = the CPU oracle (oracle/, kind
+"port") on a bounded sample of the same workload.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 T_DDPM = 1000
+DEFAULT_B = {"c2": 256, "c3": 128, "c4": 64}
+PMC_FILES = ("r2_pmc_traffic.json", "r1_pmc_traffic.json")
 
 
-def conv_instance(d):
-    """mirror of the tile selection in csrc/sdc_conv.hip::sdc_conv"""
-    ntot = d.B * d.oD * d.oH * d.oW
-    fast = (d.Cin0 % 16 == 0) and (d.Cin1 % 16 == 0)
-    ups = d.uH > 1 or d.uW > 1
-    if (d.precision == 2 and fast and d.kW == 3 and d.sW == 1 and d.uD == 1 and d.up_mode == 0
-            and (not ups or (d.uH <= 2 and d.uW <= 2 and d.kD == 1 and d.kH <= 3 and d.sH == 1 and d.Cin1 == 0))
-            and d.kD * d.kH <= 32 and d.Cout % 4 == 0 and d.Cout > 32 and d.oW % 2 == 0 and d.oW >= 16
-            and (d.oW % 128 == 0 or 128 % d.oW == 0)):
-        fits = lambda bn: d.oW % bn == 0 or bn % d.oW == 0
-        nblk = lambda bm, bn: ((ntot + bn - 1) // bn) * ((d.Cout + bm - 1) // bm)
-        if ups:
-            if d.Cout > 64 and nblk(128, 128) >= 256:
-                return "conv_wg_kernel<128,128,4,2,16,512,ups>"
-            if d.Cout <= 64 and fits(256) and nblk(64, 256) >= 256:
-                return "conv_wg_kernel<64,256,2,4,16,512,ups>"
-            return "conv_wg_kernel<64,128,2,2,16,256,ups>"
-        if d.Cout > 64:
-            if fits(256) and nblk(128, 256) >= 256:
-                return "conv_wg_kernel<128,256,4,2,16,512>"
-            return "conv_wg_kernel<128,128,4,2,16,512>" if nblk(128, 128) >= 256 else "conv_wg_kernel<64,128,2,2,16,256>"
-        if fits(512) and nblk(64, 512) >= 512:
-            return "conv_wg_kernel<64,512,1,8,16,512>"
-        if fits(256) and nblk(64, 256) >= 256:
-            return "conv_wg_kernel<64,256,2,4,16,512>"
-        return "conv_wg_kernel<64,128,2,2,16,256>"
-    if (d.kW == 7 and d.sW == 1 and d.uD == d.uH == d.uW == 1 and d.up_mode == 0 and d.kD * d.kH <= 64 and d.Cout % 4 == 0
-            and d.Cout > 32 and (d.oW % 128 == 0 or (128 % d.oW == 0 and d.oW >= 16))):
-        return "conv_rh_kernel<64,128,2,2,7,true>"
-    blocks = ((ntot + 127) // 128) * ((d.Cout + 63) // 64)
-    if d.Cout > 64 and ntot >= 128 * 256:
-        tile = "128,128,2,2"
-    elif 32 < d.Cout <= 64 and ntot >= 256 * 1024:
-        tile = "64,256,1,4"
-    elif d.Cout > 32 and blocks >= 1024:
-        tile = "64,128,2,2"
-    elif d.Cout > 32:
-        tile = "64,64,2,2"
-    else:
-        tile = "32,128,1,4"
-    bn = int(tile.split(",")[1])
-    dense = lambda st: st[4] == 1 and st[3] == d.iW and st[2] == d.iH * d.iW and st[0] % 4 == 0 and st[1] % 4 == 0
-    if (d.precision != 1 and fast and d.kD * d.kH * d.kW == 1 and d.sD == d.sH == d.sW == 1 and d.uD == d.uH == d.uW == 1
-            and d.up_mode == 0 and (d.oD * d.oH * d.oW) % 4 == 0 and d.Cout % 4 == 0 and d.Cout > 32
-            and dense(d.x0s) and (d.Cin1 == 0 or dense(d.x1s))):
-        return f"conv_pw_kernel<{tile}>"
-    rowhalo = (fast and not tile.startswith("32") and d.sW == 1 and d.uD == d.uH == d.uW == 1 and d.up_mode == 0
-               and d.kW == 3 and d.kD * d.kH <= 32 and d.Cout % 4 == 0
-               and (d.oW % bn == 0 or (bn % d.oW == 0 and d.oW >= 16)))
-    if rowhalo:
-        return f"conv_rh_kernel<{tile},3,false>"
-    return f"conv_kernel<{tile},{'true' if fast else 'false'}>"
+# --------------------------------------------------------------------------- launcher (N > 1 without a torchrun parent)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
-def conv_flops(d):
-    return 2.0 * d.B * d.oD * d.oH * d.oW * d.Cout * (d.Cin0 + d.Cin1) * d.kD * d.kH * d.kW
-
-
-def time_conv_calls(plan, lib, stream, reps=3):
-    """HIP-event timing of every sdc_conv call of the plan, grouped by kernel template instance."""
-    from safediffcon_amd._lib import check
-    e0, e1 = C.c_void_p(), C.c_void_p()
-    check(lib.sdc_event_create(C.byref(e0)))
-    check(lib.sdc_event_create(C.byref(e1)))
-    groups = {}
-    for fn, args in plan.calls:
-        if fn is not lib.sdc_conv and fn is not lib.sdc_conv_gn:      # (conv_gn = the same kernels + statistics epilogue)
-            continue
-        d = args[0]._obj
-        fn(*args, stream)                                    # warm
-        check(lib.sdc_event_record(e0, stream))
-        for _ in range(reps):
-            fn(*args, stream)
-        check(lib.sdc_event_record(e1, stream))
-        ms = C.c_float()
-        check(lib.sdc_event_elapsed_ms(e0, e1, C.byref(ms)))
-        g = groups.setdefault(conv_instance(d), dict(launches=0, ms=0.0, flops=0.0))
-        g["launches"] += 1
-        g["ms"] += ms.value / reps
-        g["flops"] += conv_flops(d)
-    lib.sdc_event_destroy(e0)
-    lib.sdc_event_destroy(e1)
-    return groups
+def launch_workers(n, argv):
+    """Parent of `bench.py --gpus N`: no GPU call here (a process that has initialised HIP must not spawn the ranks)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd, env=env)
 
 
 # --------------------------------------------------------------------------- workloads
-def workload(name, dim, B, dev, rank, world, precision=0):
-    """-> (description, sampler, prepare() -> _Loop, conformal_Q)"""
+def workload(name, dim, B, dev, rank, world, precision=2):
+    """-> dict(desc, gd, prep() -> _Loop, conformal=dict(Q, n_cal, alpha, ms), calib(...) -> calibration-mode _Loop)"""
+    import torch
     import safediffcon_amd as sdc
     from safediffcon_amd import conformal
     torch.manual_seed(0)                                   # weights: default nn-style init under seed 0
     g1 = torch.Generator().manual_seed(1 + rank)           # conditions: seed 1 (+rank: every shard differs)
-    n_cal = max(8, 1000 // world) if name != "c4" else max(8, 200 // world)
+    n_tot = 200 if name == "c4" else 1000                  # calibration set: 8x25 (2d/inference_2d.py) / 4x250 (1D) / 1x1000 (tokamak)
+    n_cal = max(8, n_tot // world)
+
+    def quantile(kind, pred, truth, gpar, alpha, **kw):
+        """score kernel on this rank's calibration shard -> all-gather (RCCL) -> normalise / sort / rank select"""
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s, w = conformal.scores_and_weights(kind, pred, truth, gpar, **{k: v for k, v in kw.items() if k != "smoke"})
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        Q = float(conformal.weighted_quantile(s, w, alpha, smoke=kw.get("smoke", False))[0].item())
+        t2 = time.perf_counter()
+        return dict(Q=Q, n_cal_per_rank=n_cal, n_cal=n_cal * world, alpha=alpha, score_kernel_ms=round((t1 - t0) * 1e3, 3),
+                    allgather_quantile_ms=round((t2 - t1) * 1e3, 3))
+
     if name == "c2":
         dim = dim or 64
         net = sdc.Unet2D(dim=dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1).to(dev)
@@ -133,14 +92,18 @@ def workload(name, dim, B, dev, rank, world, precision=0):
                                           train_on_padded_locations=False).to(dev)
         u0 = (0.1 * torch.randn(B, 128, generator=g1)).clamp(-0.1, 0.3).to(dev)
         uT = (0.1 * torch.randn(B, 128, generator=g1)).clamp(-0.1, 0.3).to(dev)
-        # conformal quantile: synthetic calibration shard -> HIP score kernel -> all-gather -> rank select
         pred = (0.1 * torch.randn(n_cal, 3, 16, 128, generator=g1)).to(dev)
         truth = (0.1 * torch.randn(n_cal, 3, 16, 128, generator=g1)).to(dev)
-        s, w = conformal.scores_and_weights("burgers", pred, truth, [500.0, 0.8 ** 2, 0.0, 10.0])
-        Q = float(conformal.weighted_quantile(s, w, 0.98)[0].item())
-        guid = sdc.BurgersGuidance(Q, 500.0, 0.8, use_max_safety=True)     # 1D/configs/inference_config.py:122
+        cf = quantile("burgers", pred, truth, [500.0, 0.8 ** 2, 0.0, 10.0], 0.98)
+        guid = sdc.BurgersGuidance(cf["Q"], 500.0, 0.8, use_max_safety=True)     # 1D/configs/inference_config.py:122
         prep = lambda: gd.sample(batch_size=B, clip_denoised=True, u_init=u0, u_final=uT, guidance_u0=True,   # noqa: E731
                                  nablaJ=guid, J_scheduler=None, enable_grad=False, _prepare=True)
+
+        def calib(Bc):      # 1D/inference/conformal.py:53-65: unguided, w_groundtruth imposed, two noise draws per step
+            wgt = (0.05 * torch.randn(Bc, 16, 128, generator=g1)).to(dev)
+            return gd.sample(batch_size=Bc, clip_denoised=True, guidance_u0=False, u_init=u0[:Bc], u_final=uT[:Bc],
+                             w_groundtruth=wgt, nablaJ=None, enable_grad=False, _prepare=True)
+        cal_B, cal_batches = 250, 4
         desc = f"C2: 1D Burgers Unet2D dim={dim} (1,2,4,8) state (B,3,16,128), guided 1000-step DDPM, conformal quantile on"
     elif name == "c3":
         dim = dim or 256
@@ -153,12 +116,16 @@ def workload(name, dim, B, dev, rank, world, precision=0):
         pred = (0.5 + 0.3 * torch.randn(n_cal, 12, 128, generator=g1)).to(dev)
         truth = (0.5 + 0.3 * torch.randn(n_cal, 12, 128, generator=g1)).to(dev)
         tgt_cal = (1.0 + 0.3 * torch.randn(n_cal, 3, 122, generator=g1)).to(dev)
-        s, w = conformal.scores_and_weights("tokamak", pred, truth, [0.0, 1.0, 0.01, 4.98, 0.0], target=tgt_cal)
-        Q = float(conformal.weighted_quantile(s, w, 0.9)[0].item())
+        cf = quantile("tokamak", pred, truth, [0.0, 1.0, 0.01, 4.98, 0.0], 0.9, target=tgt_cal)
         # tokamak/scripts/finetune.sh:13, configs/inference_config.py:25,107-111 (the pipeline always uses Q = 0.0)
         guid = sdc.TokamakGuidance(target, 122, w_obj=0.0, w_safe=1.0, guidance_scaler=0.01, Q=0.0, safety_threshold=4.98)
         prep = lambda: gd.sample(batch_size=B, clip_denoised=True, u_init=u0, u_final=uT, guidance_u0=True,   # noqa: E731
                                  nablaJ=guid, J_scheduler=None, enable_grad=False, _prepare=True)
+
+        def calib(Bc):      # tokamak/inference/conformal.py:62-74 (DDPM + w_groundtruth hits the reference's IndexError: unguided only)
+            return gd.sample(batch_size=Bc, clip_denoised=True, guidance_u0=False, u_init=u0[:Bc], u_final=uT[:Bc],
+                             nablaJ=None, enable_grad=False, _prepare=True)
+        cal_B, cal_batches = 125, 8
         desc = f"C3: tokamak Unet1D dim={dim} (1,2,4,8) state (B,12,128), guided 1000-step DDPM"
     elif name == "c4":
         dim = dim or 64
@@ -168,20 +135,38 @@ def workload(name, dim, B, dev, rank, world, precision=0):
         init = (0.5 * torch.rand(B, 64, 64, generator=g1)).to(dev)
         pred = (0.3 * torch.randn(n_cal, 32, 7, 64, 64, generator=g1)).to(dev)
         truth = (0.3 * torch.randn(n_cal, 32, 7, 64, 64, generator=g1)).to(dev)
-        s, w = conformal.scores_and_weights("smoke", pred, truth, [0.9, 0.1, 0.0, 100.0])
-        Q = float(conformal.weighted_quantile(s, w, 0.04, smoke=True)[0].item())
+        cf = quantile("smoke", pred, truth, [0.9, 0.1, 0.0, 100.0], 0.04, smoke=True)
         del pred, truth
-        guid = sdc.SmokeGuidance(Q, w_safe=0.9, safe_bound=0.1)            # 2d/scripts/posttrain.sh:20-21
+        guid = sdc.SmokeGuidance(cf["Q"], w_safe=0.9, safe_bound=0.1)            # 2d/scripts/posttrain.sh:20-21
         prep = lambda: gd.sample(batch_size=B, design_fn=guid, enable_grad=False, init=init, _prepare=True)  # noqa: E731
-        desc = f"C4: 2D smoke Unet3D_with_Conv3D dim={dim} (1,2,4) state (B,32,7,64,64), guided 1000-step DDPM"
+
+        def calib(Bc):      # 2d/inference_2d.py:129-134: unguided, frame-0 density and the two control channels imposed
+            control = (0.3 * torch.randn(Bc, 32, 2, 64, 64, generator=g1)).to(dev)
+            return gd.sample(batch_size=Bc, design_fn=None, enable_grad=False, init=init[:Bc], control=control, _prepare=True)
+        cal_B, cal_batches = 25, 8
+        tag = "C5" if world == 8 else "C4"
+        desc = (f"{tag}: 2D smoke Unet3D_with_Conv3D dim={dim} (1,2,4) state (B,32,7,64,64), B={B} per GPU, guided 1000-step DDPM, "
+                f"conformal quantile on")
     else:
         raise SystemExit(f"unknown workload {name}")
     net.precision = precision
-    return desc, gd, prep, Q
+    return dict(desc=desc, gd=gd, prep=prep, conformal=cf, calib=calib, cal_B=cal_B, cal_batches=cal_batches)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(name, batch, steps, dim):
     """the CPU oracle's guided p_sample step (U-Net + autograd guidance + posterior update), torch fp32 on the host cores"""
+    import torch
     from oracle import nets as onets, samplers as osam, schedules as osched
     from oracle.detweights import det_params, det_tensor
     import safediffcon_amd as sdc
@@ -214,51 +199,175 @@ def cpu_baseline(name, batch, steps, dim):
             ts.append(time.perf_counter() - t0)
     s_per_step = sum(ts[1:]) / steps
     return dict(value=batch / (T_DDPM * s_per_step), unit="trajectories/s", cores=torch.get_num_threads(), kind="port",
+                cpu_model=cpu_model(), logical_cpus_visible=os.cpu_count(),
                 sample=f"{steps} guided p_sample steps (after 1 warm-up) at B={batch} of the same workload, "
                        f"{s_per_step * 1e3:.0f} ms/step, extrapolated x{T_DDPM} steps per trajectory")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
-    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: 256 / 128 / 64 for c2 / c3 / c4)")
-    ap.add_argument("--dim", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-direct", "split-bf16"],
-                    help="conv arithmetic: fp32 MFMA with Winograd F(2,3) along W on the 3-tap convs (default), fp32 direct "
-                         "form everywhere, or the opt-in 3-pass split-bf16 MFMA")
-    ap.add_argument("--no-extra", action="store_true", help="skip the additional split-bf16 measurement at N=1")
-    ap.add_argument("--full-sample", action="store_true",
-                    help="also time ONE complete 1000-step sample() call (validates value = B / (1000 * step time))")
-    ap.add_argument("--cpu-batch", type=int, default=0)
-    ap.add_argument("--cpu-steps", type=int, default=3)
-    a = ap.parse_args()
+def cpu_c1_full():
+    """BASELINE configs[0] ("C1") in full on the host cores: Unet2D dim 64, B=16, unguided 1000-step p_sample_loop through the
+    CPU oracle ("C1 timed in full").  Minutes of CPU time: run with --cpu-c1-full, not part of the default line."""
+    import torch
+    from oracle import nets as onets, samplers as osam, schedules as osched
+    from oracle.detweights import det_params, det_tensor
+    import safediffcon_amd as sdc
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
+    net = sdc.Unet2D(dim=64, channels=3, resnet_block_groups=1)
+    P = det_params([(k, tuple(v.shape)) for k, v in net.state_dict().items()], 0)
+    tabs = osched.make_tables("cosine", T_DDPM)
+    B = 16
+    u0, uT = det_tensor((B, 128), 2, 0.1), det_tensor((B, 128), 3, 0.1)
+    g = torch.Generator().manual_seed(2)
+    noise = lambda i: torch.randn(B, 3, 16, 128, generator=g)      # noqa: E731
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = osam.sample_burgers(lambda a, b: onets.unet_burgers(P, a, b, dim=64), tabs, B, noise, u_init=u0, u_final=uT,
+                                  nablaJ=None, enable_grad=False)
+    el = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    return dict(workload="C1: 1D Burgers Unet2D dim=64, B=16, unguided 1000-step DDPM, CPU oracle (port) in full", seconds=round(el, 2),
+                value=round(B / el, 5), unit="trajectories/s", ms_per_step=round(el * 1e3 / T_DDPM, 2), cores=torch.get_num_threads(),
+                cpu_model=cpu_model(), logical_cpus_visible=os.cpu_count())
 
+
+def pmc_traffic(kernel, wl):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; collected
+    separately with rocprofv3 --pmc by tools/pmc_traffic.py -- bench.py cannot run the profiler on itself)"""
+    for fn in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as fh:
+                ent = json.load(fh).get(kernel, {})
+        except (OSError, ValueError):
+            continue
+        if ent.get("workload", "c2") == wl and ent.get("traffic_bytes"):
+            return ent["traffic_bytes"], ent.get("algorithmic_bytes"), fn
+    return None, None, None
+
+
+def build_roofline(S, lib, stream, step_ms, wl):
+    """stage / kernel timings of the plan with HIP events on the launch stream -> the `roofline` object"""
+    import stages as stg
+    stages, kernels = stg.time_plan(S.ent["plan"], lib, stream)
+    convs = {k: v for k, v in kernels.items() if k.startswith("conv")}
+    name, g = max(convs.items(), key=lambda kv: kv[1]["ms"])
+    sec = g["ms"] * 1e-3
+    issued, eff = g["issued"] / sec / 1e12, g["flops"] / sec / 1e12
+    traffic, alg_bytes, src = pmc_traffic(name, wl)
+    roof = dict(bound="mfma", kernel=name, achieved=round(issued, 2), peak=stg.PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                frac=round(issued / stg.PEAK_F32_MFMA_TFLOPS, 4), frac_issued=round(issued / stg.PEAK_F32_MFMA_TFLOPS, 4),
+                effective_tflops=round(eff, 2), mfma_share_of_direct_form=round(g["issued"] / g["flops"], 4),
+                flops="achieved = MFMA FLOPs the kernel executes per second (Winograd issues 2/3 [F(2,3) along W] or 4/9 "
+                      "[F(2x2,3x3)] of the direct-form multiply-adds); effective_tflops = direct-form (algorithmic) FLOPs per second",
+                traffic=traffic, traffic_source=src, algorithmic_bytes_per_launch=alg_bytes,
+                sustained_peak_measured=123.0,   # bare v_mfma_f32_32x32x2 loop on an MI355X of this pool (tools/mfma_peak.hip)
+                launches_per_step=g["launches"], avg_launch_ms=round(g["ms"] / g["launches"], 4),
+                share_of_step=round(g["ms"] / step_ms, 3))
+
+    def mfma_stage(v):
+        s = v["ms"] * 1e-3
+        return dict(bound="mfma", achieved=round(v["issued"] / s / 1e12, 2), peak=stg.PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(v["issued"] / s / 1e12 / stg.PEAK_F32_MFMA_TFLOPS, 4), launches=v["launches"], ms_per_step=round(v["ms"], 3))
+
+    def hbm_stage(v, ms=None, by=None):
+        ms = v["ms"] if ms is None else ms
+        by = v["bytes"] if by is None else by
+        gbs = by / (ms * 1e-3) / 1e9
+        return dict(bound="hbm", achieved=round(gbs, 1), peak=stg.PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / stg.PEAK_HBM_GBS, 4),
+                    launches=v["launches"], ms_per_step=round(ms, 3))
+    st = {}
+    for k, v in stages.items():
+        if k.startswith("groupnorm apply"):
+            st["gn_apply_silu"] = hbm_stage(v)
+        elif k.startswith("fused temporal-attention block"):
+            st["ta_block_w" + k.split("width ")[1].split(" ")[0]] = mfma_stage(v)
+        elif k == "temporal attention core":
+            st["tattn_core"] = mfma_stage(v)
+        elif k.startswith("fused LinearAttention"):
+            st["la_block"] = mfma_stage(v)
+    # every temporal-attention launch together (fused blocks + unfused cores): the north star's "MFMA utilisation on temporal attention"
+    ta = [v for k, v in stages.items() if k.startswith("fused temporal-attention block") or k == "temporal attention core"]
+    if ta:
+        tot = dict(ms=sum(v["ms"] for v in ta), issued=sum(v["issued"] for v in ta), launches=sum(v["launches"] for v in ta))
+        st["temporal_attention_all"] = mfma_stage(tot)
+    # the Conv+GN+SiLU block as a whole: two-pass algorithmic bytes 4 (N_in + 3 N_out) + 4 nW over conv + finalize + apply time.
+    # It is MFMA-bound by >= 40x in fp32 (SURVEY 8d caveat), so its HBM fraction is small by construction; the HBM-bound piece is
+    # gn_apply_silu above.
+    blk = [v for k, v in stages.items() if "GroupNorm statistics in the epilogue" in k]
+    gna = [v for k, v in stages.items() if k.startswith("groupnorm apply") or k.startswith("groupnorm stats")]
+    if blk and gna:
+        ms = sum(v["ms"] for v in blk) + sum(v["ms"] for v in gna)
+        by = sum(v["bytes"] for v in blk) + sum(v["bytes"] for v in gna if v["bytes"])
+        e = hbm_stage(dict(launches=sum(v["launches"] for v in blk)), ms, by)
+        e["mfma_issued_tflops"] = round(sum(v["issued"] for v in blk) / (ms * 1e-3) / 1e12, 2)
+        e["note"] = "conv (GN statistics in its epilogue) + finalize + apply/SiLU; fp32-MFMA bound, see roofline.frac"
+        st["conv_gn_silu_block"] = e
+    roof["stages"] = st
+    roof["all_kernels"] = {k: dict(launches=v["launches"], ms_per_step=round(v["ms"], 3),
+                                   **({"issued_tflops": round(v["issued"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                       "effective_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["issued"] else
+                                      {"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}))
+                           for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0}
+    roof["stage_sum_ms"] = round(sum(v["ms"] for v in stages.values()), 3)
+    return roof
+
+
+def selftest_worker(a):
+    """`--selftest-launcher`: the launcher / rendezvous / relay path without a GPU (CPU tests, gloo): every rank contributes
+    a shard of synthetic conformal (score, weight) pairs, the all-gather + quantile epilogue runs, the max-over-ranks timer is
+    all-reduced and rank 0 prints a line of the same shape as the real one."""
+    import torch
+    import torch.distributed as dist
+    from safediffcon_amd import conformal
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    backend = os.environ.get("SDC_DIST_BACKEND", "gloo")
+    if world > 1:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7)
+    n = 200
+    scores, weights = torch.rand(n, generator=g), torch.rand(n, generator=g) * 3
+    per = n // world
+    t0 = time.perf_counter()
+    Q, _ = conformal.weighted_quantile(scores[rank * per:(rank + 1) * per], weights[rank * per:(rank + 1) * per], 0.04, smoke=True)
+    el = torch.tensor([time.perf_counter() - t0])
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "selftest (launcher + conformal all-gather, no GPU)", "n_gpus": world, "backend": backend,
+                          "dist_world_size": dist.get_world_size() if world > 1 else 1, "conformal_Q": round(float(Q), 6),
+                          "allgather_quantile_ms": round(el.item() * 1e3, 3)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------- worker
+def worker(a):
+    import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" IS RCCL on ROCm.  SDC_DIST_BACKEND=gloo + SDC_FORCE_DEVICE=0 exist only to rehearse the multi-process
         # path on a one-GPU box (RCCL refuses two ranks on one device).
-        dist.init_process_group(os.environ.get("SDC_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+        backend = os.environ.get("SDC_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     local = int(os.environ.get("SDC_FORCE_DEVICE", local))
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
     from safediffcon_amd import _lib
     lib = _lib.get_lib()
-    B = a.batch or {"c2": 256, "c3": 128, "c4": 64}[a.workload]
+    wl = "c4" if a.workload == "c5" else a.workload
+    B = a.batch or DEFAULT_B[wl]
     prec = {"fp32": 2, "fp32-direct": 0, "split-bf16": 1}[a.precision]
-    desc, gd, prep, Q = workload(a.workload, a.dim, B, dev, rank, world, prec)
-
     side = torch.cuda.Stream(device=dev)
-    torch.manual_seed(2 + rank)                            # noise: seed 2
 
     def timed(S, warmup, steps):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks"""
@@ -284,63 +393,73 @@ def main():
             el = tt.item()
         return el
 
-    extra = None
+    extra = {}
     with torch.cuda.stream(side), torch.no_grad():
-        S = prep()
+        W = workload(wl, a.dim, B, dev, rank, world, prec)
+        torch.manual_seed(2 + rank)                            # noise: seed 2 (+rank)
+        S = W["prep"]()
         S.init()
         dt = timed(S, a.warmup, a.steps)
         finite = bool(torch.isfinite(S.x).all().item())
-
-        roof = None
-        if rank == 0:
-            groups = time_conv_calls(S.ent["plan"], lib, side.cuda_stream)
-            name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
-            avg_ms = g["ms"] / g["launches"]
-            ach = g["flops"] / g["launches"] / (avg_ms * 1e-3) / 1e12
-            # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE), collected separately with
-            # rocprofv3 --pmc and committed under profiles/ (bench.py cannot run the profiler on itself)
-            traffic = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
-                    ent = json.load(fh).get(name, {})
-                    if ent.get("workload", "c2") == a.workload:      # counters were collected on this workload's shape only
-                        traffic = ent.get("traffic_bytes")
-            except OSError:
-                pass
-            roof = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
-                        sustained_peak_measured=123.0,   # bare v_mfma_f32_32x32x2 loop on this device (tools/mfma_peak.hip)
-                        flops="algorithmic (direct-form) conv FLOPs per launch; a conv_wg_kernel (Winograd F(2,3) along W) "
-                              "issues 2/3 of them as MFMA work" if "conv_wg" in name else "algorithmic conv FLOPs per launch",
-                        launches_per_step=g["launches"],
-                        avg_launch_ms=round(avg_ms, 4), share_of_step=round(g["ms"] / (dt / a.steps * 1e3), 3),
-                        all_conv_instances={k: dict(launches=v["launches"], ms_per_step=round(v["ms"], 3),
-                                                    tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2))
-                                            for k, v in groups.items()})
+        step_ms = dt / a.steps * 1e3
+        roof = build_roofline(S, lib, side.cuda_stream, step_ms, wl) if rank == 0 else None
         S.close()
-        if world == 1 and prec == 2 and not a.no_extra:
-            # the other two conv modes on the same workload and harness, reported beside the headline
-            def other(mode):
-                gd.model.precision = mode
-                S2 = prep()
+
+        if world == 1 and not a.no_extra:
+            # calibration pass: the unguided calibration-mode sampler at the reference's calibration batch size, a
+            # bounded number of steps (a full pass is cal_batches x 1000 steps), then score -> all-gather -> quantile on its output
+            from safediffcon_amd import conformal
+            Bc = W["cal_B"]
+            Sc = W["calib"](Bc)
+            Sc.init()
+            dtc = timed(Sc, 2, a.cal_steps)
+            pred = Sc.x.clone()
+            Sc.close()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            kind = {"c2": "burgers", "c3": "tokamak", "c4": "smoke"}[wl]
+            gpar = {"c2": [500.0, 0.64, 0.0, 10.0], "c3": [0.0, 1.0, 0.01, 4.98, 0.0], "c4": [0.9, 0.1, 0.0, 100.0]}[wl]
+            kw = dict(target=torch.ones(Bc, 3, 122, device=dev)) if wl == "c3" else {}
+            s_, w_ = conformal.scores_and_weights(kind, pred, pred.flip(0), gpar, **kw)
+            Qc = float(conformal.weighted_quantile(s_, w_, W["conformal"]["alpha"], smoke=(wl == "c4"))[0].item())
+            tq = time.perf_counter() - t0
+            msc = dtc / a.cal_steps * 1e3
+            extra["calibration"] = {
+                "what": f"calibration-mode sampler (unguided; conditions + ground-truth channels imposed"
+                        f"{'; two noise draws per step' if wl == 'c2' else ''}) at the reference's calibration batch {Bc}, "
+                        f"{a.cal_steps} timed steps; then score kernel -> all-gather -> normalise/sort/rank on its output",
+                "batch": Bc, "batches_per_pass": W["cal_batches"], "ms_per_step": round(msc, 3),
+                "projected_seconds_per_full_pass": round(W["cal_batches"] * T_DDPM * msc / 1e3, 1),
+                "score_allgather_quantile_ms": round(tq * 1e3, 3), "Q_on_partial_trajectories": round(Qc, 6)}
+            del pred
+            # the other single-GPU BASELINE configs, a few steps each through the same harness
+            for other in [w for w in ("c2", "c3", "c4") if w != wl and w in a.extra_workloads.split(",")]:
+                W2 = workload(other, 0, DEFAULT_B[other], dev, rank, world, prec)
+                S2 = W2["prep"]()
                 S2.init()
-                dt_ = timed(S2, a.warmup, a.steps)
-                ok_ = bool(torch.isfinite(S2.x).all().item())
+                dt2 = timed(S2, 3, a.extra_steps)
+                ok2 = bool(torch.isfinite(S2.x).all().item())
                 S2.close()
-                gd.model.precision = 2
-                return dt_, ok_
-            dt0, ok0 = other(0)
-            dt2, ok2 = other(1)
-            extra = {"fp32_direct": {"value": round(B / (T_DDPM * dt0 / a.steps), 4), "unit": "trajectories/s",
-                                     "ms_per_step": round(dt0 / a.steps * 1e3, 4), "finite": ok0,
-                                     "note": "precision=0: every conv in the direct implicit-GEMM form (k-ordered fp32 FMA chains)"},
-                     "split_bf16": {"value": round(B / (T_DDPM * dt2 / a.steps), 4), "unit": "trajectories/s",
-                                    "ms_per_step": round(dt2 / a.steps * 1e3, 4), "finite": ok2,
-                                    "note": "opt-in precision=1: convs as 3-pass split-bf16 MFMA (~16 mantissa bits); eps-MSE vs the "
-                                            "fp32 oracle 6.7e-10 (C2) / 2.3e-10 (C4) at full width (tests/test_gpu_fullsize.py), "
-                                            "gate 1e-5; NOT bit-compatible with fp32, so `value` above stays the fp32 number"}}
+                extra[other] = {"workload": W2["desc"], "batch": DEFAULT_B[other], "steps": a.extra_steps,
+                                "ms_per_step": round(dt2 / a.extra_steps * 1e3, 4),
+                                "value": round(DEFAULT_B[other] / (T_DDPM * dt2 / a.extra_steps), 4), "unit": "trajectories/s", "finite": ok2}
+                del W2, S2
+            if a.other_precisions:
+                def other_prec(mode):
+                    W["gd"].model.precision = mode
+                    S2 = W["prep"]()
+                    S2.init()
+                    dt_ = timed(S2, a.warmup, a.steps)
+                    ok_ = bool(torch.isfinite(S2.x).all().item())
+                    S2.close()
+                    W["gd"].model.precision = prec
+                    return {"value": round(B / (T_DDPM * dt_ / a.steps), 4), "unit": "trajectories/s",
+                            "ms_per_step": round(dt_ / a.steps * 1e3, 4), "finite": ok_}
+                extra["fp32_direct"] = other_prec(0)
+                extra["split_bf16"] = other_prec(1)
+                extra["split_bf16"]["note"] = "opt-in precision=1 (~16 mantissa bits): NOT the parity mode, never `value`"
         if a.full_sample and rank == 0:
-            S3 = prep()
+            S3 = W["prep"]()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             S3.init()
@@ -350,34 +469,96 @@ def main():
             torch.cuda.synchronize()
             full_s = time.perf_counter() - t0
             S3.close()
-            extra = dict(extra or {})
             extra["full_sample"] = {"seconds_for_one_1000_step_sample": round(full_s, 3),
                                     "trajectories_per_s": round(B / full_s, 4),
                                     "note": "includes x_T draw, conditioning, graph capture and the final eager step"}
-    assert finite, "non-finite state after the timed steps"
+        if a.full_calibration and rank == 0:
+            # one complete calibration pass end to end: cal_batches x (1000-step calibration-mode sample) -> scores -> quantile
+            from safediffcon_amd import conformal
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ss, ws = [], []
+            for _ in range(W["cal_batches"]):
+                Sc = W["calib"](W["cal_B"])
+                Sc.init()
+                for _ in range(Sc.n_main):
+                    Sc.step()
+                Sc.final()
+                kind = {"c2": "burgers", "c3": "tokamak", "c4": "smoke"}[wl]
+                gpar = {"c2": [500.0, 0.64, 0.0, 10.0], "c3": [0.0, 1.0, 0.01, 4.98, 0.0], "c4": [0.9, 0.1, 0.0, 100.0]}[wl]
+                kw = dict(target=torch.ones(W["cal_B"], 3, 122, device=dev)) if wl == "c3" else {}
+                s_, w_ = conformal.scores_and_weights(kind, Sc.x, Sc.x.flip(0), gpar, **kw)
+                ss.append(s_), ws.append(w_)
+                Sc.close()
+            Qf = float(conformal.weighted_quantile(torch.cat(ss), torch.cat(ws), W["conformal"]["alpha"], smoke=(wl == "c4"))[0].item())
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            extra["full_calibration"] = {"n": W["cal_B"] * W["cal_batches"], "seconds": round(el, 2), "Q": round(Qf, 6),
+                                         "note": "complete calibration pass: sampling (1000 steps per batch) + score + quantile"}
+    if not finite:
+        raise SystemExit("non-finite state after the timed steps")
 
-    ms_per_step = dt / a.steps * 1e3
     value = world * B / (T_DDPM * dt / a.steps)
     if rank == 0:
+        cf = W["conformal"]
         out = {
             "metric": "sampled control trajectories/sec (1000-step DDPM)", "value": round(value, 4), "unit": "trajectories/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if prec != 1 else "f32 (split-bf16 conv operands, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": desc, "batch_per_gpu": B, "global_batch": world * B, "ddpm_timesteps": T_DDPM,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(step_ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if prec != 1 else "f32 (split-bf16 conv operands, fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": W["desc"], "batch_per_gpu": B, "global_batch": world * B, "ddpm_timesteps": T_DDPM,
                        "step": "one denoising step of the whole batch (U-Net + guidance + posterior update), hipGraph replay",
-                       "parallelism": f"batch-sharded x{world}, no data-path collective", "conformal_Q": round(Q, 6)},
+                       "parallelism": f"batch-sharded x{world}, no data-path collective", "conv_precision": a.precision,
+                       "conformal_Q": round(cf["Q"], 6)},
+            "conformal": dict(cf, Q=round(cf["Q"], 6), backend=(backend or "none (single process)"),
+                              rccl_ranks=(dist.get_world_size() if world > 1 and backend == "nccl" else (1 if world == 1 else 0)),
+                              dist_world_size=world),
             "roofline": roof,
         }
-        out["config"]["conv_precision"] = a.precision
         if extra:
             out["extra"] = extra
         if not a.no_cpu_baseline and world == 1:          # reported on rank 0 at N=1 only
-            cb = a.cpu_batch or {"c2": 32, "c3": 32, "c4": 1}[a.workload]
-            out["cpu_baseline"] = cpu_baseline(a.workload, cb, a.cpu_steps if a.workload != "c4" else 1, a.dim)
+            cb = a.cpu_batch or {"c2": 32, "c3": 32, "c4": 1}[wl]
+            out["cpu_baseline"] = cpu_baseline(wl, cb, a.cpu_steps or (3 if wl != "c4" else 2), a.dim)
+        if a.cpu_c1_full:
+            out.setdefault("extra", {})["cpu_c1_full"] = cpu_c1_full()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c4", choices=["c2", "c3", "c4", "c5"],
+                    help="c4 (default) = the north-star configuration, 2D smoke B=64 per GPU; c5 = the same, named for N=8")
+    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: 256 / 128 / 64 for c2 / c3 / c4)")
+    ap.add_argument("--dim", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-direct", "split-bf16"],
+                    help="conv arithmetic: fp32 MFMA with Winograd on the 3-tap convs (default), fp32 direct form everywhere, or "
+                         "the opt-in 3-pass split-bf16 MFMA")
+    ap.add_argument("--no-extra", action="store_true", help="skip the calibration sample and the other workloads at N=1")
+    ap.add_argument("--extra-workloads", default="c2,c3", help="other configs reported under `extra` at N=1")
+    ap.add_argument("--extra-steps", type=int, default=20)
+    ap.add_argument("--cal-steps", type=int, default=5)
+    ap.add_argument("--other-precisions", action="store_true", help="also time precision 0 / 1 on the headline workload")
+    ap.add_argument("--full-sample", action="store_true",
+                    help="also time ONE complete 1000-step sample() call (validates value = B / (1000 * step time))")
+    ap.add_argument("--full-calibration", action="store_true", help="also run one complete calibration pass (minutes)")
+    ap.add_argument("--cpu-c1-full", action="store_true", help="also run BASELINE configs[0] (C1) in full on the host cores (minutes)")
+    ap.add_argument("--selftest-launcher", action="store_true", help="CPU-only check of the launcher path (tests)")
+    ap.add_argument("--cpu-batch", type=int, default=0)
+    ap.add_argument("--cpu-steps", type=int, default=0)
+    a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_workers(a.gpus, sys.argv[1:]))
+    if a.selftest_launcher:
+        return selftest_worker(a)
+    worker(a)
 
 
 if __name__ == "__main__":

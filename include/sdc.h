@@ -74,12 +74,24 @@ typedef struct SdcConvDesc {
     int32_t pD, pH, pW;          /* padding, in the (virtually upsampled) input space */
     int32_t uD, uH, uW;          /* virtual input upsample factor, 1 or 2 */
     int32_t up_mode;             /* 0 nearest, 1 zero-insert */
-    int32_t precision;           /* 0 = exact fp32 MFMA (parity mode); 1 = 3-pass split-bf16 MFMA */
+    int32_t precision;           /* conv algorithm and layout of the wp buffer:
+                                    0 = fp32 MFMA, direct implicit GEMM everywhere (k-ordered fp32 FMA chains); wp = Wp
+                                    2 = fp32 MFMA, Winograd F(2,3) along W on the 3-wide stride-1 convs (the DEFAULT fp32
+                                        mode of the drop-in nets: same fp32 accuracy, 2/3 of the matrix work); wp = Wp followed,
+                                        when kW == 3, by the transformed taps Wg[(kd*kH + kh)*4 + xi][Cin][Cout]
+                                        (G g, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], formed in fp64, rounded once);
+                                        convs the Winograd kernel does not cover run the direct kernels on the Wp part
+                                    1 = opt-in 3-pass split-bf16 MFMA (~16 mantissa bits, NOT the parity mode) */
     int64_t x0s[5], x1s[5], ys[5], rs[5];   /* element strides (b,c,d,h,w) */
 } SdcConvDesc;
 
 int sdc_conv(const SdcConvDesc* d, const float* x0, const float* x1, const float* wp, const float* bias,
              const float* residual, float* y, void* stream);
+
+/* Host-side query (measurement tooling, launches nothing): which kernel template instance sdc_conv would run for this
+ * descriptor, and the share of the direct-form multiply-adds 2*B*P*Cout*Cin*taps that it issues on the matrix cores
+ * (1 for the direct kernels, 2/3 for Winograd F(2,3) along W, 4/9 for F(2x2,3x3)). */
+int sdc_conv_describe(const SdcConvDesc* d, char* name, size_t cap, double* mfma_share);
 
 /* Conv + GroupNorm statistics of its output in one pass (the Block.proj -> Block.norm pair, 1D/model/unet.py:132-141,
  * conv3d.py:192-198): the conv epilogue leaves fp64 (sum, sum of squares) pairs per (sample, group, part) in `parts`

@@ -474,12 +474,49 @@ def gen_smoke():
          dim=dim, weight_seed=300)
 
 
+def gen_wide(which):
+    """One production-width U-Net forward per tree through the REAL reference, so that the production kernels (Winograd conv
+    tiles, fused attention blocks) meet reference output directly and not only through the oracle: Burgers dim 64 (C2
+    width), tokamak dim 256 (C3 width), smoke dim 64 with 32 frames at 32x32 (C4 width, quarter of the C4 area).
+    Inputs are det_tensor(seed) (regenerated by the test), only eps is stored."""
+    if which == "burgers":
+        sys.path.insert(0, os.path.join(REF, "1D"))
+        from model.unet import Unet2D
+        net = Unet2D(dim=64, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+        spec = load_det(net, seed=110)
+        x, t = det_tensor((2, 3, 16, 128), 111), torch.tensor([9, 731])
+        with torch.no_grad():
+            eps = net(x, t)
+        save("burgers_unet_wide", dim=64, x_seed=111, t=t, eps=eps, weight_seed=110, **spec_arrays(spec))
+    elif which == "tokamak":
+        sys.path.insert(0, os.path.join(REF, "tokamak"))
+        from model.unet import Unet1D
+        net = Unet1D(dim=256, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+        spec = load_det(net, seed=210)
+        x, t = det_tensor((2, 12, 128), 211), torch.tensor([2, 640])
+        with torch.no_grad():
+            eps = net(x, t)
+        save("tokamak_unet_wide", dim=256, x_seed=211, t=t, eps=eps, weight_seed=210, **spec_arrays(spec))
+    else:
+        sys.path.insert(0, os.path.join(HERE, "_shims"))
+        sys.path.insert(0, os.path.join(REF, "2d"))
+        from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+        net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+        spec = load_det(net, seed=310)
+        x, t = det_tensor((1, 32, 7, 32, 32), 311), torch.tensor([413])
+        with torch.no_grad():
+            eps = net(x, t)
+        save("smoke_unet_wide", dim=64, x_seed=311, t=t, eps=eps, weight_seed=310, **spec_arrays(spec))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which == "all":
-        for w in ("burgers", "tokamak", "smoke"):
+        for w in ("burgers", "tokamak", "smoke", "burgers_wide", "tokamak_wide", "smoke_wide"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
+    elif which.endswith("_wide"):
+        gen_wide(which[:-5])
     else:
         {"burgers": gen_burgers, "tokamak": gen_tokamak, "smoke": gen_smoke}[which]()

@@ -35,6 +35,7 @@ SIGNATURES = {
     "sdc_version": (C.c_int, []),
     "sdc_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
     "sdc_conv": (C.c_int, [C.POINTER(SdcConvDesc), _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _stream]),
+    "sdc_conv_describe": (C.c_int, [C.POINTER(SdcConvDesc), C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]),
     "sdc_conv_gnparts": (C.c_int, [C.POINTER(SdcConvDesc), C.c_int]),
     "sdc_conv_gn": (C.c_int, [C.POINTER(SdcConvDesc), _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p, C.c_int, _stream]),
     "sdc_gn_finalize": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _i64, C.c_float, _stream]),

@@ -128,11 +128,20 @@ class ConformalCalculator:
                 if getattr(c, "InfFT_Q", None) is not None:
                     w = w * scores_and_weights("burgers", out, state, self._gpar(c.InfFT_Q), use_max=not c.use_max_safety)[1]
             else:
+                # tokamak/inference/conformal.py:62-74: the calibration samples are conditioned on the ground-truth actions
+                # (DDIM samplers; the DDPM path raises the reference's IndexError)
                 out = self.model.sample(batch_size=state.shape[0], clip_denoised=True, guidance_u0=False,
-                                        u_init=state[:, :3, 0], u_final=state[:, [0, 2], :c.nt_total], nablaJ=None,
-                                        J_scheduler=None, w_scheduler=None, enable_grad=False)
+                                        u_init=state[:, :3, 0], u_final=state[:, [0, 2], :c.nt_total],
+                                        w_groundtruth=state[:, 3:, :], nablaJ=None, J_scheduler=None, w_scheduler=None,
+                                        enable_grad=False)
                 tg = cal_targets[idx].to(self.device)
                 s, w = scores_and_weights("tokamak", out, state, self._gpar(Q), target=tg, nt=c.nt_total)
+                if getattr(c, "finetune_set", None) == "train" and getattr(c, "use_guidance", False):
+                    w = w * w                        # the same calculate_weight factor a second time (:86-93)
+                if getattr(c, "finetune_set", None) == "test" and not getattr(c, "wo_post_train", True):
+                    fg = c.finetune_guidance_weights   # :94-102
+                    g2 = [fg["w_obj"], fg["w_safe"], c.finetune_guidance_scaler, c.safety_threshold, float(c.finetune_quantile)]
+                    w = w * scores_and_weights("tokamak", out, state, g2, target=tg, nt=c.nt_total)[1]
             scores.append(s)
             weights.append(w)
         s = all_gather_1d(torch.cat(scores), group)

@@ -466,11 +466,10 @@ extern "C" int sdc_attn(const float* qkv, float* out, const float* rot, const fl
     const size_t lds_bytes = 2 * ksz * sizeof(float);
     SDC_REQUIRE(lds_bytes <= 160 * 1024, SDC_EINVAL, "sdc_attn: LDS footprint %zu too large", lds_bytes);
     const int ngrp = (nseq_tot + nseq - 1) / nseq;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (sdc::first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
-        attr_done = true;
     }
     hipLaunchKernelGGL(attn_kernel, dim3((unsigned)(ngrp * heads)), dim3(NT), lds_bytes, sdc::as_stream(stream), a);
     return sdc::check_launch("sdc_attn");

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include "../../include/sdc.h"
 
 namespace sdc {
@@ -26,6 +27,17 @@ inline int check_launch(const char* what) {
             return (code);             \
         }                              \
     } while (0)
+
+// Per-device one-time set-up (hipFuncSetAttribute for > 64 KB of dynamic LDS is per device): true the first time the
+// calling thread's current device is seen.  Racing threads may both see "first"; the guarded call is idempotent.
+inline bool first_use_on_device(std::atomic<uint64_t>& mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (mask.load(std::memory_order_relaxed) & bit) return false;
+    mask.fetch_or(bit, std::memory_order_relaxed);
+    return true;
+}
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -1441,11 +1441,10 @@ void launch_wg(const ConvArgs& a, hipStream_t s) {
     constexpr int KSMAX = BN + (BN / 16) * 2;
     constexpr int NCOLH = (KSMAX + 63) / 64;
     const size_t lds = (2u * 4u * SK * BM + 2u * SK * (NCOLH * 64 + 8)) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};
+    if (sdc::first_use_on_device(attr)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
     }
     hipLaunchKernelGGL((conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS>), grid, dim3(NTH), lds, s, a);
 }
@@ -1455,11 +1454,10 @@ void launch_rh_bf3(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
     constexpr int KSMAX = BN + (BN / 16) * 2;
     const size_t lds = (2u * 3u * BM * LDK + 2u * KSMAX * LDK) * sizeof(unsigned short);
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};
+    if (sdc::first_use_on_device(attr)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rh_bf3_kernel<BM, BN, WM, WN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
     }
     hipLaunchKernelGGL((conv_rh_bf3_kernel<BM, BN, WM, WN>), grid, dim3(NT), lds, s, a);
 }
@@ -1468,14 +1466,25 @@ template <int BM, int BN, int WM, int WN>
 void launch_bf3(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
     const size_t lds = 2u * (2u * BM * LDK + 2u * BN * LDK) * sizeof(unsigned short);
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};
+    if (sdc::first_use_on_device(attr)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf3_kernel<BM, BN, WM, WN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
     }
     hipLaunchKernelGGL((conv_bf3_kernel<BM, BN, WM, WN>), grid, dim3(NT), lds, s, a);
 }
+
+// what the dispatch chose for the last descriptor (sdc_conv_describe): kernel template instance and the share of the
+// direct-form multiply-adds it issues on the matrix cores (Winograd forms issue fewer)
+thread_local const char* tl_pick = "";
+thread_local double tl_factor = 1.0;
+thread_local bool tl_describe = false;
+#define SDC_PICK(nm, f)                      \
+    do {                                     \
+        tl_pick = (nm);                      \
+        tl_factor = (f);                     \
+        if (tl_describe) return SDC_OK;      \
+    } while (0)
 
 int ilog2_exact(int v) {
     if (v == 1) return 0;
@@ -1485,7 +1494,7 @@ int ilog2_exact(int v) {
 }
 
 template <int BM, int BN, int WM, int WN>
-void launch(const ConvArgs& a, bool fast, hipStream_t s) {
+int launch(const ConvArgs& a, bool fast, hipStream_t s, const char* n_rh, const char* n_fast, const char* n_gen) {
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
     const SdcConvDesc& d = a.d;
     // row-halo kernel: stride 1 along W, no virtual upsampling, kW == 3 (with kW == 1 there is no halo to share and
@@ -1495,13 +1504,20 @@ void launch(const ConvArgs& a, bool fast, hipStream_t s) {
                     ((d.oW % BN == 0) || (BN % d.oW == 0 && d.oW >= 16)) &&
                     (reinterpret_cast<uintptr_t>(a.wp) % 16 == 0);
     if constexpr (BM >= 64) {
-        if (rh) { hipLaunchKernelGGL((conv_rh_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(NT), 0, s, a); return; }
+        if (rh) { SDC_PICK(n_rh, 1.0); hipLaunchKernelGGL((conv_rh_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(NT), 0, s, a); return SDC_OK; }
     }
-    if (fast)
+    if (fast) {
+        SDC_PICK(n_fast, 1.0);
         hipLaunchKernelGGL((conv_kernel<BM, BN, WM, WN, true>), grid, dim3(NT), 0, s, a);
-    else
+    } else {
+        SDC_PICK(n_gen, 1.0);
         hipLaunchKernelGGL((conv_kernel<BM, BN, WM, WN, false>), grid, dim3(NT), 0, s, a);
+    }
+    return SDC_OK;
 }
+#define SDC_LAUNCH(BM, BN, WM, WN)                                                                      \
+    launch<BM, BN, WM, WN>(a, fast, s, "conv_rh_kernel<" #BM "," #BN "," #WM "," #WN ",3,false>",        \
+                           "conv_kernel<" #BM "," #BN "," #WM "," #WN ",true>", "conv_kernel<" #BM "," #BN "," #WM "," #WN ",false>")
 
 // Winograd (precision 2) coverage and tile choice, shared by the dispatch and by sdc_conv_gnparts.
 // 8-wave workgroups (two waves per SIMD) share one staged weight tile; the bigger the tile the fewer L2->LDS bytes
@@ -1577,6 +1593,20 @@ extern "C" int sdc_conv_gn(const SdcConvDesc* dp, const float* x0, const float* 
     return conv_impl(dp, x0, x1, wp, bias, residual, y, parts, G, stream);
 }
 
+extern "C" int sdc_conv_describe(const SdcConvDesc* dp, char* name, size_t cap, double* mfma_share) {
+    SDC_REQUIRE(dp, SDC_ENULL, "sdc_conv_describe: null descriptor");
+    float* const dummy = reinterpret_cast<float*>(uintptr_t(256));   // aligned, never dereferenced: nothing is launched
+    tl_describe = true;
+    tl_pick = "";
+    tl_factor = 1.0;
+    const int rc = conv_impl(dp, dummy, dp->Cin1 > 0 ? dummy : nullptr, dummy, nullptr, nullptr, dummy, nullptr, 0, nullptr);
+    tl_describe = false;
+    if (rc != SDC_OK) return rc;
+    if (name && cap) { std::strncpy(name, tl_pick, cap - 1); name[cap - 1] = 0; }
+    if (mfma_share) *mfma_share = tl_factor;
+    return SDC_OK;
+}
+
 namespace {
 
 int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const float* wp, const float* bias,
@@ -1626,11 +1656,11 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
                          d.kD * d.kH <= 32 && ((d.oW % bn == 0) || (bn % d.oW == 0 && d.oW >= 16));
         // (the 128x128 row-halo form needs 84 KB of LDS = one workgroup per CU and measured slower than the plain one)
         if (rh3 && !big) {
-            if (wide) launch_rh_bf3<64, 256, 1, 4>(a, s);
-            else launch_rh_bf3<64, 128, 2, 2>(a, s);
-        } else if (big) launch_bf3<128, 128, 2, 2>(a, s);
-        else if (wide) launch_bf3<64, 256, 1, 4>(a, s);
-        else launch_bf3<64, 128, 2, 2>(a, s);
+            if (wide) { SDC_PICK("conv_rh_bf3_kernel<64,256,1,4>", 1.0); launch_rh_bf3<64, 256, 1, 4>(a, s); }
+            else { SDC_PICK("conv_rh_bf3_kernel<64,128,2,2>", 1.0); launch_rh_bf3<64, 128, 2, 2>(a, s); }
+        } else if (big) { SDC_PICK("conv_bf3_kernel<128,128,2,2>", 1.0); launch_bf3<128, 128, 2, 2>(a, s); }
+        else if (wide) { SDC_PICK("conv_bf3_kernel<64,256,1,4>", 1.0); launch_bf3<64, 256, 1, 4>(a, s); }
+        else { SDC_PICK("conv_bf3_kernel<64,128,2,2>", 1.0); launch_bf3<64, 128, 2, 2>(a, s); }
         return sdc::check_launch("sdc_conv[bf16x3]");
     }
     // fp32 Winograd F(2,3) along W: 3-wide stride-1 taps, whole 16-channel chunks, even rows
@@ -1645,16 +1675,16 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
             a.gn_part = gn_part; a.gn_G = gn_G; a.gn_cpg = d.Cout / gn_G; a.gn_S = d.oD * d.oH * d.oW;
         }
         if (wgp.ups) {
-            if (wgp.pick == 6) launch_wg<128, 128, 4, 2, 16, 512, true>(a, s);
-            else if (wgp.pick == 7) launch_wg<64, 256, 2, 4, 16, 512, true>(a, s);
-            else launch_wg<64, 128, 2, 2, 16, 256, true>(a, s);
+            if (wgp.pick == 6) { SDC_PICK("conv_wg_kernel<128,128,4,2,16,512,ups>", 2.0 / 3.0); launch_wg<128, 128, 4, 2, 16, 512, true>(a, s); }
+            else if (wgp.pick == 7) { SDC_PICK("conv_wg_kernel<64,256,2,4,16,512,ups>", 2.0 / 3.0); launch_wg<64, 256, 2, 4, 16, 512, true>(a, s); }
+            else { SDC_PICK("conv_wg_kernel<64,128,2,2,16,256,ups>", 2.0 / 3.0); launch_wg<64, 128, 2, 2, 16, 256, true>(a, s); }
             return sdc::check_launch("sdc_conv[winograd,upsample]");
         }
-        if (wgp.pick == 6) launch_wg<128, 128, 4, 2, 16, 512>(a, s);
-        else if (wgp.pick == 7) launch_wg<64, 256, 2, 4, 16, 512>(a, s);
-        else if (wgp.pick == 9) launch_wg<128, 256, 4, 2, 16, 512>(a, s);       // (2 x 4 waves measured the same)
-        else if (wgp.pick == 10) launch_wg<64, 512, 1, 8, 16, 512>(a, s);     // (each wave: both 32-row tiles x 32 pairs; measured 3 % ahead of 1 x 2)
-        else launch_wg<64, 128, 2, 2, 16>(a, s);
+        if (wgp.pick == 6) { SDC_PICK("conv_wg_kernel<128,128,4,2,16,512>", 2.0 / 3.0); launch_wg<128, 128, 4, 2, 16, 512>(a, s); }
+        else if (wgp.pick == 7) { SDC_PICK("conv_wg_kernel<64,256,2,4,16,512>", 2.0 / 3.0); launch_wg<64, 256, 2, 4, 16, 512>(a, s); }
+        else if (wgp.pick == 9) { SDC_PICK("conv_wg_kernel<128,256,4,2,16,512>", 2.0 / 3.0); launch_wg<128, 256, 4, 2, 16, 512>(a, s); }       // (2 x 4 waves measured the same)
+        else if (wgp.pick == 10) { SDC_PICK("conv_wg_kernel<64,512,1,8,16,512>", 2.0 / 3.0); launch_wg<64, 512, 1, 8, 16, 512>(a, s); }     // (each wave: both 32-row tiles x 32 pairs; measured 3 % ahead of 1 x 2)
+        else { SDC_PICK("conv_wg_kernel<64,128,2,2,16,256>", 2.0 / 3.0); launch_wg<64, 128, 2, 2, 16>(a, s); }
         return sdc::check_launch("sdc_conv[winograd]");
     }
     SDC_REQUIRE(!gn_part, SDC_EINVAL, "sdc_conv_gn: shape not covered by the fused statistics (sdc_conv_gnparts returned 0)");
@@ -1669,10 +1699,10 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
             reinterpret_cast<uintptr_t>(x0) % 16 == 0 && (d.Cin1 == 0 || reinterpret_cast<uintptr_t>(x1) % 16 == 0) &&
             reinterpret_cast<uintptr_t>(wp) % 16 == 0) {
             const int64_t b64x128 = (int64_t)((a.Ntot + 127) / 128) * ((d.Cout + 63) / 64);
-            if (d.Cout > 64 && a.Ntot >= 128 * 256) launch_pw<128, 128, 2, 2>(a, s);
-            else if (d.Cout <= 64 && a.Ntot >= 256 * 1024) launch_pw<64, 256, 1, 4>(a, s);
-            else if (b64x128 >= 1024) launch_pw<64, 128, 2, 2>(a, s);
-            else launch_pw<64, 64, 2, 2>(a, s);
+            if (d.Cout > 64 && a.Ntot >= 128 * 256) { SDC_PICK("conv_pw_kernel<128,128,2,2>", 1.0); launch_pw<128, 128, 2, 2>(a, s); }
+            else if (d.Cout <= 64 && a.Ntot >= 256 * 1024) { SDC_PICK("conv_pw_kernel<64,256,1,4>", 1.0); launch_pw<64, 256, 1, 4>(a, s); }
+            else if (b64x128 >= 1024) { SDC_PICK("conv_pw_kernel<64,128,2,2>", 1.0); launch_pw<64, 128, 2, 2>(a, s); }
+            else { SDC_PICK("conv_pw_kernel<64,64,2,2>", 1.0); launch_pw<64, 64, 2, 2>(a, s); }
             return sdc::check_launch("sdc_conv[pointwise]");
         }
     }
@@ -1681,6 +1711,7 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
         d.Cout % 4 == 0 && d.Cout > 32 && small && ((d.oW % 128 == 0) || (128 % d.oW == 0 && d.oW >= 16)) &&
         reinterpret_cast<uintptr_t>(wp) % 16 == 0) {
         dim3 grid((a.Ntot + 127) / 128, (d.Cout + 63) / 64);
+        SDC_PICK("conv_rh_kernel<64,128,2,2,7,true>", 1.0);
         hipLaunchKernelGGL((conv_rh_kernel<64, 128, 2, 2, 7, true>), grid, dim3(NT), 0, s, a);
         return sdc::check_launch("sdc_conv[stem]");
     }
@@ -1688,24 +1719,26 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
     static const int force_tile = getenv("SDC_TILE") ? atoi(getenv("SDC_TILE")) : 0;   // tuning knob: 1..5 picks a tile
     if (force_tile && d.Cout > 32) {
         switch (force_tile) {
-            case 1: launch<128, 128, 2, 2>(a, fast, s); break;
-            case 2: launch<64, 256, 1, 4>(a, fast, s); break;
-            case 3: launch<64, 128, 2, 2>(a, fast, s); break;
-            case 4: launch<64, 64, 2, 2>(a, fast, s); break;
-            default: launch<32, 128, 1, 4>(a, fast, s); break;
+            case 1: SDC_LAUNCH(128, 128, 2, 2); break;
+            case 2: SDC_LAUNCH(64, 256, 1, 4); break;
+            case 3: SDC_LAUNCH(64, 128, 2, 2); break;
+            case 4: SDC_LAUNCH(64, 64, 2, 2); break;
+            default: SDC_LAUNCH(32, 128, 1, 4); break;
         }
+        if (tl_describe) return SDC_OK;
         return sdc::check_launch("sdc_conv");
     }
     if (d.Cout > 64 && a.Ntot >= 128 * 256)
-        launch<128, 128, 2, 2>(a, fast, s);
+        SDC_LAUNCH(128, 128, 2, 2);
     else if (d.Cout > 32 && d.Cout <= 64 && a.Ntot >= 256 * 1024)
-        launch<64, 256, 1, 4>(a, fast, s);     // wide tile: each wave owns 64x64 (2x2 MFMA tiles) like the 128x128 case
+        SDC_LAUNCH(64, 256, 1, 4);     // wide tile: each wave owns 64x64 (2x2 MFMA tiles) like the 128x128 case
     else if (d.Cout > 32 && blocks64x128 >= 1024)
-        launch<64, 128, 2, 2>(a, fast, s);
+        SDC_LAUNCH(64, 128, 2, 2);
     else if (d.Cout > 32)
-        launch<64, 64, 2, 2>(a, fast, s);      // small-N layers: twice the workgroups, >= 2 per CU
+        SDC_LAUNCH(64, 64, 2, 2);      // small-N layers: twice the workgroups, >= 2 per CU
     else
-        launch<32, 128, 1, 4>(a, fast, s);
+        SDC_LAUNCH(32, 128, 1, 4);
+    if (tl_describe) return SDC_OK;
     return sdc::check_launch("sdc_conv");
 }
 

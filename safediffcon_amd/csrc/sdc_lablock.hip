@@ -417,12 +417,11 @@ extern "C" int sdc_linattn_block(const float* x, const float* g_pre, const float
         g2((unsigned)((a.ntiles + a.tiles_per_blk - 1) / a.tiles_per_blk), (unsigned)nseq);
     const size_t ldsb = sizeof(float) * (size_t)((C + HID) * XP + 8 * TT);          // pass 1
     const size_t ldsb2 = ldsb + sizeof(float) * (size_t)(C * XP + 2 * C);          // pass 2: + raw tile, bias, gain
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};
+    if (sdc::first_use_on_device(attr)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(la_blk_ctx<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(la_blk_out<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(la_blk_out<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr = true;
     }
     if (C == 64) {
         hipLaunchKernelGGL(la_blk_ctx<64>, g1, dim3(NT), ldsb, s, a);

@@ -225,10 +225,9 @@ extern "C" int sdc_tattn_block(const float* x, const float* g_pre, const float* 
     a.x = x; a.g = g_pre; a.wqkv = wqkv; a.wo = wo; a.rot = rot; a.bias = bias; a.y = y;
     a.inner = inner; a.eps = eps; a.so = so; a.sc = sc; a.st = st;
     const size_t ldsb = sizeof(float) * (size_t)(C * XP + 4 * 32 * 33 + 2 * 32 * 16 + 1024);
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};
+    if (sdc::first_use_on_device(attr)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ta_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
     }
     hipLaunchKernelGGL(ta_block_kernel, dim3((unsigned)nblk), dim3(NT), ldsb, sdc::as_stream(stream), a);
     return sdc::check_launch("sdc_tattn_block");

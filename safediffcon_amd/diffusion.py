@@ -150,6 +150,21 @@ class SmokeGuidance(GuidanceSpec):
         return -(1 - self._f(self.w_safe)) * succ + self._f(self.w_safe) * safe
 
 
+def _splitmix64(v):
+    v = (v + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    v = ((v ^ (v >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    v = ((v ^ (v >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return v ^ (v >> 31)
+
+
+def _mix_rank(seed, rank=None):
+    """seed ^ splitmix64(rank) for rank > 0 (rank 0 / single process: unchanged)"""
+    if rank is None:
+        import torch.distributed as dist
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    return seed if rank == 0 else (seed ^ _splitmix64(rank)) & ((1 << 62) - 1)
+
+
 # --------------------------------------------------------------------------- sampler core
 class _State:
     """Per-(batch size) device state: step counters, guidance scalars, condition buffers, captured graphs."""
@@ -357,7 +372,10 @@ class _SamplerBase(nn.Module):
         if L.fused:
             gp = guide.gpar()
             st.gpar.copy_(torch.tensor(gp + [0.0] * (8 - len(gp)), dtype=torch.float32))
-        L.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        # Philox key: drawn from torch's global CPU generator (so torch.manual_seed reproduces a run) and mixed with the
+        # process rank: ranks of a batch-sharded run that all call torch.manual_seed(cfg.seed) must not sample their
+        # shards from one and the same noise stream (dist.py)
+        L.seed = _mix_rank(int(torch.randint(0, 2 ** 62, (1,)).item()))
         L.noise = noise
         if noise is not None and st.noise is None:
             st.noise = torch.empty(B * per, dtype=torch.float32, device=dev)
@@ -451,7 +469,14 @@ class _Loop:
         self.ent["plan"].run(stream)
         check(lib.sdc_step_update(C.byref(self.d_x0), p(x), p(eps), 0, p(self.coef), p(row), p(st.draw_dev), 0, 0, 0,
                                   0, 0, 0, 0, 0, 0, p(st.x0), stream), "sdc_step_update[x0]")
-        g = self.guide(st.x0.view(self.shape))
+        # the reference calls nablaJ / design_fn on ``x_start.clone().detach().requires_grad_()`` inside torch.enable_grad()
+        # (1D/model/diffusion.py:261-266, 2d/ddpm/diffusion_2d.py:250-252): its own closures (get_finetune_guidance,
+        # InferencePipeline.design_fn) call torch.autograd.grad on their argument directly
+        with torch.enable_grad():
+            xc = st.x0.view(self.shape).detach().clone().requires_grad_()
+            g = self.guide(xc)
+        if isinstance(g, torch.Tensor):
+            g = g.detach()
         gk = (g if isinstance(g, torch.Tensor) else torch.zeros_like(x) + g).to(torch.float32).contiguous()
         d_up = self.mk(guide=2, impose=(0 if (last and not self.impose_last) else 1))
         check(lib.sdc_step_update(C.byref(d_up), p(x), p(eps), p(gk), p(self.coef), p(row), p(st.draw_dev),

@@ -1,6 +1,10 @@
 """Batch-of-trajectories sharding: trajectories are independent given the weights, so the
 batch axis is split in contiguous blocks over one process per GPU; weights are replicated; no collective runs
-during the 1000 denoising steps.  The only exchange is the conformal all-gather (safediffcon_amd.conformal)."""
+during the 1000 denoising steps.  The only exchange is the conformal all-gather (safediffcon_amd.conformal).
+
+Noise: every sample() call draws its Philox key from torch's global CPU generator and mixes the process rank into it
+(diffusion._mix_rank), so ranks that all call ``torch.manual_seed(cfg.seed)`` -- the usual launcher pattern -- still
+sample their shards from different noise streams (rank 0 and a single-process run use the plain key)."""
 import os
 
 import torch

@@ -287,8 +287,19 @@ class _HipUNet(nn.Module):
         except KeyError:
             return False
 
+    def _drop_plans(self):
+        """device moves / dtype casts invalidate bound pointers: destroy the captured graphs, forget the plans"""
+        for e in self._plans.values():
+            g = e.get("graph")
+            if g is not None:
+                torch.cuda.synchronize(e["x"].device)
+                e["plan"].lib.sdc_graph_destroy(g)
+                e["graph"] = None
+        self._plans = {}
+        self._side = None
+
     def _apply(self, fn, *a, **k):
-        self._plans = {}          # device moves invalidate bound pointers
+        self._drop_plans()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, sd, strict=True, **kw):
@@ -382,7 +393,7 @@ class _HipUNet(nn.Module):
             # ~330 launches per forward: replayed as one hipGraph (captured once per input shape on a private stream;
             # the repacked weights, the conditioning table and x / eps live in buffers the graph keeps pointing at)
             cur = torch.cuda.current_stream(x.device)
-            if self._side is None:
+            if self._side is None or self._side.device != x.device:
                 self._side = torch.cuda.Stream(x.device)
             side = self._side
             side.wait_stream(cur)

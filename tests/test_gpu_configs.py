@@ -1,0 +1,234 @@
+"""-m gpu: the BASELINE.json configurations round 1 left untested (VERDICT r1 "Close the untested configs"):
+C4 at the full batch of 64, C3's guided sampler at B=128, the calibration (double-draw, unguided) branch at C2 width,
+and one production-width reference fixture per tree (tests/golden/*_unet_wide.npz, written by the REAL reference through
+oracle/make_goldens.py), so that the production kernels meet reference output directly.
+Tolerances: fp32 kernels vs the fp32 CPU reference differ by summation order only; eps-MSE <= 1e-5 is the north-star gate,
+the element-wise gates below are ~5x the errors measured on MI355X (printed by every test)."""
+import pytest
+import torch
+
+import safediffcon_amd as sdc
+from oracle import nets as onets
+from oracle import samplers as osam
+from oracle import schedules as osched
+from oracle.detweights import det_noise, det_params, det_tensor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _spec(net):
+    return [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+
+
+def _mse(a, b):
+    return ((a - b) ** 2).mean().item()
+
+
+def _report(tag, got, want):
+    err = (got - want).abs().max().item()
+    print(f"[measured] {tag}: max|err| {err:.3e}  eps-MSE {_mse(got, want):.3e}  (|ref|max {want.abs().max().item():.3f})")
+    return err
+
+
+# ------------------------------------------------------------------ production-width reference fixtures
+def test_wide_fixtures_from_the_reference(golden):
+    g = golden("burgers_unet_wide")
+    net = sdc.Unet2D(dim=64, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+    net.load_state_dict(det_params(g.spec(), int(g.scalar("weight_seed"))))
+    net.to(DEV)
+    x = det_tensor((2, 3, 16, 128), int(g.scalar("x_seed")))
+    eps = net(x.to(DEV), g["t"].to(DEV)).cpu()
+    assert _report("burgers dim 64 vs reference", eps, g["eps"]) < 5e-5 and _mse(eps, g["eps"]) <= 1e-9
+
+    g = golden("tokamak_unet_wide")
+    net = sdc.Unet1D(dim=256, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+    net.load_state_dict(det_params(g.spec(), int(g.scalar("weight_seed"))))
+    net.to(DEV)
+    x = det_tensor((2, 12, 128), int(g.scalar("x_seed")))
+    eps = net(x.to(DEV), g["t"].to(DEV)).cpu()
+    assert _report("tokamak dim 256 vs reference", eps, g["eps"]) < 5e-5 and _mse(eps, g["eps"]) <= 1e-9
+
+    g = golden("smoke_unet_wide")
+    net = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+    net.load_state_dict(det_params(g.spec(), int(g.scalar("weight_seed"))))
+    net.to(DEV)
+    x = det_tensor((1, 32, 7, 32, 32), int(g.scalar("x_seed")))
+    eps = net(x.to(DEV), g["t"].to(DEV)).cpu()
+    assert _report("smoke dim 64, 32 frames 32x32 vs reference", eps, g["eps"]) < 2e-4 and _mse(eps, g["eps"]) <= 1e-8
+    used = {fn.__name__ for fn, _ in net.entry(tuple(x.shape), 1)["plan"].calls}
+    assert {"sdc_tattn_block", "sdc_linattn_block", "sdc_conv_gn"} <= used      # the production kernels ran
+
+
+# ------------------------------------------------------------------ C4 at the full batch
+def test_c4_batch64_forward_and_sampler():
+    """Unet3D_with_Conv3D(64,(1,2,4),7) at B=64 (2.1 GB level-0 activations): one forward against the oracle on one of the 64
+    samples, batch independence (the same sample alone gives the same eps), then two guided sampler steps with injected
+    noise: the sample run alone follows the same trajectory, conditions imposed, finite."""
+    net = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+    P = det_params(_spec(net), 31)
+    net.load_state_dict(P)
+    net.to(DEV)
+    B, k = 64, 37
+    x = det_tensor((B, 32, 7, 64, 64), 33)
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(34))
+    eps = net(x.to(DEV), t.to(DEV))
+    assert torch.isfinite(eps).all()
+    ref = onets.unet_smoke(P, x[k:k + 1], t[k:k + 1], dim=64, dim_mults=(1, 2, 4))
+    assert _report("C4 B=64 forward, sample 37 vs oracle", eps[k:k + 1].cpu(), ref) < 1e-3 and _mse(eps[k:k + 1].cpu(), ref) <= 1e-8
+    alone = net(x[k:k + 1].to(DEV), t[k:k + 1].to(DEV))
+    assert _report("C4 sample 37: in the batch of 64 vs alone", eps[k:k + 1].cpu(), alone.cpu()) < 2e-5
+    last = net(x[B - 1:].to(DEV), t[B - 1:].to(DEV))                   # the far end of the batch: largest offsets
+    assert _report("C4 sample 63: in the batch of 64 vs alone", eps[B - 1:].cpu(), last.cpu()) < 2e-5
+    del eps, alone, last
+
+    T = 2
+    gs = sdc.GaussianDiffusionSmoke(net, image_size=64, frames=32, timesteps=T, standard_fixed_ratio=100.0).to(DEV)
+    init = det_tensor((B, 64, 64), 43, 0.2).abs()
+    noise = det_noise((B, 32, 7, 64, 64), 7000)
+    guid = sdc.SmokeGuidance(0.01, 0.9, 0.1)
+    out = gs.sample(batch_size=B, design_fn=guid, init=init.to(DEV), noise=noise)
+    assert torch.isfinite(out).all() and torch.equal(out[:, 0, 0].cpu(), init)
+    one = gs.sample(batch_size=1, design_fn=guid, init=init[k:k + 1].to(DEV), noise=lambda i: noise(i)[k:k + 1])
+    assert _report("C4 2-step guided trajectory, sample 37: batch of 64 vs alone", out[k:k + 1].cpu(), one.cpu()) < 1e-4
+
+
+# ------------------------------------------------------------------ C3 guided sampler at the full batch
+def test_c3_guided_sampler_batch128():
+    """tokamak/model/diffusion.py:310-372 at C3 size: Unet1D dim 256, B=128, TokamakGuidance (finetune.sh weights), 3 steps
+    with injected noise; the oracle runs the first and the last trajectory of the batch."""
+    net = sdc.Unet1D(dim=256, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+    P = det_params(_spec(net), 21)
+    net.load_state_dict(P)
+    net.to(DEV)
+    T, B, idx = 3, 128, [0, 127]
+    gd = sdc.GaussianDiffusionTokamak(net, seq_length=128, nt=122, timesteps=T).to(DEV)
+    u0 = det_tensor((B, 3), 51, 0.1) + 0.6
+    uT = det_tensor((B, 2, 122), 52, 0.1) + 0.6
+    target = det_tensor((B, 3, 122), 53, 0.3) + 1.0
+    noise = det_noise((B, 12, 128), 5400)
+    args = dict(w_obj=0.3, w_safe=1.0, guidance_scaler=0.5, Q=0.05, safety_threshold=4.98)
+    out = gd.sample(batch_size=B, u_init=u0, u_final=uT, nablaJ=sdc.TokamakGuidance(target, 122, **args), enable_grad=False,
+                    noise=noise).cpu()
+    assert torch.isfinite(out).all()
+    tabs = osched.make_tables("cosine", T)
+    ref = osam.sample_tokamak(lambda a, b: onets.unet_tokamak(P, a, b, dim=256), tabs, 2, lambda i: noise(i)[idx], u_init=u0[idx],
+                              u_final=uT[idx], nablaJ=osam.tokamak_guidance(target[idx], 122, 0.05, 4.98, 0.3, 1.0, 0.5),
+                              enable_grad=False)
+    assert _report("C3 3-step guided trajectory, samples 0/127 of 128 vs oracle", out[idx], ref) < 5e-4
+
+
+# ------------------------------------------------------------------ calibration branch at C2 width
+def test_calibration_double_draw_at_c2_width():
+    """1D/model/diffusion.py:421-423 (guidance_u0=False): two noise draws per step, w_groundtruth imposed, unguided -- at
+    the C2 width (dim 64), 3 steps, against the oracle."""
+    net = sdc.Unet2D(dim=64, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+    P = det_params(_spec(net), 11)
+    net.load_state_dict(P)
+    net.to(DEV)
+    T, B = 3, 4
+    gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=T, temporal=True, use_conv2d=True,
+                                      is_condition_u0=True, is_condition_uT=True, condition_idx=10).to(DEV)
+    u0, uT, wgt = det_tensor((B, 128), 61, 0.1), det_tensor((B, 128), 62, 0.1), det_tensor((B, 16, 128), 63, 0.05)
+    noise = det_noise((B, 3, 16, 128), 6400)
+    out = gd.sample(batch_size=B, clip_denoised=True, guidance_u0=False, u_init=u0, u_final=uT, w_groundtruth=wgt, nablaJ=None,
+                    enable_grad=False, noise=noise).cpu()
+    tabs = osched.make_tables("cosine", T)
+    ref = osam.sample_burgers(lambda a, b: onets.unet_burgers(P, a, b, dim=64), tabs, B, noise, u_init=u0, u_final=uT,
+                              guidance_u0=False, w_groundtruth=wgt, nablaJ=None, enable_grad=False)
+    assert _report("C2-width calibration (double-draw) trajectory vs oracle", out, ref) < 2e-4
+    # the Philox route consumes two draw indices per step as well: graph replay == eager call list
+    outs = []
+    for use_graph in (True, False):
+        gd.use_graph = use_graph
+        torch.manual_seed(9)
+        outs.append(gd.sample(batch_size=B, guidance_u0=False, u_init=u0.to(DEV), u_final=uT.to(DEV), w_groundtruth=wgt.to(DEV),
+                              nablaJ=None, enable_grad=False))
+    assert torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------ advisor findings (round 1)
+def test_reference_style_guidance_closures_get_a_grad_enabled_leaf(golden):
+    """The reference's own closures call torch.autograd.grad on their argument directly (1D/inference/inference_ft.py:158,
+    2d/inference_2d.py:189-195): the sampler must hand them a leaf that requires grad, inside enable_grad."""
+    spec = golden("burgers_unet").spec()
+    net = sdc.Unet2D(dim=8, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+    net.load_state_dict(det_params(spec, 100))
+    net.to(DEV)
+    g = golden("burgers_traj_guided")
+    gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=8, temporal=True, use_conv2d=True,
+                                      is_condition_u0=True, is_condition_uT=True, condition_idx=10,
+                                      train_on_padded_locations=False).to(DEV)
+    noise = det_noise((2, 3, 16, 128), int(g.scalar("noise_seed")))
+    Q, w, ub = g.scalar("Q"), g.scalar("w_score"), g.scalar("u_bound")
+
+    def get_finetune_guidance(x):                   # shape of 1D/utils/guidance.py:79-85: no enable_grad, no requires_grad_ of its own
+        assert x.requires_grad and torch.is_grad_enabled()
+        s = (x * 10.0)[:, 2, :11, :].mean(dim=(-1, -2))
+        J = torch.clamp(s + Q - ub ** 2, min=0) * w
+        return torch.autograd.grad(J, x, grad_outputs=torch.ones_like(J))[0]
+    out = gd.sample(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True,
+                    nablaJ=get_finetune_guidance, J_scheduler=lambda t: 1.0, enable_grad=False, noise=noise).cpu()
+    assert _report("burgers guided trajectory through a reference-style closure vs reference fixture", out, g["out"]) < 2e-4
+
+    spec = golden("smoke_unet").spec()
+    g = golden("smoke_traj_guided")
+    net3 = sdc.Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2, 4), channels=7)
+    net3.load_state_dict(det_params(spec, 300))
+    net3.to(DEV)
+    gs = sdc.GaussianDiffusionSmoke(net3, image_size=16, frames=8, timesteps=8, loss_type="l2",
+                                    standard_fixed_ratio=g.scalar("ratio")).to(DEV)
+    R = torch.tensor(sdc.diffusion.SMOKE_RESCALER, dtype=torch.float32, device=DEV).reshape(1, 1, 7, 1, 1)
+    Qs, ws, sb = g.scalar("Q"), g.scalar("w_safe"), g.scalar("safe_bound")
+
+    def design_fn(x):                               # 2d/inference_2d.py:189-195
+        st = x * R
+        guidance = -(1 - ws) * st[:, :, 5].mean((-1, -2, -3)) + ws * torch.clamp(st[:, -1, 6].mean((-1, -2)) + Qs - sb, min=0)
+        return torch.autograd.grad(guidance.sum(), x)[0]
+    out = gs.sample(batch_size=2, design_fn=design_fn, enable_grad=False, init=g["init"],
+                    noise=det_noise((2, 8, 7, 16, 16), int(g.scalar("noise_seed")))).cpu()
+    assert _report("smoke guided trajectory through a reference-style design_fn vs reference fixture", out, g["out"]) < 1e-3
+
+
+def test_tokamak_conformal_ddim_passes_ground_truth_actions(golden):
+    """tokamak/inference/conformal.py:62-102: calibration samples conditioned on the ground-truth actions (DDIM path) and
+    the conditional extra weight factors, against the oracle's arithmetic on the same sampled outputs."""
+    import types
+    from safediffcon_amd import conformal
+    spec = golden("tokamak_unet").spec()
+    P = det_params(spec, 200)
+    net = sdc.Unet1D(dim=8, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+    net.load_state_dict(P)
+    net.to(DEV)
+    T, S_, eta = 20, 5, 1.0
+    gd = sdc.GaussianDiffusionTokamak(net, seq_length=128, nt=122, timesteps=T, sampling_timesteps=S_, ddim_sampling_eta=eta).to(DEV)
+    Bc, nb = 4, 2
+    states = [det_tensor((Bc, 12, 128), 970 + i, 0.3) + 0.5 for i in range(nb)]
+    targets = det_tensor((nb * Bc, 3, 122), 975, 0.3) + 1.0
+    items = [(states[i], torch.arange(i * Bc, (i + 1) * Bc)) for i in range(nb)]
+    base = dict(device=DEV, num_cal_batch=nb, nt_total=122, guidance_scaler=0.5, safety_threshold=3.6,
+                guidance_weights={"w_obj": 0.7, "w_safe": 0.3})
+    Q = 0.1
+    w1 = osam.tokamak_weight(torch.cat(states), targets, 122, Q, 3.6, 0.7, 0.3, 0.5)
+    w2 = osam.tokamak_weight(torch.cat(states), targets, 122, 0.2, 3.6, 0.1, 0.9, 0.25)
+    cases = [(dict(finetune_set="train", use_guidance=False), w1),
+             (dict(finetune_set="train", use_guidance=True), w1 * w1),
+             (dict(finetune_set="test", wo_post_train=False, finetune_quantile=0.2, finetune_guidance_scaler=0.25,
+                   finetune_guidance_weights={"w_obj": 0.1, "w_safe": 0.9}), w1 * w2)]
+    for extra, want_w in cases:
+        cfg = types.SimpleNamespace(**base, **extra)
+        calc = conformal.ConformalCalculator(gd, cfg, kind="tokamak")
+        torch.manual_seed(4)
+        ws, nw, st = calc.get_conformal_scores(iter(items), Q, cal_targets=targets)
+        torch.testing.assert_close(nw.cpu(), osam.normalize_weights(want_w), rtol=2e-4, atol=1e-6)
+        # the samples behind the scores: same Philox keys (torch.manual_seed), drawn with and without the ground-truth actions
+        torch.manual_seed(4)
+        outs = [gd.sample(batch_size=Bc, clip_denoised=True, guidance_u0=False, u_init=s[:, :3, 0].to(DEV),
+                          u_final=s[:, [0, 2], :122].to(DEV), w_groundtruth=s[:, 3:, :].to(DEV), nablaJ=None, enable_grad=False).cpu()
+                for s in states]
+        want_s = torch.cat([osam.tokamak_score(o, s, 122) for o, s in zip(outs, states)])
+        torch.testing.assert_close(ws.cpu(), osam.normalize_weights(want_w) * want_s, rtol=2e-4, atol=1e-6)
+    torch.manual_seed(4)
+    plain = gd.sample(batch_size=Bc, guidance_u0=False, u_init=states[0][:, :3, 0].to(DEV), u_final=states[0][:, [0, 2], :122].to(DEV),
+                      nablaJ=None, enable_grad=False).cpu()
+    assert not torch.allclose(plain, outs[0])          # the actions condition the samples
