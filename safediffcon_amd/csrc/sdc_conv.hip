@@ -55,6 +55,7 @@ struct ConvArgs {
     int lgD, lgH, lgW;
     int rowhalo;   // allow the row-halo kernel (env SDC_NO_ROWHALO=1 disables it for A/B timing)
     int vec2;      // Winograd epilogue: y (and residual) rows allow 8-byte accesses at even positions
+    const float* wg2;   // F(2x2,3x3) taps [kd][16][Cin][Cout] (precision 3)
     // GroupNorm partial sums of the output (sdc_conv_gn): fp64 (sum, sum of squares) per (sample, group, part)
     double* gn_part;
     int gn_G, gn_cpg, gn_nparts, gn_S;
@@ -1435,6 +1436,418 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
     wg_epilogue<TM, TP, BM, BN, WM, WN>(a, acc, m0 + wm * (TM * 32), n0 / 2 + wn * (TP * 32), lane, ldsw, wave, m0, n0);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// precision = 3: fp32 Winograd F(2x2, 3x3) over (H, W) for the 3x3 (Conv2d) / 3x3x3 (Conv3d, direct along D) stride-1
+// convs: per 2x2 output tile and its 4x4 input patch d,  Y = A^T [ (G g G^T) . (B^T d B) ] A  with the same G, B^T, A^T as
+// the 1-D form above applied along H and along W -- 16 products per 4 outputs instead of 36: 4/9 of the direct fp32 MFMA
+// work (the 1-D form: 2/3).  The caller stores U[kd][j*4+xi][ci][co] = sum_{kh,kw} G[j][kh] G[xi][kw] w[co][ci][kd][kh][kw]
+// (fp64, rounded once) behind the 1-D taps.  16 GEMMs over K = kD*Cin with N = tiles:
+//   * workgroup = 4 waves, ONE per SIMD (16 components x 32x32 accumulators = 256 registers per wave), 64 output
+//     channels x 64 tiles (= RP whole row pairs of W/2 tiles, 256 output positions); K stages of 8 channels.
+//   * B: every lane stages columns of the RP row pairs: the 4 input rows under a row pair are loaded, the H transform
+//     (d0-d2, d1+d2, d2-d1, d1-d3) is applied in registers and the 4 transformed rows go to LDS [k][row pair][j][W+2] (the two
+//     halo columns are the zero padding -- whole rows only, W in {16,32,64,128} -- written once).  The W transform is the
+//     same two-adds-per-fragment step as in the 1-D kernel, on ds_read_b64 pairs.
+//   * A: U tile [16][8][64] per stage with 16-byte loads, scalar base + fixed lane offset.
+//   * stage st+2 is fetched during the second half of stage st and parked in LDS during the first half of stage st+1.
+// Results differ from the direct form by rounding order (measured ~2e-6 of the output scale vs fp64; the 1-D form 6e-7).
+constexpr int W2_SK = 8;          // channels per stage
+constexpr int W2_BM = 64;         // output channels per workgroup
+constexpr int W2_TILES = 64;      // 2x2 tiles per workgroup
+constexpr int W2_KP = 640;        // LDS floats per staged k row (max over W of RP * rstride)
+constexpr int W2_NBUF = 3;        // LDS ring of stage buffers
+constexpr int W2_ASZ = 16 * W2_SK * W2_BM, W2_BSZ = W2_SK * W2_KP;
+
+// single fp32 VALU ops the SLP vectoriser cannot pack: v_pk_add_f32 beside MFMAs is slower than two v_add_f32, and packing
+// the transforms made the compiler shuffle freshly read LDS values through copies (an lgkmcnt(0) stall per fragment row)
+__device__ __forceinline__ float vsub1(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vadd1(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+__host__ __device__ inline int w2_rstride(int oW) {      // floats per row-pair block: 4 rows x (W + 2), padded so that the row
+    return 4 * (oW + 2) + (oW == 32 ? 24 : (oW == 16 ? 8 : 0));   // pairs a 32-lane read spans fall on different banks
+}
+
+__global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
+    constexpr int SK = W2_SK, BM = W2_BM, NTH = 256;
+    extern __shared__ __attribute__((aligned(16))) float ldsw[];
+    float* const As = ldsw;                          // [3][16][SK][BM]
+    float* const Bs = ldsw + W2_NBUF * W2_ASZ;       // [3][SK][W2_KP]
+
+    const SdcConvDesc& d = a.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = SDC_UNIFORM(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int MT = (d.Cout + BM - 1) / BM;
+    // consecutive logical blocks (one XCD, dispatched back to back) share an input tile: m fastest
+    const int lb = xcd_tile(blockIdx.x, gridDim.x);
+    const int m0 = (lb % MT) * BM;
+    const int tile0 = (lb / MT) * W2_TILES;
+    const int lgW = a.lgW;                     // log2(oW) (reused field: no upsampling here)
+    const int oW = d.oW, TW = oW >> 1, H2 = d.oH >> 1;
+    const int rowp = oW + 2;
+    const int rstride = w2_rstride(oW);
+    const int RPtot = d.B * d.oD * H2;
+    const int rp0 = tile0 >> (lgW - 1);
+    const bool two = d.Cin1 > 0;
+    const float r_H2 = 1.0f / (float)H2, r_oD = 1.0f / (float)d.oD;
+    auto split_rp = [&](int rp, int& ob, int& od, int& hp) {      // rp < 2^20 (host check): float quotients are exact
+        const int q = (int)(((float)rp + 0.5f) * r_H2);
+        hp = rp - q * H2;
+        ob = (int)(((float)q + 0.5f) * r_oD);
+        od = q - ob * d.oD;
+    };
+
+    // ---- gather state: this lane's two columns (lane, lane + 64) of the 128 staged columns
+    int v0[2], v1[2], ldw[2];
+    uint32_t msk[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int cidx = lane + 64 * t;
+        const int r = cidx >> lgW, col = cidx & (oW - 1);
+        const int rp = rp0 + r;
+        ldw[t] = r * rstride + 1 + col;
+        v0[t] = 0; v1[t] = 0; msk[t] = 0;
+        if (rp < RPtot) {
+            int ob, od, hp;
+            split_rp(rp, ob, od, hp);
+            const int id0 = od - d.pD, ih0 = 2 * hp - 1;
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m |= (ih0 + j >= 0 && ih0 + j < d.iH) ? (1u << j) : 0u;
+            for (int kd = 0; kd < d.kD; ++kd) m |= (id0 + kd >= 0 && id0 + kd < d.iD) ? (16u << kd) : 0u;
+            msk[t] = m;
+            v0[t] = (int)(ob * d.x0s[0] + id0 * d.x0s[2] + ih0 * d.x0s[3] + col * d.x0s[4]);
+            if (two) v1[t] = (int)(ob * d.x1s[0] + id0 * d.x1s[2] + ih0 * d.x1s[3] + col * d.x1s[4]);
+        }
+    }
+    // this lane's tile inside the staged rows: (d0,d1) of transformed row j at boff + j*rowp, (d2,d3) 2 floats further
+    int boff;
+    {
+        const int n = wn * 32 + l31;
+        boff = (n >> (lgW - 1)) * rstride + 2 * (n & (TW - 1));
+    }
+    // weight fetch: 8 float4 per thread per stage; lane part of the address fixed for the whole kernel
+    uint32_t a_voff[8];
+    bool a_ok[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = tid + i * NTH;
+        const int c4 = (f & 15) * 4, row = f >> 4;             // row = comp * SK + kr
+        const int comp = row / SK, kr = row % SK;
+        a_ok[i] = (m0 + c4) < d.Cout;
+        a_voff[i] = (uint32_t)(((int64_t)(comp * a.Cin + kr) * d.Cout + (a_ok[i] ? (m0 + c4) : 0)) * 4);
+    }
+    // zero the halo columns of the three buffers once (never written again)
+    {
+        const int RP = W2_TILES / TW;
+        for (int e = tid; e < W2_NBUF * SK * RP * 4 * 2; e += NTH) {
+            const int side = e & 1, j = (e >> 1) & 3, rest = e >> 3;
+            const int r = rest % RP, kb = rest / RP;            // kb = buf * SK + k
+            Bs[kb * W2_KP + r * rstride + j * rowp + (side ? oW + 1 : 0)] = 0.0f;
+        }
+    }
+
+    float breg[2][2][4];          // [k row of this wave][column t][source row j]
+    float4 areg[8];
+    uint32_t mbits = 0;
+    int s_kd = 0, s_ci = 0;
+    // loop-invariant descriptor fields as values (selecting between the x0 / x1 FIELDS inside the loop turns into pointer
+    // selects + scalar loads whose lgkmcnt waits also drain the LDS reads)
+    const int64_t xs1_0 = d.x0s[1], xs1_1 = d.x1s[1];
+    const int dsb_0 = (int)d.x0s[2] * 4, dsb_1 = (int)d.x1s[2] * 4, hsb_0 = (int)d.x0s[3] * 4, hsb_1 = (int)d.x1s[3] * 4;   // bytes
+    const int cin0 = d.Cin0, cin = a.Cin, kDn = d.kD, coutn = d.Cout;
+    const float* const wg2p = a.wg2;
+    const float* const x0p = a.x0;
+    const float* const x1p = two ? a.x1 : a.x0;
+    const int vb00 = v0[0] * 4, vb01 = v0[1] * 4, vb10 = two ? v1[0] * 4 : 0, vb11 = two ? v1[1] * 4 : 0;   // byte offsets
+    const uint32_t mk0 = msk[0], mk1 = msk[1];
+    typedef const __attribute__((address_space(1))) char* gchar_p;
+    typedef float nfloat4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) nfloat4* gfloat4_p;
+    // stage fetch state (scalar part set by fetch_begin, lane offsets by fetch_offsets(t))
+    gfloat_p f_w = uniform_ptr(wg2p);
+    gfloat_p f_x0 = uniform_ptr(x0p), f_x1 = uniform_ptr(x0p);     // the two channel rows of this wave
+    int f_first = 1, f_kd = 0;
+    uint32_t l_off[2][4];
+    auto fetch_begin = [&]() {
+        const bool first = s_ci < cin0;
+        const int64_t sc = first ? xs1_0 : xs1_1;
+        const float* bsel = first ? x0p : x1p;
+        const int cbase = (first ? s_ci : s_ci - cin0) + wave * 2;
+        f_x0 = uniform_ptr(bsel + (int64_t)cbase * sc);
+        f_x1 = uniform_ptr(bsel + (int64_t)(cbase + 1) * sc);
+        f_w = uniform_ptr(wg2p + ((int64_t)(s_kd * 16) * cin + s_ci) * coutn);
+        f_first = first ? 1 : 0;
+        f_kd = s_kd;
+        s_ci += SK;
+        // (past the last stage the walk wraps to the first one: the extra fetches of the pipeline tail stay in bounds and are
+        // never consumed)
+        if (s_ci >= cin) { s_ci = 0; if (++s_kd == kDn) s_kd = 0; }
+    };
+    auto fetch_offsets = [&](int t) {
+        const uint32_t mm = t ? mk1 : mk0;
+        const uint32_t dok = (mm >> (4 + f_kd)) & 1u;
+        const uint32_t jm = dok ? (mm & 15u) : 0u;
+        mbits = t ? (mbits | (jm << 4)) : jm;
+        const int hsb = f_first ? hsb_0 : hsb_1;
+        const int o0 = (f_first ? (t ? vb01 : vb00) : (t ? vb11 : vb10)) + f_kd * (f_first ? dsb_0 : dsb_1);
+        const int o1 = o0 + hsb, o2 = o1 + hsb, o3 = o2 + hsb;
+        l_off[t][0] = (jm & 1u) ? (uint32_t)o0 : 0u;
+        l_off[t][1] = (jm & 2u) ? (uint32_t)o1 : 0u;
+        l_off[t][2] = (jm & 4u) ? (uint32_t)o2 : 0u;
+        l_off[t][3] = (jm & 8u) ? (uint32_t)o3 : 0u;
+    };
+    auto fetch_a = [&](int i, float4 (&ar)[8]) {
+        const nfloat4 wv = *(gfloat4_p)((gchar_p)f_w + a_voff[i]);
+        ar[i] = make_float4(wv.x, wv.y, wv.z, wv.w);
+    };
+    auto fetch_b = [&](int kr, int t, float (&br)[2][2][4]) {
+        const gfloat_p rb = kr ? f_x1 : f_x0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) br[kr][t][j] = ld_sv(rb, l_off[t][j]);
+    };
+    // (weight rows beyond Cout read column 0 of the tile instead of zeros: they only feed output rows that are never stored)
+    auto park_a = [&](int buf, int i, const float4 (&ar)[8]) {
+        const int f = tid + i * NTH;
+        *reinterpret_cast<float4*>(As + buf * W2_ASZ + (f >> 4) * BM + (f & 15) * 4) = ar[i];
+    };
+    auto park_b = [&](int buf, int kr, int t, const float (&br)[2][2][4], uint32_t mb) {
+        const float d0 = ((mb >> (t * 4 + 0)) & 1u) ? br[kr][t][0] : 0.0f;
+        const float d1 = ((mb >> (t * 4 + 1)) & 1u) ? br[kr][t][1] : 0.0f;
+        const float d2 = ((mb >> (t * 4 + 2)) & 1u) ? br[kr][t][2] : 0.0f;
+        const float d3 = ((mb >> (t * 4 + 3)) & 1u) ? br[kr][t][3] : 0.0f;
+        float* dst = Bs + buf * W2_BSZ + (wave * 2 + kr) * W2_KP + ldw[t];
+        dst[0] = vsub1(d0, d2);
+        dst[rowp] = vadd1(d1, d2);
+        dst[2 * rowp] = vsub1(d2, d1);
+        dst[3 * rowp] = vsub1(d1, d3);
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+
+    const int nstages = d.kD * (a.Cin / SK);
+    const int am = wm * 32 + l31;
+    float fa[2][16];
+    float2 fb[4][2];
+    float bt[2][16];
+    auto read_b = [&](const float* Bk, int j) {                 // (d0,d1), (d2,d3) of transformed row j under this lane's tile
+        const float2* bp = reinterpret_cast<const float2*>(Bk + j * rowp);
+        fb[j][0] = bp[0];
+        fb[j][1] = bp[1];
+    };
+    auto transform = [&](int set, int j) {                      // W transform of row j
+        const float2 p0 = fb[j][0], p1 = fb[j][1];
+        bt[set][j * 4 + 0] = vsub1(p0.x, p1.x);
+        bt[set][j * 4 + 1] = vadd1(p0.y, p1.x);
+        bt[set][j * 4 + 2] = vsub1(p1.x, p0.y);
+        bt[set][j * 4 + 3] = vsub1(p0.y, p1.y);
+    };
+    {   // prologue: the fetches of the first two stages travel together; stage 0 is parked in buffer 0
+        float breg0[2][2][4];
+        float4 areg0[8];
+        fetch_begin();
+        fetch_offsets(0);
+        fetch_offsets(1);
+        const uint32_t mbits0 = mbits;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fetch_a(i, areg0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fetch_b(q >> 1, q & 1, breg0);
+        fetch_begin();
+        fetch_offsets(0);
+        fetch_offsets(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fetch_a(i, areg);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fetch_b(q >> 1, q & 1, breg);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) park_a(0, i, areg0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) park_b(0, q >> 1, q & 1, breg0, mbits0);
+    }
+    __syncthreads();
+    {
+        const float* A0 = As + lh * BM + am;
+        const float* B0 = Bs + lh * W2_KP + boff;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) fa[0][c] = A0[(c * SK) * BM];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) read_b(B0, j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) transform(0, j);
+    }
+
+    // Main loop.  LDS ring of three stage buffers and ONE barrier per stage, after the stage's parking stores (end of k-step 1):
+    // stage st computes from buffer st % 3 and parks stage st+1 in buffer (st+1) % 3 during its k-steps 0-1, re-using each
+    // register piece for the fetch of stage st+2 as soon as it is parked (a fetch then has four k-steps to arrive); its last
+    // k-step already reads the first fragments of stage st+1, so the MFMA stream runs through the stage boundary.  The
+    // non-MFMA work of a k-step is cut into 16 slots, one behind each MFMA, in source order (sched_barrier).
+    int rbuf = 0;
+    for (int st = 0; st < nstages; ++st) {
+        const int wbuf = rbuf == W2_NBUF - 1 ? 0 : rbuf + 1;
+        const float* Ab = As + rbuf * W2_ASZ + lh * BM + am;
+        const float* Bb = Bs + rbuf * W2_BSZ + lh * W2_KP + boff;
+        const float* An = As + wbuf * W2_ASZ + lh * BM + am;
+        const float* Bn = Bs + wbuf * W2_BSZ + lh * W2_KP + boff;
+        uint32_t mb_park = mbits;                                // masks of the pieces still in registers (stage st+1)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int set = ks & 1, nset = set ^ 1;
+            const float* Ak = ks < 3 ? Ab + (2 * (ks + 1)) * BM : An;          // fragments of the next k-step
+            const float* Bk = ks < 3 ? Bb + (2 * (ks + 1)) * W2_KP : Bn;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][c], bt[set][c], acc[c], 0, 0, 0);
+                // -- fragments of the next k-step: B rows first (their W transform closes the k-step), then the 16 A values
+                if (c < 4) read_b(Bk, c);
+                else if (c < 12) { fa[nset][2 * (c - 4)] = Ak[((2 * (c - 4)) * SK) * BM]; fa[nset][2 * (c - 4) + 1] = Ak[((2 * (c - 4) + 1) * SK) * BM]; }
+                else transform(nset, c - 12);
+                // -- staging: k-step p = 0, 1 parks piece p of stage st+1 and re-fetches it for stage st+2
+                if (ks < 2) {
+                    const int p = ks;
+                    if (c < 4) park_a(wbuf, 2 * c + p, areg);
+                    else if (c == 4) park_b(wbuf, 0, p, breg, mb_park);
+                    else if (c == 5) park_b(wbuf, 1, p, breg, mb_park);
+                    else if (c == 6) { if (p == 0) fetch_begin(); }
+                    else if (c == 7) fetch_offsets(p);
+                    else if (c < 12) fetch_a(2 * (c - 8) + p, areg);
+                    else if (c == 12) fetch_b(0, p, breg);
+                    else if (c == 13) fetch_b(1, p, breg);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ks == 1) __syncthreads();
+        }
+        rbuf = wbuf;
+    }
+
+    // ---- epilogue: output transform Y = A^T M A on the accumulators, bias, residual, GroupNorm partial sums
+    const bool v2 = a.vec2;
+    const bool gn = a.gn_part != nullptr;
+    double gs[4], gq[4];
+#pragma unroll
+    for (int b4 = 0; b4 < 4; ++b4) { gs[b4] = 0.0; gq[b4] = 0.0; }
+    {
+        const int cob = m0 + wm * 32 + 4 * lh;
+        float bv[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int co = cob + (rr & 3) + 8 * (rr >> 2);
+            bv[rr] = a.bias ? a.bias[co < d.Cout ? co : d.Cout - 1] : 0.0f;
+        }
+        const int n = tile0 + wn * 32 + l31;
+        const int rp = n >> (lgW - 1), tw = n & (TW - 1);
+        const bool pok = rp < RPtot;
+        int ob = 0, od = 0, hp = 0;
+        if (pok) split_rp(rp, ob, od, hp);
+        const int64_t yoff = ob * d.ys[0] + od * d.ys[2] + (2 * hp) * d.ys[3] + (2 * tw) * d.ys[4];
+        float r00[16], r01[16], r10[16], r11[16];
+        if (a.res) {
+            const int64_t roff = ob * d.rs[0] + od * d.rs[2] + (2 * hp) * d.rs[3] + (2 * tw) * d.rs[4];
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int co = cob + (rr & 3) + 8 * (rr >> 2);
+                const float* rp0_ = a.res + roff + (co < d.Cout ? co : d.Cout - 1) * d.rs[1];
+                const float* rp1_ = rp0_ + d.rs[3];
+                if (v2) {
+                    const float2 t0 = *reinterpret_cast<const float2*>(rp0_), t1 = *reinterpret_cast<const float2*>(rp1_);
+                    r00[rr] = t0.x; r01[rr] = t0.y; r10[rr] = t1.x; r11[rr] = t1.y;
+                } else { r00[rr] = rp0_[0]; r01[rr] = rp0_[d.rs[4]]; r10[rr] = rp1_[0]; r11[rr] = rp1_[d.rs[4]]; }
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) { r00[rr] = 0.0f; r01[rr] = 0.0f; r10[rr] = 0.0f; r11[rr] = 0.0f; }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int co = cob + (rr & 3) + 8 * (rr >> 2);
+            float t0[4], t1[4];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                const float M0 = acc[0 + xi][rr], M1 = acc[4 + xi][rr], M2 = acc[8 + xi][rr], M3 = acc[12 + xi][rr];
+                t0[xi] = (M0 + M1) + M2;
+                t1[xi] = (M1 - M2) - M3;
+            }
+            const float y00 = ((t0[0] + t0[1]) + t0[2]) + bv[rr] + r00[rr];
+            const float y01 = ((t0[1] - t0[2]) - t0[3]) + bv[rr] + r01[rr];
+            const float y10 = ((t1[0] + t1[1]) + t1[2]) + bv[rr] + r10[rr];
+            const float y11 = ((t1[1] - t1[2]) - t1[3]) + bv[rr] + r11[rr];
+            if (pok && co < d.Cout) {
+                float* yp = a.y + yoff + co * d.ys[1];
+                float* yq = yp + d.ys[3];
+                if (v2) {
+                    *reinterpret_cast<float2*>(yp) = make_float2(y00, y01);
+                    *reinterpret_cast<float2*>(yq) = make_float2(y10, y11);
+                } else { yp[0] = y00; yp[d.ys[4]] = y01; yq[0] = y10; yq[d.ys[4]] = y11; }
+                if (gn) {
+                    gs[rr >> 2] += ((double)y00 + (double)y01) + ((double)y10 + (double)y11);
+                    gq[rr >> 2] += ((double)y00 * y00 + (double)y01 * y01) + ((double)y10 * y10 + (double)y11 * y11);
+                }
+            }
+        }
+    }
+    if (gn) {
+        // same layout as wg_epilogue: scr[wave][4][2]; 8-row block t of the workgroup's 64 rows = (wm = t / 4, k = t % 4)
+        double* scr = reinterpret_cast<double*>(ldsw);
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4) {
+            const double s1 = sdc::wave_sum(gs[b4]), q1 = sdc::wave_sum(gq[b4]);
+            if (lane == 0) { scr[(wave * 4 + b4) * 2] = s1; scr[(wave * 4 + b4) * 2 + 1] = q1; }
+        }
+        __syncthreads();
+        const int ngl = a.gn_cpg >= BM ? 1 : BM / a.gn_cpg;       // groups inside this workgroup's rows
+        if (tid < ngl) {
+            const int r0 = a.gn_cpg >= BM ? 0 : tid * a.gn_cpg, r1 = a.gn_cpg >= BM ? BM : r0 + a.gn_cpg;   // local rows
+            double sum = 0.0, sq = 0.0;
+            for (int blk = r0 / 8; blk < r1 / 8; ++blk) {
+                const int wmi = blk >> 2, k = blk & 3;
+                for (int wni = 0; wni < 2; ++wni) {
+                    sum += scr[((wmi * 2 + wni) * 4 + k) * 2];
+                    sq += scr[((wmi * 2 + wni) * 4 + k) * 2 + 1];
+                }
+            }
+            if (m0 + r0 < d.Cout) {
+                const int g = (m0 + r0) / a.gn_cpg;
+                const int p0 = tile0 * 4;                          // first output position of the workgroup (whole row pairs)
+                const int b = p0 / a.gn_S, ntl = (p0 - b * a.gn_S) / (W2_TILES * 4);
+                const int idx = a.gn_cpg >= BM ? ntl * (a.gn_cpg / BM) + (m0 - g * a.gn_cpg) / BM : ntl;
+                double* pp = a.gn_part + (((int64_t)b * a.gn_G + g) * a.gn_nparts + idx) * 2;
+                pp[0] = sum; pp[1] = sq;
+            }
+        }
+    }
+}
+
+// coverage of the F(2x2,3x3) kernel (precision 3)
+bool wg2_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
+    const int64_t rptot = (int64_t)d.B * d.oD * (d.oH / 2);
+    return d.precision == 3 && rowhalo && small && d.kH == 3 && d.kW == 3 && (d.kD == 1 || d.kD == 3) &&
+           d.sD == 1 && d.sH == 1 && d.sW == 1 && d.uD == 1 && d.uH == 1 && d.uW == 1 && d.up_mode == 0 &&
+           d.pH == 1 && d.pW == 1 && d.pD == d.kD / 2 && d.oH == d.iH && d.oW == d.iW && d.oD == d.iD &&
+           (d.oW == 16 || d.oW == 32 || d.oW == 64 || d.oW == 128) && d.oH % 2 == 0 &&
+           d.Cin0 % W2_SK == 0 && d.Cin1 % W2_SK == 0 && d.Cout % 4 == 0 && d.Cout > 32 && rptot < (1 << 20) &&
+           ((int64_t)d.kD * 9 * (d.Cin0 + d.Cin1) * d.Cout) % 4 == 0;
+}
+
+void launch_wg2(const ConvArgs& a, hipStream_t s) {
+    const SdcConvDesc& d = a.d;
+    const int64_t tiles = (int64_t)d.B * d.oD * (d.oH / 2) * (d.oW / 2);
+    const int MT = (d.Cout + W2_BM - 1) / W2_BM;
+    dim3 grid((unsigned)(((tiles + W2_TILES - 1) / W2_TILES) * MT));
+    const size_t lds = (size_t)W2_NBUF * (W2_ASZ + W2_BSZ) * sizeof(float);
+    static std::atomic<uint64_t> attr{0};
+    if (sdc::first_use_on_device(attr))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wg2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(conv_wg2_kernel, grid, dim3(256), lds, s, a);
+}
+
 template <int BM, int BN, int WM, int WN, int SK, int NTH = 256, bool UPS = false>
 void launch_wg(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
@@ -1486,6 +1899,12 @@ thread_local bool tl_describe = false;
         if (tl_describe) return SDC_OK;      \
     } while (0)
 
+int ilog2_pow2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
 int ilog2_exact(int v) {
     if (v == 1) return 0;
     if (v == 2) return 1;
@@ -1527,7 +1946,7 @@ struct WgPick { int pick, bm, bn; bool ups; };
 WgPick wg_pick(const SdcConvDesc& d, int64_t ntot, bool small, bool rowhalo) {
     WgPick w{0, 0, 0, false};
     w.ups = (d.uH > 1 || d.uW > 1);      // nearest x2 upsampling folded into the gather: one input, kD = 1, kH <= 3
-    if (!(d.precision == 2 && rowhalo && d.kW == 3 && d.sW == 1 && d.uD == 1 && d.up_mode == 0 &&
+    if (!((d.precision == 2 || d.precision == 3) && rowhalo && d.kW == 3 && d.sW == 1 && d.uD == 1 && d.up_mode == 0 &&
           (!w.ups || (d.uH <= 2 && d.uW <= 2 && d.kD == 1 && d.kH <= 3 && d.sH == 1 && d.Cin1 == 0)) &&
           d.kD * d.kH <= 32 && d.Cin0 % 16 == 0 && d.Cin1 % 16 == 0 && small && d.Cout % 4 == 0 && d.Cout > 32 &&
           d.oW % 2 == 0 && d.oW >= 16 && ((int64_t)d.kD * d.kH * d.kW * (d.Cin0 + d.Cin1) * d.Cout) % 4 == 0))
@@ -1584,6 +2003,8 @@ extern "C" int sdc_conv_gnparts(const SdcConvDesc* dp, int G) {
     if (!dp) return 0;
     static const int no_rh = getenv("SDC_NO_ROWHALO") ? atoi(getenv("SDC_NO_ROWHALO")) : 0;
     const int64_t ntot = (int64_t)dp->B * dp->oD * dp->oH * dp->oW;
+    static const int no_wg2 = getenv("SDC_NO_WG2") ? atoi(getenv("SDC_NO_WG2")) : 0;
+    if (!no_wg2 && wg2_ok(*dp, conv_small(*dp), !no_rh)) return gn_parts_for(*dp, WgPick{20, W2_BM, W2_TILES * 4, false}, G);
     return gn_parts_for(*dp, wg_pick(*dp, ntot, conv_small(*dp), !no_rh), G);
 }
 
@@ -1617,8 +2038,8 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
     SDC_REQUIRE(d.Cin1 == 0 || x1, SDC_ENULL, "sdc_conv: Cin1 > 0 but x1 is null");
     SDC_REQUIRE(d.kD > 0 && d.kH > 0 && d.kW > 0 && d.sD > 0 && d.sH > 0 && d.sW > 0, SDC_EINVAL,
                 "sdc_conv: bad kernel/stride");
-    SDC_REQUIRE(d.precision >= 0 && d.precision <= 2, SDC_EINVAL, "sdc_conv: precision must be 0 (fp32 MFMA), 1 (split-bf16) or 2 (fp32 Winograd)");
-    SDC_REQUIRE(!gn_part || d.precision == 2, SDC_EINVAL, "sdc_conv_gn: fused GroupNorm statistics need precision 2 (sdc_conv_gnparts returned 0)");
+    SDC_REQUIRE(d.precision >= 0 && d.precision <= 3, SDC_EINVAL, "sdc_conv: precision must be 0 (fp32 MFMA), 1 (split-bf16), 2 (fp32 Winograd along W) or 3 (fp32 Winograd over H and W)");
+    SDC_REQUIRE(!gn_part || d.precision >= 2, SDC_EINVAL, "sdc_conv_gn: fused GroupNorm statistics need precision 2 or 3 (sdc_conv_gnparts returned 0)");
     ConvArgs a;
     a.d = d;
     a.lgD = ilog2_exact(d.uD); a.lgH = ilog2_exact(d.uH); a.lgW = ilog2_exact(d.uW);
@@ -1644,6 +2065,7 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
     static const int no_rh = getenv("SDC_NO_ROWHALO") ? atoi(getenv("SDC_NO_ROWHALO")) : 0;
     a.rowhalo = !no_rh;
     a.vec2 = 0;
+    a.wg2 = nullptr;
     a.gn_part = nullptr; a.gn_G = a.gn_cpg = a.gn_nparts = a.gn_S = 0;
     const bool fast = (d.Cin0 % BK == 0) && (d.Cin1 % BK == 0) && small && d.Cout < (1 << 30);
     hipStream_t s = sdc::as_stream(stream);
@@ -1663,10 +2085,26 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
         else { SDC_PICK("conv_bf3_kernel<64,128,2,2>", 1.0); launch_bf3<64, 128, 2, 2>(a, s); }
         return sdc::check_launch("sdc_conv[bf16x3]");
     }
+    auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
+    // fp32 Winograd F(2x2,3x3) over (H, W): 3x3 / 3x3x3 stride-1 convs over whole rows
+    static const int no_wg2 = getenv("SDC_NO_WG2") ? atoi(getenv("SDC_NO_WG2")) : 0;
+    if (!no_wg2 && wg2_ok(d, small, a.rowhalo != 0) && reinterpret_cast<uintptr_t>(wp) % 16 == 0) {
+        a.vec2 = even(d.ys) && reinterpret_cast<uintptr_t>(y) % 8 == 0 &&
+                 (!residual || (even(d.rs) && reinterpret_cast<uintptr_t>(residual) % 8 == 0));
+        a.wg2 = wp + (int64_t)a.Ktot * d.Cout + (int64_t)(a.Ktot / 3 * 4) * d.Cout;
+        a.lgW = ilog2_pow2(d.oW);
+        if (gn_part) {
+            a.gn_nparts = gn_parts_for(d, WgPick{20, W2_BM, W2_TILES * 4, false}, gn_G);
+            SDC_REQUIRE(a.gn_nparts > 0, SDC_EINVAL, "sdc_conv_gn: shape not covered by the fused statistics (sdc_conv_gnparts returned 0)");
+            a.gn_part = gn_part; a.gn_G = gn_G; a.gn_cpg = d.Cout / gn_G; a.gn_S = d.oD * d.oH * d.oW;
+        }
+        SDC_PICK("conv_wg2_kernel<64,64t,8>", 4.0 / 9.0);
+        launch_wg2(a, s);
+        return sdc::check_launch("sdc_conv[winograd 2x2]");
+    }
     // fp32 Winograd F(2,3) along W: 3-wide stride-1 taps, whole 16-channel chunks, even rows
     const WgPick wgp = wg_pick(d, ntot, small, a.rowhalo != 0);
     if (wgp.pick && reinterpret_cast<uintptr_t>(wp) % 16 == 0) {
-        auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
         a.vec2 = even(d.ys) && reinterpret_cast<uintptr_t>(y) % 8 == 0 &&
                  (!residual || (even(d.rs) && reinterpret_cast<uintptr_t>(residual) % 8 == 0));
         if (gn_part) {

@@ -61,7 +61,8 @@ class Plan:
     def __init__(self, device, precision=0):
         self.device = torch.device(device)
         self.lib = _lib.get_lib()
-        self.precision = int(precision)   # 0 direct fp32 MFMA | 1 split-bf16 conv | 2 fp32 Winograd F(2,3) along W (include/sdc.h)
+        self.precision = int(precision)   # 0 direct fp32 MFMA | 1 split-bf16 conv | 2 fp32 Winograd F(2,3) along W | 3 (default of the
+                                          # nets) fp32 Winograd F(2x2,3x3) over (H, W) where covered, else as 2 (include/sdc.h)
         self.calls = []          # (fn, args, keepalive)
         self.pool = Pool(self.device)
         self.keep = []           # descriptors / tensors that must outlive the plan
@@ -157,9 +158,10 @@ class Plan:
                     return wp.reshape(-1)
                 return torch.cat([wp.reshape(-1), hi.reshape(-1).view(torch.float32), lo.reshape(-1).view(torch.float32)])
             return self.packed(fn3)
-        if self.precision == 2:
+        if self.precision in (2, 3):
             # fp32 Wp followed by the Winograd F(2,3) taps along W, [(kd*kH + kh)*4 + xi][Cin][Cout]:
-            # G g with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], formed in fp64 and rounded once
+            # G g with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], formed in fp64 and rounded once;
+            # precision 3 appends, for 3x3 (kH = kW = 3) taps, the F(2x2,3x3) taps G g G^T over (H, W): [kd][j*4 + xi][Cin][Cout]
             def fnw():
                 wp = fn().to(torch.float32)
                 t = w() if callable(w) else w
@@ -168,7 +170,11 @@ class Plan:
                 t5 = as5(t).to(torch.float64)                 # (Cout, Cin, kD, kH, 3)
                 G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64, device=t5.device)
                 u = torch.einsum("xk,oidhk->dhxio", G, t5)    # (kD, kH, 4, Cin, Cout)
-                return torch.cat([wp.reshape(-1), u.reshape(-1).to(torch.float32)])
+                parts = [wp.reshape(-1), u.reshape(-1).to(torch.float32)]
+                if self.precision == 3 and t5.shape[3] == 3:
+                    u2 = torch.einsum("jh,xk,oidhk->djxio", G, G, t5)   # (kD, 4, 4, Cin, Cout)
+                    parts.append(u2.reshape(-1).to(torch.float32))
+                return torch.cat(parts)
             return self.packed(fnw)
         return self.packed(fn)
 
@@ -199,7 +205,8 @@ class Plan:
         nw = k[0] * k[1] * k[2] * (c0 + c1) * cout
         split = wp.dim() == 1 and wp.numel() == 2 * nw
         wino = wp.dim() == 1 and k[2] == 3 and wp.numel() == nw + nw // 3 * 4
-        assert split or wino or wp.numel() == nw, (wp.shape, k, c0, c1, cout)
+        wino2 = wp.dim() == 1 and k[1] == 3 and k[2] == 3 and wp.numel() == nw + nw // 3 * 4 + nw // 9 * 16
+        assert split or wino or wino2 or wp.numel() == nw, (wp.shape, k, c0, c1, cout)
         d = SdcConvDesc()
         d.B, d.Cin0, d.Cin1, d.Cout = B, c0, c1, cout
         d.iD, d.iH, d.iW = iD, iH, iW
@@ -208,7 +215,7 @@ class Plan:
         d.sD, d.sH, d.sW = stride
         d.pD, d.pH, d.pW = pad
         d.uD, d.uH, d.uW = up
-        d.up_mode, d.precision = up_mode, (1 if split else 2 if wino else 0)
+        d.up_mode, d.precision = up_mode, (1 if split else 3 if wino2 else 2 if wino else 0)
         d.x0s[:] = _s5(x)
         d.x1s[:] = _s5(x1) if x1 is not None else (0,) * 5
         d.ys[:] = _s5(out)

@@ -359,6 +359,77 @@ def test_conv_winograd_mode(plan_cls, case):
 
 
 @pytest.mark.parametrize("case", [
+    dict(nd=2, B=5, cin=64, cout=64, sp=(16, 128), G=1),                      # Burgers top level: one row pair per workgroup
+    dict(nd=2, B=3, cin=32, cout=128, sp=(8, 64), cin1=32, G=8),              # two inputs (skip concat), two m-tiles
+    dict(nd=2, B=7, cin=16, cout=96, sp=(4, 32), residual=True, G=0),         # ragged Cout (96 = 64 + 32), 4 row pairs per tile, partial last tile
+    dict(nd=2, B=3, cin=24, cout=64, sp=(6, 16), G=0),                        # 16-wide rows: 8 row pairs per tile, 3 pairs per image, Cin % 8 == 0 only
+    dict(nd=3, B=2, cin=64, cout=64, sp=(5, 8, 64), residual=True, G=8),      # 3x3x3: depth padding at both ends
+    dict(nd=3, B=1, cin=40, cout=256, sp=(3, 16, 32), cin1=24, G=8),          # 3x3x3, concat, 4 m-tiles
+    dict(nd=3, B=2, cin=32, cout=64, sp=(2, 2, 16), G=0),                     # one row pair per image
+])
+def test_conv_winograd_2d_mode(plan_cls, case):
+    """precision=3: fp32 Winograd F(2x2,3x3) over (H, W) (3x3 and 3x3x3 stride-1 convs over whole rows), against torch in
+    fp64 and beside the direct kernel (precision 0): still fp32 end to end, the error stays within a few fp32 ulps of the
+    output scale (gate 1e-5 of the output scale).  With G > 0 the GroupNorm statistics come out of its epilogue."""
+    from safediffcon_amd.engine import as5
+    nd, B, cin, cout, sp = case["nd"], case["B"], case["cin"], case["cout"], case["sp"]
+    cin1, G = case.get("cin1", 0), case["G"]
+    x, x1 = det_tensor((B, cin, *sp), 191), (det_tensor((B, cin1, *sp), 192) if cin1 else None)
+    w, b = det_tensor((cout, cin + cin1, *([3] * nd)), 193, 0.2), det_tensor((cout,), 194, 0.1)
+    xin = x if x1 is None else torch.cat((x, x1), 1)
+    ref = (F.conv2d, F.conv3d)[nd - 2](xin.double(), w.double(), b.double(), padding=1)
+    res = det_tensor(tuple(ref.shape), 195) if case.get("residual") else None
+    if res is not None:
+        ref = ref + res.double()
+    outs, names = {}, {}
+    for prec in (0, 3):
+        plan = plan_cls(DEV, precision=prec)
+        k3, p3 = (1,) * (3 - nd) + (3,) * nd, (0,) * (3 - nd) + (1,) * nd
+        out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, k3,
+                        x1=None if x1 is None else as5(x1.to(DEV)), pad=p3,
+                        residual=None if res is None else as5(res.to(DEV)), gn_groups=G if prec == 3 else 0)
+        d = plan.calls[0][1][0]._obj
+        buf = C.create_string_buffer(128)
+        assert plan.lib.sdc_conv_describe(C.byref(d), buf, 128, None) == 0
+        names[prec] = buf.value.decode()
+        if prec == 3 and G:
+            assert plan.calls[0][0] is plan.lib.sdc_conv_gn            # statistics fused into this kernel's epilogue
+            gam, bet = det_tensor((cout,), 196, 0.3) + 1.0, det_tensor((cout,), 197, 0.2)
+            y = plan.pool.get(tuple(out.shape))
+            plan.gn_silu(out, gam.to(DEV), bet.to(DEV), G, out=y)
+        _run(plan)
+        outs[prec] = out.cpu().reshape(ref.shape).double()
+        if prec == 3 and G:
+            refn = F.silu(F.group_norm(ref, G, gam.double(), bet.double(), 1e-5))
+            torch.testing.assert_close(y.cpu().reshape(ref.shape).double(), refn, rtol=1e-4, atol=2e-5)
+    assert names[3].startswith("conv_wg2_kernel") and not names[0].startswith("conv_wg")
+    scale = ref.abs().max().item()
+    e0 = (outs[0] - ref).abs().max().item() / scale
+    e3 = (outs[3] - ref).abs().max().item() / scale
+    print(f"[measured] rel err vs fp64: direct {e0:.2e}  winograd F(2x2,3x3) {e3:.2e}")
+    assert e0 < 4e-6 and e3 < 1e-5, (e0, e3)
+
+
+def test_conv_winograd_2d_falls_back_where_not_covered(plan_cls):
+    """precision 3 on shapes the F(2x2,3x3) kernel does not take: odd row counts, rows wider than 128 or not a power of
+    two, Conv1d -- run the F(2,3)-along-W or the direct kernel on the same weight buffer and stay correct."""
+    from safediffcon_amd.engine import as5
+    for nd, B, cin, cout, sp in ((2, 2, 32, 64, (5, 32)), (2, 1, 16, 64, (4, 48)), (1, 3, 48, 64, (128,)), (2, 2, 32, 64, (4, 256))):
+        x = det_tensor((B, cin, *sp), 201)
+        w, b = det_tensor((cout, cin, *([3] * nd)), 202, 0.2), det_tensor((cout,), 203, 0.1)
+        ref = (F.conv1d, F.conv2d)[nd - 1](x.double(), w.double(), b.double(), padding=1)
+        plan = plan_cls(DEV, precision=3)
+        out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, (1,) * (3 - nd) + (3,) * nd,
+                        pad=(0,) * (3 - nd) + (1,) * nd)
+        buf = C.create_string_buffer(128)
+        plan.lib.sdc_conv_describe(C.byref(plan.calls[0][1][0]._obj), buf, 128, None)
+        assert not buf.value.decode().startswith("conv_wg2")
+        _run(plan)
+        err = (out.cpu().reshape(ref.shape).double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 6e-6, (sp, buf.value, err)
+
+
+@pytest.mark.parametrize("case", [
     dict(B=6, cin=128, cout=64, sp=(8, 64), up=(2, 2)),        # Upsample2d: 16x128 out, Cout 64
     dict(B=40, cin=256, cout=128, sp=(4, 32), up=(2, 2)),      # 128-row tile
     dict(B=3, cin=64, cout=96, sp=(1, 64), up=(1, 2)),         # tokamak Upsample (1-D): kH = 1

@@ -76,3 +76,30 @@ def test_winograd_taps(plan):
                 torch.testing.assert_close(y1, (d[1:4] * gk).sum(), rtol=1e-5, atol=1e-6)
     # 1x1 weights carry no Winograd taps
     assert plan.conv_weight(torch.randn(4, 3, 1, 1, 1)).numel() == 12
+
+
+def test_winograd_2d_taps():
+    """precision 3: [Wp | Wg (along W) | Wg2 (over H and W)]: the 2x2 output tile from the 16 transformed products equals
+    the direct 3x3 correlation of the 4x4 patch, for every (kd, ci, co)."""
+    p3 = Plan("cpu", precision=3)
+    g = torch.Generator().manual_seed(3)
+    cin, cout, kD = 3, 4, 3
+    w = torch.randn(cout, cin, kD, 3, 3, generator=g)
+    buf = p3.conv_weight(w)
+    nw = kD * 9 * cin * cout
+    assert buf.numel() == nw + nw // 3 * 4 + nw // 9 * 16
+    u = buf[nw + nw // 3 * 4:].double().reshape(kD, 4, 4, cin, cout)            # (kd, j, xi, ci, co)
+    d = torch.randn(4, 4, generator=g, dtype=torch.float64)
+    Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+    At = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
+    V = Bt @ d @ Bt.t()
+    for kd in range(kD):
+        for ci in range(cin):
+            for co in range(cout):
+                Y = At @ (u[kd, :, :, ci, co] * V) @ At.t()
+                gk = w[co, ci, kd].double()
+                want = torch.stack([torch.stack([(d[a:a + 3, b:b + 3] * gk).sum() for b in range(2)]) for a in range(2)])
+                torch.testing.assert_close(Y, want, rtol=1e-5, atol=1e-6)
+    # taps that are not 3x3 over (H, W) keep the precision-2 layout (Conv1d k3: along W only)
+    w1 = torch.randn(4, 3, 1, 1, 3, generator=g)
+    assert p3.conv_weight(w1).numel() == 36 + 48

@@ -10,7 +10,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import safediffcon_amd as sdc  # noqa: E402
 from safediffcon_amd import _lib  # noqa: E402
-from bench import conv_flops, conv_instance  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import stages  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "burgers"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
@@ -26,7 +27,7 @@ elif which == "tokamak":
 else:
     net = sdc.Unet3D_with_Conv3D(dim=dim, dim_mults=(1, 2, 4), channels=7).to(dev)
     shape = (B, 32, 7, 64, 64)
-net.precision = int(os.environ.get('SDC_PRECISION', '0'))
+net.precision = int(os.environ.get('SDC_PRECISION', '3'))
 ent = net.entry(shape, B)
 net.bind_cond(ent, None)
 stream = torch.cuda.current_stream(dev).cuda_stream
@@ -48,6 +49,7 @@ for fn, args in ent["plan"].calls:
     tot[name] = tot.get(name, 0.0) + t
     if fn is lib.sdc_conv or fn is lib.sdc_conv_gn:
         d = args[0]._obj
-        print(f"{conv_instance(d):34s} {d.Cin0 + d.Cin1:5d} {d.Cout:5d} {d.kD}x{d.kH}x{d.kW:<3d} "
-              f"{d.oD}x{d.oH}x{d.oW:<6d} {t:8.4f} {conv_flops(d) / t / 1e9:7.1f}")
+        w = stages.classify(lib, fn, args)
+        print(f"{w['kernel']:38s} {d.Cin0 + d.Cin1:5d} {d.Cout:5d} {d.kD}x{d.kH}x{d.kW:<3d} "
+              f"{d.oD}x{d.oH}x{d.oW:<6d} {t:8.4f} {w['flops'] / t / 1e9:7.1f} (issued {w['issued'] / t / 1e9:6.1f})")
 print({k: round(v, 3) for k, v in tot.items()}, "sum", round(sum(tot.values()), 3))
