@@ -1441,21 +1441,28 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
 // precision = 3: fp32 Winograd F(2x2, 3x3) over (H, W) for the 3x3 (Conv2d) / 3x3x3 (Conv3d, direct along D) stride-1
 // convs: per 2x2 output tile and its 4x4 input patch d,  Y = A^T [ (G g G^T) . (B^T d B) ] A  with the same G, B^T, A^T as
 // the 1-D form above applied along H and along W -- 16 products per 4 outputs instead of 36: 4/9 of the direct fp32 MFMA
-// work (the 1-D form: 2/3).  The caller stores U[kd][j*4+xi][ci][co] = sum_{kh,kw} G[j][kh] G[xi][kw] w[co][ci][kd][kh][kw]
-// (fp64, rounded once) behind the 1-D taps.  16 GEMMs over K = kD*Cin with N = tiles:
+// work (the 1-D form: 2/3).  The caller stores U[kd][ci][co][j*4+xi] = sum_{kh,kw} G[j][kh] G[xi][kw] w[co][ci][kd][kh][kw]
+// (fp64, rounded once; the 16 components of one (ci, co) contiguous) behind the 1-D taps.  16 GEMMs over K = kD*Cin, N = tiles:
 //   * workgroup = 4 waves, ONE per SIMD (16 components x 32x32 accumulators = 256 registers per wave), 64 output
 //     channels x 64 tiles (= RP whole row pairs of W/2 tiles, 256 output positions); K stages of 8 channels.
 //   * B: every lane stages columns of the RP row pairs: the 4 input rows under a row pair are loaded, the H transform
-//     (d0-d2, d1+d2, d2-d1, d1-d3) is applied in registers and the 4 transformed rows go to LDS [k][row pair][j][W+2] (the two
+//     (d0-d2, d1+d2, d2-d1, d1-d3) is applied in registers and the 4 transformed rows go to LDS [k][j][row pair][W+2] (the two
 //     halo columns are the zero padding -- whole rows only, W in {16,32,64,128} -- written once).  The W transform is the
 //     same two-adds-per-fragment step as in the 1-D kernel, on ds_read_b64 pairs.
-//   * A: U tile [16][8][64] per stage with 16-byte loads, scalar base + fixed lane offset.
-//   * stage st+2 is fetched during the second half of stage st and parked in LDS during the first half of stage st+1.
-// Results differ from the direct form by rounding order (measured ~2e-6 of the output scale vs fp64; the 1-D form 6e-7).
+//   * A: U tile [8][64][16] per stage with 16-byte loads (scalar base + fixed lane offset), parked with one ds_write_b128
+//     and read back as four ds_read_b128 per k-step (16-byte chunks XOR-swizzled by (row >> 2) & 3: conflict-free).
+//   * LDS ring of three stage buffers, ONE barrier per stage; stage st+2 is fetched while stage st computes.
+// What decides this kernel's speed (measured by switching parts off, tools/wg_probe.py): the fp32 MFMA runs at the fp32
+// VALU rate and nothing a wave issues between two of its MFMAs is hidden behind them -- every LDS / VMEM / VALU / SALU
+// instruction of the loop adds its issue time.  So the loop is written for instruction COUNT: W is a template parameter
+// (all LDS and row offsets are immediates), the fetch addresses are scalar bases + lane offsets that never change, the
+// padding masks are skipped by whole waves whose rows are all inside the image.
+// Results differ from the direct form by rounding order (measured 2-6e-7 of the output scale vs fp64; direct form 1-2e-6).
 constexpr int W2_SK = 8;          // channels per stage
 constexpr int W2_BM = 64;         // output channels per workgroup
 constexpr int W2_TILES = 64;      // 2x2 tiles per workgroup
-constexpr int W2_KP = 640;        // LDS floats per staged k row (max over W of RP * rstride)
+constexpr int W2_JS = 144;        // LDS floats between the 4 transformed rows of a k row (>= RP * (W + 2))
+constexpr int W2_KP = 4 * W2_JS;  // LDS floats per staged k row
 constexpr int W2_NBUF = 3;        // LDS ring of stage buffers
 constexpr int W2_ASZ = 16 * W2_SK * W2_BM, W2_BSZ = W2_SK * W2_KP;
 
@@ -1464,15 +1471,18 @@ constexpr int W2_ASZ = 16 * W2_SK * W2_BM, W2_BSZ = W2_SK * W2_KP;
 __device__ __forceinline__ float vsub1(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vadd1(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-__host__ __device__ inline int w2_rstride(int oW) {      // floats per row-pair block: 4 rows x (W + 2), padded so that the row
-    return 4 * (oW + 2) + (oW == 32 ? 24 : (oW == 16 ? 8 : 0));   // pairs a 32-lane read spans fall on different banks
-}
-
+template <int OW, int DBG>
 __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     constexpr int SK = W2_SK, BM = W2_BM, NTH = 256;
+    constexpr int TW = OW / 2, RP = W2_TILES / TW, ROWP = OW + 2;
+    constexpr int LGW = OW == 128 ? 7 : (OW == 64 ? 6 : (OW == 32 ? 5 : 4));
+    static_assert(RP * ROWP <= W2_JS, "row block does not fit");
+    typedef float nfloat4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) char* gchar_p;
+    typedef const __attribute__((address_space(1))) nfloat4* gfloat4_p;
     extern __shared__ __attribute__((aligned(16))) float ldsw[];
-    float* const As = ldsw;                          // [3][16][SK][BM]
-    float* const Bs = ldsw + W2_NBUF * W2_ASZ;       // [3][SK][W2_KP]
+    float* const As = ldsw;                          // [3][SK][BM][16]  (chunk q of row m at slot q ^ ((m >> 2) & 3))
+    float* const Bs = ldsw + W2_NBUF * W2_ASZ;       // [3][SK][4][W2_JS]
 
     const SdcConvDesc& d = a.d;
     const int tid = threadIdx.x;
@@ -1485,12 +1495,9 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     const int lb = xcd_tile(blockIdx.x, gridDim.x);
     const int m0 = (lb % MT) * BM;
     const int tile0 = (lb / MT) * W2_TILES;
-    const int lgW = a.lgW;                     // log2(oW) (reused field: no upsampling here)
-    const int oW = d.oW, TW = oW >> 1, H2 = d.oH >> 1;
-    const int rowp = oW + 2;
-    const int rstride = w2_rstride(oW);
+    const int H2 = d.oH >> 1;
     const int RPtot = d.B * d.oD * H2;
-    const int rp0 = tile0 >> (lgW - 1);
+    const int rp0 = tile0 >> (LGW - 1);
     const bool two = d.Cin1 > 0;
     const float r_H2 = 1.0f / (float)H2, r_oD = 1.0f / (float)d.oD;
     auto split_rp = [&](int rp, int& ob, int& od, int& hp) {      // rp < 2^20 (host check): float quotients are exact
@@ -1500,130 +1507,125 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         od = q - ob * d.oD;
     };
 
-    // ---- gather state: this lane's two columns (lane, lane + 64) of the 128 staged columns
-    int v0[2], v1[2], ldw[2];
-    uint32_t msk[2];
+    // ---- gather state: this lane's two columns (lane, lane + 64) of the 128 staged columns.  Byte offset of (b, od, 2hp, col)
+    // inside one channel of x0 / x1 (>= 0 always); the depth-tap shift (kd - pD) planes is added once per stage, the row shift
+    // (j - 1) rows is an instruction immediate.
+    uint32_t vp0[2], vp1[2], msk[2];
+    int ldw[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int cidx = lane + 64 * t;
-        const int r = cidx >> lgW, col = cidx & (oW - 1);
+        const int r = cidx >> LGW, col = cidx & (OW - 1);
         const int rp = rp0 + r;
-        ldw[t] = r * rstride + 1 + col;
-        v0[t] = 0; v1[t] = 0; msk[t] = 0;
+        ldw[t] = r * ROWP + 1 + col;
+        vp0[t] = 0; vp1[t] = 0; msk[t] = 0;
         if (rp < RPtot) {
             int ob, od, hp;
             split_rp(rp, ob, od, hp);
-            const int id0 = od - d.pD, ih0 = 2 * hp - 1;
             uint32_t m = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) m |= (ih0 + j >= 0 && ih0 + j < d.iH) ? (1u << j) : 0u;
-            for (int kd = 0; kd < d.kD; ++kd) m |= (id0 + kd >= 0 && id0 + kd < d.iD) ? (16u << kd) : 0u;
+            for (int j = 0; j < 4; ++j) m |= (2 * hp - 1 + j >= 0 && 2 * hp - 1 + j < d.iH) ? (1u << j) : 0u;
+            for (int kd = 0; kd < d.kD; ++kd) m |= (od - d.pD + kd >= 0 && od - d.pD + kd < d.iD) ? (16u << kd) : 0u;
             msk[t] = m;
-            v0[t] = (int)(ob * d.x0s[0] + id0 * d.x0s[2] + ih0 * d.x0s[3] + col * d.x0s[4]);
-            if (two) v1[t] = (int)(ob * d.x1s[0] + id0 * d.x1s[2] + ih0 * d.x1s[3] + col * d.x1s[4]);
+            vp0[t] = (uint32_t)(ob * d.x0s[0] + od * d.x0s[2] + (2 * hp) * OW + col) * 4u;
+            if (two) vp1[t] = (uint32_t)(ob * d.x1s[0] + od * d.x1s[2] + (2 * hp) * OW + col) * 4u;
         }
     }
-    // this lane's tile inside the staged rows: (d0,d1) of transformed row j at boff + j*rowp, (d2,d3) 2 floats further
-    int boff;
-    {
-        const int n = wn * 32 + l31;
-        boff = (n >> (lgW - 1)) * rstride + 2 * (n & (TW - 1));
+    // whole-wave validity per depth tap: bit kd set = every element this wave fetches for that tap is inside the image
+    uint32_t wave_ok = 0;
+    for (int kd = 0; kd < d.kD; ++kd) {
+        const uint32_t need = 15u | (16u << kd);
+        const bool ok = (msk[0] & need) == need && (msk[1] & need) == need;
+        if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) wave_ok |= 1u << kd;
     }
-    // weight fetch: 8 float4 per thread per stage; lane part of the address fixed for the whole kernel
-    uint32_t a_voff[8];
-    bool a_ok[8];
+    wave_ok = SDC_UNIFORM(wave_ok);
+    // this lane's tile inside the staged rows (floats): (d0,d1) of transformed row j at boff + j*JS, (d2,d3) 2 floats further
+    const int nloc = wn * 32 + l31;
+    const int boff = lh * W2_KP + (nloc >> (LGW - 1)) * ROWP + 2 * (nloc & (TW - 1));
+    // A fragments: row (k = 2ks + lh, m): four 16-byte chunks, chunk q at slot q ^ ((m >> 2) & 3)
+    const int arow = wm * 32 + l31;
+    int aoff[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int f = tid + i * NTH;
-        const int c4 = (f & 15) * 4, row = f >> 4;             // row = comp * SK + kr
-        const int comp = row / SK, kr = row % SK;
-        a_ok[i] = (m0 + c4) < d.Cout;
-        a_voff[i] = (uint32_t)(((int64_t)(comp * a.Cin + kr) * d.Cout + (a_ok[i] ? (m0 + c4) : 0)) * 4);
-    }
+    for (int q = 0; q < 4; ++q) aoff[q] = (lh * BM + arow) * 16 + 4 * (q ^ ((arow >> 2) & 3));
+    // weight fetch / park: float4 f = tid + 256 i: k = i, m = tid >> 2, chunk = tid & 3
+    const int pm = tid >> 2, pq = tid & 3;
+    const int apark = pm * 16 + 4 * (pq ^ ((pm >> 2) & 3));                        // + i * BM * 16 floats
+    const int pmc = (m0 + pm) < d.Cout ? (m0 + pm) : d.Cout - 1;                   // rows beyond Cout: any valid row (never stored)
+    uint32_t a_voff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a_voff[i] = (uint32_t)(((int64_t)i * d.Cout + pmc) * 16 + 4 * pq) * 4u;
     // zero the halo columns of the three buffers once (never written again)
-    {
-        const int RP = W2_TILES / TW;
-        for (int e = tid; e < W2_NBUF * SK * RP * 4 * 2; e += NTH) {
-            const int side = e & 1, j = (e >> 1) & 3, rest = e >> 3;
-            const int r = rest % RP, kb = rest / RP;            // kb = buf * SK + k
-            Bs[kb * W2_KP + r * rstride + j * rowp + (side ? oW + 1 : 0)] = 0.0f;
-        }
+    for (int e = tid; e < W2_NBUF * SK * 4 * RP * 2; e += NTH) {
+        const int side = e & 1, r = (e >> 1) % RP, kj = (e >> 1) / RP;             // kj = (buf * SK + k) * 4 + j
+        Bs[kj * W2_JS + r * ROWP + (side ? OW + 1 : 0)] = 0.0f;
     }
 
     float breg[2][2][4];          // [k row of this wave][column t][source row j]
-    float4 areg[8];
+    nfloat4 areg[8];
     uint32_t mbits = 0;
     int s_kd = 0, s_ci = 0;
-    // loop-invariant descriptor fields as values (selecting between the x0 / x1 FIELDS inside the loop turns into pointer
-    // selects + scalar loads whose lgkmcnt waits also drain the LDS reads)
-    const int64_t xs1_0 = d.x0s[1], xs1_1 = d.x1s[1];
-    const int dsb_0 = (int)d.x0s[2] * 4, dsb_1 = (int)d.x1s[2] * 4, hsb_0 = (int)d.x0s[3] * 4, hsb_1 = (int)d.x1s[3] * 4;   // bytes
-    const int cin0 = d.Cin0, cin = a.Cin, kDn = d.kD, coutn = d.Cout;
+    const int64_t xs1_0 = d.x0s[1], xs1_1 = d.x1s[1], xs2_0 = d.x0s[2], xs2_1 = d.x1s[2];
+    const int cin0 = d.Cin0, cin = a.Cin, kDn = d.kD, coutn = d.Cout, pDn = d.pD;
     const float* const wg2p = a.wg2;
     const float* const x0p = a.x0;
     const float* const x1p = two ? a.x1 : a.x0;
-    const int vb00 = v0[0] * 4, vb01 = v0[1] * 4, vb10 = two ? v1[0] * 4 : 0, vb11 = two ? v1[1] * 4 : 0;   // byte offsets
-    const uint32_t mk0 = msk[0], mk1 = msk[1];
-    typedef const __attribute__((address_space(1))) char* gchar_p;
-    typedef float nfloat4 __attribute__((ext_vector_type(4)));
-    typedef const __attribute__((address_space(1))) nfloat4* gfloat4_p;
-    // stage fetch state (scalar part set by fetch_begin, lane offsets by fetch_offsets(t))
-    gfloat_p f_w = uniform_ptr(wg2p);
-    gfloat_p f_x0 = uniform_ptr(x0p), f_x1 = uniform_ptr(x0p);     // the two channel rows of this wave
-    int f_first = 1, f_kd = 0;
-    uint32_t l_off[2][4];
+    // stage fetch state: scalar bases (weights; the two channel rows of this wave), the lane offsets of the selected input
+    gfloat_p f_w = uniform_ptr(wg2p), f_x0 = uniform_ptr(x0p), f_x1 = uniform_ptr(x0p);
+    uint32_t voff[2] = {vp0[0], vp0[1]};
+    int f_fast = 0;
     auto fetch_begin = [&]() {
         const bool first = s_ci < cin0;
         const int64_t sc = first ? xs1_0 : xs1_1;
         const float* bsel = first ? x0p : x1p;
         const int cbase = (first ? s_ci : s_ci - cin0) + wave * 2;
+        const uint32_t dsb = (uint32_t)((s_kd - pDn) * (int)(first ? xs2_0 : xs2_1) * 4);   // bytes, two's complement
         f_x0 = uniform_ptr(bsel + (int64_t)cbase * sc);
         f_x1 = uniform_ptr(bsel + (int64_t)(cbase + 1) * sc);
-        f_w = uniform_ptr(wg2p + ((int64_t)(s_kd * 16) * cin + s_ci) * coutn);
-        f_first = first ? 1 : 0;
-        f_kd = s_kd;
+        f_w = uniform_ptr(wg2p + ((int64_t)(s_kd * cin + s_ci) * coutn) * 16);
+        f_fast = (wave_ok >> s_kd) & 1;
+        voff[0] = (first ? vp0[0] : vp1[0]) + dsb;       // (>= 0 as a whole wherever the element is inside the image)
+        voff[1] = (first ? vp0[1] : vp1[1]) + dsb;
+        // padding masks of the stage (only used by waves that touch the border)
+        const uint32_t j0 = ((msk[0] >> (4 + s_kd)) & 1u) ? (msk[0] & 15u) : 0u;
+        const uint32_t j1 = ((msk[1] >> (4 + s_kd)) & 1u) ? (msk[1] & 15u) : 0u;
+        mbits = j0 | (j1 << 4);
         s_ci += SK;
         // (past the last stage the walk wraps to the first one: the extra fetches of the pipeline tail stay in bounds and are
         // never consumed)
         if (s_ci >= cin) { s_ci = 0; if (++s_kd == kDn) s_kd = 0; }
     };
-    auto fetch_offsets = [&](int t) {
-        const uint32_t mm = t ? mk1 : mk0;
-        const uint32_t dok = (mm >> (4 + f_kd)) & 1u;
-        const uint32_t jm = dok ? (mm & 15u) : 0u;
-        mbits = t ? (mbits | (jm << 4)) : jm;
-        const int hsb = f_first ? hsb_0 : hsb_1;
-        const int o0 = (f_first ? (t ? vb01 : vb00) : (t ? vb11 : vb10)) + f_kd * (f_first ? dsb_0 : dsb_1);
-        const int o1 = o0 + hsb, o2 = o1 + hsb, o3 = o2 + hsb;
-        l_off[t][0] = (jm & 1u) ? (uint32_t)o0 : 0u;
-        l_off[t][1] = (jm & 2u) ? (uint32_t)o1 : 0u;
-        l_off[t][2] = (jm & 4u) ? (uint32_t)o2 : 0u;
-        l_off[t][3] = (jm & 8u) ? (uint32_t)o3 : 0u;
-    };
-    auto fetch_a = [&](int i, float4 (&ar)[8]) {
-        const nfloat4 wv = *(gfloat4_p)((gchar_p)f_w + a_voff[i]);
-        ar[i] = make_float4(wv.x, wv.y, wv.z, wv.w);
-    };
-    auto fetch_b = [&](int kr, int t, float (&br)[2][2][4]) {
-        const gfloat_p rb = kr ? f_x1 : f_x0;
+    auto fetch_a = [&](int i, nfloat4 (&ar)[8]) { ar[i] = *(gfloat4_p)((gchar_p)f_w + a_voff[i]); };
+    // rows j - 1 of the row pair: immediate byte offsets (j - 1) * OW * 4.  A lane whose element is outside the image reads
+    // the first element of the channel instead (in bounds) and is zeroed when parked.
+    auto fetch_b = [&](int kr, int t, float (&br)[2][2][4], bool fast, uint32_t mb) {
+        const gchar_p rb = (gchar_p)(kr ? f_x1 : f_x0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) br[kr][t][j] = ld_sv(rb, l_off[t][j]);
+        for (int j = 0; j < 4; ++j) {
+            if (fast) {
+                br[kr][t][j] = *(gfloat_p)(rb + voff[t] + (j - 1) * OW * 4);
+            } else {
+                const bool ok = (mb >> (t * 4 + j)) & 1u;
+                const uint32_t o = ok ? voff[t] + (uint32_t)((j - 1) * OW * 4) : 0u;
+                br[kr][t][j] = *(gfloat_p)(rb + o);
+            }
+        }
     };
-    // (weight rows beyond Cout read column 0 of the tile instead of zeros: they only feed output rows that are never stored)
-    auto park_a = [&](int buf, int i, const float4 (&ar)[8]) {
-        const int f = tid + i * NTH;
-        *reinterpret_cast<float4*>(As + buf * W2_ASZ + (f >> 4) * BM + (f & 15) * 4) = ar[i];
+    auto park_a = [&](int buf, int i, const nfloat4 (&ar)[8]) {
+        *reinterpret_cast<nfloat4*>(As + buf * W2_ASZ + i * (BM * 16) + apark) = ar[i];
     };
-    auto park_b = [&](int buf, int kr, int t, const float (&br)[2][2][4], uint32_t mb) {
-        const float d0 = ((mb >> (t * 4 + 0)) & 1u) ? br[kr][t][0] : 0.0f;
-        const float d1 = ((mb >> (t * 4 + 1)) & 1u) ? br[kr][t][1] : 0.0f;
-        const float d2 = ((mb >> (t * 4 + 2)) & 1u) ? br[kr][t][2] : 0.0f;
-        const float d3 = ((mb >> (t * 4 + 3)) & 1u) ? br[kr][t][3] : 0.0f;
+    auto park_b = [&](int buf, int kr, int t, const float (&br)[2][2][4], bool fast, uint32_t mb) {
+        float d0 = br[kr][t][0], d1 = br[kr][t][1], d2 = br[kr][t][2], d3 = br[kr][t][3];
+        if (!fast) {
+            d0 = ((mb >> (t * 4 + 0)) & 1u) ? d0 : 0.0f;
+            d1 = ((mb >> (t * 4 + 1)) & 1u) ? d1 : 0.0f;
+            d2 = ((mb >> (t * 4 + 2)) & 1u) ? d2 : 0.0f;
+            d3 = ((mb >> (t * 4 + 3)) & 1u) ? d3 : 0.0f;
+        }
         float* dst = Bs + buf * W2_BSZ + (wave * 2 + kr) * W2_KP + ldw[t];
         dst[0] = vsub1(d0, d2);
-        dst[rowp] = vadd1(d1, d2);
-        dst[2 * rowp] = vsub1(d2, d1);
-        dst[3 * rowp] = vsub1(d1, d3);
+        dst[W2_JS] = vadd1(d1, d2);
+        dst[2 * W2_JS] = vsub1(d2, d1);
+        dst[3 * W2_JS] = vsub1(d1, d3);
     };
 
     f32x16 acc[16];
@@ -1633,12 +1635,12 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
 
     const int nstages = d.kD * (a.Cin / SK);
-    const int am = wm * 32 + l31;
-    float fa[2][16];
+    nfloat4 fa[2][4];             // [set][chunk]: components 4q .. 4q+3 of this lane's (k, m)
     float2 fb[4][2];
     float bt[2][16];
+    auto read_a = [&](const float* Ak, int set, int q) { fa[set][q] = *reinterpret_cast<const nfloat4*>(Ak + aoff[q]); };
     auto read_b = [&](const float* Bk, int j) {                 // (d0,d1), (d2,d3) of transformed row j under this lane's tile
-        const float2* bp = reinterpret_cast<const float2*>(Bk + j * rowp);
+        const float2* bp = reinterpret_cast<const float2*>(Bk + boff + j * W2_JS);
         fb[j][0] = bp[0];
         fb[j][1] = bp[1];
     };
@@ -1649,40 +1651,34 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         bt[set][j * 4 + 2] = vsub1(p1.x, p0.y);
         bt[set][j * 4 + 3] = vsub1(p0.y, p1.y);
     };
+    int fast_park;                // the pieces still in registers were fetched on the no-mask path
     {   // prologue: the fetches of the first two stages travel together; stage 0 is parked in buffer 0
         float breg0[2][2][4];
-        float4 areg0[8];
+        nfloat4 areg0[8];
         fetch_begin();
-        fetch_offsets(0);
-        fetch_offsets(1);
         const uint32_t mbits0 = mbits;
 #pragma unroll
         for (int i = 0; i < 8; ++i) fetch_a(i, areg0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) fetch_b(q >> 1, q & 1, breg0);
+        for (int q = 0; q < 4; ++q) fetch_b(q >> 1, q & 1, breg0, false, mbits0);
         fetch_begin();
-        fetch_offsets(0);
-        fetch_offsets(1);
 #pragma unroll
         for (int i = 0; i < 8; ++i) fetch_a(i, areg);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) fetch_b(q >> 1, q & 1, breg);
+        for (int q = 0; q < 4; ++q) fetch_b(q >> 1, q & 1, breg, false, mbits);
+        fast_park = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) park_a(0, i, areg0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) park_b(0, q >> 1, q & 1, breg0, mbits0);
+        for (int q = 0; q < 4; ++q) park_b(0, q >> 1, q & 1, breg0, false, mbits0);
     }
     __syncthreads();
-    {
-        const float* A0 = As + lh * BM + am;
-        const float* B0 = Bs + lh * W2_KP + boff;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) fa[0][c] = A0[(c * SK) * BM];
+    for (int q = 0; q < 4; ++q) read_a(As, 0, q);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) read_b(B0, j);
+    for (int j = 0; j < 4; ++j) read_b(Bs, j);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) transform(0, j);
-    }
+    for (int j = 0; j < 4; ++j) transform(0, j);
 
     // Main loop.  LDS ring of three stage buffers and ONE barrier per stage, after the stage's parking stores (end of k-step 1):
     // stage st computes from buffer st % 3 and parks stage st+1 in buffer (st+1) % 3 during its k-steps 0-1, re-using each
@@ -1692,38 +1688,40 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     int rbuf = 0;
     for (int st = 0; st < nstages; ++st) {
         const int wbuf = rbuf == W2_NBUF - 1 ? 0 : rbuf + 1;
-        const float* Ab = As + rbuf * W2_ASZ + lh * BM + am;
-        const float* Bb = Bs + rbuf * W2_BSZ + lh * W2_KP + boff;
-        const float* An = As + wbuf * W2_ASZ + lh * BM + am;
-        const float* Bn = Bs + wbuf * W2_BSZ + lh * W2_KP + boff;
-        uint32_t mb_park = mbits;                                // masks of the pieces still in registers (stage st+1)
+        const float* Ab = As + rbuf * W2_ASZ;
+        const float* Bb = Bs + rbuf * W2_BSZ;
+        const float* An = As + wbuf * W2_ASZ;
+        const float* Bn = Bs + wbuf * W2_BSZ;
+        const uint32_t mb_park = mbits;                          // masks of the pieces still in registers (stage st+1)
+        const bool fpark = fast_park != 0;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int set = ks & 1, nset = set ^ 1;
-            const float* Ak = ks < 3 ? Ab + (2 * (ks + 1)) * BM : An;          // fragments of the next k-step
+            const float* Ak = ks < 3 ? Ab + (2 * (ks + 1)) * (BM * 16) : An;      // fragments of the next k-step
             const float* Bk = ks < 3 ? Bb + (2 * (ks + 1)) * W2_KP : Bn;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][c], bt[set][c], acc[c], 0, 0, 0);
-                // -- fragments of the next k-step: B rows first (their W transform closes the k-step), then the 16 A values
-                if (c < 4) read_b(Bk, c);
-                else if (c < 12) { fa[nset][2 * (c - 4)] = Ak[((2 * (c - 4)) * SK) * BM]; fa[nset][2 * (c - 4) + 1] = Ak[((2 * (c - 4) + 1) * SK) * BM]; }
-                else transform(nset, c - 12);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][c >> 2][c & 3], bt[set][c], acc[c], 0, 0, 0);
+                // -- fragments of the next k-step: B rows first (their W transform closes the k-step), then the A chunks
+                if (DBG & 2) {}
+                else if (c < 4) read_b(Bk, c);
+                else if (c >= 6 && c < 10) read_a(Ak, nset, c - 6);
+                else if (c >= 12) transform(nset, c - 12);
                 // -- staging: k-step p = 0, 1 parks piece p of stage st+1 and re-fetches it for stage st+2
-                if (ks < 2) {
+                if (ks < 2 && !(DBG & 1)) {
                     const int p = ks;
                     if (c < 4) park_a(wbuf, 2 * c + p, areg);
-                    else if (c == 4) park_b(wbuf, 0, p, breg, mb_park);
-                    else if (c == 5) park_b(wbuf, 1, p, breg, mb_park);
+                    else if (c == 4) { if (fpark) park_b(wbuf, 0, p, breg, true, 0); else park_b(wbuf, 0, p, breg, false, mb_park); }
+                    else if (c == 5) { if (fpark) park_b(wbuf, 1, p, breg, true, 0); else park_b(wbuf, 1, p, breg, false, mb_park); }
                     else if (c == 6) { if (p == 0) fetch_begin(); }
-                    else if (c == 7) fetch_offsets(p);
-                    else if (c < 12) fetch_a(2 * (c - 8) + p, areg);
-                    else if (c == 12) fetch_b(0, p, breg);
-                    else if (c == 13) fetch_b(1, p, breg);
+                    else if (c >= 8 && c < 12) fetch_a(2 * (c - 8) + p, areg);
+                    else if (c == 12) { if (f_fast) fetch_b(0, p, breg, true, 0); else fetch_b(0, p, breg, false, mbits); }
+                    else if (c == 13) { if (f_fast) fetch_b(1, p, breg, true, 0); else fetch_b(1, p, breg, false, mbits); }
+                    else if (c == 14 && p == 1) fast_park = f_fast;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (ks == 1) __syncthreads();
+            if (ks == 1 && !(DBG & 4)) __syncthreads();
         }
         rbuf = wbuf;
     }
@@ -1743,7 +1741,7 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
             bv[rr] = a.bias ? a.bias[co < d.Cout ? co : d.Cout - 1] : 0.0f;
         }
         const int n = tile0 + wn * 32 + l31;
-        const int rp = n >> (lgW - 1), tw = n & (TW - 1);
+        const int rp = n >> (LGW - 1), tw = n & (TW - 1);
         const bool pok = rp < RPtot;
         int ob = 0, od = 0, hp = 0;
         if (pok) split_rp(rp, ob, od, hp);
@@ -1833,7 +1831,9 @@ bool wg2_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
            d.pH == 1 && d.pW == 1 && d.pD == d.kD / 2 && d.oH == d.iH && d.oW == d.iW && d.oD == d.iD &&
            (d.oW == 16 || d.oW == 32 || d.oW == 64 || d.oW == 128) && d.oH % 2 == 0 &&
            d.Cin0 % W2_SK == 0 && d.Cin1 % W2_SK == 0 && d.Cout % 4 == 0 && d.Cout > 32 && rptot < (1 << 20) &&
-           ((int64_t)d.kD * 9 * (d.Cin0 + d.Cin1) * d.Cout) % 4 == 0;
+           ((int64_t)d.kD * 9 * (d.Cin0 + d.Cin1) * d.Cout) % 4 == 0 &&
+           // input rows contiguous (the row taps are instruction immediates)
+           d.x0s[4] == 1 && d.x0s[3] == d.iW && (d.Cin1 == 0 || (d.x1s[4] == 1 && d.x1s[3] == d.iW));
 }
 
 void launch_wg2(const ConvArgs& a, hipStream_t s) {
@@ -1842,10 +1842,23 @@ void launch_wg2(const ConvArgs& a, hipStream_t s) {
     const int MT = (d.Cout + W2_BM - 1) / W2_BM;
     dim3 grid((unsigned)(((tiles + W2_TILES - 1) / W2_TILES) * MT));
     const size_t lds = (size_t)W2_NBUF * (W2_ASZ + W2_BSZ) * sizeof(float);
-    static std::atomic<uint64_t> attr{0};
-    if (sdc::first_use_on_device(attr))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wg2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(conv_wg2_kernel, grid, dim3(256), lds, s, a);
+    static const int dbg = getenv("SDC_WG2_DBG") ? atoi(getenv("SDC_WG2_DBG")) : 0;     // kernel experiments: parts of the loop off
+#define W2_LAUNCH(OWV, D)                                                                                                        \
+    do {                                                                                                                         \
+        static std::atomic<uint64_t> attr{0};                                                                                    \
+        if (sdc::first_use_on_device(attr))                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wg2_kernel<OWV, D>),                                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
+        hipLaunchKernelGGL((conv_wg2_kernel<OWV, D>), grid, dim3(256), lds, s, a);                                               \
+    } while (0)
+    if (d.oW == 16 && dbg) {
+        if (dbg == 1) W2_LAUNCH(16, 1); else if (dbg == 2) W2_LAUNCH(16, 2); else W2_LAUNCH(16, 3);
+    } else if (d.oW == 64 && dbg) {
+        if (dbg == 1) W2_LAUNCH(64, 1); else if (dbg == 2) W2_LAUNCH(64, 2); else W2_LAUNCH(64, 3);
+    } else if (d.oW == 16) W2_LAUNCH(16, 0);
+    else if (d.oW == 32) W2_LAUNCH(32, 0);
+    else if (d.oW == 64) W2_LAUNCH(64, 0);
+    else W2_LAUNCH(128, 0);
 }
 
 template <int BM, int BN, int WM, int WN, int SK, int NTH = 256, bool UPS = false>

@@ -161,7 +161,7 @@ class Plan:
         if self.precision in (2, 3):
             # fp32 Wp followed by the Winograd F(2,3) taps along W, [(kd*kH + kh)*4 + xi][Cin][Cout]:
             # G g with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], formed in fp64 and rounded once;
-            # precision 3 appends, for 3x3 (kH = kW = 3) taps, the F(2x2,3x3) taps G g G^T over (H, W): [kd][j*4 + xi][Cin][Cout]
+            # precision 3 appends, for 3x3 (kH = kW = 3) taps, the F(2x2,3x3) taps G g G^T over (H, W): [kd][Cin][Cout][j*4 + xi]
             def fnw():
                 wp = fn().to(torch.float32)
                 t = w() if callable(w) else w
@@ -172,7 +172,7 @@ class Plan:
                 u = torch.einsum("xk,oidhk->dhxio", G, t5)    # (kD, kH, 4, Cin, Cout)
                 parts = [wp.reshape(-1), u.reshape(-1).to(torch.float32)]
                 if self.precision == 3 and t5.shape[3] == 3:
-                    u2 = torch.einsum("jh,xk,oidhk->djxio", G, G, t5)   # (kD, 4, 4, Cin, Cout)
+                    u2 = torch.einsum("jh,xk,oidhk->diojx", G, G, t5)   # (kD, Cin, Cout, 4, 4): 16 components contiguous
                     parts.append(u2.reshape(-1).to(torch.float32))
                 return torch.cat(parts)
             return self.packed(fnw)

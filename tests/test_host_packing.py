@@ -88,7 +88,7 @@ def test_winograd_2d_taps():
     buf = p3.conv_weight(w)
     nw = kD * 9 * cin * cout
     assert buf.numel() == nw + nw // 3 * 4 + nw // 9 * 16
-    u = buf[nw + nw // 3 * 4:].double().reshape(kD, 4, 4, cin, cout)            # (kd, j, xi, ci, co)
+    u = buf[nw + nw // 3 * 4:].double().reshape(kD, cin, cout, 4, 4).permute(0, 3, 4, 1, 2)      # stored (kd, ci, co, j, xi)
     d = torch.randn(4, 4, generator=g, dtype=torch.float64)
     Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
     At = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
