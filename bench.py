@@ -62,7 +62,7 @@ def launch_workers(n, argv):
 
 
 # --------------------------------------------------------------------------- workloads
-def workload(name, dim, B, dev, rank, world, precision=2):
+def workload(name, dim, B, dev, rank, world, precision=3):
     """-> dict(desc, gd, prep() -> _Loop, conformal=dict(Q, n_cal, alpha, ms), calib(...) -> calibration-mode _Loop)"""
     import torch
     import safediffcon_amd as sdc
@@ -366,7 +366,7 @@ def worker(a):
     lib = _lib.get_lib()
     wl = "c4" if a.workload == "c5" else a.workload
     B = a.batch or DEFAULT_B[wl]
-    prec = {"fp32": 2, "fp32-direct": 0, "split-bf16": 1}[a.precision]
+    prec = {"fp32": 3, "fp32-wino1d": 2, "fp32-direct": 0, "split-bf16": 1}[a.precision]
     side = torch.cuda.Stream(device=dev)
 
     def timed(S, warmup, steps):
@@ -538,9 +538,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: 256 / 128 / 64 for c2 / c3 / c4)")
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-direct", "split-bf16"],
-                    help="conv arithmetic: fp32 MFMA with Winograd on the 3-tap convs (default), fp32 direct form everywhere, or "
-                         "the opt-in 3-pass split-bf16 MFMA")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-wino1d", "fp32-direct", "split-bf16"],
+                    help="conv arithmetic: fp32 MFMA with Winograd F(2x2,3x3) / F(2,3) on the 3-tap convs (default), F(2,3) along W "
+                         "only, fp32 direct form everywhere, or the opt-in 3-pass split-bf16 MFMA")
     ap.add_argument("--no-extra", action="store_true", help="skip the calibration sample and the other workloads at N=1")
     ap.add_argument("--extra-workloads", default="c2,c3", help="other configs reported under `extra` at N=1")
     ap.add_argument("--extra-steps", type=int, default=20)

@@ -1445,44 +1445,62 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
 // (fp64, rounded once; the 16 components of one (ci, co) contiguous) behind the 1-D taps.  16 GEMMs over K = kD*Cin, N = tiles:
 //   * workgroup = 4 waves, ONE per SIMD (16 components x 32x32 accumulators = 256 registers per wave), 64 output
 //     channels x 64 tiles (= RP whole row pairs of W/2 tiles, 256 output positions); K stages of 8 channels.
-//   * B: every lane stages columns of the RP row pairs: the 4 input rows under a row pair are loaded, the H transform
-//     (d0-d2, d1+d2, d2-d1, d1-d3) is applied in registers and the 4 transformed rows go to LDS [k][j][row pair][W+2] (the two
-//     halo columns are the zero padding -- whole rows only, W in {16,32,64,128} -- written once).  The W transform is the
-//     same two-adds-per-fragment step as in the 1-D kernel, on ds_read_b64 pairs.
+//   * What decides the speed (tools/mfma_fill.hip, tools/wg_probe.py with parts of the loop switched off): the fp32 MFMA runs
+//     at the fp32 VALU rate and a VALU instruction issued between two MFMAs of the wave is NOT hidden behind them (~7-11
+//     cycles each, a global load ~14); ds_read_b128 / ds_write_b32 are nearly free up to two per MFMA, SALU is free.  So
+//     the loop is built to need few VALU and VMEM instructions per MFMA:
+//   * B: the whole input transform V = B^T d B happens ONCE per workgroup, when a stage is parked in LDS -- not per wave at
+//     fragment-read time.  A lane owns CPL adjacent columns of one row pair (CPL = W/16, so a 16-lane DPP row is one image
+//     row; W = 16: two rows interleaved): it loads the 4 input rows with one vector load each, applies the H transform in
+//     registers, then the W transform with the neighbour columns taken through DPP row shifts (bound_ctrl supplies the zero
+//     padding at the row ends), and stores V[k][j][tile][xi] with ds_write_b128.  A wave then reads its B fragments with four
+//     ds_read_b128 per k-step and feeds them to the MFMAs as they are.
 //   * A: U tile [8][64][16] per stage with 16-byte loads (scalar base + fixed lane offset), parked with one ds_write_b128
 //     and read back as four ds_read_b128 per k-step (16-byte chunks XOR-swizzled by (row >> 2) & 3: conflict-free).
-//   * LDS ring of three stage buffers, ONE barrier per stage; stage st+2 is fetched while stage st computes.
-// What decides this kernel's speed (measured by switching parts off, tools/wg_probe.py): the fp32 MFMA runs at the fp32
-// VALU rate and nothing a wave issues between two of its MFMAs is hidden behind them -- every LDS / VMEM / VALU / SALU
-// instruction of the loop adds its issue time.  So the loop is written for instruction COUNT: W is a template parameter
-// (all LDS and row offsets are immediates), the fetch addresses are scalar bases + lane offsets that never change, the
-// padding masks are skipped by whole waves whose rows are all inside the image.
+//   * two LDS stage buffers, ONE barrier per stage (end of k-step 2: every park of stage st+1 is done and every read of the
+//     buffer that stage st+2's parks will overwrite has returned); stage st+2 is fetched while stage st computes; the last
+//     k-step of a stage already reads the first fragments of the next one.
+//   * all LDS offsets and the row taps are immediates (W is a template parameter, input rows contiguous); the padding masks
+//     are skipped by whole waves whose rows are all inside the image.
 // Results differ from the direct form by rounding order (measured 2-6e-7 of the output scale vs fp64; direct form 1-2e-6).
 constexpr int W2_SK = 8;          // channels per stage
 constexpr int W2_BM = 64;         // output channels per workgroup
 constexpr int W2_TILES = 64;      // 2x2 tiles per workgroup
-constexpr int W2_JS = 144;        // LDS floats between the 4 transformed rows of a k row (>= RP * (W + 2))
-constexpr int W2_KP = 4 * W2_JS;  // LDS floats per staged k row
-constexpr int W2_NBUF = 3;        // LDS ring of stage buffers
-constexpr int W2_ASZ = 16 * W2_SK * W2_BM, W2_BSZ = W2_SK * W2_KP;
+constexpr int W2_NBUF = 2;        // LDS stage buffers
+constexpr int W2_ASZ = 16 * W2_SK * W2_BM, W2_BSZ = 16 * W2_SK * W2_TILES;    // floats per stage: U tile, V tile
 
-// single fp32 VALU ops the SLP vectoriser cannot pack: v_pk_add_f32 beside MFMAs is slower than two v_add_f32, and packing
-// the transforms made the compiler shuffle freshly read LDS values through copies (an lgkmcnt(0) stall per fragment row)
+// single fp32 VALU ops the SLP vectoriser cannot pack (v_pk_add_f32 beside MFMAs is slower than two v_add_f32)
 __device__ __forceinline__ float vsub1(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vadd1(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// value of lane - S / lane + S of the same 16-lane row, 0 past the row ends
+template <int S>
+__device__ __forceinline__ float dpp_prev(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + S, 0xF, 0xF, true));   // row_shr:S
+}
+template <int S>
+__device__ __forceinline__ float dpp_next(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + S, 0xF, 0xF, true));   // row_shl:S
+}
 
 template <int OW, int DBG>
 __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     constexpr int SK = W2_SK, BM = W2_BM, NTH = 256;
-    constexpr int TW = OW / 2, RP = W2_TILES / TW, ROWP = OW + 2;
+    constexpr int TW = OW / 2, RP = W2_TILES / TW;
     constexpr int LGW = OW == 128 ? 7 : (OW == 64 ? 6 : (OW == 32 ? 5 : 4));
-    static_assert(RP * ROWP <= W2_JS, "row block does not fit");
+    constexpr int CPL = OW == 16 ? 2 : OW / 16;          // adjacent columns per lane
+    constexpr int SH = OW == 16 ? 2 : 1;                 // DPP lane distance of the neighbouring column group
+    constexpr int LPK = 128 / CPL;                       // lanes per staged channel (k row)
+    constexpr int NIT = CPL == 2 ? 2 : 1;                // park items per thread and stage
+    constexpr int KPW = CPL == 8 ? 4 : 2;                // k rows per (parking) wave
+    constexpr int TPL = CPL / 2;                         // tiles per lane and row pair
     typedef float nfloat4 __attribute__((ext_vector_type(4)));
+    typedef float nfloat2 __attribute__((ext_vector_type(2)));
     typedef const __attribute__((address_space(1))) char* gchar_p;
     typedef const __attribute__((address_space(1))) nfloat4* gfloat4_p;
+    typedef const __attribute__((address_space(1))) nfloat2* gfloat2_p;
     extern __shared__ __attribute__((aligned(16))) float ldsw[];
-    float* const As = ldsw;                          // [3][SK][BM][16]  (chunk q of row m at slot q ^ ((m >> 2) & 3))
-    float* const Bs = ldsw + W2_NBUF * W2_ASZ;       // [3][SK][4][W2_JS]
+    float* const As = ldsw;                          // [2][SK][BM][16]  (chunk q of row m at slot q ^ ((m >> 2) & 3))
+    float* const Vs = ldsw + W2_NBUF * W2_ASZ;       // [2][SK][4 j][64 tiles][4 xi]
 
     const SdcConvDesc& d = a.d;
     const int tid = threadIdx.x;
@@ -1507,41 +1525,39 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         od = q - ob * d.oD;
     };
 
-    // ---- gather state: this lane's two columns (lane, lane + 64) of the 128 staged columns.  Byte offset of (b, od, 2hp, col)
-    // inside one channel of x0 / x1 (>= 0 always); the depth-tap shift (kd - pD) planes is added once per stage, the row shift
-    // (j - 1) rows is an instruction immediate.
-    uint32_t vp0[2], vp1[2], msk[2];
-    int ldw[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int cidx = lane + 64 * t;
-        const int r = cidx >> LGW, col = cidx & (OW - 1);
-        const int rp = rp0 + r;
-        ldw[t] = r * ROWP + 1 + col;
-        vp0[t] = 0; vp1[t] = 0; msk[t] = 0;
-        if (rp < RPtot) {
+    // ---- park geometry of this thread: k row inside the stage, row pair r, first column c0 (CPL columns c0 .. c0+CPL-1)
+    const bool parker = CPL != 8 || wave < 2;                      // W = 128: 128 items per stage, waves 0 and 1 park
+    const int ksub = CPL == 4 ? (lane >> 5) : (CPL == 8 ? (lane >> 4) : 0);        // k row inside the wave's group (CPL = 2: the item)
+    const int lik = lane & (LPK - 1);
+    int pr, pc0;
+    if (OW == 16) { pr = 2 * (lik >> 4) + (lik & 1); pc0 = 2 * ((lik & 15) >> 1); }
+    else { pr = lik >> 4; pc0 = (lik & 15) * CPL; }
+    // byte offset of (b, od, 2hp, c0) inside one channel of x0 / x1 plus this lane's k-row offset; the depth-tap shift
+    // (kd - pD) planes is added once per stage, the row shift (j - 1) rows is an instruction immediate
+    uint32_t vp0 = 0, vp1 = 0, msk = 0;
+    {
+        const int rp = rp0 + pr;
+        if (parker && rp < RPtot) {
             int ob, od, hp;
             split_rp(rp, ob, od, hp);
-            uint32_t m = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) m |= (2 * hp - 1 + j >= 0 && 2 * hp - 1 + j < d.iH) ? (1u << j) : 0u;
-            for (int kd = 0; kd < d.kD; ++kd) m |= (od - d.pD + kd >= 0 && od - d.pD + kd < d.iD) ? (16u << kd) : 0u;
-            msk[t] = m;
-            vp0[t] = (uint32_t)(ob * d.x0s[0] + od * d.x0s[2] + (2 * hp) * OW + col) * 4u;
-            if (two) vp1[t] = (uint32_t)(ob * d.x1s[0] + od * d.x1s[2] + (2 * hp) * OW + col) * 4u;
+            for (int j = 0; j < 4; ++j) msk |= (2 * hp - 1 + j >= 0 && 2 * hp - 1 + j < d.iH) ? (1u << j) : 0u;
+            for (int kd = 0; kd < d.kD; ++kd) msk |= (od - d.pD + kd >= 0 && od - d.pD + kd < d.iD) ? (16u << kd) : 0u;
+            vp0 = (uint32_t)(ksub * d.x0s[1] + ob * d.x0s[0] + od * d.x0s[2] + (2 * hp) * OW + pc0) * 4u;
+            if (two) vp1 = (uint32_t)(ksub * d.x1s[1] + ob * d.x1s[0] + od * d.x1s[2] + (2 * hp) * OW + pc0) * 4u;
         }
     }
     // whole-wave validity per depth tap: bit kd set = every element this wave fetches for that tap is inside the image
     uint32_t wave_ok = 0;
     for (int kd = 0; kd < d.kD; ++kd) {
         const uint32_t need = 15u | (16u << kd);
-        const bool ok = (msk[0] & need) == need && (msk[1] & need) == need;
-        if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) wave_ok |= 1u << kd;
+        if (__builtin_amdgcn_ballot_w64((msk & need) == need) == ~0ull) wave_ok |= 1u << kd;
     }
     wave_ok = SDC_UNIFORM(wave_ok);
-    // this lane's tile inside the staged rows (floats): (d0,d1) of transformed row j at boff + j*JS, (d2,d3) 2 floats further
-    const int nloc = wn * 32 + l31;
-    const int boff = lh * W2_KP + (nloc >> (LGW - 1)) * ROWP + 2 * (nloc & (TW - 1));
+    // park position: V[k][j][tile][4]; k = wave * KPW + ksub (+ item for CPL = 2), tile = pr * TW + c0 / 2 (+ t)
+    const int vpark = ((wave * KPW + ksub) * 4 * W2_TILES + pr * TW + (pc0 >> 1)) * 4;          // floats; + j * 256, + item * 1024
+    // B fragments: tile n = wn * 32 + l31 of k row 2ks + lh: four 16-byte reads (j = 0..3)
+    const int boff = (lh * 4 * W2_TILES + wn * 32 + l31) * 4;
     // A fragments: row (k = 2ks + lh, m): four 16-byte chunks, chunk q at slot q ^ ((m >> 2) & 3)
     const int arow = wm * 32 + l31;
     int aoff[4];
@@ -1554,78 +1570,95 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     uint32_t a_voff[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) a_voff[i] = (uint32_t)(((int64_t)i * d.Cout + pmc) * 16 + 4 * pq) * 4u;
-    // zero the halo columns of the three buffers once (never written again)
-    for (int e = tid; e < W2_NBUF * SK * 4 * RP * 2; e += NTH) {
-        const int side = e & 1, r = (e >> 1) % RP, kj = (e >> 1) / RP;             // kj = (buf * SK + k) * 4 + j
-        Bs[kj * W2_JS + r * ROWP + (side ? OW + 1 : 0)] = 0.0f;
-    }
 
-    float breg[2][2][4];          // [k row of this wave][column t][source row j]
+    float braw[NIT][4][CPL];      // [item][source row j][column]
     nfloat4 areg[8];
-    uint32_t mbits = 0;
     int s_kd = 0, s_ci = 0;
-    const int64_t xs1_0 = d.x0s[1], xs1_1 = d.x1s[1], xs2_0 = d.x0s[2], xs2_1 = d.x1s[2];
+    const int64_t xs1_0 = d.x0s[1], xs1_1 = d.x1s[1];
+    const int xs2_0 = (int)d.x0s[2], xs2_1 = (int)d.x1s[2];
     const int cin0 = d.Cin0, cin = a.Cin, kDn = d.kD, coutn = d.Cout, pDn = d.pD;
     const float* const wg2p = a.wg2;
     const float* const x0p = a.x0;
     const float* const x1p = two ? a.x1 : a.x0;
-    // stage fetch state: scalar bases (weights; the two channel rows of this wave), the lane offsets of the selected input
-    gfloat_p f_w = uniform_ptr(wg2p), f_x0 = uniform_ptr(x0p), f_x1 = uniform_ptr(x0p);
-    uint32_t voff[2] = {vp0[0], vp0[1]};
+    // stage fetch state: scalar bases (weights; the first channel row of this wave), the lane offset of the selected input
+    gfloat_p f_w = uniform_ptr(wg2p), f_x = uniform_ptr(x0p);
+    int64_t f_sc = 0;
+    uint32_t voff = 0, jmask = 0;
     int f_fast = 0;
     auto fetch_begin = [&]() {
         const bool first = s_ci < cin0;
-        const int64_t sc = first ? xs1_0 : xs1_1;
+        f_sc = first ? xs1_0 : xs1_1;
         const float* bsel = first ? x0p : x1p;
-        const int cbase = (first ? s_ci : s_ci - cin0) + wave * 2;
-        const uint32_t dsb = (uint32_t)((s_kd - pDn) * (int)(first ? xs2_0 : xs2_1) * 4);   // bytes, two's complement
-        f_x0 = uniform_ptr(bsel + (int64_t)cbase * sc);
-        f_x1 = uniform_ptr(bsel + (int64_t)(cbase + 1) * sc);
+        const int cbase = (first ? s_ci : s_ci - cin0) + wave * KPW;
+        const uint32_t dsb = (uint32_t)((s_kd - pDn) * (first ? xs2_0 : xs2_1) * 4);   // bytes, two's complement
+        f_x = uniform_ptr(bsel + (int64_t)cbase * f_sc);
         f_w = uniform_ptr(wg2p + ((int64_t)(s_kd * cin + s_ci) * coutn) * 16);
         f_fast = (wave_ok >> s_kd) & 1;
-        voff[0] = (first ? vp0[0] : vp1[0]) + dsb;       // (>= 0 as a whole wherever the element is inside the image)
-        voff[1] = (first ? vp0[1] : vp1[1]) + dsb;
-        // padding masks of the stage (only used by waves that touch the border)
-        const uint32_t j0 = ((msk[0] >> (4 + s_kd)) & 1u) ? (msk[0] & 15u) : 0u;
-        const uint32_t j1 = ((msk[1] >> (4 + s_kd)) & 1u) ? (msk[1] & 15u) : 0u;
-        mbits = j0 | (j1 << 4);
+        voff = (first ? vp0 : vp1) + dsb;                 // (>= 0 as a whole wherever the element is inside the image)
+        jmask = ((msk >> (4 + s_kd)) & 1u) ? (msk & 15u) : 0u;      // rows of the stage inside the image (border waves only)
         s_ci += SK;
         // (past the last stage the walk wraps to the first one: the extra fetches of the pipeline tail stay in bounds and are
         // never consumed)
         if (s_ci >= cin) { s_ci = 0; if (++s_kd == kDn) s_kd = 0; }
     };
     auto fetch_a = [&](int i, nfloat4 (&ar)[8]) { ar[i] = *(gfloat4_p)((gchar_p)f_w + a_voff[i]); };
-    // rows j - 1 of the row pair: immediate byte offsets (j - 1) * OW * 4.  A lane whose element is outside the image reads
-    // the first element of the channel instead (in bounds) and is zeroed when parked.
-    auto fetch_b = [&](int kr, int t, float (&br)[2][2][4], bool fast, uint32_t mb) {
-        const gchar_p rb = (gchar_p)(kr ? f_x1 : f_x0);
+    // the 4 input rows under the row pair, CPL adjacent columns each: one vector load per row, row tap (j - 1) as an immediate.
+    // A lane whose row is outside the image reads the first elements of the channel instead and is zeroed when parked.
+    auto fetch_b = [&](int it, float (&br)[NIT][4][CPL], bool fast, uint32_t jm) {
+        const gchar_p rb = (gchar_p)f_x + (CPL == 2 ? (int64_t)it * f_sc * 4 : 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (fast) {
-                br[kr][t][j] = *(gfloat_p)(rb + voff[t] + (j - 1) * OW * 4);
-            } else {
-                const bool ok = (mb >> (t * 4 + j)) & 1u;
-                const uint32_t o = ok ? voff[t] + (uint32_t)((j - 1) * OW * 4) : 0u;
-                br[kr][t][j] = *(gfloat_p)(rb + o);
+            const uint32_t o = (fast || ((jm >> j) & 1u)) ? voff + (uint32_t)((j - 1) * OW * 4) : 0u;
+            const gchar_p p = fast ? rb + voff + (j - 1) * OW * 4 : rb + o;
+            if (CPL == 2) { const nfloat2 v = *(gfloat2_p)p; br[it][j][0] = v.x; br[it][j][1] = v.y; }
+            else {
+#pragma unroll
+                for (int h = 0; h < CPL / 4; ++h) {
+                    const nfloat4 v = *(gfloat4_p)(p + 16 * h);
+                    br[it][j][4 * h + 0] = v.x; br[it][j][4 * h + 1] = v.y; br[it][j][4 * h + 2] = v.z; br[it][j][4 * h + 3] = v.w;
+                }
             }
         }
     };
     auto park_a = [&](int buf, int i, const nfloat4 (&ar)[8]) {
         *reinterpret_cast<nfloat4*>(As + buf * W2_ASZ + i * (BM * 16) + apark) = ar[i];
     };
-    auto park_b = [&](int buf, int kr, int t, const float (&br)[2][2][4], bool fast, uint32_t mb) {
-        float d0 = br[kr][t][0], d1 = br[kr][t][1], d2 = br[kr][t][2], d3 = br[kr][t][3];
-        if (!fast) {
-            d0 = ((mb >> (t * 4 + 0)) & 1u) ? d0 : 0.0f;
-            d1 = ((mb >> (t * 4 + 1)) & 1u) ? d1 : 0.0f;
-            d2 = ((mb >> (t * 4 + 2)) & 1u) ? d2 : 0.0f;
-            d3 = ((mb >> (t * 4 + 3)) & 1u) ? d3 : 0.0f;
+    // input transform of one item and its 4 * TPL stores: H transform per column, then per transformed row the W transform
+    // with the left / right neighbour columns through DPP
+    auto park_b = [&](int buf, int it, const float (&br)[NIT][4][CPL], bool fast, uint32_t jm) {
+        float hrow[4][CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            float d0 = br[it][0][c], d1 = br[it][1][c], d2 = br[it][2][c], d3 = br[it][3][c];
+            if (!fast) {
+                d0 = (jm & 1u) ? d0 : 0.0f;
+                d1 = (jm & 2u) ? d1 : 0.0f;
+                d2 = (jm & 4u) ? d2 : 0.0f;
+                d3 = (jm & 8u) ? d3 : 0.0f;
+            }
+            hrow[0][c] = vsub1(d0, d2);
+            hrow[1][c] = vadd1(d1, d2);
+            hrow[2][c] = vsub1(d2, d1);
+            hrow[3][c] = vsub1(d1, d3);
         }
-        float* dst = Bs + buf * W2_BSZ + (wave * 2 + kr) * W2_KP + ldw[t];
-        dst[0] = vsub1(d0, d2);
-        dst[W2_JS] = vadd1(d1, d2);
-        dst[2 * W2_JS] = vsub1(d2, d1);
-        dst[3 * W2_JS] = vsub1(d1, d3);
+        float* dst = Vs + buf * W2_BSZ + vpark + (CPL == 2 ? it * (4 * W2_TILES * 4) : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float left = dpp_prev<SH>(hrow[j][CPL - 1]);     // column c0 - 1 (0 at the left image edge)
+            const float right = dpp_next<SH>(hrow[j][0]);          // column c0 + CPL (0 at the right image edge)
+#pragma unroll
+            for (int t = 0; t < TPL; ++t) {
+                const float c0 = t == 0 ? left : hrow[j][2 * t - 1];
+                const float c1 = hrow[j][2 * t], c2 = hrow[j][2 * t + 1];
+                const float c3 = t == TPL - 1 ? right : hrow[j][2 * t + 2];
+                nfloat4 v;
+                v.x = vsub1(c0, c2);
+                v.y = vadd1(c1, c2);
+                v.z = vsub1(c2, c1);
+                v.w = vsub1(c1, c3);
+                *reinterpret_cast<nfloat4*>(dst + j * (W2_TILES * 4) + t * 4) = v;
+            }
+        }
     };
 
     f32x16 acc[16];
@@ -1635,93 +1668,83 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
 
     const int nstages = d.kD * (a.Cin / SK);
-    nfloat4 fa[2][4];             // [set][chunk]: components 4q .. 4q+3 of this lane's (k, m)
-    float2 fb[4][2];
-    float bt[2][16];
+    nfloat4 fa[2][4];             // [set][chunk j]: U components (j, xi = 0..3) of this lane's (k, m)
+    nfloat4 fv[2][4];             // [set][j]:       V components (j, xi = 0..3) of this lane's (k, tile)
     auto read_a = [&](const float* Ak, int set, int q) { fa[set][q] = *reinterpret_cast<const nfloat4*>(Ak + aoff[q]); };
-    auto read_b = [&](const float* Bk, int j) {                 // (d0,d1), (d2,d3) of transformed row j under this lane's tile
-        const float2* bp = reinterpret_cast<const float2*>(Bk + boff + j * W2_JS);
-        fb[j][0] = bp[0];
-        fb[j][1] = bp[1];
-    };
-    auto transform = [&](int set, int j) {                      // W transform of row j
-        const float2 p0 = fb[j][0], p1 = fb[j][1];
-        bt[set][j * 4 + 0] = vsub1(p0.x, p1.x);
-        bt[set][j * 4 + 1] = vadd1(p0.y, p1.x);
-        bt[set][j * 4 + 2] = vsub1(p1.x, p0.y);
-        bt[set][j * 4 + 3] = vsub1(p0.y, p1.y);
-    };
-    int fast_park;                // the pieces still in registers were fetched on the no-mask path
+    auto read_v = [&](const float* Vk, int set, int j) { fv[set][j] = *reinterpret_cast<const nfloat4*>(Vk + boff + j * (W2_TILES * 4)); };
+    int fast_park, fast_park1 = 0;     // the items still in registers were fetched on the no-mask path
+    uint32_t jm_park, jm_park1 = 0;    // their row masks otherwise
     {   // prologue: the fetches of the first two stages travel together; stage 0 is parked in buffer 0
-        float breg0[2][2][4];
+        float braw0[NIT][4][CPL];
         nfloat4 areg0[8];
         fetch_begin();
-        const uint32_t mbits0 = mbits;
+        const uint32_t jm0 = jmask;
 #pragma unroll
         for (int i = 0; i < 8; ++i) fetch_a(i, areg0);
+        if (parker) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) fetch_b(q >> 1, q & 1, breg0, false, mbits0);
+            for (int it = 0; it < NIT; ++it) fetch_b(it, braw0, false, jm0);
+        }
         fetch_begin();
 #pragma unroll
         for (int i = 0; i < 8; ++i) fetch_a(i, areg);
+        if (parker) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) fetch_b(q >> 1, q & 1, breg, false, mbits);
+            for (int it = 0; it < NIT; ++it) fetch_b(it, braw, false, jmask);
+        }
         fast_park = 0;
+        jm_park = jmask;
 #pragma unroll
         for (int i = 0; i < 8; ++i) park_a(0, i, areg0);
+        if (parker) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) park_b(0, q >> 1, q & 1, breg0, false, mbits0);
+            for (int it = 0; it < NIT; ++it) park_b(0, it, braw0, false, jm0);
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q) read_a(As, 0, q);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) read_b(Bs, j);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) transform(0, j);
+    for (int j = 0; j < 4; ++j) read_v(Vs, 0, j);
 
-    // Main loop.  LDS ring of three stage buffers and ONE barrier per stage, after the stage's parking stores (end of k-step 1):
-    // stage st computes from buffer st % 3 and parks stage st+1 in buffer (st+1) % 3 during its k-steps 0-1, re-using each
-    // register piece for the fetch of stage st+2 as soon as it is parked (a fetch then has four k-steps to arrive); its last
-    // k-step already reads the first fragments of stage st+1, so the MFMA stream runs through the stage boundary.  The
-    // non-MFMA work of a k-step is cut into 16 slots, one behind each MFMA, in source order (sched_barrier).
+    // Main loop: stage st computes from buffer st & 1 and parks stage st+1 in the other one during its k-steps 0-1, re-using
+    // each register piece for the fetch of stage st+2 as soon as it is parked (a fetch then has four k-steps to arrive); the
+    // one barrier sits at the end of k-step 2; k-step 3 reads the first fragments of stage st+1, so the MFMA stream runs
+    // through the stage boundary.  The non-MFMA work of a k-step sits in 16 slots, one behind each MFMA, in source order.
     int rbuf = 0;
     for (int st = 0; st < nstages; ++st) {
-        const int wbuf = rbuf == W2_NBUF - 1 ? 0 : rbuf + 1;
+        const int wbuf = rbuf ^ 1;
         const float* Ab = As + rbuf * W2_ASZ;
-        const float* Bb = Bs + rbuf * W2_BSZ;
+        const float* Vb = Vs + rbuf * W2_BSZ;
         const float* An = As + wbuf * W2_ASZ;
-        const float* Bn = Bs + wbuf * W2_BSZ;
-        const uint32_t mb_park = mbits;                          // masks of the pieces still in registers (stage st+1)
-        const bool fpark = fast_park != 0;
+        const float* Vn = Vs + wbuf * W2_BSZ;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int set = ks & 1, nset = set ^ 1;
-            const float* Ak = ks < 3 ? Ab + (2 * (ks + 1)) * (BM * 16) : An;      // fragments of the next k-step
-            const float* Bk = ks < 3 ? Bb + (2 * (ks + 1)) * W2_KP : Bn;
+            const float* Ak = ks < 3 ? Ab + (2 * (ks + 1)) * (BM * 16) : An;               // fragments of the next k-step
+            const float* Vk = ks < 3 ? Vb + (2 * (ks + 1)) * (4 * W2_TILES * 4) : Vn;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][c >> 2][c & 3], bt[set][c], acc[c], 0, 0, 0);
-                // -- fragments of the next k-step: B rows first (their W transform closes the k-step), then the A chunks
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][c >> 2][c & 3], fv[set][c >> 2][c & 3], acc[c], 0, 0, 0);
+                // -- fragments of the next k-step: eight 16-byte LDS reads
                 if (DBG & 2) {}
-                else if (c < 4) read_b(Bk, c);
-                else if (c >= 6 && c < 10) read_a(Ak, nset, c - 6);
-                else if (c >= 12) transform(nset, c - 12);
+                else if (c >= 8 && c < 12) read_v(Vk, nset, c - 8);
+                else if (c >= 12) read_a(Ak, nset, c - 12);
                 // -- staging: k-step p = 0, 1 parks piece p of stage st+1 and re-fetches it for stage st+2
                 if (ks < 2 && !(DBG & 1)) {
                     const int p = ks;
                     if (c < 4) park_a(wbuf, 2 * c + p, areg);
-                    else if (c == 4) { if (fpark) park_b(wbuf, 0, p, breg, true, 0); else park_b(wbuf, 0, p, breg, false, mb_park); }
-                    else if (c == 5) { if (fpark) park_b(wbuf, 1, p, breg, true, 0); else park_b(wbuf, 1, p, breg, false, mb_park); }
-                    else if (c == 6) { if (p == 0) fetch_begin(); }
+                    else if (c == 4) {
+                        if (parker && p < NIT) { if (fast_park) park_b(wbuf, p, braw, true, 0); else park_b(wbuf, p, braw, false, jm_park); }
+                    }
+                    else if (c == 5) { if (p == 0) { fetch_begin(); fast_park1 = f_fast; jm_park1 = jmask; } }
+                    else if (c == 6) { if (parker && p < NIT) { if (f_fast) fetch_b(p, braw, true, 0); else fetch_b(p, braw, false, jmask); } }
                     else if (c >= 8 && c < 12) fetch_a(2 * (c - 8) + p, areg);
-                    else if (c == 12) { if (f_fast) fetch_b(0, p, breg, true, 0); else fetch_b(0, p, breg, false, mbits); }
-                    else if (c == 13) { if (f_fast) fetch_b(1, p, breg, true, 0); else fetch_b(1, p, breg, false, mbits); }
-                    else if (c == 14 && p == 1) fast_park = f_fast;
+                    else if (c == 15 && p == 1) { fast_park = fast_park1; jm_park = jm_park1; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (ks == 1 && !(DBG & 4)) __syncthreads();
+            if (ks == 2 && !(DBG & 4)) __syncthreads();
         }
         rbuf = wbuf;
     }
@@ -1833,7 +1856,10 @@ bool wg2_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
            d.Cin0 % W2_SK == 0 && d.Cin1 % W2_SK == 0 && d.Cout % 4 == 0 && d.Cout > 32 && rptot < (1 << 20) &&
            ((int64_t)d.kD * 9 * (d.Cin0 + d.Cin1) * d.Cout) % 4 == 0 &&
            // input rows contiguous (the row taps are instruction immediates)
-           d.x0s[4] == 1 && d.x0s[3] == d.iW && (d.Cin1 == 0 || (d.x1s[4] == 1 && d.x1s[3] == d.iW));
+           d.x0s[4] == 1 && d.x0s[3] == d.iW && (d.Cin1 == 0 || (d.x1s[4] == 1 && d.x1s[3] == d.iW)) &&
+           // ... and read with 8 / 16-byte vector loads
+           d.x0s[0] % 4 == 0 && d.x0s[1] % 4 == 0 && d.x0s[2] % 4 == 0 &&
+           (d.Cin1 == 0 || (d.x1s[0] % 4 == 0 && d.x1s[1] % 4 == 0 && d.x1s[2] % 4 == 0));
 }
 
 void launch_wg2(const ConvArgs& a, hipStream_t s) {
@@ -2101,7 +2127,8 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
     auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
     // fp32 Winograd F(2x2,3x3) over (H, W): 3x3 / 3x3x3 stride-1 convs over whole rows
     static const int no_wg2 = getenv("SDC_NO_WG2") ? atoi(getenv("SDC_NO_WG2")) : 0;
-    if (!no_wg2 && wg2_ok(d, small, a.rowhalo != 0) && reinterpret_cast<uintptr_t>(wp) % 16 == 0) {
+    if (!no_wg2 && wg2_ok(d, small, a.rowhalo != 0) && reinterpret_cast<uintptr_t>(wp) % 16 == 0 &&
+        reinterpret_cast<uintptr_t>(x0) % 16 == 0 && (d.Cin1 == 0 || reinterpret_cast<uintptr_t>(x1) % 16 == 0)) {
         a.vec2 = even(d.ys) && reinterpret_cast<uintptr_t>(y) % 8 == 0 &&
                  (!residual || (even(d.rs) && reinterpret_cast<uintptr_t>(residual) % 8 == 0));
         a.wg2 = wp + (int64_t)a.Ktot * d.Cout + (int64_t)(a.Ktot / 3 * 4) * d.Cout;
