@@ -16,6 +16,7 @@
 // buffer afterwards (one barrier per chunk).
 #include "sdc_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -1472,14 +1473,35 @@ constexpr int W2_ASZ = 16 * W2_SK * W2_BM, W2_BSZ = 16 * W2_SK * W2_TILES;    //
 // single fp32 VALU ops the SLP vectoriser cannot pack (v_pk_add_f32 beside MFMAs is slower than two v_add_f32)
 __device__ __forceinline__ float vsub1(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vadd1(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// value of lane - S / lane + S of the same 16-lane row, 0 past the row ends
+// Packed / DPP forms of the park-time transform (a VALU instruction between two fp32 MFMAs costs the same whether it
+// produces one result or two, and a DPP operand is free):
+typedef float w2f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ w2f2 pk_add2(w2f2 a, w2f2 b) { w2f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ w2f2 pk_sub2(w2f2 a, w2f2 b) { w2f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ w2f2 pk_mul2(w2f2 a, w2f2 b) { w2f2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// a * b - c ;  c - a * b
+__device__ __forceinline__ w2f2 pk_fms2(w2f2 a, w2f2 b, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ w2f2 pk_fnma2(w2f2 a, w2f2 b, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// (c1, c2) -> (c1 + c2, c2 - c1)
+__device__ __forceinline__ w2f2 pk_sumdiff(w2f2 c) {
+    w2f2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(c));
+    return r;
+}
+// value of lane - S of the same 16-lane row (0 past the row end) minus b;  a minus the value of lane + S
 template <int S>
-__device__ __forceinline__ float dpp_prev(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + S, 0xF, 0xF, true));   // row_shr:S
+__device__ __forceinline__ float sub_prev(float x, float b) {
+    float r;
+    if (S == 1) asm("v_sub_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(x), "v"(b));
+    else asm("v_sub_f32_dpp %0, %1, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(x), "v"(b));
+    return r;
 }
 template <int S>
-__device__ __forceinline__ float dpp_next(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + S, 0xF, 0xF, true));   // row_shl:S
+__device__ __forceinline__ float sub_next(float a, float x) {
+    float r;
+    if (S == 1) asm("v_subrev_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(x), "v"(a));
+    else asm("v_subrev_f32_dpp %0, %1, %2 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(x), "v"(a));
+    return r;
 }
 
 template <int OW, int DBG>
@@ -1533,27 +1555,23 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     if (OW == 16) { pr = 2 * (lik >> 4) + (lik & 1); pc0 = 2 * ((lik & 15) >> 1); }
     else { pr = lik >> 4; pc0 = (lik & 15) * CPL; }
     // byte offset of (b, od, 2hp, c0) inside one channel of x0 / x1 plus this lane's k-row offset; the depth-tap shift
-    // (kd - pD) planes is added once per stage, the row shift (j - 1) rows is an instruction immediate
-    uint32_t vp0 = 0, vp1 = 0, msk = 0;
+    // (kd - pD) planes is added once per stage.  Zero padding without per-element masks: the row above / below the row pair
+    // is fetched from a clamped (valid) row and multiplied by a 0 / 1 factor inside the H transform (one fused op, no extra
+    // instruction); a depth tap outside the volume reads the lane's own plane and is multiplied by 0 the same way.
+    uint32_t vp0 = 0, vp1 = 0, dmsk = 0, rsel0 = 0, rsel3 = 0;
+    float m0f = 0.0f, m3f = 0.0f;
     {
         const int rp = rp0 + pr;
         if (parker && rp < RPtot) {
             int ob, od, hp;
             split_rp(rp, ob, od, hp);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) msk |= (2 * hp - 1 + j >= 0 && 2 * hp - 1 + j < d.iH) ? (1u << j) : 0u;
-            for (int kd = 0; kd < d.kD; ++kd) msk |= (od - d.pD + kd >= 0 && od - d.pD + kd < d.iD) ? (16u << kd) : 0u;
+            if (hp > 0) { m0f = 1.0f; rsel0 = OW * 4; }                       // row 2hp - 1 exists
+            if (2 * hp + 2 < d.iH) { m3f = 1.0f; rsel3 = 2 * OW * 4; }        // row 2hp + 2 exists
+            for (int kd = 0; kd < d.kD; ++kd) dmsk |= (od - d.pD + kd >= 0 && od - d.pD + kd < d.iD) ? (1u << kd) : 0u;
             vp0 = (uint32_t)(ksub * d.x0s[1] + ob * d.x0s[0] + od * d.x0s[2] + (2 * hp) * OW + pc0) * 4u;
             if (two) vp1 = (uint32_t)(ksub * d.x1s[1] + ob * d.x1s[0] + od * d.x1s[2] + (2 * hp) * OW + pc0) * 4u;
         }
     }
-    // whole-wave validity per depth tap: bit kd set = every element this wave fetches for that tap is inside the image
-    uint32_t wave_ok = 0;
-    for (int kd = 0; kd < d.kD; ++kd) {
-        const uint32_t need = 15u | (16u << kd);
-        if (__builtin_amdgcn_ballot_w64((msk & need) == need) == ~0ull) wave_ok |= 1u << kd;
-    }
-    wave_ok = SDC_UNIFORM(wave_ok);
     // park position: V[k][j][tile][4]; k = wave * KPW + ksub (+ item for CPL = 2), tile = pr * TW + c0 / 2 (+ t)
     const int vpark = ((wave * KPW + ksub) * 4 * W2_TILES + pr * TW + (pc0 >> 1)) * 4;          // floats; + j * 256, + item * 1024
     // B fragments: tile n = wn * 32 + l31 of k row 2ks + lh: four 16-byte reads (j = 0..3)
@@ -1571,7 +1589,7 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) a_voff[i] = (uint32_t)(((int64_t)i * d.Cout + pmc) * 16 + 4 * pq) * 4u;
 
-    float braw[NIT][4][CPL];      // [item][source row j][column]
+    w2f2 braw[NIT][4][TPL];       // [item][source row j][column pair]
     nfloat4 areg[8];
     int s_kd = 0, s_ci = 0;
     const int64_t xs1_0 = d.x0s[1], xs1_1 = d.x1s[1];
@@ -1580,11 +1598,12 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     const float* const wg2p = a.wg2;
     const float* const x0p = a.x0;
     const float* const x1p = two ? a.x1 : a.x0;
-    // stage fetch state: scalar bases (weights; the first channel row of this wave), the lane offset of the selected input
+    // stage fetch state: scalar bases (weights; the first channel row of this wave), the lane offsets of the selected input
+    // (rows 2hp / 2hp+1 at voff / voff + W*4, the clamped rows above / below at voff0 / voff3), the stage's 0 / 1 factors
     gfloat_p f_w = uniform_ptr(wg2p), f_x = uniform_ptr(x0p);
     int64_t f_sc = 0;
-    uint32_t voff = 0, jmask = 0;
-    int f_fast = 0;
+    uint32_t voff = 0, voff0 = 0, voff3 = 0;
+    w2f2 mk0 = {0.f, 0.f}, mk3 = {0.f, 0.f}, mk12 = {0.f, 0.f};
     auto fetch_begin = [&]() {
         const bool first = s_ci < cin0;
         f_sc = first ? xs1_0 : xs1_1;
@@ -1593,9 +1612,14 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         const uint32_t dsb = (uint32_t)((s_kd - pDn) * (first ? xs2_0 : xs2_1) * 4);   // bytes, two's complement
         f_x = uniform_ptr(bsel + (int64_t)cbase * f_sc);
         f_w = uniform_ptr(wg2p + ((int64_t)(s_kd * cin + s_ci) * coutn) * 16);
-        f_fast = (wave_ok >> s_kd) & 1;
-        voff = (first ? vp0 : vp1) + dsb;                 // (>= 0 as a whole wherever the element is inside the image)
-        jmask = ((msk >> (4 + s_kd)) & 1u) ? (msk & 15u) : 0u;      // rows of the stage inside the image (border waves only)
+        const bool dv = (dmsk >> s_kd) & 1u;
+        voff = (first ? vp0 : vp1) + (dv ? dsb : 0u);
+        voff0 = voff - rsel0;
+        voff3 = voff + rsel3;
+        const float md = dv ? 1.0f : 0.0f, a0 = dv ? m0f : 0.0f, a3 = dv ? m3f : 0.0f;
+        mk12 = w2f2{md, md};
+        mk0 = w2f2{a0, a0};
+        mk3 = w2f2{a3, a3};
         s_ci += SK;
         // (past the last stage the walk wraps to the first one: the extra fetches of the pipeline tail stay in bounds and are
         // never consumed)
@@ -1604,61 +1628,57 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     auto fetch_a = [&](int i, nfloat4 (&ar)[8]) { ar[i] = *(gfloat4_p)((gchar_p)f_w + a_voff[i]); };
     // the 4 input rows under the row pair, CPL adjacent columns each: one vector load per row, row tap (j - 1) as an immediate.
     // A lane whose row is outside the image reads the first elements of the channel instead and is zeroed when parked.
-    auto fetch_b = [&](int it, float (&br)[NIT][4][CPL], bool fast, uint32_t jm) {
+    auto fetch_b_row = [&](int it, int j, w2f2 (&br)[NIT][4][TPL]) {
         const gchar_p rb = (gchar_p)f_x + (CPL == 2 ? (int64_t)it * f_sc * 4 : 0);
+        const gchar_p p = j == 0 ? rb + voff0 : (j == 3 ? rb + voff3 : (j == 1 ? rb + voff : rb + voff + OW * 4));
+        if (CPL == 2) { const nfloat2 v = *(gfloat2_p)p; br[it][j][0] = w2f2{v.x, v.y}; }
+        else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t o = (fast || ((jm >> j) & 1u)) ? voff + (uint32_t)((j - 1) * OW * 4) : 0u;
-            const gchar_p p = fast ? rb + voff + (j - 1) * OW * 4 : rb + o;
-            if (CPL == 2) { const nfloat2 v = *(gfloat2_p)p; br[it][j][0] = v.x; br[it][j][1] = v.y; }
-            else {
-#pragma unroll
-                for (int h = 0; h < CPL / 4; ++h) {
-                    const nfloat4 v = *(gfloat4_p)(p + 16 * h);
-                    br[it][j][4 * h + 0] = v.x; br[it][j][4 * h + 1] = v.y; br[it][j][4 * h + 2] = v.z; br[it][j][4 * h + 3] = v.w;
-                }
+            for (int h = 0; h < CPL / 4; ++h) {
+                const nfloat4 v = *(gfloat4_p)(p + 16 * h);
+                br[it][j][2 * h] = w2f2{v.x, v.y};
+                br[it][j][2 * h + 1] = w2f2{v.z, v.w};
             }
         }
+    };
+    auto fetch_b = [&](int it, w2f2 (&br)[NIT][4][TPL]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fetch_b_row(it, j, br);
     };
     auto park_a = [&](int buf, int i, const nfloat4 (&ar)[8]) {
         *reinterpret_cast<nfloat4*>(As + buf * W2_ASZ + i * (BM * 16) + apark) = ar[i];
     };
-    // input transform of one item and its 4 * TPL stores: H transform per column, then per transformed row the W transform
-    // with the left / right neighbour columns through DPP
-    auto park_b = [&](int buf, int it, const float (&br)[NIT][4][CPL], bool fast, uint32_t jm) {
-        float hrow[4][CPL];
+    // input transform of one item: H transform per column pair (packed), then per transformed row j the W transform of the
+    // lane's TPL tiles -- V0 = c0 - c2, (V1, V2) = (c1 + c2, c2 - c1) packed, V3 = c1 - c3, the neighbour columns c0 / c3 of the
+    // edge tiles through DPP -- and one 16-byte store per tile, slot order (V1, V2, V0, V3)
+    w2f2 hrow[4][TPL];
+    auto park_b_h = [&](int it, const w2f2 (&br)[NIT][4][TPL], w2f2 k0, w2f2 k12, w2f2 k3) {
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            float d0 = br[it][0][c], d1 = br[it][1][c], d2 = br[it][2][c], d3 = br[it][3][c];
-            if (!fast) {
-                d0 = (jm & 1u) ? d0 : 0.0f;
-                d1 = (jm & 2u) ? d1 : 0.0f;
-                d2 = (jm & 4u) ? d2 : 0.0f;
-                d3 = (jm & 8u) ? d3 : 0.0f;
-            }
-            hrow[0][c] = vsub1(d0, d2);
-            hrow[1][c] = vadd1(d1, d2);
-            hrow[2][c] = vsub1(d2, d1);
-            hrow[3][c] = vsub1(d1, d3);
+        for (int t = 0; t < TPL; ++t) {
+            const w2f2 t1 = pk_mul2(br[it][1][t], k12), t2 = pk_mul2(br[it][2][t], k12);
+            hrow[0][t] = pk_fms2(br[it][0][t], k0, t2);          // d0 - d2
+            hrow[1][t] = pk_add2(t1, t2);                        // d1 + d2
+            hrow[2][t] = pk_sub2(t2, t1);                        // d2 - d1
+            hrow[3][t] = pk_fnma2(br[it][3][t], k3, t1);         // d1 - d3
         }
-        float* dst = Vs + buf * W2_BSZ + vpark + (CPL == 2 ? it * (4 * W2_TILES * 4) : 0);
+    };
+    auto park_b_w = [&](int buf, int it, int j) {
+        float* dst = Vs + buf * W2_BSZ + vpark + (CPL == 2 ? it * (4 * W2_TILES * 4) : 0) + j * (W2_TILES * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float left = dpp_prev<SH>(hrow[j][CPL - 1]);     // column c0 - 1 (0 at the left image edge)
-            const float right = dpp_next<SH>(hrow[j][0]);          // column c0 + CPL (0 at the right image edge)
-#pragma unroll
-            for (int t = 0; t < TPL; ++t) {
-                const float c0 = t == 0 ? left : hrow[j][2 * t - 1];
-                const float c1 = hrow[j][2 * t], c2 = hrow[j][2 * t + 1];
-                const float c3 = t == TPL - 1 ? right : hrow[j][2 * t + 2];
-                nfloat4 v;
-                v.x = vsub1(c0, c2);
-                v.y = vadd1(c1, c2);
-                v.z = vsub1(c2, c1);
-                v.w = vsub1(c1, c3);
-                *reinterpret_cast<nfloat4*>(dst + j * (W2_TILES * 4) + t * 4) = v;
-            }
+        for (int t = 0; t < TPL; ++t) {
+            const w2f2 cc = hrow[j][t];
+            const w2f2 sd = pk_sumdiff(cc);
+            const float v0 = t == 0 ? sub_prev<SH>(hrow[j][TPL - 1].y, cc.y) : vsub1(hrow[j][t - 1].y, cc.y);
+            const float v3 = t == TPL - 1 ? sub_next<SH>(cc.x, hrow[j][0].x) : vsub1(cc.x, hrow[j][t + 1].x);
+            nfloat4 v;
+            v.x = sd.x; v.y = sd.y; v.z = v0; v.w = v3;
+            *reinterpret_cast<nfloat4*>(dst + t * 4) = v;
         }
+    };
+    auto park_b = [&](int buf, int it, const w2f2 (&br)[NIT][4][TPL], w2f2 k0, w2f2 k12, w2f2 k3) {
+        park_b_h(it, br, k0, k12, k3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) park_b_w(buf, it, j);
     };
 
     f32x16 acc[16];
@@ -1672,33 +1692,31 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     nfloat4 fv[2][4];             // [set][j]:       V components (j, xi = 0..3) of this lane's (k, tile)
     auto read_a = [&](const float* Ak, int set, int q) { fa[set][q] = *reinterpret_cast<const nfloat4*>(Ak + aoff[q]); };
     auto read_v = [&](const float* Vk, int set, int j) { fv[set][j] = *reinterpret_cast<const nfloat4*>(Vk + boff + j * (W2_TILES * 4)); };
-    int fast_park, fast_park1 = 0;     // the items still in registers were fetched on the no-mask path
-    uint32_t jm_park, jm_park1 = 0;    // their row masks otherwise
+    w2f2 pk0, pk12, pk3, nk0 = {0.f, 0.f}, nk12 = {0.f, 0.f}, nk3 = {0.f, 0.f};     // 0 / 1 factors of the items still in registers
     {   // prologue: the fetches of the first two stages travel together; stage 0 is parked in buffer 0
-        float braw0[NIT][4][CPL];
+        w2f2 braw0[NIT][4][TPL];
         nfloat4 areg0[8];
         fetch_begin();
-        const uint32_t jm0 = jmask;
+        const w2f2 q0 = mk0, q12 = mk12, q3 = mk3;
 #pragma unroll
         for (int i = 0; i < 8; ++i) fetch_a(i, areg0);
         if (parker) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) fetch_b(it, braw0, false, jm0);
+            for (int it = 0; it < NIT; ++it) fetch_b(it, braw0);
         }
         fetch_begin();
 #pragma unroll
         for (int i = 0; i < 8; ++i) fetch_a(i, areg);
         if (parker) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) fetch_b(it, braw, false, jmask);
+            for (int it = 0; it < NIT; ++it) fetch_b(it, braw);
         }
-        fast_park = 0;
-        jm_park = jmask;
+        pk0 = mk0; pk12 = mk12; pk3 = mk3;
 #pragma unroll
         for (int i = 0; i < 8; ++i) park_a(0, i, areg0);
         if (parker) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) park_b(0, it, braw0, false, jm0);
+            for (int it = 0; it < NIT; ++it) park_b(0, it, braw0, q0, q12, q3);
         }
     }
     __syncthreads();
@@ -1710,7 +1728,8 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     // Main loop: stage st computes from buffer st & 1 and parks stage st+1 in the other one during its k-steps 0-1, re-using
     // each register piece for the fetch of stage st+2 as soon as it is parked (a fetch then has four k-steps to arrive); the
     // one barrier sits at the end of k-step 2; k-step 3 reads the first fragments of stage st+1, so the MFMA stream runs
-    // through the stage boundary.  The non-MFMA work of a k-step sits in 16 slots, one behind each MFMA, in source order.
+    // through the stage boundary.  The non-MFMA work of a k-step sits in 16 slots, one behind each MFMA, in source order;
+    // no branch inside the loop (a per-slot fast / masked choice cost conservative vmcnt waits at every join).
     int rbuf = 0;
     for (int st = 0; st < nstages; ++st) {
         const int wbuf = rbuf ^ 1;
@@ -1725,7 +1744,9 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
             const float* Vk = ks < 3 ? Vb + (2 * (ks + 1)) * (4 * W2_TILES * 4) : Vn;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][c >> 2][c & 3], fv[set][c >> 2][c & 3], acc[c], 0, 0, 0);
+                // component (j = c >> 2, xi = c & 3): V slot order in LDS is (V1, V2, V0, V3)
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][c >> 2][c & 3],
+                                                              fv[set][c >> 2][(c & 3) == 0 ? 2 : ((c & 3) == 3 ? 3 : (c & 3) - 1)], acc[c], 0, 0, 0);
                 // -- fragments of the next k-step: eight 16-byte LDS reads
                 if (DBG & 2) {}
                 else if (c >= 8 && c < 12) read_v(Vk, nset, c - 8);
@@ -1733,14 +1754,16 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
                 // -- staging: k-step p = 0, 1 parks piece p of stage st+1 and re-fetches it for stage st+2
                 if (ks < 2 && !(DBG & 1)) {
                     const int p = ks;
-                    if (c < 4) park_a(wbuf, 2 * c + p, areg);
-                    else if (c == 4) {
-                        if (parker && p < NIT) { if (fast_park) park_b(wbuf, p, braw, true, 0); else park_b(wbuf, p, braw, false, jm_park); }
+                    const bool bwork = parker && p < NIT;
+                    if (c < 4) { if (!(DBG & 32)) park_a(wbuf, 2 * c + p, areg); }
+                    else if (c == 4) { if (bwork && !(DBG & 8)) park_b_h(p, braw, pk0, pk12, pk3); }
+                    else if (c < 9) { if (bwork && !(DBG & 8)) park_b_w(wbuf, p, c - 5); }
+                    else if (c == 9) { if (p == 0) { fetch_begin(); nk0 = mk0; nk12 = mk12; nk3 = mk3; } }
+                    else if (c < 14) {
+                        if (bwork && !(DBG & 16)) fetch_b_row(p, c - 10, braw);
+                        if (c >= 12 && !(DBG & 64)) fetch_a(2 * (c - 12) + p, areg);
                     }
-                    else if (c == 5) { if (p == 0) { fetch_begin(); fast_park1 = f_fast; jm_park1 = jmask; } }
-                    else if (c == 6) { if (parker && p < NIT) { if (f_fast) fetch_b(p, braw, true, 0); else fetch_b(p, braw, false, jmask); } }
-                    else if (c >= 8 && c < 12) fetch_a(2 * (c - 8) + p, areg);
-                    else if (c == 15 && p == 1) { fast_park = fast_park1; jm_park = jm_park1; }
+                    else { if (!(DBG & 64)) fetch_a(2 * (c - 12) + p, areg); if (c == 15 && p == 1) { pk0 = nk0; pk12 = nk12; pk3 = nk3; } }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1878,9 +1901,11 @@ void launch_wg2(const ConvArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((conv_wg2_kernel<OWV, D>), grid, dim3(256), lds, s, a);                                               \
     } while (0)
     if (d.oW == 16 && dbg) {
-        if (dbg == 1) W2_LAUNCH(16, 1); else if (dbg == 2) W2_LAUNCH(16, 2); else W2_LAUNCH(16, 3);
-    } else if (d.oW == 64 && dbg) {
-        if (dbg == 1) W2_LAUNCH(64, 1); else if (dbg == 2) W2_LAUNCH(64, 2); else W2_LAUNCH(64, 3);
+        switch (dbg) {
+            case 1: W2_LAUNCH(16, 1); break; case 2: W2_LAUNCH(16, 2); break; case 3: W2_LAUNCH(16, 3); break;
+            case 10: W2_LAUNCH(16, 2 + 8); break; case 18: W2_LAUNCH(16, 2 + 16); break; case 34: W2_LAUNCH(16, 2 + 32); break;
+            case 66: W2_LAUNCH(16, 2 + 64); break; case 26: W2_LAUNCH(16, 2 + 8 + 16); break; default: W2_LAUNCH(16, 2 + 32 + 64); break;
+        }
     } else if (d.oW == 16) W2_LAUNCH(16, 0);
     else if (d.oW == 32) W2_LAUNCH(32, 0);
     else if (d.oW == 64) W2_LAUNCH(64, 0);

@@ -3,7 +3,7 @@ C4 at the full batch of 64, C3's guided sampler at B=128, the calibration (doubl
 and one production-width reference fixture per tree (tests/golden/*_unet_wide.npz, written by the REAL reference through
 oracle/make_goldens.py), so that the production kernels meet reference output directly.
 Tolerances: fp32 kernels vs the fp32 CPU reference differ by summation order only; eps-MSE <= 1e-5 is the north-star gate,
-the element-wise gates below are ~5x the errors measured on MI355X (printed by every test)."""
+the element-wise gates below are ~5x the errors measured on MI355X (printed by every test, `pytest -s`)."""
 import pytest
 import torch
 
@@ -47,7 +47,7 @@ def test_wide_fixtures_from_the_reference(golden):
     net.to(DEV)
     x = det_tensor((2, 12, 128), int(g.scalar("x_seed")))
     eps = net(x.to(DEV), g["t"].to(DEV)).cpu()
-    assert _report("tokamak dim 256 vs reference", eps, g["eps"]) < 5e-5 and _mse(eps, g["eps"]) <= 1e-9
+    assert _report("tokamak dim 256 vs reference", eps, g["eps"]) < 8e-5 and _mse(eps, g["eps"]) <= 1e-9
 
     g = golden("smoke_unet_wide")
     net = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
@@ -55,7 +55,7 @@ def test_wide_fixtures_from_the_reference(golden):
     net.to(DEV)
     x = det_tensor((1, 32, 7, 32, 32), int(g.scalar("x_seed")))
     eps = net(x.to(DEV), g["t"].to(DEV)).cpu()
-    assert _report("smoke dim 64, 32 frames 32x32 vs reference", eps, g["eps"]) < 2e-4 and _mse(eps, g["eps"]) <= 1e-8
+    assert _report("smoke dim 64, 32 frames 32x32 vs reference", eps, g["eps"]) < 5e-5 and _mse(eps, g["eps"]) <= 1e-9
     used = {fn.__name__ for fn, _ in net.entry(tuple(x.shape), 1)["plan"].calls}
     assert {"sdc_tattn_block", "sdc_linattn_block", "sdc_conv_gn"} <= used      # the production kernels ran
 
@@ -75,7 +75,7 @@ def test_c4_batch64_forward_and_sampler():
     eps = net(x.to(DEV), t.to(DEV))
     assert torch.isfinite(eps).all()
     ref = onets.unet_smoke(P, x[k:k + 1], t[k:k + 1], dim=64, dim_mults=(1, 2, 4))
-    assert _report("C4 B=64 forward, sample 37 vs oracle", eps[k:k + 1].cpu(), ref) < 1e-3 and _mse(eps[k:k + 1].cpu(), ref) <= 1e-8
+    assert _report("C4 B=64 forward, sample 37 vs oracle", eps[k:k + 1].cpu(), ref) < 6e-5 and _mse(eps[k:k + 1].cpu(), ref) <= 1e-9
     alone = net(x[k:k + 1].to(DEV), t[k:k + 1].to(DEV))
     assert _report("C4 sample 37: in the batch of 64 vs alone", eps[k:k + 1].cpu(), alone.cpu()) < 2e-5
     last = net(x[B - 1:].to(DEV), t[B - 1:].to(DEV))                   # the far end of the batch: largest offsets
@@ -136,7 +136,7 @@ def test_calibration_double_draw_at_c2_width():
     tabs = osched.make_tables("cosine", T)
     ref = osam.sample_burgers(lambda a, b: onets.unet_burgers(P, a, b, dim=64), tabs, B, noise, u_init=u0, u_final=uT,
                               guidance_u0=False, w_groundtruth=wgt, nablaJ=None, enable_grad=False)
-    assert _report("C2-width calibration (double-draw) trajectory vs oracle", out, ref) < 2e-4
+    assert _report("C2-width calibration (double-draw) trajectory vs oracle", out, ref) < 3e-4
     # the Philox route consumes two draw indices per step as well: graph replay == eager call list
     outs = []
     for use_graph in (True, False):
@@ -187,7 +187,7 @@ def test_reference_style_guidance_closures_get_a_grad_enabled_leaf(golden):
         return torch.autograd.grad(guidance.sum(), x)[0]
     out = gs.sample(batch_size=2, design_fn=design_fn, enable_grad=False, init=g["init"],
                     noise=det_noise((2, 8, 7, 16, 16), int(g.scalar("noise_seed")))).cpu()
-    assert _report("smoke guided trajectory through a reference-style design_fn vs reference fixture", out, g["out"]) < 1e-3
+    assert _report("smoke guided trajectory through a reference-style design_fn vs reference fixture", out, g["out"]) < 3e-4
 
 
 def test_tokamak_conformal_ddim_passes_ground_truth_actions(golden):

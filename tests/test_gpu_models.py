@@ -13,7 +13,17 @@ from oracle.detweights import det_noise, det_params, det_tensor
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 EPS_TOL = dict(rtol=5e-4, atol=5e-5)
-TRAJ_TOL = dict(rtol=2e-3, atol=2e-4)
+TRAJ_GATE = 5e-4          # max |x_0 - reference| over an 8-step trajectory, |x| <= 1 (clip_denoised): ~5x the largest error
+                          # measured on MI355X (printed per fixture by _traj; 1.0e-4 .. 1.4e-4 on the guided tokamak runs)
+
+
+def _traj(out, ref, tag=""):
+    """trajectory parity: print the measured error, gate on the absolute maximum (the state is clipped to [-1, 1])"""
+    import inspect
+    err = (out - ref).abs().max().item()
+    who = inspect.stack()[1].function
+    print(f"[measured] {who} {tag}: max|err| {err:.3e}  MSE {((out - ref) ** 2).mean().item():.3e}")
+    assert err < TRAJ_GATE, (who, tag, err)
 
 
 def _mse(a, b):
@@ -114,16 +124,16 @@ def test_burgers_trajectories_golden(golden):
     guid = sdc.BurgersGuidance(g.scalar("Q"), g.scalar("w_score"), g.scalar("u_bound"))
     out = gd.sample(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True, nablaJ=guid,
                     J_scheduler=lambda t: 1.0, w_scheduler=None, enable_grad=False, noise=noise).cpu()
-    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    _traj(out, g["out"])
     # the same guidance passed as an opaque callable takes the split (x0 -> callable -> update) route
     out2 = gd.sample(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True,
                      nablaJ=lambda x: guid(x), J_scheduler=lambda t: 1.0, enable_grad=False, noise=noise).cpu()
-    torch.testing.assert_close(out2, g["out"], **TRAJ_TOL)
+    _traj(out2, g["out"])
     g = golden("burgers_traj_calib")
     out = gd.sample(batch_size=2, clip_denoised=True, guidance_u0=False, u_init=g["u0"], u_final=g["uT"],
                     w_groundtruth=g["w_gt"], nablaJ=None, J_scheduler=None, w_scheduler=None, enable_grad=False,
                     noise=noise).cpu()
-    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    _traj(out, g["out"])
 
 
 def test_tokamak_trajectories_golden(golden):
@@ -136,11 +146,11 @@ def test_tokamak_trajectories_golden(golden):
                                g.scalar("thr"))
     out = gd.sample(batch_size=2, clip_denoised=True, guidance_u0=True, u_init=g["u0"], u_final=g["uT"], nablaJ=guid,
                     J_scheduler=lambda t: 1.0, w_scheduler=None, enable_grad=False, noise=noise).cpu()
-    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    _traj(out, g["out"])
     g = golden("tokamak_traj_calib")
     out = gd.sample(batch_size=2, clip_denoised=True, guidance_u0=False, u_init=g["u0"], u_final=g["uT"], nablaJ=None,
                     enable_grad=False, noise=noise).cpu()
-    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    _traj(out, g["out"])
     with pytest.raises(IndexError):     # reference bug reproduced
         gd.sample(batch_size=2, guidance_u0=False, u_init=g["u0"], u_final=g["uT"], w_groundtruth=torch.zeros(2, 9, 128))
 
@@ -154,10 +164,10 @@ def test_smoke_trajectories_golden(golden):
     noise = det_noise((2, 8, 7, 16, 16), int(g.scalar("noise_seed")))
     guid = sdc.SmokeGuidance(g.scalar("Q"), g.scalar("w_safe"), g.scalar("safe_bound"))
     out = gd.sample(batch_size=2, design_fn=guid, enable_grad=False, init=g["init"], noise=noise).cpu()
-    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    _traj(out, g["out"])
     g = golden("smoke_traj_calib")
     out = gd.sample(batch_size=2, design_fn=None, init=g["init"], control=g["control"], noise=noise).cpu()
-    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    _traj(out, g["out"])
 
 
 def test_tokamak_mixed_guidance_and_amax_vs_oracle(golden):
@@ -176,7 +186,7 @@ def test_tokamak_mixed_guidance_and_amax_vs_oracle(golden):
     tabs = osched.make_tables("cosine", T)
     ref = osam.sample_tokamak(lambda x, t: onets.unet_tokamak(P, x, t, dim=8), tabs, B, noise, u_init=u0, u_final=uT,
                               nablaJ=osam.tokamak_guidance(target, 122, 0.1, 3.6, 0.7, 0.3, 0.5), enable_grad=False)
-    torch.testing.assert_close(out, ref, **TRAJ_TOL)
+    _traj(out, ref)
 
     spec = golden("burgers_unet").spec()
     P = det_params(spec, 100)
@@ -190,7 +200,7 @@ def test_tokamak_mixed_guidance_and_amax_vs_oracle(golden):
     tabs = osched.make_tables("cosine", T)
     ref = osam.sample_burgers(lambda x, t: onets.unet_burgers(P, x, t, dim=8), tabs, B, noise, u_init=u0, u_final=uT,
                               nablaJ=osam.burgers_guidance(0.01, 500.0, 0.05, False), enable_grad=False)
-    torch.testing.assert_close(out, ref, **TRAJ_TOL)
+    _traj(out, ref)
 
 
 def test_graph_and_eager_paths_agree_and_conditions_hold(golden):
@@ -235,14 +245,14 @@ def test_ddim_trajectories_golden(golden):
     guid = sdc.BurgersGuidance(g.scalar("Q"), g.scalar("w_score"), g.scalar("u_bound"))
     out = gd.sample(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True, nablaJ=guid,
                     J_scheduler=lambda t: 1.0, enable_grad=False, noise=noise).cpu()
-    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    _traj(out, g["out"])
     out = gd.sample(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True,
                     nablaJ=lambda x: guid(x), enable_grad=False, noise=noise).cpu()          # opaque-callable route
-    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    _traj(out, g["out"])
     g = golden("burgers_ddim_calib")
     out = gd.sample(batch_size=2, clip_denoised=True, guidance_u0=False, u_init=g["u0"], u_final=g["uT"],
                     w_groundtruth=g["w_gt"], nablaJ=None, enable_grad=False, noise=noise).cpu()
-    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    _traj(out, g["out"])
     # Philox + hipGraph route: bit-identical to the eager call list, finite
     gd.guidance_u0 = True
     outs = []
@@ -260,11 +270,11 @@ def test_ddim_trajectories_golden(golden):
                                g.scalar("thr"))
     out = gt.sample(batch_size=2, guidance_u0=True, u_init=g["u0"], u_final=g["uT"], nablaJ=guid, enable_grad=False,
                     noise=noise).cpu()
-    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    _traj(out, g["out"])
     g = golden("tokamak_ddim_calib")
     out = gt.sample(batch_size=2, guidance_u0=False, u_init=g["u0"], u_final=g["uT"], w_groundtruth=g["w_gt"], nablaJ=None,
                     enable_grad=False, noise=noise).cpu()
-    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    _traj(out, g["out"])
 
     g = golden("smoke_ddim_guided")
     net = _load(sdc.Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2, 4), channels=7), golden("smoke_unet").spec(), 300)
@@ -273,10 +283,10 @@ def test_ddim_trajectories_golden(golden):
     noise = det_noise((2, 8, 7, 16, 16), int(g.scalar("noise_seed")))
     out = gs.sample(batch_size=2, design_fn=sdc.SmokeGuidance(g.scalar("Q"), g.scalar("w_safe"), g.scalar("safe_bound")),
                     init=g["init"], noise=noise).cpu()
-    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    _traj(out, g["out"])
     g = golden("smoke_ddim_calib")
     out = gs.sample(batch_size=2, design_fn=None, init=g["init"], control=g["control"], noise=noise).cpu()
-    torch.testing.assert_close(out, g["out"], **TRAJ_TOL)
+    _traj(out, g["out"])
 
 
 def test_conformal_pipelines_end_to_end(golden):

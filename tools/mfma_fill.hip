@@ -27,6 +27,10 @@ __global__ __launch_bounds__(256) void fill_loop(float* out, const float* in, in
     for (int i = 0; i < 4; ++i) r4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const uint32_t laddr = (uint32_t)(tid * 16);            // bytes, conflict-free b128
     const float* gp = in + tid;
+    const uint32_t goff = (uint32_t)(tid * 16);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 p2[4];
+    for (int i = 0; i < 4; ++i) p2[i] = f32x2{in[(tid + i) & 4095], in[(tid + 7 * i) & 4095]};
     uint32_t sacc = 0;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -43,9 +47,16 @@ __global__ __launch_bounds__(256) void fill_loop(float* out, const float* in, in
                 else if (KIND == 7) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc));
                 else if (KIND == 9) asm volatile("ds_read_b32 %0, %1" : "=v"(v[(n + 4) & 7]) : "v"(laddr));
                 else if (KIND == 10) asm volatile("s_nop 0");
+                else if (KIND == 11) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(p2[(n + 2) & 3]) : "v"(p2[n & 1]), "v"(p2[(n + 1) & 1]));
+                else if (KIND == 12) asm volatile("v_sub_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(v[(n + 4) & 7]) : "v"(v[n & 3]), "v"(v[(n + 1) & 3]));
+                else if (KIND == 13) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r4[n & 3]) : "v"(goff), "s"(in));
+                else if (KIND == 14) asm volatile("global_load_dword %0, %1, %2" : "=v"(v[(n + 4) & 7]) : "v"(goff), "s"(in));
+                else if (KIND == 15) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + tid * 4), (__attribute__((address_space(3))) void*)(lds + 8192), 16, 0, 0);
+                else if (KIND == 16) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(v[(n + 4) & 7]) : "v"(v[n & 3]), "v"(v[(n + 1) & 3]), "v"(v[(n + 2) & 3]));
+                else if (KIND == 17) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(v[(n + 4) & 7]) : "v"(v[n & 3]), "v"(v[(n + 1) & 3]));
             }
             if (KIND == 2 || KIND == 3 || KIND == 4 || KIND == 5 || KIND == 9) { if ((c & 3) == 3) asm volatile("s_waitcnt lgkmcnt(0)"); }
-            if (KIND == 6) { if ((c & 7) == 7) asm volatile("s_waitcnt vmcnt(0)"); }
+            if (KIND == 6 || KIND == 13 || KIND == 14 || KIND == 15) { if ((c & 7) == 7) asm volatile("s_waitcnt vmcnt(0)"); }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -53,7 +64,7 @@ __global__ __launch_bounds__(256) void fill_loop(float* out, const float* in, in
     for (int i = 0; i < 16; ++i)
         for (int r = 0; r < 16; ++r) s += acc[i][r];
     for (int i = 0; i < 8; ++i) s += v[i];
-    for (int i = 0; i < 4; ++i) s += r4[i][0] + r4[i][3];
+    for (int i = 0; i < 4; ++i) s += r4[i][0] + r4[i][3] + p2[i][0] + p2[i][1];
     out[blockIdx.x * 256 + tid] = s + lds[tid];
 }
 
@@ -98,6 +109,13 @@ int main() {
     ROW(4, "ds_write_b32")
     ROW(5, "ds_write_b128")
     ROW(6, "global_load_dword")
+    ROW(11, "v_pk_add_f32")
+    ROW(12, "v_sub_f32_dpp row_shr:1")
+    ROW(16, "v_fma_f32")
+    ROW(17, "v_cndmask_b32")
+    ROW(13, "global_load_dwordx4 saddr")
+    ROW(14, "global_load_dword saddr")
+    ROW(15, "global_load_lds_dwordx4")
     ROW(7, "s_add_u32")
     ROW(10, "s_nop 0")
     return 0;
