@@ -1831,8 +1831,10 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
                     *reinterpret_cast<float2*>(yq) = make_float2(y10, y11);
                 } else { yp[0] = y00; yp[d.ys[4]] = y01; yq[0] = y10; yq[d.ys[4]] = y11; }
                 if (gn) {
-                    gs[rr >> 2] += ((double)y00 + (double)y01) + ((double)y10 + (double)y11);
-                    gq[rr >> 2] += ((double)y00 * y00 + (double)y01 * y01) + ((double)y10 * y10 + (double)y11 * y11);
+                    // the 2x2 tile in fp32 (1e-7 relative on a 4-element partial sum), fp64 from there on: the sums stay
+                    // independent of the batch the trajectory is launched with (the tile grid cuts every sample alike)
+                    gs[rr >> 2] += (double)((y00 + y01) + (y10 + y11));
+                    gq[rr >> 2] += (double)fmaf(y00, y00, fmaf(y01, y01, fmaf(y10, y10, y11 * y11)));
                 }
             }
         }
@@ -2163,7 +2165,8 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
             SDC_REQUIRE(a.gn_nparts > 0, SDC_EINVAL, "sdc_conv_gn: shape not covered by the fused statistics (sdc_conv_gnparts returned 0)");
             a.gn_part = gn_part; a.gn_G = gn_G; a.gn_cpg = d.Cout / gn_G; a.gn_S = d.oD * d.oH * d.oW;
         }
-        SDC_PICK("conv_wg2_kernel<64,64t,8>", 4.0 / 9.0);
+        SDC_PICK(d.oW == 16 ? "conv_wg2_kernel<16>" : (d.oW == 32 ? "conv_wg2_kernel<32>" : (d.oW == 64 ? "conv_wg2_kernel<64>" : "conv_wg2_kernel<128>")),
+                 4.0 / 9.0);
         launch_wg2(a, s);
         return sdc::check_launch("sdc_conv[winograd 2x2]");
     }
