@@ -1772,71 +1772,87 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         rbuf = wbuf;
     }
 
-    // ---- epilogue: output transform Y = A^T M A on the accumulators, bias, residual, GroupNorm partial sums
+    if (DBG & 128) {      // experiment: no epilogue (keeps the accumulators alive through one store)
+        float sdbg = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sdbg += acc[c][0];
+        if (sdbg == 12345.678f) a.y[0] = sdbg;
+        return;
+    }
+    // ---- epilogue: output transform Y = A^T M A on the accumulators, bias, residual, GroupNorm partial sums.
+    // Every VALU instruction here is exposed (nothing else runs on the CU): the channel part of the output / residual / bias
+    // addresses is scalar (rows of a lane differ by whole channels), the lane part one 32-bit offset for all 16 rows.
     const bool v2 = a.vec2;
     const bool gn = a.gn_part != nullptr;
     double gs[4], gq[4];
 #pragma unroll
     for (int b4 = 0; b4 < 4; ++b4) { gs[b4] = 0.0; gq[b4] = 0.0; }
     {
-        const int cob = m0 + wm * 32 + 4 * lh;
-        float bv[16];
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            const int co = cob + (rr & 3) + 8 * (rr >> 2);
-            bv[rr] = a.bias ? a.bias[co < d.Cout ? co : d.Cout - 1] : 0.0f;
-        }
+        const int cob = m0 + wm * 32;                       // wave-uniform; this lane's rows: cob + 4 lh + (rr & 3) + 8 (rr >> 2)
         const int n = tile0 + wn * 32 + l31;
         const int rp = n >> (LGW - 1), tw = n & (TW - 1);
         const bool pok = rp < RPtot;
         int ob = 0, od = 0, hp = 0;
         if (pok) split_rp(rp, ob, od, hp);
-        const int64_t yoff = ob * d.ys[0] + od * d.ys[2] + (2 * hp) * d.ys[3] + (2 * tw) * d.ys[4];
-        float r00[16], r01[16], r10[16], r11[16];
-        if (a.res) {
-            const int64_t roff = ob * d.rs[0] + od * d.rs[2] + (2 * hp) * d.rs[3] + (2 * tw) * d.rs[4];
+        // lane offsets in bytes (host check: the y / residual spans stay below 2^32 bytes), the 4 lh rows folded in
+        const uint32_t yoff = (uint32_t)(ob * d.ys[0] + od * d.ys[2] + (2 * hp) * d.ys[3] + (2 * tw) * d.ys[4] + (4 * lh) * d.ys[1]) * 4u;
+        const uint32_t roff = a.res ? (uint32_t)(ob * d.rs[0] + od * d.rs[2] + (2 * hp) * d.rs[3] + (2 * tw) * d.rs[4] + (4 * lh) * d.rs[1]) * 4u : 0u;
+        const int64_t ycs = d.ys[1], rcs = d.rs[1];
+        const uint32_t yrow = (uint32_t)d.ys[3] * 4u, rrow = (uint32_t)d.rs[3] * 4u, ycol = (uint32_t)d.ys[4] * 4u, rcol = (uint32_t)d.rs[4] * 4u;
+        const bool full = m0 + BM <= d.Cout;                // all 64 rows of the workgroup exist
+        typedef __attribute__((address_space(1))) char* gwchar_p;
+        typedef __attribute__((address_space(1))) float* gwfloat_p;
+        typedef __attribute__((address_space(1))) nfloat2* gwfloat2_p;
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                const int co = cob + (rr & 3) + 8 * (rr >> 2);
-                const float* rp0_ = a.res + roff + (co < d.Cout ? co : d.Cout - 1) * d.rs[1];
-                const float* rp1_ = rp0_ + d.rs[3];
-                if (v2) {
-                    const float2 t0 = *reinterpret_cast<const float2*>(rp0_), t1 = *reinterpret_cast<const float2*>(rp1_);
-                    r00[rr] = t0.x; r01[rr] = t0.y; r10[rr] = t1.x; r11[rr] = t1.y;
-                } else { r00[rr] = rp0_[0]; r01[rr] = rp0_[d.rs[4]]; r10[rr] = rp1_[0]; r11[rr] = rp1_[d.rs[4]]; }
-            }
-        } else {
+        for (int g4 = 0; g4 < 4; ++g4) {                    // 8-row blocks: rows cob + 8 g4 + 4 lh + (0..3)
+            float bs = 0.0f, bq = 0.0f;
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) { r00[rr] = 0.0f; r01[rr] = 0.0f; r10[rr] = 0.0f; r11[rr] = 0.0f; }
-        }
+            for (int r3 = 0; r3 < 4; ++r3) {
+                const int rr = g4 * 4 + r3;
+                const int cou = cob + 8 * g4 + r3;          // wave-uniform part of the row
+                const bool rok = full || (cou + 4 * lh) < d.Cout;
+                const int coc = full ? cou : (cou < d.Cout - 4 ? cou : d.Cout - 8);       // clamped: in-bounds addresses for the tail
+                float t0[4], t1[4];
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            const int co = cob + (rr & 3) + 8 * (rr >> 2);
-            float t0[4], t1[4];
-#pragma unroll
-            for (int xi = 0; xi < 4; ++xi) {
-                const float M0 = acc[0 + xi][rr], M1 = acc[4 + xi][rr], M2 = acc[8 + xi][rr], M3 = acc[12 + xi][rr];
-                t0[xi] = (M0 + M1) + M2;
-                t1[xi] = (M1 - M2) - M3;
-            }
-            const float y00 = ((t0[0] + t0[1]) + t0[2]) + bv[rr] + r00[rr];
-            const float y01 = ((t0[1] - t0[2]) - t0[3]) + bv[rr] + r01[rr];
-            const float y10 = ((t1[0] + t1[1]) + t1[2]) + bv[rr] + r10[rr];
-            const float y11 = ((t1[1] - t1[2]) - t1[3]) + bv[rr] + r11[rr];
-            if (pok && co < d.Cout) {
-                float* yp = a.y + yoff + co * d.ys[1];
-                float* yq = yp + d.ys[3];
-                if (v2) {
-                    *reinterpret_cast<float2*>(yp) = make_float2(y00, y01);
-                    *reinterpret_cast<float2*>(yq) = make_float2(y10, y11);
-                } else { yp[0] = y00; yp[d.ys[4]] = y01; yq[0] = y10; yq[d.ys[4]] = y11; }
-                if (gn) {
-                    // the 2x2 tile in fp32 (1e-7 relative on a 4-element partial sum), fp64 from there on: the sums stay
-                    // independent of the batch the trajectory is launched with (the tile grid cuts every sample alike)
-                    gs[rr >> 2] += (double)((y00 + y01) + (y10 + y11));
-                    gq[rr >> 2] += (double)fmaf(y00, y00, fmaf(y01, y01, fmaf(y10, y10, y11 * y11)));
+                for (int xi = 0; xi < 4; ++xi) {
+                    const float M0 = acc[0 + xi][rr], M1 = acc[4 + xi][rr], M2 = acc[8 + xi][rr], M3 = acc[12 + xi][rr];
+                    t0[xi] = (M0 + M1) + M2;
+                    t1[xi] = (M1 - M2) - M3;
+                }
+                float bv = 0.0f;
+                if (a.bias) bv = a.bias[(full ? cou : coc) + 4 * lh];
+                float y00 = ((t0[0] + t0[1]) + t0[2]) + bv;
+                float y01 = ((t0[1] - t0[2]) - t0[3]) + bv;
+                float y10 = ((t1[0] + t1[1]) + t1[2]) + bv;
+                float y11 = ((t1[1] - t1[2]) - t1[3]) + bv;
+                if (a.res) {
+                    const gchar_p rb = (gchar_p)uniform_ptr(a.res + (int64_t)coc * rcs);
+                    if (v2) {
+                        const nfloat2 u0 = *(gfloat2_p)(rb + roff), u1 = *(gfloat2_p)(rb + roff + rrow);
+                        y00 += u0.x; y01 += u0.y; y10 += u1.x; y11 += u1.y;
+                    } else {
+                        y00 += *(gfloat_p)(rb + roff); y01 += *(gfloat_p)(rb + roff + rcol);
+                        y10 += *(gfloat_p)(rb + roff + rrow); y11 += *(gfloat_p)(rb + roff + rrow + rcol);
+                    }
+                }
+                if (pok && rok) {
+                    const gwchar_p yb = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(a.y + (int64_t)coc * ycs);
+                    if (v2) {
+                        *(gwfloat2_p)(yb + yoff) = nfloat2{y00, y01};
+                        *(gwfloat2_p)(yb + yoff + yrow) = nfloat2{y10, y11};
+                    } else {
+                        *(gwfloat_p)(yb + yoff) = y00; *(gwfloat_p)(yb + yoff + ycol) = y01;
+                        *(gwfloat_p)(yb + yoff + yrow) = y10; *(gwfloat_p)(yb + yoff + yrow + ycol) = y11;
+                    }
+                    // GroupNorm sums: the 2x2 tile and the 4 rows of the block in fp32 (1e-7 relative on a 16-element partial
+                    // sum), fp64 from there on -- independent of the batch a trajectory is launched with (the tile grid cuts
+                    // every sample alike)
+                    bs += (y00 + y01) + (y10 + y11);
+                    bq = fmaf(y00, y00, fmaf(y01, y01, fmaf(y10, y10, fmaf(y11, y11, bq))));
                 }
             }
+            gs[g4] = (double)bs;
+            gq[g4] = (double)bq;
         }
     }
     if (gn) {
@@ -1871,6 +1887,10 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     }
 }
 
+inline int64_t span5(const int64_t* st, int b, int c, int dd, int h, int w) {
+    return (int64_t)(b - 1) * st[0] + (int64_t)(c - 1) * st[1] + (int64_t)(dd - 1) * st[2] + (int64_t)(h - 1) * st[3] + (int64_t)(w - 1) * st[4];
+}
+
 // coverage of the F(2x2,3x3) kernel (precision 3)
 bool wg2_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
     const int64_t rptot = (int64_t)d.B * d.oD * (d.oH / 2);
@@ -1882,6 +1902,8 @@ bool wg2_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
            ((int64_t)d.kD * 9 * (d.Cin0 + d.Cin1) * d.Cout) % 4 == 0 &&
            // input rows contiguous (the row taps are instruction immediates)
            d.x0s[4] == 1 && d.x0s[3] == d.iW && (d.Cin1 == 0 || (d.x1s[4] == 1 && d.x1s[3] == d.iW)) &&
+           // the epilogue addresses y / the residual with 32-bit byte offsets from per-channel scalar bases
+           span5(d.ys, d.B, 8, d.oD, d.oH, d.oW) < (1ll << 30) && span5(d.rs, d.B, 8, d.oD, d.oH, d.oW) < (1ll << 30) &&
            // ... and read with 8 / 16-byte vector loads
            d.x0s[0] % 4 == 0 && d.x0s[1] % 4 == 0 && d.x0s[2] % 4 == 0 &&
            (d.Cin1 == 0 || (d.x1s[0] % 4 == 0 && d.x1s[1] % 4 == 0 && d.x1s[2] % 4 == 0));
@@ -1902,11 +1924,10 @@ void launch_wg2(const ConvArgs& a, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
         hipLaunchKernelGGL((conv_wg2_kernel<OWV, D>), grid, dim3(256), lds, s, a);                                               \
     } while (0)
-    if (d.oW == 16 && dbg) {
+    if (d.oW == 64 && dbg) {
         switch (dbg) {
-            case 1: W2_LAUNCH(16, 1); break; case 2: W2_LAUNCH(16, 2); break; case 3: W2_LAUNCH(16, 3); break;
-            case 10: W2_LAUNCH(16, 2 + 8); break; case 18: W2_LAUNCH(16, 2 + 16); break; case 34: W2_LAUNCH(16, 2 + 32); break;
-            case 66: W2_LAUNCH(16, 2 + 64); break; case 26: W2_LAUNCH(16, 2 + 8 + 16); break; default: W2_LAUNCH(16, 2 + 32 + 64); break;
+            case 1: W2_LAUNCH(64, 1); break; case 2: W2_LAUNCH(64, 2); break; case 3: W2_LAUNCH(64, 3); break;
+            case 128: W2_LAUNCH(64, 128); break; default: W2_LAUNCH(64, 3 + 128); break;
         }
     } else if (d.oW == 16) W2_LAUNCH(16, 0);
     else if (d.oW == 32) W2_LAUNCH(32, 0);
