@@ -537,11 +537,13 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
 
     float breg[KROWS][NCOL];
     float4 areg[NA4];
-    uint32_t mbits = 0;                          // bit r*NCOL+t: (k row r, column sweep t) of the stage in flight is valid
+    uint64_t mbits = 0;                          // bit r*NCOL+t: (k row r, column sweep t) of the stage in flight is valid
     int s_kd = 0, s_kh = 0, s_ci = 0;            // stage walk: kd, kh outer; channel chunk inner
 
     int s_st = 0;                                // GEN: stage number (k rows 16*s_st ..)
     const int KR = d.kD * d.kH * a.Cin;          // GEN: number of (kd, kh, ci) rows
+    // (runtime integer divisions cost ~25 VALU instructions each, and VALU work is not hidden behind fp32 MFMAs)
+    const float r_cin = 1.0f / (float)a.Cin, r_kh = 1.0f / (float)d.kH;
     bool a_rowok[NA4];
 
     auto load_stage = [&]() {
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
                 const bool ok = (smask[t] >> tapbit) & 1u;
                 off[t] = ok ? (int64_t)(first ? v0[t] : v1[t]) + toff : 0;          // !ok: a safe in-bounds address
 #pragma unroll
-                for (int r = 0; r < KROWS; ++r) mbits |= (ok ? 1u : 0u) << (r * NCOL + t);
+                for (int r = 0; r < KROWS; ++r) mbits |= (ok ? 1ull : 0ull) << (r * NCOL + t);
             }
 #pragma unroll
             for (int r = 0; r < KROWS; ++r)
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
                 const int kw = row / BK, kr = s_st * BK + row % BK;
                 const bool ok = kr < KR;
                 const int krc = ok ? kr : 0;
-                const int kdkh = krc / a.Cin, ci = krc - kdkh * a.Cin;
+                const int kdkh = (int)(((float)krc + 0.5f) * r_cin), ci = krc - kdkh * a.Cin;      // exact: krc < 2^20
                 const int64_t wrow = (int64_t)(kdkh * KW + kw) * a.Cin + ci;
                 areg[i] = *reinterpret_cast<const float4*>(a.wp + wrow * d.Cout + a_col[i]);
                 a_rowok[i] = ok;
@@ -596,8 +598,8 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
                 const int kr = SDC_UNIFORM(s_st * BK + wave * KROWS + r);
                 const bool rok = kr < KR;
                 const int krc = rok ? kr : 0;
-                const int kdkh = krc / a.Cin, ci = krc - kdkh * a.Cin;
-                const int kd = kdkh / d.kH, kh = kdkh - kd * d.kH;
+                const int kdkh = (int)(((float)krc + 0.5f) * r_cin), ci = krc - kdkh * a.Cin;
+                const int kd = (int)(((float)kdkh + 0.5f) * r_kh), kh = kdkh - kd * d.kH;
                 const bool first = ci < d.Cin0;
                 const float* base = first ? a.x0 + ci * d.x0s[1] + kd * d.x0s[2] + kh * d.x0s[3]
                                           : a.x1 + (ci - d.Cin0) * d.x1s[1] + kd * d.x1s[2] + kh * d.x1s[3];
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
                         const bool ok = rok && ((smask[t] >> kdkh) & 1ull);
                         const int64_t off = ok ? (int64_t)(first ? v0[t] : v1[t]) : 0;
                         breg[r][t] = ok ? base[off] : (first ? a.x0 : a.x1)[0];
-                        mbits |= (ok ? 1u : 0u) << (r * NCOL + t);
+                        mbits |= (ok ? 1ull : 0ull) << (r * NCOL + t);
                     }
                 }
             }
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
 #pragma unroll
             for (int t = 0; t < NCOL; ++t) {
                 const int cidx = lane + 64 * t;
-                if (cidx < ks_stride) Bs[buf][(wave * KROWS + r) * ks_stride + cidx] = ((mbits >> (r * NCOL + t)) & 1u) ? breg[r][t] : 0.0f;
+                if (cidx < ks_stride) Bs[buf][(wave * KROWS + r) * ks_stride + cidx] = ((mbits >> (r * NCOL + t)) & 1ull) ? breg[r][t] : 0.0f;
             }
     };
 
@@ -2237,6 +2239,19 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
     if (a.rowhalo && d.kW == 7 && d.sW == 1 && d.uD == 1 && d.uH == 1 && d.uW == 1 && d.up_mode == 0 && d.kD * d.kH <= 64 &&
         d.Cout % 4 == 0 && d.Cout > 32 && small && ((d.oW % 128 == 0) || (128 % d.oW == 0 && d.oW >= 16)) &&
         reinterpret_cast<uintptr_t>(wp) % 16 == 0) {
+        static const int stem_tile = getenv("SDC_STEM_TILE") ? atoi(getenv("SDC_STEM_TILE")) : 0;
+        if (stem_tile == 256 && (d.oW % 256 == 0 || 256 % d.oW == 0)) {
+            dim3 grid((a.Ntot + 255) / 256, (d.Cout + 63) / 64);
+            SDC_PICK("conv_rh_kernel<64,256,1,4,7,true>", 1.0);
+            hipLaunchKernelGGL((conv_rh_kernel<64, 256, 1, 4, 7, true>), grid, dim3(NT), 0, s, a);
+            return sdc::check_launch("sdc_conv[stem]");
+        }
+        if (stem_tile == 512 && (d.oW % 512 == 0 || 512 % d.oW == 0)) {
+            dim3 grid((a.Ntot + 511) / 512, (d.Cout + 63) / 64);
+            SDC_PICK("conv_rh_kernel<64,512,1,4,7,true>", 1.0);
+            hipLaunchKernelGGL((conv_rh_kernel<64, 512, 1, 4, 7, true>), grid, dim3(NT), 0, s, a);
+            return sdc::check_launch("sdc_conv[stem]");
+        }
         dim3 grid((a.Ntot + 127) / 128, (d.Cout + 63) / 64);
         SDC_PICK("conv_rh_kernel<64,128,2,2,7,true>", 1.0);
         hipLaunchKernelGGL((conv_rh_kernel<64, 128, 2, 2, 7, true>), grid, dim3(NT), 0, s, a);
