@@ -13,8 +13,10 @@ from oracle.detweights import det_noise, det_params, det_tensor
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 EPS_TOL = dict(rtol=5e-4, atol=5e-5)
-TRAJ_GATE = 5e-4          # max |x_0 - reference| over an 8-step trajectory, |x| <= 1 (clip_denoised): ~5x the largest error
-                          # measured on MI355X (printed per fixture by _traj; 1.0e-4 .. 1.4e-4 on the guided tokamak runs)
+# max |x_0 - reference| over an 8-step trajectory (|x| <= 1, clip_denoised) -- gates at ~5x the largest error measured on
+# MI355X (printed per fixture by _traj, `pytest -s`): DDPM loops 7.7e-5, DDIM loops (eps re-derived through 1/b, 20 -> 5 steps) 2.8e-4
+TRAJ_GATE = 4e-4
+DDIM_GATE = 1.5e-3
 
 
 def _traj(out, ref, tag=""):
@@ -22,8 +24,9 @@ def _traj(out, ref, tag=""):
     import inspect
     err = (out - ref).abs().max().item()
     who = inspect.stack()[1].function
-    print(f"[measured] {who} {tag}: max|err| {err:.3e}  MSE {((out - ref) ** 2).mean().item():.3e}")
-    assert err < TRAJ_GATE, (who, tag, err)
+    gate = DDIM_GATE if "ddim" in who else TRAJ_GATE
+    print(f"[measured] {who} {tag}: max|err| {err:.3e}  MSE {((out - ref) ** 2).mean().item():.3e}  (gate {gate:.1e})")
+    assert err < gate, (who, tag, err)
 
 
 def _mse(a, b):
