@@ -74,13 +74,18 @@ typedef struct SdcConvDesc {
     int32_t pD, pH, pW;          /* padding, in the (virtually upsampled) input space */
     int32_t uD, uH, uW;          /* virtual input upsample factor, 1 or 2 */
     int32_t up_mode;             /* 0 nearest, 1 zero-insert */
-    int32_t precision;           /* conv algorithm and layout of the wp buffer:
+    int32_t precision;           /* conv algorithm and layout of the wp buffer (0, 2 and 3 are fp32 end to end and differ by
+                                    rounding order only; the drop-in nets use 3):
                                     0 = fp32 MFMA, direct implicit GEMM everywhere (k-ordered fp32 FMA chains); wp = Wp
-                                    2 = fp32 MFMA, Winograd F(2,3) along W on the 3-wide stride-1 convs (the DEFAULT fp32
-                                        mode of the drop-in nets: same fp32 accuracy, 2/3 of the matrix work); wp = Wp followed,
-                                        when kW == 3, by the transformed taps Wg[(kd*kH + kh)*4 + xi][Cin][Cout]
-                                        (G g, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], formed in fp64, rounded once);
-                                        convs the Winograd kernel does not cover run the direct kernels on the Wp part
+                                    2 = fp32 MFMA, Winograd F(2,3) along W on the 3-wide stride-1 convs (2/3 of the matrix
+                                        work); wp = Wp followed, when kW == 3, by the transformed taps
+                                        Wg[(kd*kH + kh)*4 + xi][Cin][Cout]  (G g, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]],
+                                        formed in fp64, rounded once); convs the kernel does not cover run the direct kernels
+                                    3 = as 2, plus Winograd F(2x2,3x3) over (H, W) for the 3x3 / 3x3x3 stride-1 pad-1 convs over
+                                        whole contiguous rows of 16 / 32 / 64 / 128 columns (4/9 of the matrix work): when
+                                        kH == kW == 3 the buffer is Wp | Wg | Wg2 with Wg2[kd][ci][co][j*4 + xi] =
+                                        sum_{kh,kw} G[j][kh] G[xi][kw] w[co][ci][kd][kh][kw]; other tap shapes: layout of 2.
+                                        Shapes the F(2x2,3x3) kernel does not take fall back to 2's kernels on the same buffer.
                                     1 = opt-in 3-pass split-bf16 MFMA (~16 mantissa bits, NOT the parity mode) */
     int64_t x0s[5], x1s[5], ys[5], rs[5];   /* element strides (b,c,d,h,w) */
 } SdcConvDesc;
@@ -97,7 +102,7 @@ int sdc_conv_describe(const SdcConvDesc* d, char* name, size_t cap, double* mfma
  * conv3d.py:192-198): the conv epilogue leaves fp64 (sum, sum of squares) pairs per (sample, group, part) in `parts`
  * (B * G * nparts pairs) and sdc_gn_finalize turns them into the {mean, rstd} table sdc_gn_apply reads -- y is not read
  * again for the statistics.  sdc_conv_gnparts is a host-side query: nparts for this descriptor, or 0 when the fused form
- * does not cover it (then run sdc_conv + sdc_gn_stats).  Covered: the precision-2 Winograd convs whose tile grid
+ * does not cover it (then run sdc_conv + sdc_gn_stats).  Covered: the precision-2 / 3 Winograd convs whose tile grid
  * lines up with the samples and groups. */
 int sdc_conv_gnparts(const SdcConvDesc* d, int G);
 int sdc_conv_gn(const SdcConvDesc* d, const float* x0, const float* x1, const float* wp, const float* bias,

@@ -17,6 +17,7 @@
 //   3. y (64 ch x 32 frames per wave) through LDS -> + x -> stores in 32-byte runs.
 // x is read twice (the second time for the residual, L2/MALL-warm), y written once.  fp32 MFMA throughout.
 #include "sdc_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -32,6 +33,7 @@ struct TaArgs {
     int inner;               // pixels per outer index (H*W)
     float eps;
     int64_t so, sc, st;      // element (o, c, pixel i, frame f) at o*so + c*sc + f*st + i
+    int dbg;                 // kernel experiments (SDC_TA_DBG): 1 no head loop, 2 no weight fetches, 4 no softmax / rotary
 };
 
 __device__ __forceinline__ int crow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
@@ -43,6 +45,7 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
     float* const rotc = biasT + 4 * 32 * 33;      // [32][16]
     float* const rots = rotc + 32 * 16;           // [32][16]
     float* const red = rots + 32 * 16;            // [2][2][256] LayerNorm partials
+    float* const wl = red + 1024;                 // [2][8192] weights of one head: Wq | Wk | Wv ([64 c][32 d] each) | Wo ([32 d][64 co])
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     // XCD-aware numbering: the 4 pixel groups sharing a 128-byte line stay on one XCD (speed only)
@@ -76,6 +79,15 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
 #pragma unroll
         for (int c = 0; c < 32; ++c) xs[(half * 32 + c) * XP + hw * 33 + f] = v[c] * rstd * a.g[half * 32 + c];
     }
+    {   // head 0's weights
+        typedef float nfloat4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            *reinterpret_cast<nfloat4*>(wl + i * 2048 + (tid >> 3) * 32 + (tid & 7) * 4) =
+                *reinterpret_cast<const nfloat4*>(a.wqkv + (int64_t)(tid >> 3) * 384 + i * 128 + (tid & 7) * 4);
+        *reinterpret_cast<nfloat4*>(wl + 6144 + (tid >> 4) * 64 + (tid & 15) * 4) =
+            *reinterpret_cast<const nfloat4*>(a.wo + (int64_t)(tid >> 4) * C + (tid & 15) * 4);
+    }
     for (int e = tid; e < 4 * 32 * 32; e += NT) {
         const int h = e >> 10, q = (e >> 5) & 31, kk = e & 31;
         biasT[(h * 32 + kk) * 33 + q] = a.bias ? a.bias[e] : 0.0f;
@@ -95,53 +107,56 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
         for (int r = 0; r < 16; ++r) yacc[i][r] = 0.f;
     const float scale = 0.17677669529663687f;
 
-    // Weight fragments (A operands) are fetched a whole 32-step chain ahead into two rotating register sets: a load
-    // consumed a few instructions after its issue exposed the L1/L2 latency on every matrix instruction.
-    float w0[32], w1[32];
-    auto fetch_w = [&](float (&w)[32], int head, int part) {
-        const float* wp = a.wqkv + part * 128 + head * 32 + l31;
+    // The weights of a head (32 KB) are staged in LDS once per workgroup with 16-byte loads -- four per thread -- and shared by
+    // the 8 waves; per-wave dword fetches of the fragments (512 per lane) cost 12 % of the kernel.  Two buffers: the next
+    // head's weights are fetched before the head's chains and parked after them, one barrier per head.
+    typedef float nfloat4 __attribute__((ext_vector_type(4)));
+    nfloat4 wreg[4];
+    auto fetch_head = [&](int head) {
+        if (a.dbg & 2) return;
 #pragma unroll
-        for (int ks = 0; ks < 32; ++ks) w[ks] = wp[(int64_t)(2 * ks + lh) * 384];
+        for (int i = 0; i < 3; ++i) {                    // q, k, v: rows c = 0..63, 32 columns of this head
+            const int rem = tid, c = rem >> 3, c4 = (rem & 7) * 4;
+            wreg[i] = *reinterpret_cast<const nfloat4*>(a.wqkv + (int64_t)c * 384 + i * 128 + head * 32 + c4);
+        }
+        {                                                // Wo rows d = 0..31 of this head, 64 columns
+            const int dd = tid >> 4, c4 = (tid & 15) * 4;
+            wreg[3] = *reinterpret_cast<const nfloat4*>(a.wo + (int64_t)(head * 32 + dd) * C + c4);
+        }
     };
-    auto project = [&](const float (&w)[32], f32x16& acc) {
+    auto park_head = [&](int buf) {
+        float* w = wl + buf * 8192;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<nfloat4*>(w + i * 2048 + (tid >> 3) * 32 + (tid & 7) * 4) = wreg[i];
+        *reinterpret_cast<nfloat4*>(w + 6144 + (tid >> 4) * 64 + (tid & 15) * 4) = wreg[3];
+    };
+    // q / k [32 d][32 f]: A = W[c][d = l31] from LDS, B = xn[c][f]
+    auto project = [&](const float* w, f32x16& acc) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 32; ++ks)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ks], xs[(2 * ks + lh) * XP + hw * 33 + l31], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(2 * ks + lh) * 32 + l31], xs[(2 * ks + lh) * XP + hw * 33 + l31], acc, 0, 0, 0);
     };
     // V is formed transposed (operands swapped: [frame rows][d columns]) so that its accumulator registers are the A
     // fragments of O^T = V P as they stand
-    auto project_t = [&](const float (&w)[32], f32x16& acc) {
+    auto project_t = [&](const float* w, f32x16& acc) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 32; ++ks)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[(2 * ks + lh) * XP + hw * 33 + l31], w[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[(2 * ks + lh) * XP + hw * 33 + l31], w[(2 * ks + lh) * 32 + l31], acc, 0, 0, 0);
     };
-    fetch_w(w0, 0, 0);
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every arbitration against its SIMD partner otherwise
-    for (int head = 0; head < 4; ++head) {
-        // q, k, v [32 d][32 f]: A = W[(part, head)][d = l31][c], B = xn[c][f]
+    for (int head = 0; head < ((a.dbg & 1) ? 0 : 4); ++head) {
+        const float* wh = wl + (head & 1) * 8192;
+        __syncthreads();                           // this head's weights are in LDS; every wave is done with the other buffer
+        if (head < 3) fetch_head(head + 1);
         f32x16 pr[3];
-        fetch_w(w1, head, 1);
-        __builtin_amdgcn_sched_barrier(0);         // keep the whole fetch ahead of the chain it overlaps with
-        project(w0, pr[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch_w(w0, head, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        project(w1, pr[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        {   // output-projection fragments of this head: Wo_p[(head*32 + d)][co], co = l31 and 32 + l31
-            const float* woh = a.wo + (int64_t)(head * 32) * C + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { w1[2 * r] = woh[crow(r, lh) * C]; w1[2 * r + 1] = woh[crow(r, lh) * C + 32]; }   // d in accumulator-row order
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        project_t(w0, pr[2]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (head < 3) fetch_w(w0, head + 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        project(wh, pr[0]);
+        project(wh + 2048, pr[1]);
+        project_t(wh + 4096, pr[2]);
+        if (head < 3) park_head((head + 1) & 1);
         // q * scale, rotary on (d = 2m, 2m+1) pairs = registers (r, r+1) for even r; frame = l31
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
@@ -191,9 +206,10 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
         for (int r = 0; r < 16; ++r) oacc[r] += oacc2[r];
         // y[co][f] += sum_d Wo[co][head*32 + d] O^T[d][f]:  A = Wo fragments (w1, d in accumulator-row order), B = O^T registers
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            yacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2 * r], oacc[r], yacc[0], 0, 0, 0);
-            yacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2 * r + 1], oacc[r], yacc[1], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) {             // Wo rows d in accumulator-row order
+            const float* wor = wh + 6144 + crow(r, lh) * 64 + l31;
+            yacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wor[0], oacc[r], yacc[0], 0, 0, 0);
+            yacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wor[32], oacc[r], yacc[1], 0, 0, 0);
         }
     }
     __syncthreads();                               // every wave is done reading xn
@@ -224,7 +240,9 @@ extern "C" int sdc_tattn_block(const float* x, const float* g_pre, const float* 
     TaArgs a;
     a.x = x; a.g = g_pre; a.wqkv = wqkv; a.wo = wo; a.rot = rot; a.bias = bias; a.y = y;
     a.inner = inner; a.eps = eps; a.so = so; a.sc = sc; a.st = st;
-    const size_t ldsb = sizeof(float) * (size_t)(C * XP + 4 * 32 * 33 + 2 * 32 * 16 + 1024);
+    static const int dbg = getenv("SDC_TA_DBG") ? atoi(getenv("SDC_TA_DBG")) : 0;
+    a.dbg = dbg;
+    const size_t ldsb = sizeof(float) * (size_t)(C * XP + 4 * 32 * 33 + 2 * 32 * 16 + 1024 + 2 * 8192);
     static std::atomic<uint64_t> attr{0};
     if (sdc::first_use_on_device(attr)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ta_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
