@@ -415,6 +415,85 @@ __global__ __launch_bounds__(NT) void tattn_kernel(const AttnArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------ softmax attention over 256 contiguous tokens on the matrix cores
+// The smoke net's mid spatial attention (conv3d.py:450-452,548: 16x16 = 256 tokens, heads 4 x 32, no rotary / bias).  One
+// workgroup = one (sequence, head): K [d][tok] and V [d][tok] (pitch 257: the O product reads V down a column) are staged in
+// LDS; wave w owns the query blocks w and w + 4 (32 queries each).  Per query block, S^T[key][query] = K . Q^T over the 8 key
+// blocks stays in registers (8 x 16 accumulators: the 256 scores of one query sit in two lanes), softmax runs on them, and the
+// P registers are the B operands of O^T[d][query] = V . P as they stand.  2048 MFMAs per workgroup instead of 2 x 256 x 32
+// scalar FMA loops per query (attn_kernel computed Q.K^T twice): 13.9 -> ~70 TFLOP/s.
+constexpr int A2_VP = 257;
+__global__ __launch_bounds__(NT) void attn256_kernel(const AttnArgs a) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const Ks = lds;                       // [32 d][256 tok]
+    float* const Vs = lds + 32 * 256;            // [32 d][257]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.x % a.heads, sq = blockIdx.x / a.heads;
+    const int o = sq / a.inner, i = sq - o * a.inner;
+    const float* qb = a.qkv + o * a.so + i * a.si + (int64_t)(head * DH) * a.sc;
+    const float* kb = qb + (int64_t)(a.heads * DH) * a.sc;
+    const float* vb = kb + (int64_t)(a.heads * DH) * a.sc;
+    typedef float nfloat4 __attribute__((ext_vector_type(4)));
+    // stage K and V: 32 rows x 256 tokens each, 16-byte loads (8 per thread per tensor)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int f = tid + it * NT;               // float4 index: row d = f >> 6, 4 tokens at (f & 63) * 4
+        const int d = f >> 6, t4 = (f & 63) * 4;
+        const nfloat4 kv = *reinterpret_cast<const nfloat4*>(kb + (int64_t)d * a.sc + t4);
+        const nfloat4 vv = *reinterpret_cast<const nfloat4*>(vb + (int64_t)d * a.sc + t4);
+        *reinterpret_cast<nfloat4*>(Ks + d * 256 + t4) = kv;
+        float* vp = Vs + d * A2_VP + t4;
+        vp[0] = vv.x; vp[1] = vv.y; vp[2] = vv.z; vp[3] = vv.w;
+    }
+    __syncthreads();
+    const float scale = 0.17677669529663687f;
+    float* ob = a.out + o * a.oso + i * a.osi + (int64_t)(head * DH) * a.osc;
+    for (int u = 0; u < 2; ++u) {
+        const int q0 = (wave + 4 * u) * 32;
+        // B fragments of Q^T: B[d = 2s + lh][query = l31]
+        float qf[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) qf[s] = qb[(int64_t)(2 * s + lh) * a.sc + q0 + l31] * scale;
+        f32x16 sc[8];
+#pragma unroll
+        for (int kbk = 0; kbk < 8; ++kbk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kbk][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)           // A[key = l31][d = 2s + lh]
+                sc[kbk] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(2 * s + lh) * 256 + kbk * 32 + l31], qf[s], sc[kbk], 0, 0, 0);
+        }
+        // lane (query = l31, half lh) holds keys kbk*32 + (r&3) + 8*(r>>2) + 4*lh
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kbk = 0; kbk < 8; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kbk][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kbk = 0; kbk < 8; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[kbk][r] = expf(sc[kbk][r] - mx); sum += sc[kbk][r]; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        // O^T[d][query] = sum_key V[d][key] P[key][query]: A[d = l31][key], B = P registers (k-step r of block kbk)
+        f32x16 oacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+#pragma unroll
+        for (int kbk = 0; kbk < 8; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[l31 * A2_VP + kbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh], sc[kbk][r], oacc, 0, 0, 0);
+        // lane (query = l31, half lh) holds d = (r&3) + 8*(r>>2) + 4*lh: 128-byte runs along the tokens
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.osc + q0 + l31] = oacc[r] * inv;
+    }
+}
+
 }  // namespace
 
 extern "C" int sdc_linattn(const float* qkv, float* ctx, float* out, int outer, int inner, int heads, int64_t n,
@@ -448,6 +527,15 @@ extern "C" int sdc_attn(const float* qkv, float* out, const float* rot, const fl
         const int nblk = (outer * inner / TA_NS) * heads;
         hipLaunchKernelGGL(tattn_kernel, dim3((unsigned)nblk), dim3(NT), 0, sdc::as_stream(stream), a);
         return sdc::check_launch("sdc_attn[mfma]");
+    }
+    if (a.tok_contig && ntok == 256 && !rot && !bias && o_st == 1 && q_sc % 4 == 0 && q_so % 4 == 0 && q_si % 4 == 0 &&
+        reinterpret_cast<uintptr_t>(qkv) % 16 == 0) {
+        const size_t ldsb = sizeof(float) * (size_t)(32 * 256 + 32 * A2_VP);
+        static std::atomic<uint64_t> attr2{0};
+        if (sdc::first_use_on_device(attr2))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(attn256_kernel, dim3((unsigned)(outer * inner * heads)), dim3(NT), ldsb, sdc::as_stream(stream), a);
+        return sdc::check_launch("sdc_attn[mfma 256]");
     }
     int nseq = NT / ntok;
     if (nseq < 1) nseq = 1;
