@@ -651,23 +651,32 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
     for (int st = 0; st < nstages; ++st) {
         const int buf = st & 1;
         if (st + 1 < nstages) load_stage();
-#pragma unroll
-        for (int kw = 0; kw < KW; ++kw) {
-            float af[BK / 2][TM], bf[BK / 2][TN];
+        // The fragments of tap kw+1 are read (all of them, ahead of the fence) while the MFMAs of tap kw run: left to itself
+        // the scheduler sinks every LDS read next to its use and the wave waits out the LDS latency once per 4 MFMAs.
+        float af[2][BK / 2][TM], bf[2][BK / 2][TN];
+        auto read_tap = [&](int kw, int set) {
 #pragma unroll
             for (int ks = 0; ks < BK / 2; ++ks) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[ks][i] = As[buf][kw][2 * ks + lh][am + i * 32];
+                for (int i = 0; i < TM; ++i) af[set][ks][i] = As[buf][kw][2 * ks + lh][am + i * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[ks][j] = Bs[buf][(2 * ks + lh) * ks_stride + boff[j] + kw];
+                for (int j = 0; j < TN; ++j) bf[set][ks][j] = Bs[buf][(2 * ks + lh) * ks_stride + boff[j] + kw];
             }
+        };
+        read_tap(0, 0);
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+            const int set = kw & 1;
+            if (kw + 1 < KW) read_tap(kw + 1, set ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < BK / 2; ++ks)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][ks][i], bf[set][ks][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (st + 1 < nstages) store_stage(buf ^ 1);
         __syncthreads();
