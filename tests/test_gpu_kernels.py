@@ -410,6 +410,30 @@ def test_conv_winograd_2d_mode(plan_cls, case):
     assert e0 < 4e-6 and e3 < 1e-5, (e0, e3)
 
 
+def test_conv_winograd_2d_strided_output_and_residual(plan_cls):
+    """F(2x2,3x3) kernel writing through a strided view (every other column of a wider buffer) with a residual read
+    through another strided view: the scalar (non 8-byte) store / load path of its epilogue."""
+    from safediffcon_amd.engine import as5
+    B, cin, cout, sp = 3, 32, 96, (8, 32)
+    x = det_tensor((B, cin, *sp), 211)
+    w, b = det_tensor((cout, cin, 3, 3), 212, 0.2), det_tensor((cout,), 213, 0.1)
+    res = det_tensor((B, cout, *sp), 214)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + res.double()
+    plan = plan_cls(DEV, precision=3)
+    ybuf = torch.full((B, cout, 1, sp[0], 2 * sp[1]), 7.0, device=DEV)
+    rbuf = torch.zeros((B, cout, 1, sp[0], 2 * sp[1] + 2), device=DEV)
+    rbuf[..., 1:2 * sp[1] + 1:2] = as5(res.to(DEV))
+    out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, (1, 3, 3), pad=(0, 1, 1),
+                    residual=rbuf[..., 1:2 * sp[1] + 1:2], out=ybuf[..., ::2])
+    buf = C.create_string_buffer(128)
+    plan.lib.sdc_conv_describe(C.byref(plan.calls[0][1][0]._obj), buf, 128, None)
+    assert buf.value.decode().startswith("conv_wg2_kernel")
+    _run(plan)
+    err = (out.cpu().reshape(ref.shape).double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-5, err
+    assert torch.all(ybuf[..., 1::2] == 7.0)                       # the columns in between are untouched
+
+
 def test_conv_winograd_2d_falls_back_where_not_covered(plan_cls):
     """precision 3 on shapes the F(2x2,3x3) kernel does not take: odd row counts, rows wider than 128 or not a power of
     two, Conv1d -- run the F(2,3)-along-W or the direct kernel on the same weight buffer and stay correct."""
