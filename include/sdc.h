@@ -74,8 +74,8 @@ typedef struct SdcConvDesc {
     int32_t pD, pH, pW;          /* padding, in the (virtually upsampled) input space */
     int32_t uD, uH, uW;          /* virtual input upsample factor, 1 or 2 */
     int32_t up_mode;             /* 0 nearest, 1 zero-insert */
-    int32_t precision;           /* conv algorithm and layout of the wp buffer (0, 2 and 3 are fp32 end to end and differ by
-                                    rounding order only; the drop-in nets use 3):
+    int32_t precision;           /* conv algorithm and layout of the wp buffer (0, 2, 3 and 4 are fp32 end to end and differ by
+                                    rounding order only; the drop-in nets use 4):
                                     0 = fp32 MFMA, direct implicit GEMM everywhere (k-ordered fp32 FMA chains); wp = Wp
                                     2 = fp32 MFMA, Winograd F(2,3) along W on the 3-wide stride-1 convs (2/3 of the matrix
                                         work); wp = Wp followed, when kW == 3, by the transformed taps
@@ -86,6 +86,12 @@ typedef struct SdcConvDesc {
                                         kH == kW == 3 the buffer is Wp | Wg | Wg2 with Wg2[kd][ci][co][j*4 + xi] =
                                         sum_{kh,kw} G[j][kh] G[xi][kw] w[co][ci][kd][kh][kw]; other tap shapes: layout of 2.
                                         Shapes the F(2x2,3x3) kernel does not take fall back to 2's kernels on the same buffer.
+                                    4 = as 3, plus Winograd F(2x2x2,3x3x3) over (D, H, W) for the 3x3x3 stride-1 pad-1 convs with
+                                        an even depth, rows of 16 / 32 / 64 columns and Cout % 64 == 0 (8/27 of the matrix work):
+                                        when kD == kH == kW == 3 the buffer is Wp | Wg | Wg2 | Wg3 with Wg3[jd][ci][co][j*4 + xi]
+                                        = sum_{kd,kh,kw} G[jd][kd] G[j][kh] G[xi][kw] w[co][ci][kd][kh][kw]; other tap shapes:
+                                        layout of 3.  y is used as scratch for partial plane sums while the kernel runs (it
+                                        must not alias an input).  Shapes it does not take fall back to 3's kernels.
                                     1 = opt-in 3-pass split-bf16 MFMA (~16 mantissa bits, NOT the parity mode) */
     int64_t x0s[5], x1s[5], ys[5], rs[5];   /* element strides (b,c,d,h,w) */
 } SdcConvDesc;
@@ -95,14 +101,14 @@ int sdc_conv(const SdcConvDesc* d, const float* x0, const float* x1, const float
 
 /* Host-side query (measurement tooling, launches nothing): which kernel template instance sdc_conv would run for this
  * descriptor, and the share of the direct-form multiply-adds 2*B*P*Cout*Cin*taps that it issues on the matrix cores
- * (1 for the direct kernels, 2/3 for Winograd F(2,3) along W, 4/9 for F(2x2,3x3)). */
+ * (1 for the direct kernels, 2/3 for Winograd F(2,3) along W, 4/9 for F(2x2,3x3), 8/27 for F(2x2x2,3x3x3)). */
 int sdc_conv_describe(const SdcConvDesc* d, char* name, size_t cap, double* mfma_share);
 
 /* Conv + GroupNorm statistics of its output in one pass (the Block.proj -> Block.norm pair, 1D/model/unet.py:132-141,
  * conv3d.py:192-198): the conv epilogue leaves fp64 (sum, sum of squares) pairs per (sample, group, part) in `parts`
  * (B * G * nparts pairs) and sdc_gn_finalize turns them into the {mean, rstd} table sdc_gn_apply reads -- y is not read
  * again for the statistics.  sdc_conv_gnparts is a host-side query: nparts for this descriptor, or 0 when the fused form
- * does not cover it (then run sdc_conv + sdc_gn_stats).  Covered: the precision-2 / 3 Winograd convs whose tile grid
+ * does not cover it (then run sdc_conv + sdc_gn_stats).  Covered: the precision-2 / 3 / 4 Winograd convs whose tile grid
  * lines up with the samples and groups. */
 int sdc_conv_gnparts(const SdcConvDesc* d, int G);
 int sdc_conv_gn(const SdcConvDesc* d, const float* x0, const float* x1, const float* wp, const float* bias,

@@ -56,7 +56,7 @@ struct ConvArgs {
     int lgD, lgH, lgW;
     int rowhalo;   // allow the row-halo kernel (env SDC_NO_ROWHALO=1 disables it for A/B timing)
     int vec2;      // Winograd epilogue: y (and residual) rows allow 8-byte accesses at even positions
-    const float* wg2;   // F(2x2,3x3) taps [kd][16][Cin][Cout] (precision 3)
+    const float* wg2;   // F(2x2,3x3) taps [kd][Cin][Cout][16] (precision 3) / F(2x2x2,3x3x3) taps [jd][Cin][Cout][16] (precision 4)
     // GroupNorm partial sums of the output (sdc_conv_gn): fp64 (sum, sum of squares) per (sample, group, part)
     double* gn_part;
     int gn_G, gn_cpg, gn_nparts, gn_S;
@@ -1499,6 +1499,31 @@ __device__ __forceinline__ w2f2 pk_sumdiff(w2f2 c) {
     asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(c));
     return r;
 }
+// (c1, c2) -> (c1 + c2, c1 - c2);  (s.x + a.x, s.y - a.y);  a * a + c
+__device__ __forceinline__ w2f2 pk_sumdiff_fwd(w2f2 c) {
+    w2f2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(c));
+    return r;
+}
+__device__ __forceinline__ w2f2 pk_addsub(w2f2 s, w2f2 a) { w2f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(s), "v"(a)); return r; }
+__device__ __forceinline__ w2f2 pk_sqacc(w2f2 a, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(r) : "v"(a), "v"(c)); return r; }
+// Sums over the 64 lanes of eight fp64 values per lane with 10 exchanges instead of 48: halve the value set at the xor-32,
+// -16 and -8 levels (each lane keeps the half its lane bit selects), then an all-reduce of the one value left over xor 4, 2, 1.
+// Afterwards every lane holds the wave total of value (lane >> 3).  Fixed order: the result does not depend on anything but
+// the 512 inputs.
+__device__ __forceinline__ double wave_sum8(const double (&v)[8], int lane) {
+    double w[4], u[2];
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (b5 ? v[4 + i] : v[i]) + __shfl_xor(b5 ? v[i] : v[4 + i], 32, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) u[i] = (b4 ? w[2 + i] : w[i]) + __shfl_xor(b4 ? w[i] : w[2 + i], 16, 64);
+    double t = (b3 ? u[1] : u[0]) + __shfl_xor(b3 ? u[0] : u[1], 8, 64);
+    t += __shfl_xor(t, 4, 64);
+    t += __shfl_xor(t, 2, 64);
+    t += __shfl_xor(t, 1, 64);
+    return t;
+}
 // value of lane - S of the same 16-lane row (0 past the row end) minus b;  a minus the value of lane + S
 template <int S>
 __device__ __forceinline__ float sub_prev(float x, float b) {
@@ -1697,6 +1722,15 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     for (int c = 0; c < 16; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+    // The bias is the start value of component (j, xi) = (1, 1): A^T M A hands that component to each of the 2x2 outputs with
+    // coefficient +1.  Register r of a lane is channel m0 + 32 wm + 8 (r >> 2) + 4 lh + (r & 3).
+    if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m0 + wm * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+            acc[5][r] = a.bias[co < d.Cout ? co : d.Cout - 1];
+        }
+    }
 
     const int nstages = d.kD * (a.Cin / SK);
     nfloat4 fa[2][4];             // [set][chunk j]: U components (j, xi = 0..3) of this lane's (k, m)
@@ -1790,14 +1824,17 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         if (sdbg == 12345.678f) a.y[0] = sdbg;
         return;
     }
-    // ---- epilogue: output transform Y = A^T M A on the accumulators, bias, residual, GroupNorm partial sums.
-    // Every VALU instruction here is exposed (nothing else runs on the CU): the channel part of the output / residual / bias
-    // addresses is scalar (rows of a lane differ by whole channels), the lane part one 32-bit offset for all 16 rows.
+    // ---- epilogue: output transform Y = A^T M A on the accumulators, residual, GroupNorm partial sums.
+    // Every instruction here is exposed (nothing else runs on the CU), so the common case -- all 64 channels and all 64
+    // tiles of the workgroup exist, 8-byte stores allowed, no residual -- is straight-line code: per channel row 16
+    // accumulator reads, 12 packed adds (the H stage on the component pairs (xi 0, 3) and (1, 2), which hands the W stage
+    // its operands already paired; its results are the two adjacent outputs of a row), two 8-byte stores from a scalar
+    // channel base stepped by the channel stride, 4 packed ops for the GroupNorm sums.
     const bool v2 = a.vec2;
     const bool gn = a.gn_part != nullptr;
-    double gs[4], gq[4];
+    double gv[8];                                           // 8-row block g4: gv[2 g4] = sum, gv[2 g4 + 1] = sum of squares
 #pragma unroll
-    for (int b4 = 0; b4 < 4; ++b4) { gs[b4] = 0.0; gq[b4] = 0.0; }
+    for (int i = 0; i < 8; ++i) gv[i] = 0.0;
     {
         const int cob = m0 + wm * 32;                       // wave-uniform; this lane's rows: cob + 4 lh + (rr & 3) + 8 (rr >> 2)
         const int n = tile0 + wn * 32 + l31;
@@ -1814,66 +1851,93 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         typedef __attribute__((address_space(1))) char* gwchar_p;
         typedef __attribute__((address_space(1))) float* gwfloat_p;
         typedef __attribute__((address_space(1))) nfloat2* gwfloat2_p;
+        if (full && v2 && !a.res && rp0 + RP <= RPtot) {
+            gwchar_p yb = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(a.y + (int64_t)cob * ycs);
+            const int64_t rstep = ycs * 4, gstep = ycs * 20;                // bytes: the next row, the first row of the next block
+            const uint32_t yoff1 = yoff + yrow;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {                    // 8-row blocks: rows cob + 8 g4 + 4 lh + (0..3)
-            float bs = 0.0f, bq = 0.0f;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                w2f2 bs2 = {0.f, 0.f}, bq2 = {0.f, 0.f};
 #pragma unroll
-            for (int r3 = 0; r3 < 4; ++r3) {
-                const int rr = g4 * 4 + r3;
-                const int cou = cob + 8 * g4 + r3;          // wave-uniform part of the row
-                const bool rok = full || (cou + 4 * lh) < d.Cout;
-                const int coc = full ? cou : (cou < d.Cout - 4 ? cou : d.Cout - 8);       // clamped: in-bounds addresses for the tail
-                float t0[4], t1[4];
+                for (int r3 = 0; r3 < 4; ++r3) {
+                    const int rr = g4 * 4 + r3;
+                    w2f2 pa[4], pb[4];                      // per j: (M[j][0], M[j][3]), (M[j][1], M[j][2])
 #pragma unroll
-                for (int xi = 0; xi < 4; ++xi) {
-                    const float M0 = acc[0 + xi][rr], M1 = acc[4 + xi][rr], M2 = acc[8 + xi][rr], M3 = acc[12 + xi][rr];
-                    t0[xi] = (M0 + M1) + M2;
-                    t1[xi] = (M1 - M2) - M3;
-                }
-                float bv = 0.0f;
-                if (a.bias) bv = a.bias[(full ? cou : coc) + 4 * lh];
-                float y00 = ((t0[0] + t0[1]) + t0[2]) + bv;
-                float y01 = ((t0[1] - t0[2]) - t0[3]) + bv;
-                float y10 = ((t1[0] + t1[1]) + t1[2]) + bv;
-                float y11 = ((t1[1] - t1[2]) - t1[3]) + bv;
-                if (a.res) {
-                    const gchar_p rb = (gchar_p)uniform_ptr(a.res + (int64_t)coc * rcs);
-                    if (v2) {
-                        const nfloat2 u0 = *(gfloat2_p)(rb + roff), u1 = *(gfloat2_p)(rb + roff + rrow);
-                        y00 += u0.x; y01 += u0.y; y10 += u1.x; y11 += u1.y;
-                    } else {
-                        y00 += *(gfloat_p)(rb + roff); y01 += *(gfloat_p)(rb + roff + rcol);
-                        y10 += *(gfloat_p)(rb + roff + rrow); y11 += *(gfloat_p)(rb + roff + rrow + rcol);
+                    for (int j = 0; j < 4; ++j) {
+                        pa[j] = w2f2{acc[4 * j][rr], acc[4 * j + 3][rr]};
+                        pb[j] = w2f2{acc[4 * j + 1][rr], acc[4 * j + 2][rr]};
                     }
+                    const w2f2 t0a = pk_add2(pk_add2(pa[0], pa[1]), pa[2]), t1a = pk_sub2(pk_sub2(pa[1], pa[2]), pa[3]);
+                    const w2f2 t0b = pk_add2(pk_add2(pb[0], pb[1]), pb[2]), t1b = pk_sub2(pk_sub2(pb[1], pb[2]), pb[3]);
+                    const w2f2 z0 = pk_addsub(pk_sumdiff_fwd(t0b), t0a);    // (y00, y01)
+                    const w2f2 z1 = pk_addsub(pk_sumdiff_fwd(t1b), t1a);    // (y10, y11)
+                    *(gwfloat2_p)(yb + yoff) = nfloat2{z0.x, z0.y};
+                    *(gwfloat2_p)(yb + yoff1) = nfloat2{z1.x, z1.y};
+                    bs2 = pk_add2(bs2, pk_add2(z0, z1));
+                    bq2 = pk_sqacc(z1, pk_sqacc(z0, bq2));
+                    yb += r3 < 3 ? rstep : gstep;
                 }
-                if (pok && rok) {
-                    const gwchar_p yb = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(a.y + (int64_t)coc * ycs);
-                    if (v2) {
-                        *(gwfloat2_p)(yb + yoff) = nfloat2{y00, y01};
-                        *(gwfloat2_p)(yb + yoff + yrow) = nfloat2{y10, y11};
-                    } else {
-                        *(gwfloat_p)(yb + yoff) = y00; *(gwfloat_p)(yb + yoff + ycol) = y01;
-                        *(gwfloat_p)(yb + yoff + yrow) = y10; *(gwfloat_p)(yb + yoff + yrow + ycol) = y11;
-                    }
-                    // GroupNorm sums: the 2x2 tile and the 4 rows of the block in fp32 (1e-7 relative on a 16-element partial
-                    // sum), fp64 from there on -- independent of the batch a trajectory is launched with (the tile grid cuts
-                    // every sample alike)
-                    bs += (y00 + y01) + (y10 + y11);
-                    bq = fmaf(y00, y00, fmaf(y01, y01, fmaf(y10, y10, fmaf(y11, y11, bq))));
-                }
+                gv[2 * g4] = (double)(bs2.x + bs2.y);
+                gv[2 * g4 + 1] = (double)(bq2.x + bq2.y);
             }
-            gs[g4] = (double)bs;
-            gq[g4] = (double)bq;
+        } else {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {                // 8-row blocks: rows cob + 8 g4 + 4 lh + (0..3)
+                float bs = 0.0f, bq = 0.0f;
+#pragma unroll
+                for (int r3 = 0; r3 < 4; ++r3) {
+                    const int rr = g4 * 4 + r3;
+                    const int cou = cob + 8 * g4 + r3;      // wave-uniform part of the row
+                    const bool rok = full || (cou + 4 * lh) < d.Cout;
+                    const int coc = full ? cou : (cou < d.Cout - 4 ? cou : d.Cout - 8);       // clamped: in-bounds addresses for the tail
+                    float t0[4], t1[4];
+#pragma unroll
+                    for (int xi = 0; xi < 4; ++xi) {
+                        const float M0 = acc[0 + xi][rr], M1 = acc[4 + xi][rr], M2 = acc[8 + xi][rr], M3 = acc[12 + xi][rr];
+                        t0[xi] = (M0 + M1) + M2;
+                        t1[xi] = (M1 - M2) - M3;
+                    }
+                    float y00 = (t0[0] + t0[1]) + t0[2];
+                    float y01 = (t0[1] - t0[2]) - t0[3];
+                    float y10 = (t1[0] + t1[1]) + t1[2];
+                    float y11 = (t1[1] - t1[2]) - t1[3];
+                    if (a.res) {
+                        const gchar_p rb = (gchar_p)uniform_ptr(a.res + (int64_t)coc * rcs);
+                        if (v2) {
+                            const nfloat2 u0 = *(gfloat2_p)(rb + roff), u1 = *(gfloat2_p)(rb + roff + rrow);
+                            y00 += u0.x; y01 += u0.y; y10 += u1.x; y11 += u1.y;
+                        } else {
+                            y00 += *(gfloat_p)(rb + roff); y01 += *(gfloat_p)(rb + roff + rcol);
+                            y10 += *(gfloat_p)(rb + roff + rrow); y11 += *(gfloat_p)(rb + roff + rrow + rcol);
+                        }
+                    }
+                    if (pok && rok) {
+                        const gwchar_p yb = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(a.y + (int64_t)coc * ycs);
+                        if (v2) {
+                            *(gwfloat2_p)(yb + yoff) = nfloat2{y00, y01};
+                            *(gwfloat2_p)(yb + yoff + yrow) = nfloat2{y10, y11};
+                        } else {
+                            *(gwfloat_p)(yb + yoff) = y00; *(gwfloat_p)(yb + yoff + ycol) = y01;
+                            *(gwfloat_p)(yb + yoff + yrow) = y10; *(gwfloat_p)(yb + yoff + yrow + ycol) = y11;
+                        }
+                        // GroupNorm sums: the 2x2 tile and the 4 rows of the block in fp32 (1e-7 relative on a 16-element partial
+                        // sum), fp64 from there on -- independent of the batch a trajectory is launched with (the tile grid cuts
+                        // every sample alike)
+                        bs += (y00 + y01) + (y10 + y11);
+                        bq = fmaf(y00, y00, fmaf(y01, y01, fmaf(y10, y10, fmaf(y11, y11, bq))));
+                    }
+                }
+                gv[2 * g4] = (double)bs;
+                gv[2 * g4 + 1] = (double)bq;
+            }
         }
     }
     if (gn) {
-        // same layout as wg_epilogue: scr[wave][4][2]; 8-row block t of the workgroup's 64 rows = (wm = t / 4, k = t % 4)
-        double* scr = reinterpret_cast<double*>(ldsw);
-#pragma unroll
-        for (int b4 = 0; b4 < 4; ++b4) {
-            const double s1 = sdc::wave_sum(gs[b4]), q1 = sdc::wave_sum(gq[b4]);
-            if (lane == 0) { scr[(wave * 4 + b4) * 2] = s1; scr[(wave * 4 + b4) * 2 + 1] = q1; }
-        }
+        // scr[wave][4][2] behind the stage buffers (a wave may get here while another still reads its last fragments);
+        // 8-row block t of the workgroup's 64 rows = (wm = t / 4, k = t % 4)
+        double* scr = reinterpret_cast<double*>(ldsw + W2_NBUF * (W2_ASZ + W2_BSZ));
+        const double tot = wave_sum8(gv, lane);
+        if ((lane & 7) == 0) scr[wave * 8 + (lane >> 3)] = tot;
         __syncthreads();
         const int ngl = a.gn_cpg >= BM ? 1 : BM / a.gn_cpg;       // groups inside this workgroup's rows
         if (tid < ngl) {
@@ -1905,7 +1969,7 @@ inline int64_t span5(const int64_t* st, int b, int c, int dd, int h, int w) {
 // coverage of the F(2x2,3x3) kernel (precision 3)
 bool wg2_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
     const int64_t rptot = (int64_t)d.B * d.oD * (d.oH / 2);
-    return d.precision == 3 && rowhalo && small && d.kH == 3 && d.kW == 3 && (d.kD == 1 || d.kD == 3) &&
+    return d.precision >= 3 && rowhalo && small && d.kH == 3 && d.kW == 3 && (d.kD == 1 || d.kD == 3) &&
            d.sD == 1 && d.sH == 1 && d.sW == 1 && d.uD == 1 && d.uH == 1 && d.uW == 1 && d.up_mode == 0 &&
            d.pH == 1 && d.pW == 1 && d.pD == d.kD / 2 && d.oH == d.iH && d.oW == d.iW && d.oD == d.iD &&
            (d.oW == 16 || d.oW == 32 || d.oW == 64 || d.oW == 128) && d.oH % 2 == 0 &&
@@ -1925,7 +1989,7 @@ void launch_wg2(const ConvArgs& a, hipStream_t s) {
     const int64_t tiles = (int64_t)d.B * d.oD * (d.oH / 2) * (d.oW / 2);
     const int MT = (d.Cout + W2_BM - 1) / W2_BM;
     dim3 grid((unsigned)(((tiles + W2_TILES - 1) / W2_TILES) * MT));
-    const size_t lds = (size_t)W2_NBUF * (W2_ASZ + W2_BSZ) * sizeof(float);
+    const size_t lds = (size_t)W2_NBUF * (W2_ASZ + W2_BSZ) * sizeof(float) + 4 * 8 * sizeof(double);     // stage buffers + GroupNorm scratch
     static const int dbg = getenv("SDC_WG2_DBG") ? atoi(getenv("SDC_WG2_DBG")) : 0;     // kernel experiments: parts of the loop off
 #define W2_LAUNCH(OWV, D)                                                                                                        \
     do {                                                                                                                         \
@@ -1944,6 +2008,432 @@ void launch_wg2(const ConvArgs& a, hipStream_t s) {
     else if (d.oW == 32) W2_LAUNCH(32, 0);
     else if (d.oW == 64) W2_LAUNCH(64, 0);
     else W2_LAUNCH(128, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// precision = 4: fp32 Winograd F(2x2x2, 3x3x3) for the 3x3x3 stride-1 convs -- the F(2x2,3x3) kernel above with the same
+// transform applied along the depth as well: 64 products per 8 outputs instead of 216, i.e. 2/3 of the MFMA work of the
+// (H, W)-only form and 8/27 of the direct form.  The caller stores U3[jd][ci][co][j*4+xi] = sum G[jd][kd] G[j][kh] G[xi][kw] w
+// behind the F(2x2,3x3) taps.
+//   * A workgroup owns 64 output channels x 64 (h, w) tiles x ONE PAIR of output planes (2 dp, 2 dp + 1) and walks the four
+//     depth components jd one after the other with the 16 (j, xi) accumulators of the kernel above.  The K loop of pass jd
+//     runs over the input channels only; its B operand is the (H, W) transform of the depth combination
+//        jd 0: s[-1] - s[1],   jd 1: s[0] + s[1],   jd 2: s[1] - s[0],   jd 3: s[0] - s[2]      (s[i] = input plane 2 dp + i)
+//     which costs two row loads and one packed multiply-add more per row than the plain slice (the signs, the zero planes
+//     past the volume and the zero rows above / below the image are factors of the same fused ops).
+//   * At the end of pass jd the (H, W) output transform m_jd of the accumulators is folded into the two output planes,
+//        y[2 dp] = m0 + m1 + m2,      y[2 dp + 1] = m1 - m2 - m3,
+//     by read-modify-write of y by the lane that owns the element (a lane's own loads and stores of one address stay
+//     ordered): pass 0 stores plane 0, pass 1 adds to plane 0 and stores plane 1, pass 2 finishes plane 0 and subtracts
+//     from plane 1, pass 3 finishes plane 1.  The partial planes are read back from L2 / MALL; the residual and the GroupNorm
+//     sums are applied to the finished values.  The fetch pipeline of the next pass (two stages in flight) runs through
+//     the fold, so only its own instructions are exposed.
+// Coverage: what the F(2x2,3x3) kernel takes, and kD = 3, even depth, W in {16, 32, 64}, Cout % 64 == 0, the row pairs of
+// a workgroup inside one plane, 8-byte aligned output rows.
+__device__ __forceinline__ uint64_t lo64(float k) { return (uint64_t)__builtin_bit_cast(uint32_t, k); }
+// a * k, a * k + c with a wave-uniform factor k (both halves)
+__device__ __forceinline__ w2f2 pks_mul(w2f2 a, float k) { w2f2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "s"(lo64(k))); return r; }
+__device__ __forceinline__ w2f2 pks_fma(w2f2 a, float k, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "s"(lo64(k)), "v"(c)); return r; }
+__device__ __forceinline__ w2f2 pk_fma2(w2f2 a, w2f2 b, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+template <int OW>
+__global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
+    constexpr int SK = W2_SK, BM = W2_BM;
+    constexpr int TW = OW / 2, RP = W2_TILES / TW;
+    constexpr int LGW = OW == 64 ? 6 : (OW == 32 ? 5 : 4);
+    constexpr int CPL = OW == 16 ? 2 : OW / 16;          // adjacent columns per lane
+    constexpr int SH = OW == 16 ? 2 : 1;                 // DPP lane distance of the neighbouring column group
+    constexpr int LPK = 128 / CPL;                       // lanes per staged channel (k row)
+    constexpr int NIT = CPL == 2 ? 2 : 1;                // park items per thread and stage
+    constexpr int KPW = 2;                               // k rows per (parking) wave
+    constexpr int TPL = CPL / 2;                         // tiles per lane and row pair
+    typedef float nfloat4 __attribute__((ext_vector_type(4)));
+    typedef float nfloat2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) char* gchar_p;
+    typedef const __attribute__((address_space(1))) nfloat4* gfloat4_p;
+    typedef const __attribute__((address_space(1))) nfloat2* gfloat2_p;
+    typedef __attribute__((address_space(1))) char* gwchar_p;
+    typedef __attribute__((address_space(1))) nfloat2* gwfloat2_p;
+    extern __shared__ __attribute__((aligned(16))) float ldsw[];
+    float* const As = ldsw;                          // [2][SK][BM][16]  (chunk q of row m at slot q ^ ((m >> 2) & 3))
+    float* const Vs = ldsw + W2_NBUF * W2_ASZ;       // [2][SK][4 j][64 tiles][4 xi]
+
+    const SdcConvDesc& d = a.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = SDC_UNIFORM(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int MT = d.Cout / BM;
+    const int lb = xcd_tile(blockIdx.x, gridDim.x);
+    const int m0 = (lb % MT) * BM;
+    const int tile0 = (lb / MT) * W2_TILES;
+    const int H2 = d.oH >> 1, D2 = d.oD >> 1;
+    // the workgroup's RP row pairs lie in one plane pair (host check: H2 % RP == 0): (sample ob, planes od, od + 1, first row pair hp0)
+    int ob, od, hp0;
+    {
+        const int rp0 = tile0 >> (LGW - 1);          // < 2^20 (host check): the float quotients are exact
+        const int q = (int)(((float)rp0 + 0.5f) * (1.0f / (float)H2));
+        const int b = (int)(((float)q + 0.5f) * (1.0f / (float)D2));
+        hp0 = SDC_UNIFORM(rp0 - q * H2);
+        ob = SDC_UNIFORM(b);
+        od = SDC_UNIFORM(2 * (q - b * D2));
+    }
+    const bool two = d.Cin1 > 0;
+
+    // ---- park geometry of this thread: k row inside the stage, row pair, first column (CPL columns)
+    const int ksub = CPL == 4 ? (lane >> 5) : 0;                    // k row inside the wave's pair (CPL = 2: the item)
+    const int lik = lane & (LPK - 1);
+    int pr, pc0;
+    if (OW == 16) { pr = 2 * (lik >> 4) + (lik & 1); pc0 = 2 * ((lik & 15) >> 1); }
+    else { pr = lik >> 4; pc0 = (lik & 15) * CPL; }
+    // lane part of the input addresses (bytes): k row, row 2 hp, column; the rows above / below the pair are fetched from a
+    // clamped (valid) row and multiplied by 0 where they fall outside the image.  Sample, plane and channel are scalar.
+    const int hp = hp0 + pr;
+    const bool up_ok = hp > 0, dn_ok = 2 * hp + 2 < d.iH;
+    const w2f2 m0p = {up_ok ? 1.0f : 0.0f, up_ok ? 1.0f : 0.0f}, m3p = {dn_ok ? 1.0f : 0.0f, dn_ok ? 1.0f : 0.0f};
+    const uint32_t rsel0 = up_ok ? OW * 4 : 0, rsel3 = dn_ok ? 2 * OW * 4 : 0;
+    const uint32_t vp0 = (uint32_t)(ksub * d.x0s[1] + (2 * hp) * OW + pc0) * 4u;
+    const uint32_t vp1 = two ? (uint32_t)(ksub * d.x1s[1] + (2 * hp) * OW + pc0) * 4u : 0u;
+    const int vpark = ((wave * KPW + ksub) * 4 * W2_TILES + pr * TW + (pc0 >> 1)) * 4;          // floats; + j * 256, + item * 1024
+    const int boff = (lh * 4 * W2_TILES + wn * 32 + l31) * 4;
+    const int arow = wm * 32 + l31;
+    int aoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) aoff[q] = (lh * BM + arow) * 16 + 4 * (q ^ ((arow >> 2) & 3));
+    const int pm = tid >> 2, pq = tid & 3;
+    const int apark = pm * 16 + 4 * (pq ^ ((pm >> 2) & 3));                        // + i * BM * 16 floats
+    uint32_t a_voff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a_voff[i] = (uint32_t)(((int64_t)i * d.Cout + m0 + pm) * 16 + 4 * pq) * 4u;
+
+    w2f2 braw[NIT][2][4][TPL];    // [item][depth slice a / b][source row j][column pair]
+    nfloat4 areg[8];
+    int s_jd = 0, s_ci = 0;
+    const int64_t xs1_0 = d.x0s[1], xs1_1 = d.x1s[1];
+    const int cin0 = d.Cin0, cin = a.Cin, coutn = d.Cout;
+    const float* const wg3p = a.wg2;
+    // sample and plane folded into the bases
+    const float* const x0p = a.x0 + (int64_t)ob * d.x0s[0] + (int64_t)od * d.x0s[2];
+    const float* const x1p = two ? a.x1 + (int64_t)ob * d.x1s[0] + (int64_t)od * d.x1s[2] : x0p;
+    const int64_t xs2_0 = d.x0s[2], xs2_1 = two ? d.x1s[2] : d.x0s[2];
+    const uint32_t lo_u = od > 0, hi_u = od + 2 < d.iD;          // planes od - 1 / od + 2 exist
+    gfloat_p f_w = uniform_ptr(wg3p), f_xa = uniform_ptr(x0p), f_xb = f_xa;
+    int64_t f_sc = 0;
+    uint32_t voff = 0, voff0 = 0, voff3 = 0;
+    float mka = 0.f, mkb = 0.f;
+    auto fetch_begin = [&]() {
+        const bool first = s_ci < cin0;
+        f_sc = first ? xs1_0 : xs1_1;
+        const int64_t xs2 = first ? xs2_0 : xs2_1;
+        const int cbase = (first ? s_ci : s_ci - cin0) + wave * KPW;
+        const float* bsel = (first ? x0p : x1p) + (int64_t)cbase * f_sc;
+        // planes (relative to od) and signs of depth component s_jd; a plane outside the volume: plane od with factor 0
+        // (integer arithmetic on the float bits: nested selects became branches, and a branch in this loop costs
+        // conservative memory waits at its join)
+        const uint32_t j0 = s_jd == 0, j2 = s_jd == 2, j3 = s_jd == 3;
+        const int da = -(int)(j0 & lo_u);                                    // -1 | 0 | 0 | 0
+        const int db = 1 + (int)j3 * (hi_u ? 1 : -1);                        //  1 | 1 | 1 | 2 (0 past the volume)
+        mka = __builtin_bit_cast(float, (0x3F800000u & ((j0 & (lo_u ^ 1u)) - 1u)) | (j2 << 31));       // lo_ok | 1 | -1 | 1
+        mkb = __builtin_bit_cast(float, (0x3F800000u & ((j3 & (hi_u ^ 1u)) - 1u)) | ((j0 | (j3 & hi_u)) << 31));   // -1 | 1 | 1 | -hi_ok
+        f_xa = uniform_ptr(bsel + da * xs2);
+        f_xb = uniform_ptr(bsel + db * xs2);
+        f_w = uniform_ptr(wg3p + ((int64_t)(s_jd * cin + s_ci) * coutn) * 16);
+        voff = first ? vp0 : vp1;
+        voff0 = voff - rsel0;
+        voff3 = voff + rsel3;
+        s_ci += SK;
+        // (past the last stage the walk wraps to the first one: the extra fetches of the pipeline tail stay in bounds and are
+        // never consumed)
+        if (s_ci >= cin) { s_ci = 0; if (++s_jd == 4) s_jd = 0; }
+    };
+    auto fetch_a = [&](int i, nfloat4 (&ar)[8]) { ar[i] = *(gfloat4_p)((gchar_p)f_w + a_voff[i]); };
+    auto fetch_b_row = [&](int it, int sl, int j, w2f2 (&br)[NIT][2][4][TPL]) {
+        const gchar_p rb = (gchar_p)(sl ? f_xb : f_xa) + (CPL == 2 ? (int64_t)it * f_sc * 4 : 0);
+        const gchar_p p = j == 0 ? rb + voff0 : (j == 3 ? rb + voff3 : (j == 1 ? rb + voff : rb + voff + OW * 4));
+        if (CPL == 2) { const nfloat2 v = *(gfloat2_p)p; br[it][sl][j][0] = w2f2{v.x, v.y}; }
+        else {
+            const nfloat4 v = *(gfloat4_p)p;
+            br[it][sl][j][0] = w2f2{v.x, v.y};
+            br[it][sl][j][1] = w2f2{v.z, v.w};
+        }
+    };
+    auto fetch_b = [&](int it, w2f2 (&br)[NIT][2][4][TPL]) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) fetch_b_row(it, r >> 2, r & 3, br);
+    };
+    auto park_a = [&](int buf, int i, const nfloat4 (&ar)[8]) {
+        *reinterpret_cast<nfloat4*>(As + buf * W2_ASZ + i * (BM * 16) + apark) = ar[i];
+    };
+    // depth combination e_j = ca a_j + cb b_j of the two planes fused with the H transform (packed, per column pair), then
+    // the W transform as in the kernel above
+    w2f2 hrow[4][TPL];
+    auto park_b_h = [&](int it, const w2f2 (&br)[NIT][2][4][TPL], float ca, float cb) {
+        const w2f2 ka0 = pks_mul(m0p, ca), kb0 = pks_mul(m0p, cb), ka3 = pks_mul(m3p, ca), kb3 = pks_mul(m3p, cb);
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) {
+            const w2f2 e1 = pks_fma(br[it][1][1][t], cb, pks_mul(br[it][0][1][t], ca));
+            const w2f2 e2 = pks_fma(br[it][1][2][t], cb, pks_mul(br[it][0][2][t], ca));
+            hrow[0][t] = pk_fma2(br[it][1][0][t], kb0, pk_fms2(br[it][0][0][t], ka0, e2));       // e0 - e2
+            hrow[1][t] = pk_add2(e1, e2);
+            hrow[2][t] = pk_sub2(e2, e1);
+            hrow[3][t] = pk_fnma2(br[it][1][3][t], kb3, pk_fnma2(br[it][0][3][t], ka3, e1));     // e1 - e3
+        }
+    };
+    auto park_b_w = [&](int buf, int it, int j) {
+        float* dst = Vs + buf * W2_BSZ + vpark + (CPL == 2 ? it * (4 * W2_TILES * 4) : 0) + j * (W2_TILES * 4);
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) {
+            const w2f2 cc = hrow[j][t];
+            const w2f2 sd = pk_sumdiff(cc);
+            const float v0 = t == 0 ? sub_prev<SH>(hrow[j][TPL - 1].y, cc.y) : vsub1(hrow[j][t - 1].y, cc.y);
+            const float v3 = t == TPL - 1 ? sub_next<SH>(cc.x, hrow[j][0].x) : vsub1(cc.x, hrow[j][t + 1].x);
+            nfloat4 v;
+            v.x = sd.x; v.y = sd.y; v.z = v0; v.w = v3;
+            *reinterpret_cast<nfloat4*>(dst + t * 4) = v;
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+
+    const int S1 = a.Cin / SK;                       // stages per depth component
+    nfloat4 fa[2][4];
+    nfloat4 fv[2][4];
+    auto read_a = [&](const float* Ak, int set, int q) { fa[set][q] = *reinterpret_cast<const nfloat4*>(Ak + aoff[q]); };
+    auto read_v = [&](const float* Vk, int set, int j) { fv[set][j] = *reinterpret_cast<const nfloat4*>(Vk + boff + j * (W2_TILES * 4)); };
+    float pka, pkb, nka = 0.f, nkb = 0.f;            // factors of the items still in registers
+    {   // prologue: the fetches of the first two stages travel together; stage 0 is parked in buffer 0
+        w2f2 braw0[NIT][2][4][TPL];
+        nfloat4 areg0[8];
+        fetch_begin();
+        const float qa = mka, qb = mkb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fetch_a(i, areg0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) fetch_b(it, braw0);
+        fetch_begin();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fetch_a(i, areg);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) fetch_b(it, braw);
+        pka = mka; pkb = mkb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) park_a(0, i, areg0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            park_b_h(it, braw0, qa, qb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) park_b_w(0, it, j);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) read_a(As, 0, q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) read_v(Vs, 0, j);
+
+    // ---- output geometry: this lane's tile n (row pair hp0 + n / TW of the plane pair, tile column n % TW), channel rows
+    // cob + 8 (rr >> 2) + 4 lh + (rr & 3); lane offsets in bytes with the 4 lh rows folded in, channel bases scalar
+    const int cob = m0 + wm * 32;
+    const int nloc = wn * 32 + l31;
+    const int ohp = hp0 + (nloc >> (LGW - 1)), otw = nloc & (TW - 1);
+    const uint32_t yoff = (uint32_t)((2 * ohp) * d.ys[3] + (2 * otw) * d.ys[4] + (4 * lh) * d.ys[1]) * 4u;
+    const uint32_t roff = a.res ? (uint32_t)((2 * ohp) * d.rs[3] + (2 * otw) * d.rs[4] + (4 * lh) * d.rs[1]) * 4u : 0u;
+    const uint32_t yrow = (uint32_t)d.ys[3] * 4u, rrow = (uint32_t)d.rs[3] * 4u;
+    const int64_t ycs4 = d.ys[1] * 4, rcs4 = d.rs[1] * 4;        // bytes per channel
+    // plane od of sample ob, channel cob (plane od + 1: + ys[2] floats)
+    float* const y0p = a.y + (int64_t)ob * d.ys[0] + (int64_t)od * d.ys[2] + (int64_t)cob * d.ys[1];
+    const float* const r0p = a.res ? a.res + (int64_t)ob * d.rs[0] + (int64_t)od * d.rs[2] + (int64_t)cob * d.rs[1] : nullptr;
+    const bool gn = a.gn_part != nullptr;
+    double gv[8];                                    // 8-row block g4: gv[2 g4] = sum, gv[2 g4 + 1] = sum of squares (both planes)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gv[i] = 0.0;
+
+    // fold of pass jd (compile-time after unrolling) into the plane pair
+    auto fold = [&](const int jd) {
+        const bool t0 = jd <= 2, t1 = jd >= 1;                   // planes touched
+        const bool ld0 = jd == 1 || jd == 2, ld1 = jd >= 2;      // partial plane read back
+        const bool fin0 = jd == 2, fin1 = jd == 3;               // plane finished by this pass
+        const bool hasres = a.res != nullptr;
+        gwchar_p yb0 = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(y0p);
+        gwchar_p yb1 = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(y0p + d.ys[2]);
+        gchar_p rb = (gchar_p)uniform_ptr(r0p + (fin1 ? d.rs[2] : 0));
+        const uint32_t yoff1 = yoff + yrow, roff1 = roff + rrow;
+        float bias_r[16];
+        if (jd == 0 && a.bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bias_r[r] = a.bias[cob + 8 * (r >> 2) + 4 * lh + (r & 3)];
+        }
+        w2f2 pn0[4][2], pn1[4][2], rn[4][2];                     // [row of the block][row of the tile]
+        auto load_block = [&](int g4) {
+#pragma unroll
+            for (int r3 = 0; r3 < 4; ++r3) {
+                const int64_t ro = (int64_t)(8 * g4 + r3) * ycs4;
+                if (ld0) { pn0[r3][0] = *(gfloat2_p)((gchar_p)yb0 + ro + yoff); pn0[r3][1] = *(gfloat2_p)((gchar_p)yb0 + ro + yoff1); }
+                if (ld1) { pn1[r3][0] = *(gfloat2_p)((gchar_p)yb1 + ro + yoff); pn1[r3][1] = *(gfloat2_p)((gchar_p)yb1 + ro + yoff1); }
+                if ((fin0 || fin1) && hasres) {
+                    const int64_t rr = (int64_t)(8 * g4 + r3) * rcs4;
+                    rn[r3][0] = *(gfloat2_p)(rb + rr + roff); rn[r3][1] = *(gfloat2_p)(rb + rr + roff1);
+                }
+            }
+        };
+        load_block(0);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            w2f2 pc0[4][2], pc1[4][2], rc[4][2];
+#pragma unroll
+            for (int r3 = 0; r3 < 4; ++r3)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { pc0[r3][h] = pn0[r3][h]; pc1[r3][h] = pn1[r3][h]; rc[r3][h] = rn[r3][h]; }
+            if (g4 < 3) load_block(g4 + 1);
+            w2f2 bs2 = {0.f, 0.f}, bq2 = {0.f, 0.f};
+#pragma unroll
+            for (int r3 = 0; r3 < 4; ++r3) {
+                const int rr = g4 * 4 + r3;
+                const int64_t ro = (int64_t)(8 * g4 + r3) * ycs4;
+                w2f2 pa[4], pb[4];                               // per j: (M[j][0], M[j][3]), (M[j][1], M[j][2])
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pa[j] = w2f2{acc[4 * j][rr], acc[4 * j + 3][rr]};
+                    pb[j] = w2f2{acc[4 * j + 1][rr], acc[4 * j + 2][rr]};
+                }
+                const w2f2 t0a = pk_add2(pk_add2(pa[0], pa[1]), pa[2]), t1a = pk_sub2(pk_sub2(pa[1], pa[2]), pa[3]);
+                const w2f2 t0b = pk_add2(pk_add2(pb[0], pb[1]), pb[2]), t1b = pk_sub2(pk_sub2(pb[1], pb[2]), pb[3]);
+                const w2f2 z0 = pk_addsub(pk_sumdiff_fwd(t0b), t0a);        // rows 2 hp, 2 hp + 1 of m_jd
+                const w2f2 z1 = pk_addsub(pk_sumdiff_fwd(t1b), t1a);
+                if (t0) {
+                    w2f2 u0 = ld0 ? pk_add2(pc0[r3][0], z0) : z0, u1 = ld0 ? pk_add2(pc0[r3][1], z1) : z1;
+                    if (fin0 && hasres) { u0 = pk_add2(u0, rc[r3][0]); u1 = pk_add2(u1, rc[r3][1]); }
+                    *(gwfloat2_p)(yb0 + ro + yoff) = nfloat2{u0.x, u0.y};
+                    *(gwfloat2_p)(yb0 + ro + yoff1) = nfloat2{u1.x, u1.y};
+                    if (fin0) { bs2 = pk_add2(bs2, pk_add2(u0, u1)); bq2 = pk_sqacc(u1, pk_sqacc(u0, bq2)); }
+                }
+                if (t1) {
+                    w2f2 u0 = ld1 ? pk_sub2(pc1[r3][0], z0) : z0, u1 = ld1 ? pk_sub2(pc1[r3][1], z1) : z1;
+                    if (fin1 && hasres) { u0 = pk_add2(u0, rc[r3][0]); u1 = pk_add2(u1, rc[r3][1]); }
+                    *(gwfloat2_p)(yb1 + ro + yoff) = nfloat2{u0.x, u0.y};
+                    *(gwfloat2_p)(yb1 + ro + yoff1) = nfloat2{u1.x, u1.y};
+                    if (fin1) { bs2 = pk_add2(bs2, pk_add2(u0, u1)); bq2 = pk_sqacc(u1, pk_sqacc(u0, bq2)); }
+                }
+            }
+            // GroupNorm sums: the 2x2 tile and the 4 rows of the block in fp32, fp64 from there on
+            if (fin0 || fin1) { gv[2 * g4] += (double)(bs2.x + bs2.y); gv[2 * g4 + 1] += (double)(bq2.x + bq2.y); }
+        }
+        if (jd < 3) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+            // the bias rides on component (j, xi) = (1, 1) of depth component 1: coefficient +1 in all 8 outputs
+            if (jd == 0 && a.bias) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[5][r] = bias_r[r];
+            }
+        }
+    };
+
+    // Main loop, per depth component: stage st computes from buffer st & 1 and parks stage st+1 in the other one during its
+    // k-steps 0-1, re-using each register piece for the fetch of stage st+2 as soon as it is parked; one barrier at the end of
+    // k-step 2; k-step 3 reads the first fragments of stage st+1 (slots as in the kernel above, 8 row loads instead of 4).
+    int rbuf = 0;
+#pragma unroll
+    for (int jd = 0; jd < 4; ++jd) {
+        for (int st = 0; st < S1; ++st) {
+            const int wbuf = rbuf ^ 1;
+            const float* Ab = As + rbuf * W2_ASZ;
+            const float* Vb = Vs + rbuf * W2_BSZ;
+            const float* An = As + wbuf * W2_ASZ;
+            const float* Vn = Vs + wbuf * W2_BSZ;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int set = ks & 1, nset = set ^ 1;
+                const float* Ak = ks < 3 ? Ab + (2 * (ks + 1)) * (BM * 16) : An;
+                const float* Vk = ks < 3 ? Vb + (2 * (ks + 1)) * (4 * W2_TILES * 4) : Vn;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][c >> 2][c & 3],
+                                                                  fv[set][c >> 2][(c & 3) == 0 ? 2 : ((c & 3) == 3 ? 3 : (c & 3) - 1)], acc[c], 0, 0, 0);
+                    if (c >= 8 && c < 12) read_v(Vk, nset, c - 8);
+                    else if (c >= 12) read_a(Ak, nset, c - 12);
+                    if (ks < 2) {
+                        const int p = ks;
+                        const bool bwork = p < NIT;
+                        if (c < 4) park_a(wbuf, 2 * c + p, areg);
+                        else if (c == 4) { if (bwork) park_b_h(p, braw, pka, pkb); }
+                        else if (c < 8) { if (bwork) park_b_w(wbuf, p, c - 5); if (c == 7 && p == 0) { fetch_begin(); nka = mka; nkb = mkb; } }
+                        else {
+                            if (c == 8 && bwork) park_b_w(wbuf, p, 3);
+                            if (bwork) fetch_b_row(p, (c - 8) >> 2, (c - 8) & 3, braw);
+                            if (c >= 12) fetch_a(2 * (c - 12) + p, areg);
+                            if (c == 15 && p == 1) { pka = nka; pkb = nkb; }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ks == 2) __syncthreads();
+            }
+            rbuf = wbuf;
+        }
+        fold(jd);
+    }
+
+    if (gn) {
+        double* scr = reinterpret_cast<double*>(ldsw + W2_NBUF * (W2_ASZ + W2_BSZ));
+        const double tot = wave_sum8(gv, lane);
+        if ((lane & 7) == 0) scr[wave * 8 + (lane >> 3)] = tot;
+        __syncthreads();
+        const int ngl = a.gn_cpg >= BM ? 1 : BM / a.gn_cpg;       // groups inside this workgroup's rows
+        if (tid < ngl) {
+            const int r0 = a.gn_cpg >= BM ? 0 : tid * a.gn_cpg, r1 = a.gn_cpg >= BM ? BM : r0 + a.gn_cpg;   // local rows
+            double sum = 0.0, sq = 0.0;
+            for (int blk = r0 / 8; blk < r1 / 8; ++blk) {
+                const int wmi = blk >> 2, k = blk & 3;
+                for (int wni = 0; wni < 2; ++wni) {
+                    sum += scr[((wmi * 2 + wni) * 4 + k) * 2];
+                    sq += scr[((wmi * 2 + wni) * 4 + k) * 2 + 1];
+                }
+            }
+            const int g = (m0 + r0) / a.gn_cpg;
+            const int ntl = tile0 / W2_TILES - ob * (D2 * H2 * TW / W2_TILES);      // part of the sample (512 positions each)
+            const int idx = a.gn_cpg >= BM ? ntl * (a.gn_cpg / BM) + (m0 - g * a.gn_cpg) / BM : ntl;
+            double* pp = a.gn_part + (((int64_t)ob * a.gn_G + g) * a.gn_nparts + idx) * 2;
+            pp[0] = sum; pp[1] = sq;
+        }
+    }
+}
+
+// coverage of the F(2x2x2,3x3x3) kernel (precision 4): the F(2x2,3x3) shapes with kD = 3, an even depth, whole 64-channel
+// blocks, the row pairs of a workgroup inside one plane, 8-byte aligned rows of y (and of the residual)
+bool wg3_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
+    auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
+    if (!(d.precision == 4 && d.kD == 3 && d.oD % 2 == 0 && (d.oW == 16 || d.oW == 32 || d.oW == 64) && d.Cout % W2_BM == 0)) return false;
+    SdcConvDesc e = d;
+    e.precision = 3;
+    if (!wg2_ok(e, small, rowhalo)) return false;
+    const int rp = W2_TILES / (d.oW / 2);
+    return (d.oH / 2) % rp == 0 && even(d.ys) && (d.rs[4] == 0 || even(d.rs));
+}
+
+void launch_wg3(const ConvArgs& a, hipStream_t s) {
+    const SdcConvDesc& d = a.d;
+    const int64_t tiles = (int64_t)d.B * (d.oD / 2) * (d.oH / 2) * (d.oW / 2);
+    dim3 grid((unsigned)((tiles / W2_TILES) * (d.Cout / W2_BM)));
+    const size_t lds = (size_t)W2_NBUF * (W2_ASZ + W2_BSZ) * sizeof(float) + 4 * 8 * sizeof(double);
+#define W3_LAUNCH(OWV)                                                                                                           \
+    do {                                                                                                                         \
+        static std::atomic<uint64_t> attr{0};                                                                                    \
+        if (sdc::first_use_on_device(attr))                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wg3_kernel<OWV>),                                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
+        hipLaunchKernelGGL((conv_wg3_kernel<OWV>), grid, dim3(256), lds, s, a);                                                  \
+    } while (0)
+    if (d.oW == 16) W3_LAUNCH(16);
+    else if (d.oW == 32) W3_LAUNCH(32);
+    else W3_LAUNCH(64);
 }
 
 template <int BM, int BN, int WM, int WN, int SK, int NTH = 256, bool UPS = false>
@@ -2044,7 +2534,7 @@ struct WgPick { int pick, bm, bn; bool ups; };
 WgPick wg_pick(const SdcConvDesc& d, int64_t ntot, bool small, bool rowhalo) {
     WgPick w{0, 0, 0, false};
     w.ups = (d.uH > 1 || d.uW > 1);      // nearest x2 upsampling folded into the gather: one input, kD = 1, kH <= 3
-    if (!((d.precision == 2 || d.precision == 3) && rowhalo && d.kW == 3 && d.sW == 1 && d.uD == 1 && d.up_mode == 0 &&
+    if (!(d.precision >= 2 && rowhalo && d.kW == 3 && d.sW == 1 && d.uD == 1 && d.up_mode == 0 &&
           (!w.ups || (d.uH <= 2 && d.uW <= 2 && d.kD == 1 && d.kH <= 3 && d.sH == 1 && d.Cin1 == 0)) &&
           d.kD * d.kH <= 32 && d.Cin0 % 16 == 0 && d.Cin1 % 16 == 0 && small && d.Cout % 4 == 0 && d.Cout > 32 &&
           d.oW % 2 == 0 && d.oW >= 16 && ((int64_t)d.kD * d.kH * d.kW * (d.Cin0 + d.Cin1) * d.Cout) % 4 == 0))
@@ -2102,6 +2592,8 @@ extern "C" int sdc_conv_gnparts(const SdcConvDesc* dp, int G) {
     static const int no_rh = getenv("SDC_NO_ROWHALO") ? atoi(getenv("SDC_NO_ROWHALO")) : 0;
     const int64_t ntot = (int64_t)dp->B * dp->oD * dp->oH * dp->oW;
     static const int no_wg2 = getenv("SDC_NO_WG2") ? atoi(getenv("SDC_NO_WG2")) : 0;
+    static const int no_wg3 = getenv("SDC_NO_WG3") ? atoi(getenv("SDC_NO_WG3")) : 0;
+    if (!no_wg2 && !no_wg3 && wg3_ok(*dp, conv_small(*dp), !no_rh)) return gn_parts_for(*dp, WgPick{21, W2_BM, W2_TILES * 8, false}, G);
     if (!no_wg2 && wg2_ok(*dp, conv_small(*dp), !no_rh)) return gn_parts_for(*dp, WgPick{20, W2_BM, W2_TILES * 4, false}, G);
     return gn_parts_for(*dp, wg_pick(*dp, ntot, conv_small(*dp), !no_rh), G);
 }
@@ -2136,8 +2628,8 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
     SDC_REQUIRE(d.Cin1 == 0 || x1, SDC_ENULL, "sdc_conv: Cin1 > 0 but x1 is null");
     SDC_REQUIRE(d.kD > 0 && d.kH > 0 && d.kW > 0 && d.sD > 0 && d.sH > 0 && d.sW > 0, SDC_EINVAL,
                 "sdc_conv: bad kernel/stride");
-    SDC_REQUIRE(d.precision >= 0 && d.precision <= 3, SDC_EINVAL, "sdc_conv: precision must be 0 (fp32 MFMA), 1 (split-bf16), 2 (fp32 Winograd along W) or 3 (fp32 Winograd over H and W)");
-    SDC_REQUIRE(!gn_part || d.precision >= 2, SDC_EINVAL, "sdc_conv_gn: fused GroupNorm statistics need precision 2 or 3 (sdc_conv_gnparts returned 0)");
+    SDC_REQUIRE(d.precision >= 0 && d.precision <= 4, SDC_EINVAL, "sdc_conv: precision must be 0 (fp32 MFMA), 1 (split-bf16), 2 (fp32 Winograd along W), 3 (fp32 Winograd over H and W) or 4 (fp32 Winograd over D, H and W)");
+    SDC_REQUIRE(!gn_part || d.precision >= 2, SDC_EINVAL, "sdc_conv_gn: fused GroupNorm statistics need precision 2, 3 or 4 (sdc_conv_gnparts returned 0)");
     ConvArgs a;
     a.d = d;
     a.lgD = ilog2_exact(d.uD); a.lgH = ilog2_exact(d.uH); a.lgW = ilog2_exact(d.uW);
@@ -2184,8 +2676,24 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
         return sdc::check_launch("sdc_conv[bf16x3]");
     }
     auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
-    // fp32 Winograd F(2x2,3x3) over (H, W): 3x3 / 3x3x3 stride-1 convs over whole rows
     static const int no_wg2 = getenv("SDC_NO_WG2") ? atoi(getenv("SDC_NO_WG2")) : 0;
+    static const int no_wg3 = getenv("SDC_NO_WG3") ? atoi(getenv("SDC_NO_WG3")) : 0;
+    // fp32 Winograd F(2x2x2,3x3x3): 3x3x3 stride-1 convs over whole rows, plane pairs
+    if (!no_wg2 && !no_wg3 && wg3_ok(d, small, a.rowhalo != 0) && reinterpret_cast<uintptr_t>(wp) % 16 == 0 &&
+        reinterpret_cast<uintptr_t>(x0) % 16 == 0 && (d.Cin1 == 0 || reinterpret_cast<uintptr_t>(x1) % 16 == 0) &&
+        reinterpret_cast<uintptr_t>(y) % 8 == 0 && (!residual || (d.rs[4] == 1 && reinterpret_cast<uintptr_t>(residual) % 8 == 0))) {
+        a.vec2 = 1;
+        a.wg2 = wp + (int64_t)a.Ktot * d.Cout + (int64_t)(a.Ktot / 3 * 4) * d.Cout + (int64_t)(a.Ktot / 9 * 16) * d.Cout;
+        if (gn_part) {
+            a.gn_nparts = gn_parts_for(d, WgPick{21, W2_BM, W2_TILES * 8, false}, gn_G);
+            SDC_REQUIRE(a.gn_nparts > 0, SDC_EINVAL, "sdc_conv_gn: shape not covered by the fused statistics (sdc_conv_gnparts returned 0)");
+            a.gn_part = gn_part; a.gn_G = gn_G; a.gn_cpg = d.Cout / gn_G; a.gn_S = d.oD * d.oH * d.oW;
+        }
+        SDC_PICK(d.oW == 16 ? "conv_wg3_kernel<16>" : (d.oW == 32 ? "conv_wg3_kernel<32>" : "conv_wg3_kernel<64>"), 8.0 / 27.0);
+        launch_wg3(a, s);
+        return sdc::check_launch("sdc_conv[winograd 2x2x2]");
+    }
+    // fp32 Winograd F(2x2,3x3) over (H, W): 3x3 / 3x3x3 stride-1 convs over whole rows
     if (!no_wg2 && wg2_ok(d, small, a.rowhalo != 0) && reinterpret_cast<uintptr_t>(wp) % 16 == 0 &&
         reinterpret_cast<uintptr_t>(x0) % 16 == 0 && (d.Cin1 == 0 || reinterpret_cast<uintptr_t>(x1) % 16 == 0)) {
         a.vec2 = even(d.ys) && reinterpret_cast<uintptr_t>(y) % 8 == 0 &&

@@ -158,7 +158,7 @@ class Plan:
                     return wp.reshape(-1)
                 return torch.cat([wp.reshape(-1), hi.reshape(-1).view(torch.float32), lo.reshape(-1).view(torch.float32)])
             return self.packed(fn3)
-        if self.precision in (2, 3):
+        if self.precision in (2, 3, 4):
             # fp32 Wp followed by the Winograd F(2,3) taps along W, [(kd*kH + kh)*4 + xi][Cin][Cout]:
             # G g with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], formed in fp64 and rounded once;
             # precision 3 appends, for 3x3 (kH = kW = 3) taps, the F(2x2,3x3) taps G g G^T over (H, W): [kd][Cin][Cout][j*4 + xi]
@@ -171,9 +171,13 @@ class Plan:
                 G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64, device=t5.device)
                 u = torch.einsum("xk,oidhk->dhxio", G, t5)    # (kD, kH, 4, Cin, Cout)
                 parts = [wp.reshape(-1), u.reshape(-1).to(torch.float32)]
-                if self.precision == 3 and t5.shape[3] == 3:
+                if self.precision >= 3 and t5.shape[3] == 3:
                     u2 = torch.einsum("jh,xk,oidhk->diojx", G, G, t5)   # (kD, Cin, Cout, 4, 4): 16 components contiguous
                     parts.append(u2.reshape(-1).to(torch.float32))
+                    if self.precision == 4 and t5.shape[2] == 3:
+                        # F(2x2x2,3x3x3) taps, G along the depth as well: [jd][Cin][Cout][j*4 + xi]
+                        u3 = torch.einsum("zd,jh,xk,oidhk->ziojx", G, G, G, t5)
+                        parts.append(u3.reshape(-1).to(torch.float32))
                 return torch.cat(parts)
             return self.packed(fnw)
         return self.packed(fn)
@@ -206,7 +210,8 @@ class Plan:
         split = wp.dim() == 1 and wp.numel() == 2 * nw
         wino = wp.dim() == 1 and k[2] == 3 and wp.numel() == nw + nw // 3 * 4
         wino2 = wp.dim() == 1 and k[1] == 3 and k[2] == 3 and wp.numel() == nw + nw // 3 * 4 + nw // 9 * 16
-        assert split or wino or wino2 or wp.numel() == nw, (wp.shape, k, c0, c1, cout)
+        wino3 = wp.dim() == 1 and tuple(k) == (3, 3, 3) and wp.numel() == nw + nw // 3 * 4 + nw // 9 * 16 + nw // 27 * 64
+        assert split or wino or wino2 or wino3 or wp.numel() == nw, (wp.shape, k, c0, c1, cout)
         d = SdcConvDesc()
         d.B, d.Cin0, d.Cin1, d.Cout = B, c0, c1, cout
         d.iD, d.iH, d.iW = iD, iH, iW
@@ -215,7 +220,7 @@ class Plan:
         d.sD, d.sH, d.sW = stride
         d.pD, d.pH, d.pW = pad
         d.uD, d.uH, d.uW = up
-        d.up_mode, d.precision = up_mode, (1 if split else 3 if wino2 else 2 if wino else 0)
+        d.up_mode, d.precision = up_mode, (1 if split else 4 if wino3 else 3 if wino2 else 2 if wino else 0)
         d.x0s[:] = _s5(x)
         d.x1s[:] = _s5(x1) if x1 is not None else (0,) * 5
         d.ys[:] = _s5(out)

@@ -410,6 +410,73 @@ def test_conv_winograd_2d_mode(plan_cls, case):
     assert e0 < 4e-6 and e3 < 1e-5, (e0, e3)
 
 
+@pytest.mark.parametrize("case", [
+    dict(B=2, cin=64, cout=64, sp=(4, 4, 64), G=8),                           # 64-wide rows: 2 row pairs per workgroup, both depth edges in every pair
+    dict(B=1, cin=16, cout=128, sp=(6, 8, 32), cin1=24, G=8),                 # concat, 2 m-tiles, interior plane pair
+    dict(B=3, cin=32, cout=64, sp=(2, 16, 16), residual=True, G=0),           # 16-wide rows (two rows interleaved per DPP row), residual
+    dict(B=1, cin=8, cout=192, sp=(8, 8, 32), residual=True, G=3),            # one stage per depth component, 3 m-tiles, a group = one m-tile
+])
+def test_conv_winograd_3d_mode(plan_cls, case):
+    """precision=4: fp32 Winograd F(2x2x2,3x3x3) over (D, H, W) against torch in fp64 and beside the direct kernel; with
+    G > 0 the GroupNorm statistics come out of its last fold.  Gate 1e-5 of the output scale, like the other fp32 modes."""
+    from safediffcon_amd.engine import as5
+    B, cin, cout, sp = case["B"], case["cin"], case["cout"], case["sp"]
+    cin1, G = case.get("cin1", 0), case["G"]
+    x, x1 = det_tensor((B, cin, *sp), 291), (det_tensor((B, cin1, *sp), 292) if cin1 else None)
+    w, b = det_tensor((cout, cin + cin1, 3, 3, 3), 293, 0.2), det_tensor((cout,), 294, 0.1)
+    xin = x if x1 is None else torch.cat((x, x1), 1)
+    ref = F.conv3d(xin.double(), w.double(), b.double(), padding=1)
+    res = det_tensor(tuple(ref.shape), 295) if case.get("residual") else None
+    if res is not None:
+        ref = ref + res.double()
+    outs, names = {}, {}
+    for prec in (0, 4):
+        plan = plan_cls(DEV, precision=prec)
+        out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, (3, 3, 3),
+                        x1=None if x1 is None else as5(x1.to(DEV)), pad=(1, 1, 1),
+                        residual=None if res is None else as5(res.to(DEV)), gn_groups=G if prec == 4 else 0)
+        d = plan.calls[0][1][0]._obj
+        buf = C.create_string_buffer(128)
+        share = C.c_double(0)
+        assert plan.lib.sdc_conv_describe(C.byref(d), buf, 128, C.byref(share)) == 0
+        names[prec] = buf.value.decode()
+        if prec == 4 and G:
+            assert plan.calls[0][0] is plan.lib.sdc_conv_gn
+            gam, bet = det_tensor((cout,), 296, 0.3) + 1.0, det_tensor((cout,), 297, 0.2)
+            y = plan.pool.get(tuple(out.shape))
+            plan.gn_silu(out, gam.to(DEV), bet.to(DEV), G, out=y)
+        _run(plan)
+        _run(plan)                                                    # a replay starts from y holding the previous result
+        outs[prec] = out.cpu().reshape(ref.shape).double()
+        if prec == 4 and G:
+            refn = F.silu(F.group_norm(ref, G, gam.double(), bet.double(), 1e-5))
+            torch.testing.assert_close(y.cpu().reshape(ref.shape).double(), refn, rtol=1e-4, atol=2e-5)
+    assert names[4].startswith("conv_wg3_kernel") and abs(share.value - 8 / 27) < 1e-12 and not names[0].startswith("conv_wg")
+    scale = ref.abs().max().item()
+    e0 = (outs[0] - ref).abs().max().item() / scale
+    e4 = (outs[4] - ref).abs().max().item() / scale
+    print(f"[measured] rel err vs fp64: direct {e0:.2e}  winograd F(2x2x2,3x3x3) {e4:.2e}")
+    assert e0 < 4e-6 and e4 < 1e-5, (e0, e4)
+
+
+def test_conv_winograd_3d_falls_back_where_not_covered(plan_cls):
+    """precision=4 descriptors the F(2x2x2,3x3x3) kernel does not take (odd depth, Cout % 64 != 0, 3x3 taps) run the
+    F(2x2,3x3) kernel on the same weight buffer."""
+    from safediffcon_amd.engine import as5
+    for B, cin, cout, sp, k in [(1, 16, 64, (3, 8, 32), (3, 3, 3)), (1, 16, 96, (4, 8, 32), (3, 3, 3)), (2, 16, 64, (1, 8, 32), (1, 3, 3))]:
+        x = det_tensor((B, cin, *sp), 301)
+        w, b = det_tensor((cout, cin, *k), 302, 0.2), det_tensor((cout,), 303, 0.1)
+        ref = F.conv3d(x.double(), w.double(), b.double(), padding=(k[0] // 2, 1, 1))
+        plan = plan_cls(DEV, precision=4)
+        out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, k, pad=(k[0] // 2, 1, 1))
+        buf = C.create_string_buffer(128)
+        plan.lib.sdc_conv_describe(C.byref(plan.calls[0][1][0]._obj), buf, 128, None)
+        assert buf.value.decode().startswith("conv_wg2_kernel"), buf.value
+        _run(plan)
+        e = (out.cpu().reshape(ref.shape).double() - ref).abs().max().item() / ref.abs().max().item()
+        assert e < 1e-5, e
+
+
 def test_conv_winograd_2d_strided_output_and_residual(plan_cls):
     """F(2x2,3x3) kernel writing through a strided view (every other column of a wider buffer) with a residual read
     through another strided view: the scalar (non 8-byte) store / load path of its epilogue."""
