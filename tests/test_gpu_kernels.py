@@ -413,8 +413,8 @@ def test_conv_winograd_2d_mode(plan_cls, case):
 @pytest.mark.parametrize("case", [
     dict(B=2, cin=64, cout=64, sp=(4, 4, 64), G=8),                           # 64-wide rows: 2 row pairs per workgroup, both depth edges in every pair
     dict(B=1, cin=16, cout=128, sp=(6, 8, 32), cin1=24, G=8),                 # concat, 2 m-tiles, interior plane pair
-    dict(B=3, cin=32, cout=64, sp=(2, 16, 16), residual=True, G=0),           # 16-wide rows (two rows interleaved per DPP row), residual
-    dict(B=1, cin=8, cout=192, sp=(8, 8, 32), residual=True, G=3),            # one stage per depth component, 3 m-tiles, a group = one m-tile
+    dict(B=3, cin=32, cout=64, sp=(2, 16, 16), G=0),                          # 16-wide rows (two rows interleaved per DPP row)
+    dict(B=1, cin=8, cout=192, sp=(8, 8, 32), G=3),                           # one stage per depth component, 3 m-tiles, a group = one m-tile
 ])
 def test_conv_winograd_3d_mode(plan_cls, case):
     """precision=4: fp32 Winograd F(2x2x2,3x3x3) over (D, H, W) against torch in fp64 and beside the direct kernel; with
@@ -460,15 +460,20 @@ def test_conv_winograd_3d_mode(plan_cls, case):
 
 
 def test_conv_winograd_3d_falls_back_where_not_covered(plan_cls):
-    """precision=4 descriptors the F(2x2x2,3x3x3) kernel does not take (odd depth, Cout % 64 != 0, 3x3 taps) run the
-    F(2x2,3x3) kernel on the same weight buffer."""
+    """precision=4 descriptors the F(2x2x2,3x3x3) kernel does not take (odd depth, Cout % 64 != 0, 3x3 taps, a fused
+    residual) run the F(2x2,3x3) kernel on the same weight buffer."""
     from safediffcon_amd.engine import as5
-    for B, cin, cout, sp, k in [(1, 16, 64, (3, 8, 32), (3, 3, 3)), (1, 16, 96, (4, 8, 32), (3, 3, 3)), (2, 16, 64, (1, 8, 32), (1, 3, 3))]:
+    for B, cin, cout, sp, k, withres in [(1, 16, 64, (3, 8, 32), (3, 3, 3), False), (1, 16, 96, (4, 8, 32), (3, 3, 3), False),
+                                         (2, 16, 64, (1, 8, 32), (1, 3, 3), False), (1, 16, 64, (4, 8, 32), (3, 3, 3), True)]:
         x = det_tensor((B, cin, *sp), 301)
         w, b = det_tensor((cout, cin, *k), 302, 0.2), det_tensor((cout,), 303, 0.1)
         ref = F.conv3d(x.double(), w.double(), b.double(), padding=(k[0] // 2, 1, 1))
+        res = det_tensor(tuple(ref.shape), 304) if withres else None
+        if withres:
+            ref = ref + res.double()
         plan = plan_cls(DEV, precision=4)
-        out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, k, pad=(k[0] // 2, 1, 1))
+        out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, k, pad=(k[0] // 2, 1, 1),
+                        residual=None if res is None else as5(res.to(DEV)))
         buf = C.create_string_buffer(128)
         plan.lib.sdc_conv_describe(C.byref(plan.calls[0][1][0]._obj), buf, 128, None)
         assert buf.value.decode().startswith("conv_wg2_kernel"), buf.value
