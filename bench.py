@@ -62,7 +62,7 @@ def launch_workers(n, argv):
 
 
 # --------------------------------------------------------------------------- workloads
-def workload(name, dim, B, dev, rank, world, precision=3):
+def workload(name, dim, B, dev, rank, world, precision=4):
     """-> dict(desc, gd, prep() -> _Loop, conformal=dict(Q, n_cal, alpha, ms), calib(...) -> calibration-mode _Loop)"""
     import torch
     import safediffcon_amd as sdc
@@ -256,8 +256,9 @@ def build_roofline(S, lib, stream, step_ms, wl):
     roof = dict(bound="mfma", kernel=name, achieved=round(issued, 2), peak=stg.PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                 frac=round(issued / stg.PEAK_F32_MFMA_TFLOPS, 4), frac_issued=round(issued / stg.PEAK_F32_MFMA_TFLOPS, 4),
                 effective_tflops=round(eff, 2), mfma_share_of_direct_form=round(g["issued"] / g["flops"], 4),
-                flops="achieved = MFMA FLOPs the kernel executes per second (Winograd issues 2/3 [F(2,3) along W] or 4/9 "
-                      "[F(2x2,3x3)] of the direct-form multiply-adds); effective_tflops = direct-form (algorithmic) FLOPs per second",
+                flops="achieved = MFMA FLOPs the kernel executes per second (Winograd issues 2/3 [F(2,3) along W], 4/9 "
+                      "[F(2x2,3x3)] or 8/27 [F(2x2x2,3x3x3)] of the direct-form multiply-adds); effective_tflops = direct-form "
+                      "(algorithmic) FLOPs per second",
                 traffic=traffic, traffic_source=src, algorithmic_bytes_per_launch=alg_bytes,
                 sustained_peak_measured=123.0,   # bare v_mfma_f32_32x32x2 loop on an MI355X of this pool (tools/mfma_peak.hip)
                 launches_per_step=g["launches"], avg_launch_ms=round(g["ms"] / g["launches"], 4),
@@ -366,7 +367,7 @@ def worker(a):
     lib = _lib.get_lib()
     wl = "c4" if a.workload == "c5" else a.workload
     B = a.batch or DEFAULT_B[wl]
-    prec = {"fp32": 3, "fp32-wino1d": 2, "fp32-direct": 0, "split-bf16": 1}[a.precision]
+    prec = {"fp32": 4, "fp32-wino2d": 3, "fp32-wino1d": 2, "fp32-direct": 0, "split-bf16": 1}[a.precision]
     side = torch.cuda.Stream(device=dev)
 
     def timed(S, warmup, steps):
@@ -538,9 +539,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: 256 / 128 / 64 for c2 / c3 / c4)")
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-wino1d", "fp32-direct", "split-bf16"],
-                    help="conv arithmetic: fp32 MFMA with Winograd F(2x2,3x3) / F(2,3) on the 3-tap convs (default), F(2,3) along W "
-                         "only, fp32 direct form everywhere, or the opt-in 3-pass split-bf16 MFMA")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-wino2d", "fp32-wino1d", "fp32-direct", "split-bf16"],
+                    help="conv arithmetic: fp32 MFMA with Winograd F(2x2x2,3x3x3) / F(2x2,3x3) / F(2,3) on the 3-tap convs (default), "
+                         "without the depth transform, F(2,3) along W only, fp32 direct form everywhere, or the opt-in 3-pass "
+                         "split-bf16 MFMA")
     ap.add_argument("--no-extra", action="store_true", help="skip the calibration sample and the other workloads at N=1")
     ap.add_argument("--extra-workloads", default="c2,c3", help="other configs reported under `extra` at N=1")
     ap.add_argument("--extra-steps", type=int, default=20)

@@ -1885,7 +1885,7 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         } else {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {                // 8-row blocks: rows cob + 8 g4 + 4 lh + (0..3)
-                float bs = 0.0f, bq = 0.0f;
+                float bsx = 0.0f, bsy = 0.0f, bqx = 0.0f, bqy = 0.0f;      // the two halves of the packed path's sums
 #pragma unroll
                 for (int r3 = 0; r3 < 4; ++r3) {
                     const int rr = g4 * 4 + r3;
@@ -1899,9 +1899,11 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
                         t0[xi] = (M0 + M1) + M2;
                         t1[xi] = (M1 - M2) - M3;
                     }
-                    float y00 = (t0[0] + t0[1]) + t0[2];
+                    // (the same association as the packed path above: a sample must come out bit-identical whichever path
+                    // the workgroup that holds it takes -- that depends on the batch it is launched with)
+                    float y00 = (t0[1] + t0[2]) + t0[0];
                     float y01 = (t0[1] - t0[2]) - t0[3];
-                    float y10 = (t1[0] + t1[1]) + t1[2];
+                    float y10 = (t1[1] + t1[2]) + t1[0];
                     float y11 = (t1[1] - t1[2]) - t1[3];
                     if (a.res) {
                         const gchar_p rb = (gchar_p)uniform_ptr(a.res + (int64_t)coc * rcs);
@@ -1925,12 +1927,12 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
                         // GroupNorm sums: the 2x2 tile and the 4 rows of the block in fp32 (1e-7 relative on a 16-element partial
                         // sum), fp64 from there on -- independent of the batch a trajectory is launched with (the tile grid cuts
                         // every sample alike)
-                        bs += (y00 + y01) + (y10 + y11);
-                        bq = fmaf(y00, y00, fmaf(y01, y01, fmaf(y10, y10, fmaf(y11, y11, bq))));
+                        bsx += y00 + y10; bsy += y01 + y11;
+                        bqx = fmaf(y10, y10, fmaf(y00, y00, bqx)); bqy = fmaf(y11, y11, fmaf(y01, y01, bqy));
                     }
                 }
-                gv[2 * g4] = (double)bs;
-                gv[2 * g4 + 1] = (double)bq;
+                gv[2 * g4] = (double)(bsx + bsy);
+                gv[2 * g4 + 1] = (double)(bqx + bqy);
             }
         }
     }
@@ -2317,7 +2319,6 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
                     s1 += r3 < 3 ? ycs4 : 5 * ycs4;
                     if (fin1) { bs2 = pk_add2(bs2, pk_add2(u0, u1)); bq2 = pk_sqacc(u1, pk_sqacc(u0, bq2)); }
                 }
-                __builtin_amdgcn_sched_barrier(0);               // row by row: hoisted accumulator reads only spill
             }
             // GroupNorm sums: the 2x2 tile and the 4 rows of the block in fp32, fp64 from there on
             if (fin0 || fin1) { gp[2 * g4] = bs2.x + bs2.y; gp[2 * g4 + 1] = bq2.x + bq2.y; }

@@ -253,10 +253,11 @@ class _HipUNet(nn.Module):
             _register(self, k, v)
         self._spec = spec
         self._plans = {}
-        # conv algorithm (include/sdc.h): 3 = fp32 Winograd, F(2x2,3x3) over (H, W) for the 3x3 / 3x3x3 stride-1 convs (4/9 of
-        # the direct form's MFMA work) and F(2,3) along W for the other 3-tap convs (default); 2 = F(2,3) along W only (2/3);
-        # 0 = fp32 direct everywhere; 1 = opt-in split-bf16.  Modes 0, 2, 3 are fp32 end to end (rounding order differs).
-        self.precision = int(os.environ.get("SDC_PRECISION", "3"))
+        # conv algorithm (include/sdc.h): 4 (default) = fp32 Winograd wherever a kernel covers the shape -- F(2x2x2,3x3x3) over
+        # (D, H, W) for the 3x3x3 stride-1 convs (8/27 of the direct form's MFMA work), F(2x2,3x3) over (H, W) for the 3x3 ones
+        # (4/9), F(2,3) along W for the other 3-tap convs (2/3); 3 = without the depth transform; 2 = F(2,3) along W only;
+        # 0 = fp32 direct everywhere; 1 = opt-in split-bf16.  Modes 0, 2, 3, 4 are fp32 end to end (rounding order differs).
+        self.precision = int(os.environ.get("SDC_PRECISION", "4"))
         # LinearAttention blocks of width 64 / 128 as the fused 3-launch form (csrc/sdc_lablock.hip); False = the
         # unfused chain norm -> 1x1 -> attention core -> 1x1 -> norm (kept for wider layers and for A/B checks)
         self.fuse_linattn = os.environ.get("SDC_NO_LABLOCK", "0") != "1"

@@ -27,7 +27,7 @@ elif which == "tokamak":
 else:
     net = sdc.Unet3D_with_Conv3D(dim=dim, dim_mults=(1, 2, 4), channels=7).to(dev)
     shape = (B, 32, 7, 64, 64)
-net.precision = int(os.environ.get('SDC_PRECISION', '3'))
+net.precision = int(os.environ.get('SDC_PRECISION', '4'))
 ent = net.entry(shape, B)
 net.bind_cond(ent, None)
 stream = torch.cuda.current_stream(dev).cuda_stream

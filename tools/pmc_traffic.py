@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from safediffcon_amd.engine import Plan, as5
 wl = sys.argv[1] if len(sys.argv) > 1 else "c4"
 dev = "cuda:0"
-prec = int(os.environ.get("SDC_PRECISION", "3"))
+prec = int(os.environ.get("SDC_PRECISION", "4"))
 plan = Plan(dev, precision=prec)
 n = 64 * 1024 * 1024                       # 256 MiB in, 256 MiB out: beyond the 256 MiB Infinity Cache together
 xa = torch.randn(n, device=dev); ya = torch.empty(n, device=dev)

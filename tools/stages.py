@@ -27,7 +27,9 @@ def classify(lib, fn, a):
         by = 4.0 * (nin + P * d.Cout * (2 if a[5] else 1) + taps * cin * d.Cout)
         kern, share = conv_kernel_of(lib, d)
         kind = f"conv {d.kD}x{d.kH}x{d.kW}" + (" (up/transposed)" if d.uH > 1 else "") + (" s2" if d.sH > 1 else "")
-        if "conv_wg2" in kern:
+        if "conv_wg3" in kern:
+            kind += " [Winograd F(2x2x2,3x3x3) over (D,H,W)]"
+        elif "conv_wg2" in kern:
             kind += " [Winograd F(2x2,3x3) over (H,W)]"
         elif "conv_wg" in kern:
             kind += " [Winograd F(2,3) along W]"
