@@ -103,3 +103,31 @@ def test_winograd_2d_taps():
     # taps that are not 3x3 over (H, W) keep the precision-2 layout (Conv1d k3: along W only)
     w1 = torch.randn(4, 3, 1, 1, 3, generator=g)
     assert p3.conv_weight(w1).numel() == 36 + 48
+
+
+def test_winograd_3d_taps():
+    """precision 4: [Wp | Wg | Wg2 | Wg3 (over D, H and W)]: the 2x2x2 output block from the 64 transformed products equals
+    the direct 3x3x3 correlation of the 4x4x4 patch, for every (ci, co); 3x3 taps keep the precision-3 layout."""
+    p4 = Plan("cpu", precision=4)
+    g = torch.Generator().manual_seed(4)
+    cin, cout = 3, 2
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g)
+    buf = p4.conv_weight(w)
+    nw = 27 * cin * cout
+    assert buf.numel() == nw + nw // 3 * 4 + nw // 9 * 16 + nw // 27 * 64
+    u3 = buf[nw + nw // 3 * 4 + nw // 9 * 16:].double().reshape(4, cin, cout, 4, 4)     # stored (jd, ci, co, j, xi)
+    d = torch.randn(4, 4, 4, generator=g, dtype=torch.float64)
+    Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+    At = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
+    V = torch.einsum("ad,bh,cw,dhw->abc", Bt, Bt, Bt, d)
+    for ci in range(cin):
+        for co in range(cout):
+            Y = torch.einsum("pa,qb,rc,abc->pqr", At, At, At, u3[:, ci, co] * V)
+            gk = w[co, ci].double()
+            want = torch.stack([torch.stack([torch.stack([(d[a:a + 3, b:b + 3, c:c + 3] * gk).sum() for c in range(2)])
+                                             for b in range(2)]) for a in range(2)])
+            torch.testing.assert_close(Y, want, rtol=1e-5, atol=1e-6)
+    # the depth components the kernel walks: planes s[-1] - s[1], s[0] + s[1], s[1] - s[0], s[0] - s[2] of the patch
+    torch.testing.assert_close(torch.einsum("ad,dhw->ahw", Bt, d), torch.stack([d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]]))
+    w2 = torch.randn(4, 3, 1, 3, 3, generator=g)
+    assert p4.conv_weight(w2).numel() == 108 + 144 + 192
