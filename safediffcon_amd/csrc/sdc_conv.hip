@@ -2107,9 +2107,9 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
     for (int q = 0; q < 4; ++q) aoff[q] = (lh * BM + arow) * 16 + 4 * (q ^ ((arow >> 2) & 3));
     const int pm = tid >> 2, pq = tid & 3;
     const int apark = pm * 16 + 4 * (pq ^ ((pm >> 2) & 3));                        // + i * BM * 16 floats
-    uint32_t a_voff[8];
+    uint32_t a_voff[4];                                  // k rows 0..3 of a stage; rows 4..7 from a second scalar base
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a_voff[i] = (uint32_t)(((int64_t)i * d.Cout + m0 + pm) * 16 + 4 * pq) * 4u;
+    for (int i = 0; i < 4; ++i) a_voff[i] = (uint32_t)(((int64_t)i * d.Cout + m0 + pm) * 16 + 4 * pq) * 4u;
 
     w2f2 braw[NIT][2][4][TPL];    // [item][depth slice a / b][source row j][column pair]
     nfloat4 areg[8];
@@ -2122,7 +2122,7 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
     const float* const x1p = two ? a.x1 + (int64_t)ob * d.x1s[0] + (int64_t)od * d.x1s[2] : x0p;
     const int64_t xs2_0 = d.x0s[2], xs2_1 = two ? d.x1s[2] : d.x0s[2];
     const uint32_t lo_u = od > 0, hi_u = od + 2 < d.iD;          // planes od - 1 / od + 2 exist
-    gfloat_p f_w = uniform_ptr(wg3p), f_xa = uniform_ptr(x0p), f_xb = f_xa;
+    gfloat_p f_w = uniform_ptr(wg3p), f_w4 = f_w, f_xa = uniform_ptr(x0p), f_xb = f_xa;
     int64_t f_sc = 0;
     uint32_t voff = 0, voff0 = 0, voff3 = 0;
     float mka = 0.f, mkb = 0.f;
@@ -2143,6 +2143,7 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
         f_xa = uniform_ptr(bsel + da * xs2);
         f_xb = uniform_ptr(bsel + db * xs2);
         f_w = uniform_ptr(wg3p + ((int64_t)(s_jd * cin + s_ci) * coutn) * 16);
+        f_w4 = uniform_ptr(wg3p + ((int64_t)(s_jd * cin + s_ci + 4) * coutn) * 16);
         voff = first ? vp0 : vp1;
         voff0 = voff - rsel0;
         voff3 = voff + rsel3;
@@ -2153,7 +2154,7 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
     };
     // (the offset passes through an empty asm so that its zero-extension is not hoisted out of the loop as a 64-bit
     // register pair: the load then takes the scalar base + 32-bit lane offset form)
-    auto fetch_a = [&](int i, nfloat4 (&ar)[8]) { uint32_t o = a_voff[i]; asm volatile("" : "+v"(o)); ar[i] = *(gfloat4_p)((gchar_p)f_w + o); };
+    auto fetch_a = [&](int i, nfloat4 (&ar)[8]) { uint32_t o = a_voff[i & 3]; asm volatile("" : "+v"(o)); ar[i] = *(gfloat4_p)((gchar_p)(i < 4 ? f_w : f_w4) + o); };
     auto fetch_b_row = [&](int it, int sl, int j, w2f2 (&br)[NIT][2][4][TPL]) __attribute__((always_inline)) {
         const gchar_p rb = (gchar_p)(sl ? f_xb : f_xa) + (CPL == 2 ? (int64_t)it * f_sc * 4 : 0);
         const gchar_p p = j == 0 ? rb + voff0 : (j == 3 ? rb + voff3 : (j == 1 ? rb + voff : rb + voff + OW * 4));
@@ -2381,7 +2382,14 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
             }
             rbuf = wbuf;
         }
-        if (!(DBG & 4)) fold(jd);
+        if (!(DBG & 4)) {
+            fold(jd);
+            // (the first fragments of the next stage, read again: carried across the fold they cost 32 registers there)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) read_a(As + rbuf * W2_ASZ, 0, q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) read_v(Vs + rbuf * W2_BSZ, 0, j);
+        }
     };
     run_pass(std::integral_constant<int, 0>{});
     run_pass(std::integral_constant<int, 1>{});
