@@ -2201,11 +2201,10 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
         }
     };
 
-    f32x16 acc[16];
+    f32x16 acc[16];                                  // (started from zero by the first MFMAs of each pass)
+    f32x16 zero16, biasv;
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) { zero16[r] = 0.0f; biasv[r] = 0.0f; }
 
     const int S1 = a.Cin / SK;                       // stages per depth component
     nfloat4 fa[2][4];
@@ -2328,25 +2327,22 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
             *reinterpret_cast<nfloat4*>(gstash) = nfloat4{gp[0], gp[1], gp[2], gp[3]};
             *reinterpret_cast<nfloat4*>(gstash + 4) = nfloat4{gp[4], gp[5], gp[6], gp[7]};
         }
-        if (jd < 3) {
+        // the bias rides on component (j, xi) = (1, 1) of depth component 1 (coefficient +1 in all 8 outputs): the start
+        // value of that accumulator in the next pass
+        if (jd == 0) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
-            // the bias rides on component (j, xi) = (1, 1) of depth component 1: coefficient +1 in all 8 outputs
-            if (jd == 0 && a.bias) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[5][r] = bias_r[r];
-            }
+            for (int r = 0; r < 16; ++r) biasv[r] = a.bias ? bias_r[r] : 0.0f;
         }
     };
     // Main loop, per depth component: stage st computes from buffer st & 1 and parks stage st+1 in the other one during its
     // k-steps 0-1, re-using each register piece for the fetch of stage st+2 as soon as it is parked; one barrier at the end of
     // k-step 2; k-step 3 reads the first fragments of stage st+1 (slots as in the kernel above, 8 row loads instead of 4).
     int rbuf = 0;
-    auto run_pass = [&](auto JD) __attribute__((always_inline)) {
-        constexpr int jd = decltype(JD)::value;
-        for (int st = 0; st < S1; ++st) {
+    // The first stage of a pass is a copy of the stage body whose first k-step starts the accumulators from zero (from the
+    // bias for component (1, 1) of depth component 1) in the MFMA itself: 256 register writes per pass less in the fold.
+    auto stage = [&](auto FIRST, const int jd) __attribute__((always_inline)) {
+        constexpr bool first = decltype(FIRST)::value;
+        {
             const int wbuf = rbuf ^ 1;
             const float* Ab = As + rbuf * W2_ASZ;
             const float* Vb = Vs + rbuf * W2_BSZ;
@@ -2359,8 +2355,9 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
                 const float* Vk = ks < 3 ? Vb + (2 * (ks + 1)) * (4 * W2_TILES * 4) : Vn;
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
+                    const f32x16 cstart = (first && ks == 0) ? ((c == 5 && jd == 1) ? biasv : zero16) : acc[c];
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][c >> 2][c & 3],
-                                                                  fv[set][c >> 2][(c & 3) == 0 ? 2 : ((c & 3) == 3 ? 3 : (c & 3) - 1)], acc[c], 0, 0, 0);
+                                                                  fv[set][c >> 2][(c & 3) == 0 ? 2 : ((c & 3) == 3 ? 3 : (c & 3) - 1)], cstart, 0, 0, 0);
                     if (c >= 8 && c < 12) read_v(Vk, nset, c - 8);
                     else if (c >= 12) read_a(Ak, nset, c - 12);
                     if (ks < 2) {
@@ -2382,6 +2379,11 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
             }
             rbuf = wbuf;
         }
+    };
+    auto run_pass = [&](auto JD) __attribute__((always_inline)) {
+        constexpr int jd = decltype(JD)::value;
+        stage(std::true_type{}, jd);
+        for (int st = 1; st < S1; ++st) stage(std::false_type{}, jd);
         if (!(DBG & 4)) {
             fold(jd);
             // (the first fragments of the next stage, read again: carried across the fold they cost 32 registers there)
