@@ -2202,6 +2202,12 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
     };
 
     f32x16 acc[16];                                  // (started from zero by the first MFMAs of each pass)
+    if (DBG & 4) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+    }
     f32x16 zero16, biasv;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { zero16[r] = 0.0f; biasv[r] = 0.0f; }
@@ -2341,7 +2347,7 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
     // The first stage of a pass is a copy of the stage body whose first k-step starts the accumulators from zero (from the
     // bias for component (1, 1) of depth component 1) in the MFMA itself: 256 register writes per pass less in the fold.
     auto stage = [&](auto FIRST, const int jd) __attribute__((always_inline)) {
-        constexpr bool first = decltype(FIRST)::value;
+        constexpr bool first = decltype(FIRST)::value && !(DBG & 4);     // (the no-fold experiment lets the passes accumulate on)
         {
             const int wbuf = rbuf ^ 1;
             const float* Ab = As + rbuf * W2_ASZ;

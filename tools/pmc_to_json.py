@@ -57,7 +57,8 @@ if kname:
     alg = 4 * (nin + nin + nw)
     rd = fc["FETCH_SIZE"] * 1024.0 * cal["fetch_factor"]
     wr = wc["WRITE_SIZE"] * 1024.0 * cal["write_factor"]
-    key = "conv_wg2_kernel<" + kname.split("<")[1].split(",")[0] + ">" if "wg2" in kname else kname
+    # bench.py's name of the instance: template name + first argument (the row width)
+    key = kname.split("<")[0] + "<" + kname.split("<")[1].split(",")[0].split(">")[0] + ">" if ("wg2" in kname or "wg3" in kname) else kname
     out[key] = dict(kernel_symbol=kname, shape=shape, workload=wl, FETCH_SIZE_KB=fc["FETCH_SIZE"], WRITE_SIZE_KB=wc["WRITE_SIZE"],
                     hbm_read_bytes=int(rd), hbm_write_bytes=int(wr), traffic_bytes=int(rd + wr), algorithmic_bytes=alg,
                     traffic_over_algorithmic=round((rd + wr) / alg, 3))
