@@ -2674,6 +2674,10 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
                 "sdc_conv: bad kernel/stride");
     SDC_REQUIRE(d.precision >= 0 && d.precision <= 4, SDC_EINVAL, "sdc_conv: precision must be 0 (fp32 MFMA), 1 (split-bf16), 2 (fp32 Winograd along W), 3 (fp32 Winograd over H and W) or 4 (fp32 Winograd over D, H and W)");
     SDC_REQUIRE(!gn_part || d.precision >= 2, SDC_EINVAL, "sdc_conv_gn: fused GroupNorm statistics need precision 2, 3 or 4 (sdc_conv_gnparts returned 0)");
+    // the caller sized `parts` with sdc_conv_gnparts(d, G), which sees the descriptor only: a kernel picked here on other
+    // grounds (pointer alignment, a residual) with a different part count would write a table the finalize pass misreads
+    const int gn_expect = gn_part ? sdc_conv_gnparts(dp, gn_G) : 0;
+#define SDC_GN_PARTS_AGREE(n) SDC_REQUIRE((n) == gn_expect, SDC_EINVAL, "sdc_conv_gn: this call runs a kernel with %d partial sums per group where sdc_conv_gnparts promised %d (misaligned pointers or a residual the descriptor does not show?)", (n), gn_expect)
     ConvArgs a;
     a.d = d;
     a.lgD = ilog2_exact(d.uD); a.lgH = ilog2_exact(d.uH); a.lgW = ilog2_exact(d.uW);
@@ -2731,6 +2735,7 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
         if (gn_part) {
             a.gn_nparts = gn_parts_for(d, WgPick{21, W2_BM, W2_TILES * 8, false}, gn_G);
             SDC_REQUIRE(a.gn_nparts > 0, SDC_EINVAL, "sdc_conv_gn: shape not covered by the fused statistics (sdc_conv_gnparts returned 0)");
+            SDC_GN_PARTS_AGREE(a.gn_nparts);
             a.gn_part = gn_part; a.gn_G = gn_G; a.gn_cpg = d.Cout / gn_G; a.gn_S = d.oD * d.oH * d.oW;
         }
         SDC_PICK(d.oW == 16 ? "conv_wg3_kernel<16>" : (d.oW == 32 ? "conv_wg3_kernel<32>" : "conv_wg3_kernel<64>"), 8.0 / 27.0);
@@ -2747,6 +2752,7 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
         if (gn_part) {
             a.gn_nparts = gn_parts_for(d, WgPick{20, W2_BM, W2_TILES * 4, false}, gn_G);
             SDC_REQUIRE(a.gn_nparts > 0, SDC_EINVAL, "sdc_conv_gn: shape not covered by the fused statistics (sdc_conv_gnparts returned 0)");
+            SDC_GN_PARTS_AGREE(a.gn_nparts);
             a.gn_part = gn_part; a.gn_G = gn_G; a.gn_cpg = d.Cout / gn_G; a.gn_S = d.oD * d.oH * d.oW;
         }
         SDC_PICK(d.oW == 16 ? "conv_wg2_kernel<16>" : (d.oW == 32 ? "conv_wg2_kernel<32>" : (d.oW == 64 ? "conv_wg2_kernel<64>" : "conv_wg2_kernel<128>")),
@@ -2762,6 +2768,7 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
         if (gn_part) {
             a.gn_nparts = gn_parts_for(d, wgp, gn_G);
             SDC_REQUIRE(a.gn_nparts > 0, SDC_EINVAL, "sdc_conv_gn: shape not covered by the fused statistics (sdc_conv_gnparts returned 0)");
+            SDC_GN_PARTS_AGREE(a.gn_nparts);
             a.gn_part = gn_part; a.gn_G = gn_G; a.gn_cpg = d.Cout / gn_G; a.gn_S = d.oD * d.oH * d.oW;
         }
         if (wgp.ups) {

@@ -415,6 +415,8 @@ def test_conv_winograd_2d_mode(plan_cls, case):
     dict(B=1, cin=16, cout=128, sp=(6, 8, 32), cin1=24, G=8),                 # concat, 2 m-tiles, interior plane pair
     dict(B=3, cin=32, cout=64, sp=(2, 16, 16), G=0),                          # 16-wide rows (two rows interleaved per DPP row)
     dict(B=1, cin=8, cout=192, sp=(8, 8, 32), G=3),                           # one stage per depth component, 3 m-tiles, a group = one m-tile
+    dict(B=1, cin=512, cout=128, sp=(2, 16, 16), G=1),                        # long K (64 stages per pass), one group over both m-tiles
+    dict(B=2, cin=16, cout=64, sp=(2, 4, 64), cin1=8, G=8, x1_pad=3),         # single plane pair; second input with its own (padded) strides
 ])
 def test_conv_winograd_3d_mode(plan_cls, case):
     """precision=4: fp32 Winograd F(2x2x2,3x3x3) over (D, H, W) against torch in fp64 and beside the direct kernel; with
@@ -430,10 +432,17 @@ def test_conv_winograd_3d_mode(plan_cls, case):
     if res is not None:
         ref = ref + res.double()
     outs, names = {}, {}
+    x1d = None
+    if x1 is not None:
+        x1d = x1.to(DEV)
+        if case.get("x1_pad"):      # a channel slice of a wider buffer: batch stride != Cin1 * channel stride
+            wide = torch.zeros(B, cin1 + case["x1_pad"], *sp, device=DEV)
+            wide[:, :cin1] = x1d
+            x1d = wide[:, :cin1]
     for prec in (0, 4):
         plan = plan_cls(DEV, precision=prec)
         out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, (3, 3, 3),
-                        x1=None if x1 is None else as5(x1.to(DEV)), pad=(1, 1, 1),
+                        x1=None if x1d is None else as5(x1d), pad=(1, 1, 1),
                         residual=None if res is None else as5(res.to(DEV)), gn_groups=G if prec == 4 else 0)
         d = plan.calls[0][1][0]._obj
         buf = C.create_string_buffer(128)
