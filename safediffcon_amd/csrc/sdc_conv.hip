@@ -56,6 +56,7 @@ struct ConvArgs {
     int lgD, lgH, lgW;
     int rowhalo;   // allow the row-halo kernel (env SDC_NO_ROWHALO=1 disables it for A/B timing)
     int vec2;      // Winograd epilogue: y (and residual) rows allow 8-byte accesses at even positions
+    int ydense;    // y (and the residual) dense per sample and below 2^30 elements: conv_epilogue addresses them as scalar channel base + 32-bit lane offset
     const float* wg2;   // F(2x2,3x3) taps [kd][Cin][Cout][16] (precision 3) / F(2x2x2,3x3x3) taps [jd][Cin][Cout][16] (precision 4)
     // GroupNorm partial sums of the output (sdc_conv_gn): fp64 (sum, sum of squares) per (sample, group, part)
     double* gn_part;
@@ -76,6 +77,65 @@ template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw, int lane) {
     const SdcConvDesc& d = a.d;
     const int l31 = lane & 31, lh = lane >> 5;
+    // Dense outputs (the usual case): a position decodes to (sample, offset inside the sample) with one float quotient and
+    // a fix-up, the channel part of every address is scalar.  The general path below spends ~25 VALU instructions per
+    // runtime integer division, six of them per 32-position tile -- a fifth of a short-K (1x1, Cin = 128) workgroup's time.
+    if (a.ydense && mw + TM * 32 <= d.Cout) {
+        typedef __attribute__((address_space(1))) char* gwchar_p;
+        typedef __attribute__((address_space(1))) float* gwfloat_p;
+        typedef const __attribute__((address_space(1))) char* gchar_p;
+        const int S = d.oD * d.oH * d.oW;
+        const float r_S = 1.0f / (float)S;
+        const int64_t ycs4 = d.ys[1] * 4, rcs4 = d.rs[1] * 4;
+        uint32_t yoff[TN], roff[TN];
+        bool pok[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int pp = nw + j * 32 + l31;
+            pok[j] = pp < a.Ntot;
+            const int p = pok[j] ? pp : 0;
+            int b = (int)((float)p * r_S);                  // within a few units of p / S, fixed up below
+            int sp = p - b * S;
+            while (sp < 0) { --b; sp += S; }
+            while (sp >= S) { ++b; sp -= S; }
+            yoff[j] = (uint32_t)(b * d.ys[0] + sp + (4 * lh) * d.ys[1]) * 4u;
+            roff[j] = a.res ? (uint32_t)(b * d.rs[0] + sp + (4 * lh) * d.rs[1]) * 4u : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int cob = mw + i * 32;                    // wave-uniform; this lane's rows: cob + 4 lh + (rr & 3) + 8 (rr >> 2)
+            gwchar_p yb = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(a.y + (int64_t)cob * d.ys[1]);
+            gchar_p rb = (gchar_p)uniform_ptr(a.res ? a.res + (int64_t)cob * d.rs[1] : a.y);
+            if (a.res) {
+                // bias and residual of the 16 rows as one batch of loads (one memory round trip per tile row, not sixteen)
+                float bv[16], rv[16][TN];
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    bv[rr] = a.bias ? a.bias[cob + 4 * lh + (rr & 3) + 8 * (rr >> 2)] : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) rv[rr][j] = *(gfloat_p)(rb + roff[j]);
+                    rb += (rr & 3) < 3 ? rcs4 : 5 * rcs4;
+                }
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if (pok[j]) *(gwfloat_p)(yb + yoff[j]) = (acc[i][j][rr] + bv[rr]) + rv[rr][j];
+                    yb += (rr & 3) < 3 ? ycs4 : 5 * ycs4;
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const float bv = a.bias ? a.bias[cob + 4 * lh + (rr & 3) + 8 * (rr >> 2)] : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if (pok[j]) *(gwfloat_p)(yb + yoff[j]) = acc[i][j][rr] + bv;
+                    yb += (rr & 3) < 3 ? ycs4 : 5 * ycs4;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int cob = mw + i * 32 + 4 * lh;
@@ -116,7 +176,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 }
 
 template <int BM, int BN, int WM, int WN, bool FAST>
-__global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void conv_kernel(const ConvArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int BROWS = BK * BN / NT;   // B-tile elements per thread
@@ -332,7 +392,9 @@ __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs a) {
 // instead of 16.  These layers have K = Cin <= 768: few chunks per tile, so the load issue and its latency, not the
 // MFMA stream, decide.  Same k-ordered fp32 FMA chains as conv_kernel.
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(NT) void conv_pw_kernel(const ConvArgs a) {
+// (at least 3 waves per SIMD = 3 workgroups per CU: at 2 the short-K layers sit out each other's prologue and epilogue; the
+// register cap this implies costs no spill)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void conv_pw_kernel(const ConvArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int NB4 = BK * BN / 4 / NT;      // float4 activation loads per thread per chunk
@@ -457,15 +519,18 @@ void launch_pw(const ConvArgs& a, hipStream_t s) {
 // LDS: As[2][KW][BK][BM], Bs[2][BK][NSEG][seg + KW - 1] with seg = min(oW, BN), NSEG = BN / seg.
 // GEN: the 16 k rows of a stage are arbitrary (kd, kh, ci) triples (flattened kr = (kd*kH + kh)*Cin + ci), so
 // Cin need not be a multiple of 16: the 7x7x7 / 7x7 / k7 stem convs (Cin = 7, 3, 12) run here with KW = 7.
-template <int BM, int BN, int WM, int WN, int KW, bool GEN>
-__global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
+template <int BM, int BN, int WM, int WN, int KW, bool GEN, int BKT = 16>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BKT == 8 ? 4 : 1))) void conv_rh_kernel(const ConvArgs a) {
+    constexpr int BK = BKT;                                     // k rows per stage (the 7-tap stem: 8, so that three workgroups fit a CU's LDS)
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int KSMAX = BN + (BN / 16) * (KW - 1);            // LDS floats per k row, worst case (16-wide rows)
     constexpr int NCOL = (KSMAX + 63) / 64;                     // 64-lane sweeps over one k row
     constexpr int KROWS = BK / (NT / 64);                       // k rows per wave per stage
-    constexpr int NA4 = KW * BK * BM / 4 / NT;                  // float4 weight loads per thread per stage
-    static_assert(NA4 >= 1, "weight tile too small");
+    constexpr int NA4T = KW * BK * BM / 4;                      // float4 weight loads per stage
+    constexpr int NA4 = (NA4T + NT - 1) / NT;                   // ... per thread (the last one partial when NT does not divide them)
+    static_assert(NA4 >= 1 && KROWS >= 1, "weight tile too small");
+    static_assert(GEN || NA4T % NT == 0, "only the generalized-row form guards a partial weight load");
 
     __shared__ __attribute__((aligned(16))) float As[2][KW][BK][BM];
     __shared__ float Bs[2][BK * KSMAX];
@@ -583,9 +648,10 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
             // weights: LDS row (kw, krl) <- Wp[((kdkh * KW + kw) * Cin + ci)], kr = 16*s_st + krl = kdkh*Cin + ci
 #pragma unroll
             for (int i = 0; i < NA4; ++i) {
-                const int row = (tid + i * NT) / (BM / 4);
+                const bool rin = tid + i * NT < NA4T;
+                const int row = rin ? (tid + i * NT) / (BM / 4) : 0;
                 const int kw = row / BK, kr = s_st * BK + row % BK;
-                const bool ok = kr < KR;
+                const bool ok = rin && kr < KR;
                 const int krc = ok ? kr : 0;
                 const int kdkh = (int)(((float)krc + 0.5f) * r_cin), ci = krc - kdkh * a.Cin;      // exact: krc < 2^20
                 const int64_t wrow = (int64_t)(kdkh * KW + kw) * a.Cin + ci;
@@ -623,7 +689,7 @@ __global__ __launch_bounds__(NT) void conv_rh_kernel(const ConvArgs a) {
             const int row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
             float4 v = areg[i];
             if (!a_ok[i] || !a_rowok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&As[buf][row / BK][row % BK][c4]) = v;
+            if (NA4T % NT == 0 || f < NA4T) *reinterpret_cast<float4*>(&As[buf][row / BK][row % BK][c4]) = v;
         }
 #pragma unroll
         for (int r = 0; r < KROWS; ++r)
@@ -2703,6 +2769,14 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
     static const int no_rh = getenv("SDC_NO_ROWHALO") ? atoi(getenv("SDC_NO_ROWHALO")) : 0;
     a.rowhalo = !no_rh;
     a.vec2 = 0;
+    {
+        auto dense = [&](const int64_t* st) { return st[4] == 1 && st[3] == d.oW && st[2] == (int64_t)d.oH * d.oW; };
+        const int64_t S = (int64_t)d.oD * d.oH * d.oW;
+        a.ydense = dense(d.ys) && S >= 128 && S < (1 << 24) && span5(d.ys, d.B, d.Cout, d.oD, d.oH, d.oW) < (1ll << 30) &&
+                   (!residual || (dense(d.rs) && span5(d.rs, d.B, d.Cout, d.oD, d.oH, d.oW) < (1ll << 30)));
+        static const int no_dense = getenv("SDC_NO_DENSE_EPI") ? atoi(getenv("SDC_NO_DENSE_EPI")) : 0;
+        if (no_dense) a.ydense = 0;
+    }
     a.wg2 = nullptr;
     a.gn_part = nullptr; a.gn_G = a.gn_cpg = a.gn_nparts = a.gn_S = 0;
     const bool fast = (d.Cin0 % BK == 0) && (d.Cin1 % BK == 0) && small && d.Cout < (1 << 30);
@@ -2822,7 +2896,8 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
         }
         dim3 grid((a.Ntot + 127) / 128, (d.Cout + 63) / 64);
         SDC_PICK("conv_rh_kernel<64,128,2,2,7,true>", 1.0);
-        hipLaunchKernelGGL((conv_rh_kernel<64, 128, 2, 2, 7, true>), grid, dim3(NT), 0, s, a);
+        if (stem_tile == 16) hipLaunchKernelGGL((conv_rh_kernel<64, 128, 2, 2, 7, true, 16>), grid, dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((conv_rh_kernel<64, 128, 2, 2, 7, true, 8>), grid, dim3(NT), 0, s, a);
         return sdc::check_launch("sdc_conv[stem]");
     }
     const int64_t blocks64x128 = (int64_t)((a.Ntot + 127) / 128) * ((d.Cout + 63) / 64);
