@@ -491,6 +491,55 @@ def test_conv_winograd_3d_falls_back_where_not_covered(plan_cls):
         assert e < 1e-5, e
 
 
+def test_conv_default_mode_over_a_sweep_of_shapes(plan_cls):
+    """precision=4 over a seeded sweep of 3x3x3 / 1x3x3 shapes (depths odd and even, rows of 8..64, channel counts on and off
+    the tile sizes, with and without a second input / residual / GroupNorm): whatever kernel the dispatch picks -- F(2x2x2),
+    F(2x2), F(2,3) or direct -- the result is the fp64 conv within 1e-5 of the output scale, and the fused statistics, where
+    offered, normalise like torch."""
+    from safediffcon_amd.engine import as5
+    g = torch.Generator().manual_seed(1234)
+    picks = {}
+    for case in range(40):
+        r = lambda *opts: opts[int(torch.randint(len(opts), (1,), generator=g))]     # noqa: E731
+        kd = r(3, 3, 1)
+        B, cin, cout = r(1, 2, 3), r(8, 16, 24, 40, 64), r(32, 64, 96, 128)
+        cin1 = r(0, 0, 8, 16)
+        D, H, W = (r(1, 2, 3, 4, 6) if kd == 3 else r(1, 2)), r(2, 4, 6, 8, 16), r(8, 16, 32, 64)
+        withres, G = r(False, False, True), r(0, 8)
+        if case >= 28:      # the last dozen lean towards what the F(2x2x2,3x3x3) kernel takes
+            kd, cout, D, withres = 3, r(64, 128), r(2, 4, 6), False
+            W = r(16, 32, 64)
+            H = r(16, 16, 32) if W == 16 else (r(8, 16) if W == 32 else r(4, 8, 12))
+        x = torch.randn(B, cin, D, H, W, generator=g)
+        x1 = torch.randn(B, cin1, D, H, W, generator=g) if cin1 else None
+        w = torch.randn(cout, cin + cin1, kd, 3, 3, generator=g) * 0.2
+        b = torch.randn(cout, generator=g) * 0.1
+        ref = F.conv3d((x if x1 is None else torch.cat((x, x1), 1)).double(), w.double(), b.double(), padding=(kd // 2, 1, 1))
+        res = torch.randn(ref.shape, generator=g) if withres else None
+        if withres:
+            ref = ref + res.double()
+        plan = plan_cls(DEV, precision=4)
+        out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, (kd, 3, 3),
+                        x1=None if x1 is None else as5(x1.to(DEV)), pad=(kd // 2, 1, 1),
+                        residual=None if res is None else as5(res.to(DEV)), gn_groups=G)
+        buf = C.create_string_buffer(128)
+        assert plan.lib.sdc_conv_describe(C.byref(plan.calls[0][1][0]._obj), buf, 128, None) == 0
+        name = buf.value.decode().split("<")[0]
+        picks[name] = picks.get(name, 0) + 1
+        if G:
+            gam, bet = torch.randn(cout, generator=g) * 0.3 + 1.0, torch.randn(cout, generator=g) * 0.2
+            y = plan.pool.get(tuple(out.shape))
+            plan.gn_silu(out, gam.to(DEV), bet.to(DEV), G, out=y)
+        _run(plan)
+        e = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        assert e < 1e-5, (case, name, tuple(x.shape), cin1, cout, kd, e)
+        if G:
+            refn = F.silu(F.group_norm(ref, G, gam.double(), bet.double(), 1e-5))
+            torch.testing.assert_close(y.cpu().double(), refn, rtol=1e-4, atol=3e-5)
+    print(f"[measured] kernels picked over the sweep: {picks}")
+    assert len(picks) >= 3 and picks.get("conv_wg3_kernel", 0) >= 8, picks
+
+
 def test_conv_winograd_2d_strided_output_and_residual(plan_cls):
     """F(2x2,3x3) kernel writing through a strided view (every other column of a wider buffer) with a residual read
     through another strided view: the scalar (non 8-byte) store / load path of its epilogue."""
