@@ -58,6 +58,21 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
     float* yb = a.y + o * a.so + i0;
 
     // ---- 1. x tile + LayerNorm over the 64 channels of a token (pixel hw, frame f): two threads per token, 32 channels each
+    // (every global read of the prologue -- x tile, head 0's weights, bias and rotary tables -- is issued before the first
+    // is used: one memory round trip instead of three)
+    typedef float nfloat4 __attribute__((ext_vector_type(4)));
+    nfloat4 w0reg[4];
+    float biasreg[8], rotreg[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        w0reg[i] = *reinterpret_cast<const nfloat4*>(a.wqkv + (int64_t)(tid >> 3) * 384 + i * 128 + (tid & 7) * 4);
+    w0reg[3] = *reinterpret_cast<const nfloat4*>(a.wo + (int64_t)(tid >> 4) * C + (tid & 15) * 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) biasreg[i] = a.bias ? a.bias[tid + i * NT] : 0.0f;
+    {
+        const float2 rr = a.rot ? *reinterpret_cast<const float2*>(a.rot + tid * 2) : make_float2(1.0f, 0.0f);
+        rotreg[0] = rr.x; rotreg[1] = rr.y;
+    }
     {
         const int tok = tid & 255, half = tid >> 8, hw = tok & 7, f = tok >> 3;
         const float* xt = xb + (int64_t)f * a.st + hw + (int64_t)(half * 32) * a.sc;
@@ -79,22 +94,17 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
 #pragma unroll
         for (int c = 0; c < 32; ++c) xs[(half * 32 + c) * XP + hw * 33 + f] = v[c] * rstd * a.g[half * 32 + c];
     }
-    {   // head 0's weights
-        typedef float nfloat4 __attribute__((ext_vector_type(4)));
+    {   // head 0's weights, the transposed bias table, the rotary table
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            *reinterpret_cast<nfloat4*>(wl + i * 2048 + (tid >> 3) * 32 + (tid & 7) * 4) =
-                *reinterpret_cast<const nfloat4*>(a.wqkv + (int64_t)(tid >> 3) * 384 + i * 128 + (tid & 7) * 4);
-        *reinterpret_cast<nfloat4*>(wl + 6144 + (tid >> 4) * 64 + (tid & 15) * 4) =
-            *reinterpret_cast<const nfloat4*>(a.wo + (int64_t)(tid >> 4) * C + (tid & 15) * 4);
-    }
-    for (int e = tid; e < 4 * 32 * 32; e += NT) {
-        const int h = e >> 10, q = (e >> 5) & 31, kk = e & 31;
-        biasT[(h * 32 + kk) * 33 + q] = a.bias ? a.bias[e] : 0.0f;
-    }
-    for (int e = tid; e < 32 * 16; e += NT) {
-        rotc[e] = a.rot ? a.rot[e * 2] : 1.0f;
-        rots[e] = a.rot ? a.rot[e * 2 + 1] : 0.0f;
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<nfloat4*>(wl + i * 2048 + (tid >> 3) * 32 + (tid & 7) * 4) = w0reg[i];
+        *reinterpret_cast<nfloat4*>(wl + 6144 + (tid >> 4) * 64 + (tid & 15) * 4) = w0reg[3];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + i * NT, h = e >> 10, q = (e >> 5) & 31, kk = e & 31;
+            biasT[(h * 32 + kk) * 33 + q] = biasreg[i];
+        }
+        rotc[tid] = rotreg[0];
+        rots[tid] = rotreg[1];
     }
     __syncthreads();
 
@@ -110,7 +120,6 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
     // The weights of a head (32 KB) are staged in LDS once per workgroup with 16-byte loads -- four per thread -- and shared by
     // the 8 waves; per-wave dword fetches of the fragments (512 per lane) cost 12 % of the kernel.  Two buffers: the next
     // head's weights are fetched before the head's chains and parked after them, one barrier per head.
-    typedef float nfloat4 __attribute__((ext_vector_type(4)));
     nfloat4 wreg[4];
     auto fetch_head = [&](int head) {
         if (a.dbg & 2) return;
@@ -222,8 +231,11 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
     {
         const int tok = tid & 255, half = tid >> 8, pw = tok & 7, f = tok >> 3;
         const int64_t off = (int64_t)f * a.st + pw + (int64_t)(half * 32) * a.sc;
-#pragma unroll 8
-        for (int c = 0; c < 32; ++c) yb[off + (int64_t)c * a.sc] = xs[(half * 32 + c) * XP + pw * 33 + f] + xb[off + (int64_t)c * a.sc];
+        float xr[32];                              // the residual: 32 loads in flight at once (in batches of 8 they cost four round trips)
+#pragma unroll
+        for (int c = 0; c < 32; ++c) xr[c] = xb[off + (int64_t)c * a.sc];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) yb[off + (int64_t)c * a.sc] = xs[(half * 32 + c) * XP + pw * 33 + f] + xr[c];
     }
 }
 
