@@ -176,7 +176,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 }
 
 template <int BM, int BN, int WM, int WN, bool FAST>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void conv_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void conv_kernel(const ConvArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int BROWS = BK * BN / NT;   // B-tile elements per thread
