@@ -12,6 +12,7 @@ What is pinned:
   * T=8 p_sample_loop trajectories, guided and calibration variants, noise injected
     by patching torch.randn / torch.randn_like while the reference loop runs
   * guidance-gradient, weight-normalisation and conformal-quantile KATs
+  * one FULL-SCHEDULE (T = 1000) guided DDPM trajectory per tree (final state), gen_long
 Weights are NOT stored: both sides rebuild them with oracle.detweights.det_params
 from the (key, shape) list stored in the fixture.
 """
@@ -509,14 +510,90 @@ def gen_wide(which):
         save("smoke_unet_wide", dim=64, x_seed=311, t=t, eps=eps, weight_seed=310, **spec_arrays(spec))
 
 
+def gen_long(which):
+    """One FULL-SCHEDULE (T = 1000) guided DDPM trajectory per tree through the REAL reference at dim 8: the real 1000-entry
+    coefficient tables are walked end to end (posterior_log_variance clamp at t = 0, sqrt_recipm1 at t = 999), the conditioning
+    writes and the guidance act 1000 times.  Noise draw i is det_noise(seed)(i); only the final state is stored."""
+    T, B, dim = 1000, 2, 8
+    stub_modules("h5py", "tensorboardX", "ema_pytorch", "IPython")
+    sys.modules["tensorboardX"].SummaryWriter = object
+    sys.modules["ema_pytorch"].EMA = object
+    sys.modules["IPython"].embed = None
+    if which == "burgers":
+        sys.path.insert(0, os.path.join(REF, "1D"))
+        from model.unet import Unet2D
+        from model.diffusion import GaussianDiffusion
+        from utils.guidance import get_finetune_guidance
+        net = Unet2D(dim=dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+        load_det(net, seed=100)
+        gd = GaussianDiffusion(net, seq_length=(16, 128), timesteps=T, temporal=True, use_conv2d=True, is_condition_u0=True,
+                               is_condition_uT=True, condition_idx=10, train_on_padded_locations=False)
+        u0, uT = det_tensor((B, 128), 130, 0.1, -0.1, 0.3), det_tensor((B, 128), 131, 0.1, -0.1, 0.3)
+        cfg = types.SimpleNamespace(use_max_safety=True, u_bound=0.05, guidance_weights={"w_score": 500.0}, InfFT_Q=None)
+        Q = 0.01
+        with injected_noise(det_noise((B, 3, 16, 128), 4000)) as st:
+            out = gd.sample(batch_size=B, clip_denoised=True, u_init=u0, u_final=uT, guidance_u0=True,
+                            nablaJ=lambda x: get_finetune_guidance(cfg, x, Q), J_scheduler=lambda t: 1.0, w_scheduler=None,
+                            enable_grad=False)
+        save("burgers_traj_long", out=out, u0=u0, uT=uT, Q=Q, w_score=500.0, u_bound=0.05, T=T, draws=st["i"], noise_seed=4000,
+             dim=dim, weight_seed=100)
+    elif which == "tokamak":
+        sys.path.insert(0, os.path.join(REF, "tokamak"))
+        stub_modules("kstar_solver")
+        sys.modules["kstar_solver"].KSTARSolver = object
+        from model.unet import Unet1D
+        from model.diffusion import GaussianDiffusion
+        from utils.guidance import GradientGuidance
+        nt = 122
+        net = Unet1D(dim=dim, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+        load_det(net, seed=200)
+        gd = GaussianDiffusion(net, seq_length=128, nt=nt, timesteps=T, use_conv2d=False, temporal=False, guidance_u0=True,
+                               is_condition_u0=True, is_condition_uT=True)
+        u0, uT = det_tensor((B, 3), 220, 0.1) + 0.6, det_tensor((B, 2, nt), 221, 0.1) + 0.6
+        target = det_tensor((B, 3, nt), 212, 0.3) + 1.0
+        g = GradientGuidance.__new__(GradientGuidance)
+        # MSE term and hinge both on (the safety-only production setting has a one-hot gradient: a weaker check)
+        g.w_obj, g.w_safe, g.guidance_scaler, g.Q, g.safety_threshold, g.nt = 0.7, 0.3, 0.5, 0.1, 3.6, nt
+        g.state_target = target
+        with injected_noise(det_noise((B, 12, 128), 4100)) as st:
+            out = gd.sample(batch_size=B, clip_denoised=True, guidance_u0=True, u_init=u0, u_final=uT, nablaJ=g,
+                            J_scheduler=lambda t: 1.0, w_scheduler=None, enable_grad=False)
+        save("tokamak_traj_long", out=out, u0=u0, uT=uT, target=target, T=T, draws=st["i"], noise_seed=4100, dim=dim,
+             weight_seed=200, w_obj=0.7, w_safe=0.3, scaler=0.5, thr=3.6, Q=0.1)
+    else:
+        sys.path.insert(0, os.path.join(HERE, "_shims"))
+        sys.path.insert(0, os.path.join(REF, "2d"))
+        from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+        from ddpm.diffusion_2d import GaussianDiffusion
+        import importlib
+        stub_modules("dataset", "dataset.apps", "dataset.apps.evaluate_solver")
+        inf = importlib.import_module("inference_2d")
+        net = Unet3D_with_Conv3D(dim=dim, dim_mults=(1, 2, 4), channels=7)
+        load_det(net, seed=300)
+        gd = GaussianDiffusion(net, image_size=16, frames=8, timesteps=T, loss_type="l2", standard_fixed_ratio=100.0)
+        gd.eval()
+        init = det_tensor((B, 16, 16), 330, 0.2).abs()
+        RES = torch.tensor([2, 19, 20, 17, 20, 1, 1.0]).reshape(1, 1, 7, 1, 1)
+        args = types.SimpleNamespace(device="cpu", w_safe=0.9, safe_bound=-5.0, standard_fixed_ratio=100.0)
+        pipe = inf.InferencePipeline.__new__(inf.InferencePipeline)
+        pipe.args_general, pipe.RESCALER, pipe.Q = args, RES, 0.01
+        with injected_noise(det_noise((B, 8, 7, 16, 16), 4200)) as st:
+            out = gd.sample(batch_size=B, design_fn=pipe.design_fn, enable_grad=False, init=init)
+        save("smoke_traj_long", out=out, init=init, T=T, draws=st["i"], noise_seed=4200, dim=dim, weight_seed=300, Q=0.01,
+             w_safe=0.9, safe_bound=-5.0, ratio=100.0)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which == "all":
-        for w in ("burgers", "tokamak", "smoke", "burgers_wide", "tokamak_wide", "smoke_wide"):
+        for w in ("burgers", "tokamak", "smoke", "burgers_wide", "tokamak_wide", "smoke_wide", "burgers_long", "tokamak_long",
+                  "smoke_long"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     elif which.endswith("_wide"):
         gen_wide(which[:-5])
+    elif which.endswith("_long"):
+        gen_long(which[:-5])
     else:
         {"burgers": gen_burgers, "tokamak": gen_tokamak, "smoke": gen_smoke}[which]()

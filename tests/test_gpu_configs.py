@@ -232,3 +232,51 @@ def test_tokamak_conformal_ddim_passes_ground_truth_actions(golden):
     plain = gd.sample(batch_size=Bc, guidance_u0=False, u_init=states[0][:, :3, 0].to(DEV), u_final=states[0][:, [0, 2], :122].to(DEV),
                       nablaJ=None, enable_grad=False).cpu()
     assert not torch.allclose(plain, outs[0])          # the actions condition the samples
+
+
+# ------------------------------------------------------------------ C4: the sampler (not only the forward) at production width
+def test_c4_width_guided_sampler_vs_oracle():
+    """2d/ddpm/diffusion_2d.py:288-322 at the C4 net width and grid: Unet3D_with_Conv3D(64,(1,2,4),7) on (B,32,7,64,64),
+    3 guided steps with injected noise, HIP sampler against oracle.samplers.sample_smoke on the CPU (mirror of
+    test_c3_guided_sampler_batch128).  The hinge is made active (safe_bound -5) so the guidance term is exercised."""
+    net = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+    P = det_params(_spec(net), 31)
+    net.load_state_dict(P)
+    net.to(DEV)
+    T, B = 3, 2
+    gs = sdc.GaussianDiffusionSmoke(net, image_size=64, frames=32, timesteps=T, standard_fixed_ratio=100.0).to(DEV)
+    init = det_tensor((B, 64, 64), 43, 0.2).abs()
+    noise = det_noise((B, 32, 7, 64, 64), 7100)
+    out = gs.sample(batch_size=B, design_fn=sdc.SmokeGuidance(0.01, 0.9, -5.0), init=init.to(DEV), noise=noise).cpu()
+    tabs = osched.make_tables("sigmoid", T)
+    ref = osam.sample_smoke(lambda a, b: onets.unet_smoke(P, a, b, dim=64, dim_mults=(1, 2, 4)), tabs, B, noise, init=init,
+                            design_fn=osam.smoke_guidance(0.01, 0.9, -5.0), ratio=100.0, shape=(32, 7, 64, 64))
+    free = osam.sample_smoke(lambda a, b: onets.unet_smoke(P, a, b, dim=64, dim_mults=(1, 2, 4)), tabs, 1, lambda i: noise(i)[:1],
+                             init=init[:1], design_fn=None, ratio=100.0, shape=(32, 7, 64, 64))
+    assert (free - ref[:1]).abs().max() > 1e-3           # the guidance mattered
+    assert _report("C4 width 3-step guided trajectory (B=2) vs oracle", out, ref) < 4e-4 and _mse(out, ref) <= 1e-9
+
+
+def test_c4_batch64_every_sample_vs_eager_oracle():
+    """C4 at B=64: EVERY one of the 64 eps maps against the oracle's functional U-Net executed by PyTorch-ROCm eager on the
+    same device (the CPU oracle covers sample 37 in test_c4_batch64_forward_and_sampler; the eager run was checked against
+    the CPU oracle in tests/test_gpu_strawman.py)."""
+    net = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+    P = det_params(_spec(net), 31)
+    net.load_state_dict(P)
+    net.to(DEV)
+    Pg = {k: v.to(DEV) for k, v in P.items()}
+    B = 64
+    x = det_tensor((B, 32, 7, 64, 64), 33).to(DEV)
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(34)).to(DEV)
+    eps = net(x, t)
+    worst_mse, worst_abs = 0.0, 0.0
+    with torch.no_grad():
+        for i in range(0, B, 4):                         # the eager net keeps every activation: 4 samples at a time
+            ref = onets.unet_smoke(Pg, x[i:i + 4], t[i:i + 4], dim=64, dim_mults=(1, 2, 4))
+            d = (eps[i:i + 4] - ref)
+            worst_mse = max(worst_mse, (d ** 2).flatten(1).mean(1).max().item())
+            worst_abs = max(worst_abs, d.abs().max().item())
+            del ref, d
+    print(f"[measured] C4 B=64, all 64 samples vs the eager-GPU oracle: worst per-sample eps-MSE {worst_mse:.3e}, max|err| {worst_abs:.3e}")
+    assert worst_mse <= 1e-9 and worst_abs < 6e-5

@@ -356,3 +356,40 @@ def test_mid_width_nets_odd_batches_vs_oracle(B):
                                onets.unet_smoke(P3, x3, t, dim=64, dim_mults=(1, 2, 4)), rtol=2e-3, atol=2e-4)
     used = {fn.__name__ for fn, _ in net3.entry(tuple(x3.shape), B)["plan"].calls}
     assert {"sdc_tattn_block", "sdc_linattn_block", "sdc_conv_gn"} <= used
+
+
+# ------------------------------------------------------------------ full schedule: T = 1000 against the REAL reference
+@pytest.mark.parametrize("tree", ["burgers", "tokamak", "smoke"])
+def test_full_schedule_trajectory_golden(golden, tree):
+    """1000 guided DDPM steps through the real 1000-entry coefficient tables (posterior_log_variance clamp at t = 0,
+    sqrt_recipm1 at t = 999), conditioning writes and guidance 1000 times, noise injected draw by draw: the HIP sampler
+    against the final state the REAL reference produced (tests/golden/*_traj_long.npz, oracle/make_goldens.py gen_long)."""
+    g = golden(tree + "_traj_long")
+    T, seed = int(g.scalar("T")), int(g.scalar("noise_seed"))
+    spec = golden(tree + "_unet").spec()
+    if tree == "burgers":
+        net = _load(sdc.Unet2D(dim=8, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1), spec, 100)
+        gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=T, temporal=True, use_conv2d=True,
+                                          is_condition_u0=True, is_condition_uT=True, condition_idx=10,
+                                          train_on_padded_locations=False).to(DEV)
+        out = gd.sample(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True,
+                        nablaJ=sdc.BurgersGuidance(g.scalar("Q"), g.scalar("w_score"), g.scalar("u_bound")),
+                        J_scheduler=lambda t: 1.0, enable_grad=False, noise=det_noise((2, 3, 16, 128), seed)).cpu()
+    elif tree == "tokamak":
+        net = _load(sdc.Unet1D(dim=8, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1), spec, 200)
+        gd = sdc.GaussianDiffusionTokamak(net, seq_length=128, nt=122, timesteps=T, guidance_u0=True).to(DEV)
+        guid = sdc.TokamakGuidance(g["target"], 122, g.scalar("w_obj"), g.scalar("w_safe"), g.scalar("scaler"), g.scalar("Q"),
+                                   g.scalar("thr"))
+        out = gd.sample(batch_size=2, clip_denoised=True, guidance_u0=True, u_init=g["u0"], u_final=g["uT"], nablaJ=guid,
+                        J_scheduler=lambda t: 1.0, enable_grad=False, noise=det_noise((2, 12, 128), seed)).cpu()
+    else:
+        net = _load(sdc.Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2, 4), channels=7), spec, 300)
+        gd = sdc.GaussianDiffusionSmoke(net, image_size=16, frames=8, timesteps=T, loss_type="l2",
+                                        standard_fixed_ratio=g.scalar("ratio")).to(DEV)
+        out = gd.sample(batch_size=2, design_fn=sdc.SmokeGuidance(g.scalar("Q"), g.scalar("w_safe"), g.scalar("safe_bound")),
+                        enable_grad=False, init=g["init"], noise=det_noise((2, 8, 7, 16, 16), seed)).cpu()
+    ref = g["out"]
+    err = (out - ref).abs().max().item()
+    print(f"[measured] {tree} T=1000 guided DDPM vs the reference: max|err| {err:.3e}  MSE {((out - ref) ** 2).mean().item():.3e}")
+    # fp32 rounding-order differences over 1000 contracting steps; gate ~5x the error measured on MI355X
+    assert err < 2e-3 and ((out - ref) ** 2).mean().item() < 1e-7

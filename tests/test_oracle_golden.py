@@ -219,3 +219,35 @@ def test_burgers_rollout_oracle_vs_reference_solver(golden):
     traj = solvers.burgers_rollout(g["u0"], g["f"])
     assert traj.shape == (3, 11, 128)
     assert torch.equal(traj, g["traj"])
+
+
+# ------------------------------------------------------------------ full schedule: T = 1000 through the real coefficient tables
+@pytest.mark.parametrize("tree", ["burgers", "tokamak", "smoke"])
+def test_full_schedule_trajectory(golden, tree):
+    """One 1000-step guided DDPM trajectory per tree produced by the REAL reference (oracle/make_goldens.py gen_long): the
+    oracle walks the same 1000-entry tables (posterior_log_variance clamp at t = 0, sqrt_recipm1 at t = 999)."""
+    g = golden(tree + "_traj_long")
+    T, dim = int(g.scalar("T")), int(g.scalar("dim"))
+    assert T == 1000 and int(g.scalar("draws")) == T       # x_T + one draw per step with t > 0
+    P = det_params(_spec(golden, tree + "_unet"), int(g.scalar("weight_seed")))
+    if tree == "burgers":
+        noise = det_noise((2, 3, 16, 128), int(g.scalar("noise_seed")))
+        out = samplers.sample_burgers(_eps_fn(nets.unet_burgers, P, dim), schedules.make_tables("cosine", T), 2, noise,
+                                      u_init=g["u0"], u_final=g["uT"], guidance_u0=True, enable_grad=False,
+                                      nablaJ=samplers.burgers_guidance(g.scalar("Q"), g.scalar("w_score"), g.scalar("u_bound")),
+                                      J_scheduler=lambda t: 1.0)
+    elif tree == "tokamak":
+        noise = det_noise((2, 12, 128), int(g.scalar("noise_seed")))
+        nablaJ = samplers.tokamak_guidance(g["target"], 122, g.scalar("Q"), g.scalar("thr"), g.scalar("w_obj"),
+                                           g.scalar("w_safe"), g.scalar("scaler"))
+        out = samplers.sample_tokamak(_eps_fn(nets.unet_tokamak, P, dim), schedules.make_tables("cosine", T), 2, noise,
+                                      u_init=g["u0"], u_final=g["uT"], nablaJ=nablaJ, J_scheduler=lambda t: 1.0,
+                                      guidance_u0=True, enable_grad=False)
+    else:
+        noise = det_noise((2, 8, 7, 16, 16), int(g.scalar("noise_seed")))
+        out = samplers.sample_smoke(_eps_fn(nets.unet_smoke, P, dim), schedules.make_tables("sigmoid", T), 2, noise,
+                                    init=g["init"], ratio=g.scalar("ratio"), shape=(8, 7, 16, 16),
+                                    design_fn=samplers.smoke_guidance(g.scalar("Q"), g.scalar("w_safe"), g.scalar("safe_bound")))
+    err = (out - g["out"]).abs().max().item()
+    print(f"{tree}: oracle vs reference after {T} steps: max|diff| {err:.3e} (|out| <= {g['out'].abs().max().item():.2f})")
+    torch.testing.assert_close(out, g["out"], rtol=1e-4, atol=2e-5)
