@@ -39,7 +39,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 T_DDPM = 1000
 DEFAULT_B = {"c2": 256, "c3": 128, "c4": 64}
-PMC_FILES = ("r2_pmc_traffic.json", "r1_pmc_traffic.json")
+PMC_FILES = ("r3_pmc_traffic.json",)      # stamped with the kernel-source hash they were collected on (tools/pmc_to_json.py)
 
 
 # --------------------------------------------------------------------------- launcher (N > 1 without a torchrun parent)
@@ -53,6 +53,11 @@ def _free_port():
 
 def launch_workers(n, argv):
     """Parent of `bench.py --gpus N`: no GPU call here (a process that has initialised HIP must not spawn the ranks)."""
+    import torch
+    if "SDC_FORCE_DEVICE" not in os.environ and "--selftest-launcher" not in argv:
+        ndev = torch.cuda.device_count()                   # (counts devices without initialising HIP)
+        if ndev < n:
+            raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible on this node")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -62,6 +67,16 @@ def launch_workers(n, argv):
 
 
 # --------------------------------------------------------------------------- workloads
+def shard_config(name, B, world):
+    """what the N-GPU line is quoted on (pure arithmetic, no GPU): per-GPU batch B, global batch, the calibration set split
+    over the ranks.  N = 8 of the smoke workload is BASELINE configs[4] ("C5": B = 512, calibration n = 8 x 25)."""
+    n_tot = 200 if name == "c4" else 1000                  # calibration set: 8x25 (2d/inference_2d.py) / 4x250 (1D) / 1x1000 (tokamak)
+    n_cal = max(8, n_tot // world)
+    tag = {"c2": "C2", "c3": "C3", "c4": "C5" if world == 8 else "C4"}[name]
+    return dict(tag=tag, batch_per_gpu=B, global_batch=B * world, n_cal_per_rank=n_cal, n_cal=n_cal * world,
+                alpha={"c2": 0.98, "c3": 0.9, "c4": 0.04}[name])
+
+
 def workload(name, dim, B, dev, rank, world, precision=4):
     """-> dict(desc, gd, prep() -> _Loop, conformal=dict(Q, n_cal, alpha, ms), calib(...) -> calibration-mode _Loop)"""
     import torch
@@ -69,14 +84,18 @@ def workload(name, dim, B, dev, rank, world, precision=4):
     from safediffcon_amd import conformal
     torch.manual_seed(0)                                   # weights: default nn-style init under seed 0
     g1 = torch.Generator().manual_seed(1 + rank)           # conditions: seed 1 (+rank: every shard differs)
-    n_tot = 200 if name == "c4" else 1000                  # calibration set: 8x25 (2d/inference_2d.py) / 4x250 (1D) / 1x1000 (tokamak)
-    n_cal = max(8, n_tot // world)
+    cfgN = shard_config(name, B, world)
+    n_cal = cfgN["n_cal_per_rank"]
 
     def quantile(kind, pred, truth, gpar, alpha, **kw):
         """score kernel on this rank's calibration shard -> all-gather (RCCL) -> normalise / sort / rank select"""
+        kw2 = {k: v for k, v in kw.items() if k != "smoke"}
+        # untimed first pass: module load of the score kernel, the communicator's first collective, torch's sort / cumsum kernels
+        s_, w_ = conformal.scores_and_weights(kind, pred, truth, gpar, **kw2)
+        conformal.weighted_quantile(s_, w_, alpha, smoke=kw.get("smoke", False))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        s, w = conformal.scores_and_weights(kind, pred, truth, gpar, **{k: v for k, v in kw.items() if k != "smoke"})
+        s, w = conformal.scores_and_weights(kind, pred, truth, gpar, **kw2)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         Q = float(conformal.weighted_quantile(s, w, alpha, smoke=kw.get("smoke", False))[0].item())
@@ -144,8 +163,7 @@ def workload(name, dim, B, dev, rank, world, precision=4):
             control = (0.3 * torch.randn(Bc, 32, 2, 64, 64, generator=g1)).to(dev)
             return gd.sample(batch_size=Bc, design_fn=None, enable_grad=False, init=init[:Bc], control=control, _prepare=True)
         cal_B, cal_batches = 25, 8
-        tag = "C5" if world == 8 else "C4"
-        desc = (f"{tag}: 2D smoke Unet3D_with_Conv3D dim={dim} (1,2,4) state (B,32,7,64,64), B={B} per GPU, guided 1000-step DDPM, "
+        desc = (f"{cfgN['tag']}: 2D smoke Unet3D_with_Conv3D dim={dim} (1,2,4) state (B,32,7,64,64), B={B} per GPU, guided 1000-step DDPM, "
                 f"conformal quantile on")
     else:
         raise SystemExit(f"unknown workload {name}")
@@ -164,44 +182,95 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(name, batch, steps, dim):
-    """the CPU oracle's guided p_sample step (U-Net + autograd guidance + posterior update), torch fp32 on the host cores"""
+def _oracle_step_seconds(name, batch, steps, dim, device):
+    """seconds per guided p_sample step (U-Net + autograd guidance + posterior update) of the oracle's functional restatement,
+    torch fp32 on `device` (cpu: the host cores; cuda: PyTorch-ROCm eager kernels -- the "hipified reference" strawman)"""
     import torch
     from oracle import nets as onets, samplers as osam, schedules as osched
     from oracle.detweights import det_params, det_tensor
     import safediffcon_amd as sdc
-    # the GPU box gives one GPU a 16-core CPU share: use exactly that many threads (oversubscribing the
-    # visible logical CPUs makes the baseline slower, not faster)
-    torch.set_num_threads(min(16, os.cpu_count() or 16))
     if name == "c2":
         net, fwd, shape = sdc.Unet2D(dim=dim or 64, channels=3, resnet_block_groups=1), onets.unet_burgers, (3, 16, 128)
         nablaJ, sched, k = osam.burgers_guidance(0.01, 500.0, 0.8), "cosine", 1.0
     elif name == "c3":
         net, fwd, shape = sdc.Unet1D(dim=dim or 256, channels=12, resnet_block_groups=1), onets.unet_tokamak, (12, 128)
-        nablaJ, sched, k = osam.tokamak_guidance(torch.ones(batch, 3, 122), 122, 0.0, 4.98, 0.0, 1.0, 0.01), "cosine", 1.0
+        nablaJ, sched, k = osam.tokamak_guidance(torch.ones(batch, 3, 122, device=device), 122, 0.0, 4.98, 0.0, 1.0, 0.01), "cosine", 1.0
     else:
         net, fwd, shape = sdc.Unet3D_with_Conv3D(dim=dim or 64, dim_mults=(1, 2, 4), channels=7), onets.unet_smoke, (32, 7, 64, 64)
         nablaJ, sched, k = osam.smoke_guidance(0.01, 0.9, 0.1), "sigmoid", 100.0
     dim = net.dim
     kw = dict(dim=dim) if name != "c4" else dict(dim=dim, dim_mults=(1, 2, 4))
     spec = [(kk, tuple(v.shape)) for kk, v in net.state_dict().items()]
-    P = det_params(spec, 0)
-    tabs = osched.make_tables(sched, T_DDPM)
-    x = det_tensor((batch, *shape), 5)
+    P = {kk: v.to(device) for kk, v in det_params(spec, 0).items()}
+    tabs = {kk: (v.to(device) if torch.is_tensor(v) else v) for kk, v in osched.make_tables(sched, T_DDPM).items()}
+    x = det_tensor((batch, *shape), 5).to(device)
+    sync = torch.cuda.synchronize if str(device).startswith("cuda") else (lambda: None)
     ts = []
     with torch.no_grad():
         for i in range(steps + 1):
             t = T_DDPM - 1 - i
+            sync()
             t0 = time.perf_counter()
-            eps = fwd(P, x, torch.full((batch,), t, dtype=torch.long), **kw)
+            eps = fwd(P, x, torch.full((batch,), t, dtype=torch.long, device=device), **kw)
             g = nablaJ(osam._x0_from_eps(tabs, x, t, eps))
             x, _ = osam._posterior_step(tabs, x, t, eps, g, k, True, torch.randn_like(x))
+            sync()
             ts.append(time.perf_counter() - t0)
-    s_per_step = sum(ts[1:]) / steps
-    return dict(value=batch / (T_DDPM * s_per_step), unit="trajectories/s", cores=torch.get_num_threads(), kind="port",
-                cpu_model=cpu_model(), logical_cpus_visible=os.cpu_count(),
-                sample=f"{steps} guided p_sample steps (after 1 warm-up) at B={batch} of the same workload, "
-                       f"{s_per_step * 1e3:.0f} ms/step, extrapolated x{T_DDPM} steps per trajectory")
+    return sum(ts[1:]) / steps
+
+
+def physical_cores():
+    """(physical cores of the host, logical CPUs this process may run on)"""
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":")[1].strip()
+                elif not ln.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    return (len(cores) or allowed), allowed
+
+
+def cpu_baseline(name, batch, steps, dim):
+    """the CPU oracle's guided p_sample step on the host cores, twice: with the 16 threads of the CPU share a one-GPU box gets
+    (`value`: what a user of that box can use) and with one thread per physical core of the host (`all_physical_cores`,
+    SURVEY 8d) -- both on the same bounded sample"""
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
+    s16 = _oracle_step_seconds(name, batch, steps, dim, "cpu")
+    n16 = torch.get_num_threads()
+    out = dict(value=batch / (T_DDPM * s16), unit="trajectories/s", cores=n16, kind="port",
+               cpu_model=cpu_model(), logical_cpus_visible=os.cpu_count(),
+               sample=f"{steps} guided p_sample steps (after 1 warm-up) at B={batch} of the same workload, "
+                      f"{s16 * 1e3:.0f} ms/step, extrapolated x{T_DDPM} steps per trajectory")
+    phys, allowed = physical_cores()
+    nall = max(1, min(phys, allowed))
+    if nall != n16:
+        torch.set_num_threads(nall)
+        sall = _oracle_step_seconds(name, batch, steps, dim, "cpu")
+        out["all_physical_cores"] = dict(value=batch / (T_DDPM * sall), unit="trajectories/s", cores=torch.get_num_threads(),
+                                         physical_cores_of_host=phys, logical_cpus_allowed=allowed,
+                                         ms_per_step=round(sall * 1e3, 1), sample="the same sample")
+        torch.set_num_threads(n16)
+    return out
+
+
+def strawman(name, batch, steps, dim, dev):
+    """the PyTorch-ROCm eager time of the same restatement on this MI355X (MIOpen / rocBLAS / aten kernels), one guided
+    denoising step -- what a hipified port of the reference would run"""
+    s = _oracle_step_seconds(name, batch, steps, dim, dev)
+    return dict(what="oracle's functional U-Net + autograd guidance + posterior update executed by PyTorch-ROCm eager on the same GPU",
+                batch=batch, steps=steps, ms_per_step=round(s * 1e3, 2), ms_per_trajectory_step=round(s * 1e3 / batch, 3),
+                value=round(batch / (T_DDPM * s), 4), unit="trajectories/s")
 
 
 def cpu_c1_full():
@@ -232,13 +301,19 @@ def cpu_c1_full():
 
 def pmc_traffic(kernel, wl):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; collected
-    separately with rocprofv3 --pmc by tools/pmc_traffic.py -- bench.py cannot run the profiler on itself)"""
+    separately with rocprofv3 --pmc by tools/pmc_traffic.py -- bench.py cannot run the profiler on itself).  The file carries
+    the hash of the kernel sources it was collected on (safediffcon_amd.build.source_hash): a record taken on other sources
+    is stale and is reported as traffic = null."""
+    from safediffcon_amd.build import source_hash
     for fn in PMC_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as fh:
-                ent = json.load(fh).get(kernel, {})
+                doc = json.load(fh)
         except (OSError, ValueError):
             continue
+        ent = doc.get(kernel, {})
+        if doc.get("kernel_source_hash") != source_hash():
+            return None, ent.get("algorithmic_bytes"), f"{fn}: STALE (collected on kernel sources {doc.get('kernel_source_hash')}, running {source_hash()})"
         if ent.get("workload", "c2") == wl and ent.get("traffic_bytes"):
             return ent["traffic_bytes"], ent.get("algorithmic_bytes"), fn
     return None, None, None
@@ -351,17 +426,24 @@ def worker(a):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     backend = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" IS RCCL on ROCm.  SDC_DIST_BACKEND=gloo + SDC_FORCE_DEVICE=0 exist only to rehearse the multi-process
-        # path on a one-GPU box (RCCL refuses two ranks on one device).
-        backend = os.environ.get("SDC_DIST_BACKEND", "nccl")
-        dist.init_process_group(backend, rank=rank, world_size=world)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     local = int(os.environ.get("SDC_FORCE_DEVICE", local))
+    ndev = torch.cuda.device_count()
+    if local >= ndev:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: rank {rank} needs device cuda:{local} but only {ndev} device(s) are visible")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # "nccl" IS RCCL on ROCm.  SDC_DIST_BACKEND=gloo + SDC_FORCE_DEVICE=0 exist only to rehearse the multi-process
+        # path on a one-GPU box (RCCL refuses two ranks on one device).  device_id binds the communicator to this rank's GPU
+        # at creation instead of at the first collective.
+        backend = os.environ.get("SDC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from safediffcon_amd import _lib
     lib = _lib.get_lib()
@@ -459,6 +541,16 @@ def worker(a):
                 extra["fp32_direct"] = other_prec(0)
                 extra["split_bf16"] = other_prec(1)
                 extra["split_bf16"]["note"] = "opt-in precision=1 (~16 mantissa bits): NOT the parity mode, never `value`"
+        if world == 1 and not a.no_extra and not a.no_strawman:
+            sb = a.strawman_batch or {"c2": 256, "c3": 128, "c4": 8}[wl]
+            try:
+                st = strawman(wl, sb, 2, a.dim, dev)
+                st["hip_ms_per_trajectory_step"] = round(step_ms / B, 3)
+                st["hip_speedup_per_trajectory"] = round((st["ms_per_step"] / sb) / (step_ms / B), 2)
+                extra["strawman"] = st
+            except RuntimeError as e:                    # e.g. out of memory in the eager net: report, do not fail the line
+                extra["strawman"] = {"error": str(e)[:200]}
+            torch.cuda.empty_cache()
         if a.full_sample and rank == 0:
             S3 = W["prep"]()
             torch.cuda.synchronize()
@@ -500,6 +592,12 @@ def worker(a):
         raise SystemExit("non-finite state after the timed steps")
 
     value = world * B / (T_DDPM * dt / a.steps)
+    # ranks the collective library itself reports: every rank contributes a device-resident 1 to an all-reduce
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
     if rank == 0:
         cf = W["conformal"]
         out = {
@@ -512,8 +610,8 @@ def worker(a):
                        "parallelism": f"batch-sharded x{world}, no data-path collective", "conv_precision": a.precision,
                        "conformal_Q": round(cf["Q"], 6)},
             "conformal": dict(cf, Q=round(cf["Q"], 6), backend=(backend or "none (single process)"),
-                              rccl_ranks=(dist.get_world_size() if world > 1 and backend == "nccl" else (1 if world == 1 else 0)),
-                              dist_world_size=world),
+                              rccl_ranks=(ranks_seen if backend == "nccl" else (1 if world == 1 else 0)),
+                              ranks_counted_by_all_reduce=ranks_seen, dist_world_size=world),
             "roofline": roof,
         }
         if extra:
@@ -553,6 +651,8 @@ def main():
     ap.add_argument("--full-calibration", action="store_true", help="also run one complete calibration pass (minutes)")
     ap.add_argument("--cpu-c1-full", action="store_true", help="also run BASELINE configs[0] (C1) in full on the host cores (minutes)")
     ap.add_argument("--selftest-launcher", action="store_true", help="CPU-only check of the launcher path (tests)")
+    ap.add_argument("--no-strawman", action="store_true", help="skip the PyTorch-ROCm eager timing of the oracle (extra.strawman)")
+    ap.add_argument("--strawman-batch", type=int, default=0)
     ap.add_argument("--cpu-batch", type=int, default=0)
     ap.add_argument("--cpu-steps", type=int, default=0)
     a = ap.parse_args()

@@ -11,6 +11,19 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and headers: stamps the PMC records under profiles/ so that
+    bench.py can tell a record collected on other kernels from a current one (no git on the GPU box)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + ["sdc_common.h"]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(HERE, "..", "include", "sdc.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale(out, deps):
     if not os.path.exists(out):
         return True
