@@ -449,7 +449,7 @@ def worker(a):
     lib = _lib.get_lib()
     wl = "c4" if a.workload == "c5" else a.workload
     B = a.batch or DEFAULT_B[wl]
-    prec = {"fp32": 4, "fp32-wino2d": 3, "fp32-wino1d": 2, "fp32-direct": 0, "split-bf16": 1}[a.precision]
+    prec = {"fp32": 4, "fp32-wino2d": 3, "fp32-wino1d": 2, "fp32-direct": 0}[a.precision]
     side = torch.cuda.Stream(device=dev)
 
     def timed(S, warmup, steps):
@@ -539,8 +539,7 @@ def worker(a):
                     return {"value": round(B / (T_DDPM * dt_ / a.steps), 4), "unit": "trajectories/s",
                             "ms_per_step": round(dt_ / a.steps * 1e3, 4), "finite": ok_}
                 extra["fp32_direct"] = other_prec(0)
-                extra["split_bf16"] = other_prec(1)
-                extra["split_bf16"]["note"] = "opt-in precision=1 (~16 mantissa bits): NOT the parity mode, never `value`"
+                extra["fp32_wino2d"] = other_prec(3)
         if world == 1 and not a.no_extra and not a.no_strawman:
             sb = a.strawman_batch or {"c2": 256, "c3": 128, "c4": 8}[wl]
             try:
@@ -604,7 +603,7 @@ def worker(a):
             "metric": "sampled control trajectories/sec (1000-step DDPM)", "value": round(value, 4), "unit": "trajectories/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(step_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if prec != 1 else "f32 (split-bf16 conv operands, fp32 accumulate)", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": W["desc"], "batch_per_gpu": B, "global_batch": world * B, "ddpm_timesteps": T_DDPM,
                        "step": "one denoising step of the whole batch (U-Net + guidance + posterior update), hipGraph replay",
                        "parallelism": f"batch-sharded x{world}, no data-path collective", "conv_precision": a.precision,
@@ -637,15 +636,14 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: 256 / 128 / 64 for c2 / c3 / c4)")
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-wino2d", "fp32-wino1d", "fp32-direct", "split-bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-wino2d", "fp32-wino1d", "fp32-direct"],
                     help="conv arithmetic: fp32 MFMA with Winograd F(2x2x2,3x3x3) / F(2x2,3x3) / F(2,3) on the 3-tap convs (default), "
-                         "without the depth transform, F(2,3) along W only, fp32 direct form everywhere, or the opt-in 3-pass "
-                         "split-bf16 MFMA")
+                         "without the depth transform, F(2,3) along W only, or the fp32 direct form everywhere")
     ap.add_argument("--no-extra", action="store_true", help="skip the calibration sample and the other workloads at N=1")
     ap.add_argument("--extra-workloads", default="c2,c3", help="other configs reported under `extra` at N=1")
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--cal-steps", type=int, default=5)
-    ap.add_argument("--other-precisions", action="store_true", help="also time precision 0 / 1 on the headline workload")
+    ap.add_argument("--other-precisions", action="store_true", help="also time precision 0 / 3 on the headline workload")
     ap.add_argument("--full-sample", action="store_true",
                     help="also time ONE complete 1000-step sample() call (validates value = B / (1000 * step time))")
     ap.add_argument("--full-calibration", action="store_true", help="also run one complete calibration pass (minutes)")

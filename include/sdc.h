@@ -61,9 +61,6 @@ int sdc_last_error(char* buf, size_t cap);
  * Output size per axis: (i*u + 2p - k)/s + 1 (i -> (i-1)*u+1 for zero insertion); up to k-1 more positions are
  * accepted and read implicit zeros past the far edge (one-sided padding), fewer compute a prefix.
  * Wp is the caller-repacked weight [K = taps*Cin][Cout] (row-major, Cout fastest).
- * precision 1 (opt-in, NOT the parity mode): split-bf16 3-pass MFMA (~16 mantissa bits); the wp buffer then holds
- * the fp32 Wp followed by the pre-split weights as bf16 [Cout][K] hi and [Cout][K] lo (k contiguous); layers the
- * split kernel does not cover (Cin % 32 != 0, Cout <= 32) silently run the exact fp32 kernel.
  */
 typedef struct SdcConvDesc {
     int32_t B, Cin0, Cin1, Cout;
@@ -92,7 +89,7 @@ typedef struct SdcConvDesc {
                                         = sum_{kd,kh,kw} G[jd][kd] G[j][kh] G[xi][kw] w[co][ci][kd][kh][kw]; other tap shapes:
                                         layout of 3.  y is used as scratch for partial plane sums while the kernel runs (it
                                         must not alias an input).  Shapes it does not take fall back to 3's kernels.
-                                    1 = opt-in 3-pass split-bf16 MFMA (~16 mantissa bits, NOT the parity mode) */
+                                    (1 was a split-bf16 mode in rounds 1-2; removed: every mode is fp32 arithmetic) */
     int64_t x0s[5], x1s[5], ys[5], rs[5];   /* element strides (b,c,d,h,w) */
 } SdcConvDesc;
 
@@ -169,7 +166,8 @@ int sdc_linattn_block(const float* x, const float* g_pre, const float* wqkv, con
  * Residual(PreNorm(dim, EinopsToAndFrom(Attention))): conv3d.py:165-184,262-275,277-353,383,402-405.
  * wqkv = packed [64][384] (bias-free Linear), wo = packed [128][64]; rot = [32][16][2] (cos, sin) or null,
  * bias = [heads][query][key] or null.  Element (o, c, pixel i, frame f) of x and y at o*so + c*sc + f*st + i;
- * inner = pixels per outer index, a multiple of 8. */
+ * inner = pixels per outer index, a multiple of 8.
+ * wqkv and wo must be 16-byte aligned, rot 8-byte aligned (vector loads); SDC_EINVAL otherwise. */
 int sdc_tattn_block(const float* x, const float* g_pre, const float* wqkv, const float* wo, const float* rot,
                     const float* bias, float* y, int outer, int inner, int C, int ntok, int64_t so, int64_t sc,
                     int64_t st, float eps, void* stream);

@@ -31,6 +31,17 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_experiments(verbose=True):
+    """libsdc_hip_exp.so: the same sources with -DSDC_KERNEL_EXPERIMENTS (dispatch overrides and the result-changing debug
+    modes of tools/*_probe.py, read from SDC_* environment variables).  Load it with SDC_LIB_PATH; never shipped or tested."""
+    out = os.path.join(HERE, "libsdc_hip_exp.so")
+    cmd = [HIPCC, *FLAGS, "-DSDC_KERNEL_EXPERIMENTS", "-shared", *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=True):
     hdrs = [os.path.join(CSRC, "sdc_common.h"), os.path.join(HERE, "..", "include", "sdc.h")]
     objs = []
@@ -52,4 +63,7 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--experiments" in sys.argv:
+        build_experiments()
+    else:
+        build(force="--force" in sys.argv)

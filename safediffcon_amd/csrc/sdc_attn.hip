@@ -532,8 +532,7 @@ extern "C" int sdc_attn(const float* qkv, float* out, const float* rot, const fl
         reinterpret_cast<uintptr_t>(qkv) % 16 == 0) {
         const size_t ldsb = sizeof(float) * (size_t)(32 * 256 + 32 * A2_VP);
         static std::atomic<uint64_t> attr2{0};
-        if (sdc::first_use_on_device(attr2))
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        SDC_LDS_OPTIN(attr2, attn256_kernel, 160 * 1024, "sdc_attn[mfma 256]");
         hipLaunchKernelGGL(attn256_kernel, dim3((unsigned)(outer * inner * heads)), dim3(NT), ldsb, sdc::as_stream(stream), a);
         return sdc::check_launch("sdc_attn[mfma 256]");
     }
@@ -555,10 +554,7 @@ extern "C" int sdc_attn(const float* qkv, float* out, const float* rot, const fl
     SDC_REQUIRE(lds_bytes <= 160 * 1024, SDC_EINVAL, "sdc_attn: LDS footprint %zu too large", lds_bytes);
     const int ngrp = (nseq_tot + nseq - 1) / nseq;
     static std::atomic<uint64_t> attr_done{0};
-    if (sdc::first_use_on_device(attr_done)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-    }
+    SDC_LDS_OPTIN(attr_done, attn_kernel, 160 * 1024, "sdc_attn");
     hipLaunchKernelGGL(attn_kernel, dim3((unsigned)(ngrp * heads)), dim3(NT), lds_bytes, sdc::as_stream(stream), a);
     return sdc::check_launch("sdc_attn");
 }

@@ -28,16 +28,29 @@ inline int check_launch(const char* what) {
         }                              \
     } while (0)
 
-// Per-device one-time set-up (hipFuncSetAttribute for > 64 KB of dynamic LDS is per device): true the first time the
-// calling thread's current device is seen.  Racing threads may both see "first"; the guarded call is idempotent.
-inline bool first_use_on_device(std::atomic<uint64_t>& mask) {
+// Per-device one-time opt-in to more than 64 KB of dynamic LDS (hipFuncSetAttribute is per device).  The device bit is
+// published only AFTER the attribute call has returned, so a second host thread on the same device either sees the bit (the
+// attribute is applied) or repeats the idempotent call itself; a failed opt-in is reported here instead of surfacing later
+// as an opaque launch error.  Keyed on the calling thread's current device, which is the device of the launch stream for
+// every in-tree caller (one process per GPU, torch's current device).
+inline int lds_optin(std::atomic<uint64_t>& mask, const void* kernel, int bytes, const char* what) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
-    if (mask.load(std::memory_order_relaxed) & bit) return false;
-    mask.fetch_or(bit, std::memory_order_relaxed);
-    return true;
+    if (mask.load(std::memory_order_acquire) & bit) return SDC_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed: %s", what, bytes, hipGetErrorString(e));
+        return SDC_EHIP;
+    }
+    mask.fetch_or(bit, std::memory_order_release);
+    return SDC_OK;
 }
+#define SDC_LDS_OPTIN(mask, kernel, bytes, what)                                                             \
+    do {                                                                                                     \
+        const int rc_ = sdc::lds_optin((mask), reinterpret_cast<const void*>(kernel), (bytes), (what));      \
+        if (rc_ != SDC_OK) return rc_;                                                                       \
+    } while (0)
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -20,6 +20,15 @@
 
 namespace {
 
+// Dispatch overrides and tuning knobs (SDC_NO_WG2, SDC_TILE, ...) exist only in experiment builds (-DSDC_KERNEL_EXPERIMENTS,
+// tools/): the shipping library reads no environment variable; the conv algorithm is chosen by SdcConvDesc.precision alone.
+#ifdef SDC_KERNEL_EXPERIMENTS
+inline int exp_env(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
+#else
+constexpr int exp_env(const char*) { return 0; }
+#endif
+
+
 constexpr int BK = 16;          // K chunk per LDS stage (BK = 32 measured no faster: the kernel is MFMA-issue bound)
 constexpr int NT = 256;
 
@@ -745,365 +754,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BKT == 8 ? 4
             __builtin_amdgcn_sched_barrier(0);
         }
         if (st + 1 < nstages) store_stage(buf ^ 1);
-        __syncthreads();
-    }
-    conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
-}
-
-// ------------------------------------------------------------------------------------------------
-// precision = 1: split-bf16 ("bf16x3") implicit GEMM.  Every fp32 operand is split x = hi + lo with hi = bf16(x),
-// lo = bf16(x - hi); the product is accumulated as lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 (fp32
-// accumulate).  The dropped lo*lo term and the residual of the split are ~2^-17 relative, i.e. the result carries
-// ~16 mantissa bits instead of 24 -- far inside the eps-MSE <= 1e-5 gate (measured ~1e-9), but NOT bit-compatible
-// with the fp32 path, so it is opt-in and never the parity default.  3 bf16 MFMAs replace 8 fp32 MFMAs per 16 k.
-// Weights arrive pre-split ([Cout][K] bf16 hi | lo, k contiguous) right behind the fp32 Wp; activations are split
-// on the fly while they are staged to LDS.  LDS rows are [m or n][32 k + 8 pad] bf16 (80-byte pitch: conflict-free
-// ds_read_b128 of the 8-k operand octets).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-constexpr int BK3 = 32;
-constexpr int LDK = BK3 + 8;
-
-__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const bf16x2 h = {(__bf16)a, (__bf16)b};
-    hi = __builtin_bit_cast(uint32_t, h);
-    const float ah = __builtin_bit_cast(float, hi << 16), bh = __builtin_bit_cast(float, hi & 0xffff0000u);
-    const bf16x2 l = {(__bf16)(a - ah), (__bf16)(b - bh)};
-    lo = __builtin_bit_cast(uint32_t, l);
-}
-
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(NT) void conv_bf3_kernel(const ConvArgs a) {
-    constexpr int TM = BM / WM / 32;
-    constexpr int TN = BN / WN / 32;
-    constexpr int NOCT = 4 * BN / NT;            // activation octets (8 k of one position) per thread per chunk
-    constexpr int OSTEP = NT / BN;               // octet stride between a thread's octets (NOCT > 1)
-    constexpr int NAO = 4 * BM / NT;             // weight octets per thread per chunk (per hi / lo array)
-    static_assert(NOCT >= 1 && NAO >= 1, "tile too small");
-    extern __shared__ __attribute__((aligned(16))) unsigned short lds3[];
-    // [buf][Ah | Al | Bh | Bl]
-    constexpr int ASZ = BM * LDK, BSZ = BN * LDK, STAGE = 2 * ASZ + 2 * BSZ;
-    auto Ah = [&](int buf) { return lds3 + buf * STAGE; };
-    auto Al = [&](int buf) { return lds3 + buf * STAGE + ASZ; };
-    auto Bh = [&](int buf) { return lds3 + buf * STAGE + 2 * ASZ; };
-    auto Bl = [&](int buf) { return lds3 + buf * STAGE + 2 * ASZ + BSZ; };
-
-    const SdcConvDesc& d = a.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int n0 = xcd_tile(blockIdx.x, gridDim.x) * BN, m0 = blockIdx.y * BM;
-    const int l31 = lane & 31, lh = lane >> 5;
-
-    // ---- this thread's output position (B loader)
-    const int bj = tid % BN;
-    const int oct0 = tid / BN;
-    const int p = n0 + bj;
-    const bool pvalid = p < a.Ntot;
-    int ow = 0, oh = 0, od = 0, ob = 0;
-    if (pvalid) {
-        int r = p;
-        ow = r % d.oW; r /= d.oW;
-        oh = r % d.oH; r /= d.oH;
-        od = r % d.oD; ob = r / d.oD;
-    }
-    const int vd0 = od * d.sD - d.pD, vh0 = oh * d.sH - d.pH, vw0 = ow * d.sW - d.pW;
-    const int mD = d.up_mode ? ((1 << a.lgD) - 1) : 0, mH = d.up_mode ? ((1 << a.lgH) - 1) : 0,
-              mW = d.up_mode ? ((1 << a.lgW) - 1) : 0;
-    int f_kd = 0, f_kh = 0, f_kw = 0, f_ci = 0;
-    bool f_ok = false, bok = false;
-    uint32_t f_v0 = 0, f_v1 = 0;
-    auto fast_tap = [&]() {
-        const int vd = vd0 + f_kd, vh = vh0 + f_kh, vw = vw0 + f_kw;
-        const int id = vd >> a.lgD, ih = vh >> a.lgH, iw = vw >> a.lgW;
-        f_ok = pvalid && vd >= 0 && vh >= 0 && vw >= 0 && id < d.iD && ih < d.iH && iw < d.iW &&
-               ((vd & mD) | (vh & mH) | (vw & mW)) == 0;
-        f_v0 = f_ok ? (uint32_t)(ob * d.x0s[0] + id * d.x0s[2] + ih * d.x0s[3] + iw * d.x0s[4]) : 0u;
-        if (d.Cin1 > 0) f_v1 = f_ok ? (uint32_t)(ob * d.x1s[0] + id * d.x1s[2] + ih * d.x1s[3] + iw * d.x1s[4]) : 0u;
-    };
-    fast_tap();
-
-    // ---- weights: pre-split bf16 [Cout][K] (hi, then lo) behind the fp32 Wp
-    const unsigned short* whi = reinterpret_cast<const unsigned short*>(a.wp + (int64_t)a.Ktot * d.Cout);
-    const unsigned short* wlo = whi + (int64_t)a.Ktot * d.Cout;
-    int a_row[NAO], a_oct[NAO];
-    bool a_ok[NAO];
-#pragma unroll
-    for (int i = 0; i < NAO; ++i) {
-        const int f = tid + i * NT;
-        a_row[i] = f >> 2; a_oct[i] = f & 3;
-        a_ok[i] = (m0 + a_row[i]) < d.Cout;
-    }
-
-    float breg[NOCT][8];
-    uint4 ahreg[NAO], alreg[NAO];
-    int kbase = 0;
-
-    auto load_chunk = [&]() {
-#pragma unroll
-        for (int i = 0; i < NAO; ++i) {
-            const int64_t off = (int64_t)(a_ok[i] ? m0 + a_row[i] : 0) * a.Ktot + kbase + a_oct[i] * 8;
-            ahreg[i] = *reinterpret_cast<const uint4*>(whi + off);
-            alreg[i] = *reinterpret_cast<const uint4*>(wlo + off);
-        }
-        const float* bsel; int sc; uint32_t voff;
-        if (f_ci < d.Cin0) { sc = (int)d.x0s[1]; bsel = a.x0 + (int64_t)f_ci * sc; voff = f_v0; }
-        else { sc = (int)d.x1s[1]; bsel = a.x1 + (int64_t)(f_ci - d.Cin0) * sc; voff = f_v1; }
-        const gfloat_p bb = uniform_ptr(bsel);
-        bok = f_ok;
-#pragma unroll
-        for (int o = 0; o < NOCT; ++o) {
-            const int oc = oct0 + o * OSTEP;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) breg[o][e] = ld_sv(bb + (oc * 8 + e) * sc, voff * 4u);
-        }
-        kbase += BK3;
-        f_ci += BK3;
-        if (f_ci >= a.Cin) {
-            f_ci = 0;
-            if (++f_kw == d.kW) { f_kw = 0; if (++f_kh == d.kH) { f_kh = 0; ++f_kd; } }
-            if (f_kd < d.kD) fast_tap();
-        }
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NAO; ++i) {
-            uint4 h = ahreg[i], l = alreg[i];
-            if (!a_ok[i]) { h = make_uint4(0, 0, 0, 0); l = h; }
-            *reinterpret_cast<uint4*>(Ah(buf) + a_row[i] * LDK + a_oct[i] * 8) = h;
-            *reinterpret_cast<uint4*>(Al(buf) + a_row[i] * LDK + a_oct[i] * 8) = l;
-        }
-#pragma unroll
-        for (int o = 0; o < NOCT; ++o) {
-            const int oc = oct0 + o * OSTEP;
-            uint4 h, l;
-            split2(bok ? breg[o][0] : 0.f, bok ? breg[o][1] : 0.f, h.x, l.x);
-            split2(bok ? breg[o][2] : 0.f, bok ? breg[o][3] : 0.f, h.y, l.y);
-            split2(bok ? breg[o][4] : 0.f, bok ? breg[o][5] : 0.f, h.z, l.z);
-            split2(bok ? breg[o][6] : 0.f, bok ? breg[o][7] : 0.f, h.w, l.w);
-            *reinterpret_cast<uint4*>(Bh(buf) + bj * LDK + oc * 8) = h;
-            *reinterpret_cast<uint4*>(Bl(buf) + bj * LDK + oc * 8) = l;
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int nchunks = a.Ktot / BK3;
-    load_chunk();
-    store_chunk(0);
-    __syncthreads();
-    const int am = wm * (TM * 32) + l31, bn = wn * (TN * 32) + l31;
-
-    for (int kc = 0; kc < nchunks; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nchunks) load_chunk();
-#pragma unroll
-        for (int ks = 0; ks < BK3 / 16; ++ks) {
-            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8*>(Ah(buf) + (am + i * 32) * LDK + ks * 16 + lh * 8);
-                al[i] = *reinterpret_cast<const bf16x8*>(Al(buf) + (am + i * 32) * LDK + ks * 16 + lh * 8);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8*>(Bh(buf) + (bn + j * 32) * LDK + ks * 16 + lh * 8);
-                bl[j] = *reinterpret_cast<const bf16x8*>(Bl(buf) + (bn + j * 32) * LDK + ks * 16 + lh * 8);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-        }
-        if (kc + 1 < nchunks) store_chunk(buf ^ 1);
-        __syncthreads();
-    }
-    conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
-}
-
-// Row-halo form of the split-bf16 kernel (3-wide taps along W, stride 1, Cin % 32 == 0): one stage = (kd, kh,
-// 32-channel chunk); the input row segment + halo is split and staged ONCE as [position][32 k] bf16 hi / lo and the
-// three kw taps read it at shifted position rows, so the gather + split work per MFMA drops 3-fold.
-// Single LDS buffer (hi + lo of three weight taps and the halo tile do not fit twice): the next stage is fetched
-// into registers while the MFMAs run and written behind a second barrier.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(NT) void conv_rh_bf3_kernel(const ConvArgs a) {
-    constexpr int KW = 3;
-    constexpr int TM = BM / WM / 32;
-    constexpr int TN = BN / WN / 32;
-    constexpr int KSMAX = BN + (BN / 16) * (KW - 1);
-    constexpr int NSLOT = (KSMAX * 4 + NT - 1) / NT;     // (position, octet) slots per thread per stage
-    constexpr int NAO = KW * 4 * BM / NT;                // weight octets per thread per stage (per hi / lo)
-    extern __shared__ __attribute__((aligned(16))) unsigned short lds3[];
-    constexpr int ASZ = KW * BM * LDK, BSZ = KSMAX * LDK;
-    unsigned short* Ah = lds3;
-    unsigned short* Al = lds3 + ASZ;
-    unsigned short* Bh = lds3 + 2 * ASZ;
-    unsigned short* Bl = lds3 + 2 * ASZ + BSZ;
-
-    const SdcConvDesc& d = a.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int n0 = xcd_tile(blockIdx.x, gridDim.x) * BN, m0 = blockIdx.y * BM;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int seg = d.oW < BN ? d.oW : BN;
-    const int nseg = BN / seg;
-    const int rowlen = seg + KW - 1;
-    const int ks_stride = nseg * rowlen;          // halo positions per stage
-    const int nslots = ks_stride * 4;
-    const bool two = d.Cin1 > 0;
-
-    // ---- per-slot gather state: slot e = tid + 256 i -> (octet = e / ks_stride, position = e % ks_stride)
-    int v0[NSLOT], v1[NSLOT], lofs[NSLOT];
-    uint32_t smask[NSLOT];
-#pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-        const int e = tid + i * NT;
-        v0[i] = 0; v1[i] = 0; smask[i] = 0; lofs[i] = -1;
-        if (e < nslots) {
-            const int oc = e / ks_stride, pos = e - oc * ks_stride;
-            lofs[i] = pos * LDK + oc * 8;
-            const int sg = pos / rowlen, cc = pos - sg * rowlen;
-            const int pseg = n0 + sg * seg;
-            if (pseg < a.Ntot) {
-                int q = pseg;
-                const int ow0 = q % d.oW; q /= d.oW;
-                const int oh = q % d.oH; q /= d.oH;
-                const int od = q % d.oD; const int ob = q / d.oD;
-                const int col = ow0 + cc - d.pW;
-                const int id0 = od * d.sD - d.pD, ih0 = oh * d.sH - d.pH;
-                uint32_t m = 0;
-                if (col >= 0 && col < d.iW)
-                    for (int kd = 0; kd < d.kD; ++kd)
-                        for (int kh = 0; kh < d.kH; ++kh)
-                            if (id0 + kd >= 0 && id0 + kd < d.iD && ih0 + kh >= 0 && ih0 + kh < d.iH)
-                                m |= 1u << (kd * d.kH + kh);
-                smask[i] = m;
-                v0[i] = (int)(ob * d.x0s[0] + (oc * 8) * d.x0s[1] + id0 * d.x0s[2] + ih0 * d.x0s[3] + col * d.x0s[4]);
-                if (two) v1[i] = (int)(ob * d.x1s[0] + (oc * 8) * d.x1s[1] + id0 * d.x1s[2] + ih0 * d.x1s[3] + col * d.x1s[4]);
-            }
-        }
-    }
-    int boff[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int pl = wn * (TN * 32) + j * 32 + l31;
-        const int sg = pl / seg;
-        boff[j] = sg * rowlen + (pl - sg * seg);
-    }
-    const unsigned short* whi = reinterpret_cast<const unsigned short*>(a.wp + (int64_t)a.Ktot * d.Cout);
-    const unsigned short* wlo = whi + (int64_t)a.Ktot * d.Cout;
-
-    float breg[NSLOT][8];
-    uint4 ahreg[NAO], alreg[NAO];
-    uint32_t mbits = 0;
-    int s_kd = 0, s_kh = 0, s_ci = 0;
-
-    auto load_stage = [&]() {
-        const int tapbit = s_kd * d.kH + s_kh;
-        // weights: LDS row (kw, co) <- W[co][((tapbit*KW + kw) * Cin + s_ci) + 0..31]
-#pragma unroll
-        for (int i = 0; i < NAO; ++i) {
-            const int f = tid + i * NT;
-            const int oc = f & 3, row = f >> 2;          // row in [0, KW*BM)
-            const int kw = row / BM, co = row - kw * BM;
-            const bool ok = (m0 + co) < d.Cout;
-            const int64_t off = (int64_t)(ok ? m0 + co : 0) * a.Ktot + (int64_t)(tapbit * KW + kw) * a.Cin + s_ci + oc * 8;
-            ahreg[i] = ok ? *reinterpret_cast<const uint4*>(whi + off) : make_uint4(0, 0, 0, 0);
-            alreg[i] = ok ? *reinterpret_cast<const uint4*>(wlo + off) : make_uint4(0, 0, 0, 0);
-        }
-        const bool first = s_ci < d.Cin0;
-        const int sc = (int)(first ? d.x0s[1] : d.x1s[1]);
-        const int64_t toff = first ? s_kd * d.x0s[2] + s_kh * d.x0s[3] : s_kd * d.x1s[2] + s_kh * d.x1s[3];
-        const float* base = first ? a.x0 + (int64_t)s_ci * sc : a.x1 + (int64_t)(s_ci - d.Cin0) * sc;
-        mbits = 0;
-#pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            const bool ok = (smask[i] >> tapbit) & 1u;
-            const float* src = ok ? base + ((int64_t)(first ? v0[i] : v1[i]) + toff) : (first ? a.x0 : a.x1);
-            const int st = ok ? sc : 0;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) breg[i][e] = src[e * st];
-            mbits |= (ok ? 1u : 0u) << i;
-        }
-        s_ci += BK3;
-        if (s_ci >= a.Cin) { s_ci = 0; if (++s_kh == d.kH) { s_kh = 0; ++s_kd; } }
-    };
-    auto store_stage = [&]() {
-#pragma unroll
-        for (int i = 0; i < NAO; ++i) {
-            const int f = tid + i * NT;
-            const int oc = f & 3, row = f >> 2;
-            *reinterpret_cast<uint4*>(Ah + row * LDK + oc * 8) = ahreg[i];
-            *reinterpret_cast<uint4*>(Al + row * LDK + oc * 8) = alreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            if (lofs[i] >= 0) {
-                const bool ok = (mbits >> i) & 1u;
-                uint4 h, l;
-                split2(ok ? breg[i][0] : 0.f, ok ? breg[i][1] : 0.f, h.x, l.x);
-                split2(ok ? breg[i][2] : 0.f, ok ? breg[i][3] : 0.f, h.y, l.y);
-                split2(ok ? breg[i][4] : 0.f, ok ? breg[i][5] : 0.f, h.z, l.z);
-                split2(ok ? breg[i][6] : 0.f, ok ? breg[i][7] : 0.f, h.w, l.w);
-                *reinterpret_cast<uint4*>(Bh + lofs[i]) = h;
-                *reinterpret_cast<uint4*>(Bl + lofs[i]) = l;
-            }
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int nstages = d.kD * d.kH * (a.Cin / BK3);
-    load_stage();
-    store_stage();
-    __syncthreads();
-    const int am = wm * (TM * 32) + l31;
-
-    for (int st = 0; st < nstages; ++st) {
-        if (st + 1 < nstages) load_stage();
-#pragma unroll
-        for (int kw = 0; kw < KW; ++kw) {
-#pragma unroll
-            for (int ks = 0; ks < BK3 / 16; ++ks) {
-                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    ah[i] = *reinterpret_cast<const bf16x8*>(Ah + (kw * BM + am + i * 32) * LDK + ks * 16 + lh * 8);
-                    al[i] = *reinterpret_cast<const bf16x8*>(Al + (kw * BM + am + i * 32) * LDK + ks * 16 + lh * 8);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    bh[j] = *reinterpret_cast<const bf16x8*>(Bh + (boff[j] + kw) * LDK + ks * 16 + lh * 8);
-                    bl[j] = *reinterpret_cast<const bf16x8*>(Bl + (boff[j] + kw) * LDK + ks * 16 + lh * 8);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
-            }
-        }
-        __syncthreads();                         // every wave is done reading this stage
-        if (st + 1 < nstages) store_stage();
         __syncthreads();
     }
     conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
@@ -2047,6 +1697,10 @@ bool wg2_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
            ((int64_t)d.kD * 9 * (d.Cin0 + d.Cin1) * d.Cout) % 4 == 0 &&
            // input rows contiguous (the row taps are instruction immediates)
            d.x0s[4] == 1 && d.x0s[3] == d.iW && (d.Cin1 == 0 || (d.x1s[4] == 1 && d.x1s[3] == d.iW)) &&
+           // the park lanes add their k row (up to 3 channel strides at W = 128, 1 otherwise) to the 32-bit byte offset of the
+           // (batch, depth, row, column) part, and the depth-tap shift is formed in 32 bits
+           span5(d.x0s, d.B, 1, d.iD, d.iH, d.iW) + 3 * d.x0s[1] < (1ll << 30) && d.x0s[2] < (1ll << 29) &&
+           (d.Cin1 == 0 || (span5(d.x1s, d.B, 1, d.iD, d.iH, d.iW) + 3 * d.x1s[1] < (1ll << 30) && d.x1s[2] < (1ll << 29))) &&
            // the epilogue addresses y / the residual with 32-bit byte offsets from per-channel scalar bases
            span5(d.ys, d.B, 8, d.oD, d.oH, d.oW) < (1ll << 30) && span5(d.rs, d.B, 8, d.oD, d.oH, d.oW) < (1ll << 30) &&
            // ... and read with 8 / 16-byte vector loads
@@ -2054,30 +1708,34 @@ bool wg2_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
            (d.Cin1 == 0 || (d.x1s[0] % 4 == 0 && d.x1s[1] % 4 == 0 && d.x1s[2] % 4 == 0));
 }
 
-void launch_wg2(const ConvArgs& a, hipStream_t s) {
+int launch_wg2(const ConvArgs& a, hipStream_t s) {
     const SdcConvDesc& d = a.d;
     const int64_t tiles = (int64_t)d.B * d.oD * (d.oH / 2) * (d.oW / 2);
     const int MT = (d.Cout + W2_BM - 1) / W2_BM;
     dim3 grid((unsigned)(((tiles + W2_TILES - 1) / W2_TILES) * MT));
     const size_t lds = (size_t)W2_NBUF * (W2_ASZ + W2_BSZ) * sizeof(float) + 4 * 8 * sizeof(double);     // stage buffers + GroupNorm scratch
-    static const int dbg = getenv("SDC_WG2_DBG") ? atoi(getenv("SDC_WG2_DBG")) : 0;     // kernel experiments: parts of the loop off
 #define W2_LAUNCH(OWV, D)                                                                                                        \
     do {                                                                                                                         \
         static std::atomic<uint64_t> attr{0};                                                                                    \
-        if (sdc::first_use_on_device(attr))                                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wg2_kernel<OWV, D>),                                    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
+        SDC_LDS_OPTIN(attr, (conv_wg2_kernel<OWV, D>), 160 * 1024, "sdc_conv[winograd 2x2]");                                    \
         hipLaunchKernelGGL((conv_wg2_kernel<OWV, D>), grid, dim3(256), lds, s, a);                                               \
     } while (0)
+#ifdef SDC_KERNEL_EXPERIMENTS
+    // parts of the loop switched off (WRONG RESULTS): never compiled into the shipping library
+    static const int dbg = exp_env("SDC_WG2_DBG");
     if (d.oW == 64 && dbg) {
         switch (dbg) {
             case 1: W2_LAUNCH(64, 1); break; case 2: W2_LAUNCH(64, 2); break; case 3: W2_LAUNCH(64, 3); break;
             case 128: W2_LAUNCH(64, 128); break; default: W2_LAUNCH(64, 3 + 128); break;
         }
-    } else if (d.oW == 16) W2_LAUNCH(16, 0);
+        return SDC_OK;
+    }
+#endif
+    if (d.oW == 16) W2_LAUNCH(16, 0);
     else if (d.oW == 32) W2_LAUNCH(32, 0);
     else if (d.oW == 64) W2_LAUNCH(64, 0);
     else W2_LAUNCH(128, 0);
+    return SDC_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2522,7 +2180,7 @@ bool wg3_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
     return (d.oH / 2) % rp == 0 && even(d.ys) && nores;
 }
 
-void launch_wg3(const ConvArgs& a, hipStream_t s) {
+int launch_wg3(const ConvArgs& a, hipStream_t s) {
     const SdcConvDesc& d = a.d;
     const int64_t tiles = (int64_t)d.B * (d.oD / 2) * (d.oH / 2) * (d.oW / 2);
     dim3 grid((unsigned)((tiles / W2_TILES) * (d.Cout / W2_BM)));
@@ -2530,59 +2188,36 @@ void launch_wg3(const ConvArgs& a, hipStream_t s) {
 #define W3_LAUNCH(OWV, D)                                                                                                        \
     do {                                                                                                                         \
         static std::atomic<uint64_t> attr{0};                                                                                    \
-        if (sdc::first_use_on_device(attr))                                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wg3_kernel<OWV, D>),                                    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
+        SDC_LDS_OPTIN(attr, (conv_wg3_kernel<OWV, D>), 160 * 1024, "sdc_conv[winograd 2x2x2]");                                  \
         hipLaunchKernelGGL((conv_wg3_kernel<OWV, D>), grid, dim3(256), lds, s, a);                                               \
     } while (0)
-    static const int dbg = getenv("SDC_WG3_DBG") ? atoi(getenv("SDC_WG3_DBG")) : 0;     // kernel experiments (2, 4: wrong results): 2 no read-back, 4 no folds, 8 all read-backs of a fold up front
+#ifdef SDC_KERNEL_EXPERIMENTS
+    // kernel experiments (2, 4: WRONG RESULTS): 2 no read-back, 4 no folds, 8 all read-backs of a fold up front
+    static const int dbg = exp_env("SDC_WG3_DBG");
     if (d.oW == 64 && dbg) {
         switch (dbg) {
             case 2: W3_LAUNCH(64, 2); break; case 8: W3_LAUNCH(64, 8); break;
             default: W3_LAUNCH(64, 4); break;
         }
-    } else if (d.oW == 16) W3_LAUNCH(16, 0);
+        return SDC_OK;
+    }
+#endif
+    if (d.oW == 16) W3_LAUNCH(16, 0);
     else if (d.oW == 32) W3_LAUNCH(32, 0);
     else W3_LAUNCH(64, 0);
+    return SDC_OK;
 }
 
 template <int BM, int BN, int WM, int WN, int SK, int NTH = 256, bool UPS = false>
-void launch_wg(const ConvArgs& a, hipStream_t s) {
+int launch_wg(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
     constexpr int KSMAX = BN + (BN / 16) * 2;
     constexpr int NCOLH = (KSMAX + 63) / 64;
     const size_t lds = (2u * 4u * SK * BM + 2u * SK * (NCOLH * 64 + 8)) * sizeof(float);
     static std::atomic<uint64_t> attr{0};
-    if (sdc::first_use_on_device(attr)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
+    SDC_LDS_OPTIN(attr, (conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS>), 160 * 1024, "sdc_conv[winograd]");
     hipLaunchKernelGGL((conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS>), grid, dim3(NTH), lds, s, a);
-}
-
-template <int BM, int BN, int WM, int WN>
-void launch_rh_bf3(const ConvArgs& a, hipStream_t s) {
-    dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
-    constexpr int KSMAX = BN + (BN / 16) * 2;
-    const size_t lds = (2u * 3u * BM * LDK + 2u * KSMAX * LDK) * sizeof(unsigned short);
-    static std::atomic<uint64_t> attr{0};
-    if (sdc::first_use_on_device(attr)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rh_bf3_kernel<BM, BN, WM, WN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-    hipLaunchKernelGGL((conv_rh_bf3_kernel<BM, BN, WM, WN>), grid, dim3(NT), lds, s, a);
-}
-
-template <int BM, int BN, int WM, int WN>
-void launch_bf3(const ConvArgs& a, hipStream_t s) {
-    dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
-    const size_t lds = 2u * (2u * BM * LDK + 2u * BN * LDK) * sizeof(unsigned short);
-    static std::atomic<uint64_t> attr{0};
-    if (sdc::first_use_on_device(attr)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf3_kernel<BM, BN, WM, WN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-    hipLaunchKernelGGL((conv_bf3_kernel<BM, BN, WM, WN>), grid, dim3(NT), lds, s, a);
+    return SDC_OK;
 }
 
 // what the dispatch chose for the last descriptor (sdc_conv_describe): kernel template instance and the share of the
@@ -2652,7 +2287,7 @@ WgPick wg_pick(const SdcConvDesc& d, int64_t ntot, bool small, bool rowhalo) {
     auto fits = [&](int bn) { return (d.oW % bn == 0) || (bn % d.oW == 0); };
     if (!fits(128)) return w;
     auto nblk = [&](int bm, int bn) { return ((ntot + bn - 1) / bn) * ((d.Cout + bm - 1) / bm); };
-    static const int wg_tile = getenv("SDC_WG_TILE") ? atoi(getenv("SDC_WG_TILE")) : 0;   // tuning knob
+    static const int wg_tile = exp_env("SDC_WG_TILE");   // tuning knob
     int pick = wg_tile;
     if (w.ups) {
         pick = (d.Cout > 64 && nblk(128, 128) >= 256) ? 6 : ((d.Cout <= 64 && fits(256) && nblk(64, 256) >= 256) ? 7 : 3);
@@ -2699,10 +2334,10 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
 
 extern "C" int sdc_conv_gnparts(const SdcConvDesc* dp, int G) {
     if (!dp) return 0;
-    static const int no_rh = getenv("SDC_NO_ROWHALO") ? atoi(getenv("SDC_NO_ROWHALO")) : 0;
+    static const int no_rh = exp_env("SDC_NO_ROWHALO");
     const int64_t ntot = (int64_t)dp->B * dp->oD * dp->oH * dp->oW;
-    static const int no_wg2 = getenv("SDC_NO_WG2") ? atoi(getenv("SDC_NO_WG2")) : 0;
-    static const int no_wg3 = getenv("SDC_NO_WG3") ? atoi(getenv("SDC_NO_WG3")) : 0;
+    static const int no_wg2 = exp_env("SDC_NO_WG2");
+    static const int no_wg3 = exp_env("SDC_NO_WG3");
     if (!no_wg2 && !no_wg3 && wg3_ok(*dp, conv_small(*dp), !no_rh)) return gn_parts_for(*dp, WgPick{21, W2_BM, W2_TILES * 8, false}, G);
     if (!no_wg2 && wg2_ok(*dp, conv_small(*dp), !no_rh)) return gn_parts_for(*dp, WgPick{20, W2_BM, W2_TILES * 4, false}, G);
     return gn_parts_for(*dp, wg_pick(*dp, ntot, conv_small(*dp), !no_rh), G);
@@ -2738,7 +2373,7 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
     SDC_REQUIRE(d.Cin1 == 0 || x1, SDC_ENULL, "sdc_conv: Cin1 > 0 but x1 is null");
     SDC_REQUIRE(d.kD > 0 && d.kH > 0 && d.kW > 0 && d.sD > 0 && d.sH > 0 && d.sW > 0, SDC_EINVAL,
                 "sdc_conv: bad kernel/stride");
-    SDC_REQUIRE(d.precision >= 0 && d.precision <= 4, SDC_EINVAL, "sdc_conv: precision must be 0 (fp32 MFMA), 1 (split-bf16), 2 (fp32 Winograd along W), 3 (fp32 Winograd over H and W) or 4 (fp32 Winograd over D, H and W)");
+    SDC_REQUIRE(d.precision == 0 || (d.precision >= 2 && d.precision <= 4), SDC_EINVAL, "sdc_conv: precision must be 0 (fp32 MFMA, direct form), 2 (fp32 Winograd along W), 3 (fp32 Winograd over H and W) or 4 (fp32 Winograd over D, H and W)");
     SDC_REQUIRE(!gn_part || d.precision >= 2, SDC_EINVAL, "sdc_conv_gn: fused GroupNorm statistics need precision 2, 3 or 4 (sdc_conv_gnparts returned 0)");
     // the caller sized `parts` with sdc_conv_gnparts(d, G), which sees the descriptor only: a kernel picked here on other
     // grounds (pointer alignment, a residual) with a different part count would write a table the finalize pass misreads
@@ -2766,7 +2401,7 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
     a.Ktot = d.kD * d.kH * d.kW * a.Cin;
     // FAST: whole K chunks share a tap, and every per-thread offset fits the 32-bit voffset of the saddr load form
     const bool small = conv_small(d);
-    static const int no_rh = getenv("SDC_NO_ROWHALO") ? atoi(getenv("SDC_NO_ROWHALO")) : 0;
+    static const int no_rh = exp_env("SDC_NO_ROWHALO");
     a.rowhalo = !no_rh;
     a.vec2 = 0;
     {
@@ -2774,32 +2409,16 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
         const int64_t S = (int64_t)d.oD * d.oH * d.oW;
         a.ydense = dense(d.ys) && S >= 128 && S < (1 << 24) && span5(d.ys, d.B, d.Cout, d.oD, d.oH, d.oW) < (1ll << 30) &&
                    (!residual || (dense(d.rs) && span5(d.rs, d.B, d.Cout, d.oD, d.oH, d.oW) < (1ll << 30)));
-        static const int no_dense = getenv("SDC_NO_DENSE_EPI") ? atoi(getenv("SDC_NO_DENSE_EPI")) : 0;
+        static const int no_dense = exp_env("SDC_NO_DENSE_EPI");
         if (no_dense) a.ydense = 0;
     }
     a.wg2 = nullptr;
     a.gn_part = nullptr; a.gn_G = a.gn_cpg = a.gn_nparts = a.gn_S = 0;
     const bool fast = (d.Cin0 % BK == 0) && (d.Cin1 % BK == 0) && small && d.Cout < (1 << 30);
     hipStream_t s = sdc::as_stream(stream);
-    // opt-in split-bf16: whole 32-channel chunks per tap, 32-bit offsets, 16-byte aligned pre-split weights
-    if (d.precision == 1 && d.Cin0 % BK3 == 0 && d.Cin1 % BK3 == 0 && small && d.Cout > 32 &&
-        reinterpret_cast<uintptr_t>(wp) % 16 == 0 && ((int64_t)a.Ktot * d.Cout) % 4 == 0) {
-        const bool big = d.Cout > 64 && a.Ntot >= 128 * 256, wide = a.Ntot >= 128 * 512;
-        const int bn = big ? 128 : (wide ? 256 : 128);
-        const bool rh3 = a.rowhalo && d.kW == 3 && d.sW == 1 && d.uD == 1 && d.uH == 1 && d.uW == 1 && d.up_mode == 0 &&
-                         d.kD * d.kH <= 32 && ((d.oW % bn == 0) || (bn % d.oW == 0 && d.oW >= 16));
-        // (the 128x128 row-halo form needs 84 KB of LDS = one workgroup per CU and measured slower than the plain one)
-        if (rh3 && !big) {
-            if (wide) { SDC_PICK("conv_rh_bf3_kernel<64,256,1,4>", 1.0); launch_rh_bf3<64, 256, 1, 4>(a, s); }
-            else { SDC_PICK("conv_rh_bf3_kernel<64,128,2,2>", 1.0); launch_rh_bf3<64, 128, 2, 2>(a, s); }
-        } else if (big) { SDC_PICK("conv_bf3_kernel<128,128,2,2>", 1.0); launch_bf3<128, 128, 2, 2>(a, s); }
-        else if (wide) { SDC_PICK("conv_bf3_kernel<64,256,1,4>", 1.0); launch_bf3<64, 256, 1, 4>(a, s); }
-        else { SDC_PICK("conv_bf3_kernel<64,128,2,2>", 1.0); launch_bf3<64, 128, 2, 2>(a, s); }
-        return sdc::check_launch("sdc_conv[bf16x3]");
-    }
     auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
-    static const int no_wg2 = getenv("SDC_NO_WG2") ? atoi(getenv("SDC_NO_WG2")) : 0;
-    static const int no_wg3 = getenv("SDC_NO_WG3") ? atoi(getenv("SDC_NO_WG3")) : 0;
+    static const int no_wg2 = exp_env("SDC_NO_WG2");
+    static const int no_wg3 = exp_env("SDC_NO_WG3");
     // fp32 Winograd F(2x2x2,3x3x3): 3x3x3 stride-1 convs over whole rows, plane pairs
     if (!no_wg2 && !no_wg3 && wg3_ok(d, small, a.rowhalo != 0) && reinterpret_cast<uintptr_t>(wp) % 16 == 0 &&
         reinterpret_cast<uintptr_t>(x0) % 16 == 0 && (d.Cin1 == 0 || reinterpret_cast<uintptr_t>(x1) % 16 == 0) &&
@@ -2813,7 +2432,7 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
             a.gn_part = gn_part; a.gn_G = gn_G; a.gn_cpg = d.Cout / gn_G; a.gn_S = d.oD * d.oH * d.oW;
         }
         SDC_PICK(d.oW == 16 ? "conv_wg3_kernel<16>" : (d.oW == 32 ? "conv_wg3_kernel<32>" : "conv_wg3_kernel<64>"), 8.0 / 27.0);
-        launch_wg3(a, s);
+        { const int rc_ = launch_wg3(a, s); if (rc_) return rc_; }
         return sdc::check_launch("sdc_conv[winograd 2x2x2]");
     }
     // fp32 Winograd F(2x2,3x3) over (H, W): 3x3 / 3x3x3 stride-1 convs over whole rows
@@ -2831,7 +2450,7 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
         }
         SDC_PICK(d.oW == 16 ? "conv_wg2_kernel<16>" : (d.oW == 32 ? "conv_wg2_kernel<32>" : (d.oW == 64 ? "conv_wg2_kernel<64>" : "conv_wg2_kernel<128>")),
                  4.0 / 9.0);
-        launch_wg2(a, s);
+        { const int rc_ = launch_wg2(a, s); if (rc_) return rc_; }
         return sdc::check_launch("sdc_conv[winograd 2x2]");
     }
     // fp32 Winograd F(2,3) along W: 3-wide stride-1 taps, whole 16-channel chunks, even rows
@@ -2846,25 +2465,25 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
             a.gn_part = gn_part; a.gn_G = gn_G; a.gn_cpg = d.Cout / gn_G; a.gn_S = d.oD * d.oH * d.oW;
         }
         if (wgp.ups) {
-            if (wgp.pick == 6) { SDC_PICK("conv_wg_kernel<128,128,4,2,16,512,ups>", 2.0 / 3.0); launch_wg<128, 128, 4, 2, 16, 512, true>(a, s); }
-            else if (wgp.pick == 7) { SDC_PICK("conv_wg_kernel<64,256,2,4,16,512,ups>", 2.0 / 3.0); launch_wg<64, 256, 2, 4, 16, 512, true>(a, s); }
-            else { SDC_PICK("conv_wg_kernel<64,128,2,2,16,256,ups>", 2.0 / 3.0); launch_wg<64, 128, 2, 2, 16, 256, true>(a, s); }
+            if (wgp.pick == 6) { SDC_PICK("conv_wg_kernel<128,128,4,2,16,512,ups>", 2.0 / 3.0); { const int rc_ = launch_wg<128, 128, 4, 2, 16, 512, true>(a, s); if (rc_) return rc_; } }
+            else if (wgp.pick == 7) { SDC_PICK("conv_wg_kernel<64,256,2,4,16,512,ups>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 256, 2, 4, 16, 512, true>(a, s); if (rc_) return rc_; } }
+            else { SDC_PICK("conv_wg_kernel<64,128,2,2,16,256,ups>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 128, 2, 2, 16, 256, true>(a, s); if (rc_) return rc_; } }
             return sdc::check_launch("sdc_conv[winograd,upsample]");
         }
-        if (wgp.pick == 6) { SDC_PICK("conv_wg_kernel<128,128,4,2,16,512>", 2.0 / 3.0); launch_wg<128, 128, 4, 2, 16, 512>(a, s); }
-        else if (wgp.pick == 7) { SDC_PICK("conv_wg_kernel<64,256,2,4,16,512>", 2.0 / 3.0); launch_wg<64, 256, 2, 4, 16, 512>(a, s); }
-        else if (wgp.pick == 9) { SDC_PICK("conv_wg_kernel<128,256,4,2,16,512>", 2.0 / 3.0); launch_wg<128, 256, 4, 2, 16, 512>(a, s); }       // (2 x 4 waves measured the same)
-        else if (wgp.pick == 10) { SDC_PICK("conv_wg_kernel<64,512,1,8,16,512>", 2.0 / 3.0); launch_wg<64, 512, 1, 8, 16, 512>(a, s); }     // (each wave: both 32-row tiles x 32 pairs; measured 3 % ahead of 1 x 2)
-        else { SDC_PICK("conv_wg_kernel<64,128,2,2,16,256>", 2.0 / 3.0); launch_wg<64, 128, 2, 2, 16>(a, s); }
+        if (wgp.pick == 6) { SDC_PICK("conv_wg_kernel<128,128,4,2,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<128, 128, 4, 2, 16, 512>(a, s); if (rc_) return rc_; } }
+        else if (wgp.pick == 7) { SDC_PICK("conv_wg_kernel<64,256,2,4,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 256, 2, 4, 16, 512>(a, s); if (rc_) return rc_; } }
+        else if (wgp.pick == 9) { SDC_PICK("conv_wg_kernel<128,256,4,2,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<128, 256, 4, 2, 16, 512>(a, s); if (rc_) return rc_; } }       // (2 x 4 waves measured the same)
+        else if (wgp.pick == 10) { SDC_PICK("conv_wg_kernel<64,512,1,8,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 512, 1, 8, 16, 512>(a, s); if (rc_) return rc_; } }     // (each wave: both 32-row tiles x 32 pairs; measured 3 % ahead of 1 x 2)
+        else { SDC_PICK("conv_wg_kernel<64,128,2,2,16,256>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 128, 2, 2, 16>(a, s); if (rc_) return rc_; } }
         return sdc::check_launch("sdc_conv[winograd]");
     }
     SDC_REQUIRE(!gn_part, SDC_EINVAL, "sdc_conv_gn: shape not covered by the fused statistics (sdc_conv_gnparts returned 0)");
     // pointwise convs over a dense layout: 16-byte loads of weights and activations
-    static const int no_pw = getenv("SDC_NO_PW") ? atoi(getenv("SDC_NO_PW")) : 0;
+    static const int no_pw = exp_env("SDC_NO_PW");
     {
         const int64_t S = (int64_t)d.oD * d.oH * d.oW;
         auto dense = [&](const int64_t* st) { return st[4] == 1 && st[3] == d.iW && st[2] == (int64_t)d.iH * d.iW && st[0] % 4 == 0 && st[1] % 4 == 0; };
-        if (!no_pw && d.precision != 1 && fast && d.kD * d.kH * d.kW == 1 && d.sD == 1 && d.sH == 1 && d.sW == 1 && d.uD == 1 && d.uH == 1 &&
+        if (!no_pw && fast && d.kD * d.kH * d.kW == 1 && d.sD == 1 && d.sH == 1 && d.sW == 1 && d.uD == 1 && d.uH == 1 &&
             d.uW == 1 && d.up_mode == 0 && d.pD == 0 && d.pH == 0 && d.pW == 0 && d.oD == d.iD && d.oH == d.iH && d.oW == d.iW &&
             S % 4 == 0 && d.Cout % 4 == 0 && d.Cout > 32 && dense(d.x0s) && (d.Cin1 == 0 || dense(d.x1s)) &&
             reinterpret_cast<uintptr_t>(x0) % 16 == 0 && (d.Cin1 == 0 || reinterpret_cast<uintptr_t>(x1) % 16 == 0) &&
@@ -2881,7 +2500,7 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
     if (a.rowhalo && d.kW == 7 && d.sW == 1 && d.uD == 1 && d.uH == 1 && d.uW == 1 && d.up_mode == 0 && d.kD * d.kH <= 64 &&
         d.Cout % 4 == 0 && d.Cout > 32 && small && ((d.oW % 128 == 0) || (128 % d.oW == 0 && d.oW >= 16)) &&
         reinterpret_cast<uintptr_t>(wp) % 16 == 0) {
-        static const int stem_tile = getenv("SDC_STEM_TILE") ? atoi(getenv("SDC_STEM_TILE")) : 0;
+        static const int stem_tile = exp_env("SDC_STEM_TILE");
         if (stem_tile == 256 && (d.oW % 256 == 0 || 256 % d.oW == 0)) {
             dim3 grid((a.Ntot + 255) / 256, (d.Cout + 63) / 64);
             SDC_PICK("conv_rh_kernel<64,256,1,4,7,true>", 1.0);
@@ -2901,7 +2520,7 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
         return sdc::check_launch("sdc_conv[stem]");
     }
     const int64_t blocks64x128 = (int64_t)((a.Ntot + 127) / 128) * ((d.Cout + 63) / 64);
-    static const int force_tile = getenv("SDC_TILE") ? atoi(getenv("SDC_TILE")) : 0;   // tuning knob: 1..5 picks a tile
+    static const int force_tile = exp_env("SDC_TILE");   // tuning knob: 1..5 picks a tile
     if (force_tile && d.Cout > 32) {
         switch (force_tile) {
             case 1: SDC_LAUNCH(128, 128, 2, 2); break;

@@ -417,12 +417,10 @@ extern "C" int sdc_linattn_block(const float* x, const float* g_pre, const float
         g2((unsigned)((a.ntiles + a.tiles_per_blk - 1) / a.tiles_per_blk), (unsigned)nseq);
     const size_t ldsb = sizeof(float) * (size_t)((C + HID) * XP + 8 * TT);          // pass 1
     const size_t ldsb2 = ldsb + sizeof(float) * (size_t)(C * XP + 2 * C);          // pass 2: + raw tile, bias, gain
-    static std::atomic<uint64_t> attr{0};
-    if (sdc::first_use_on_device(attr)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(la_blk_ctx<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(la_blk_out<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(la_blk_out<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    }
+    static std::atomic<uint64_t> attr0{0}, attr1{0}, attr2{0};
+    SDC_LDS_OPTIN(attr0, la_blk_ctx<128>, 96 * 1024, "sdc_linattn_block");
+    SDC_LDS_OPTIN(attr1, la_blk_out<128>, 128 * 1024, "sdc_linattn_block");
+    SDC_LDS_OPTIN(attr2, la_blk_out<64>, 96 * 1024, "sdc_linattn_block");
     if (C == 64) {
         hipLaunchKernelGGL(la_blk_ctx<64>, g1, dim3(NT), ldsb, s, a);
         hipLaunchKernelGGL(la_blk_mid<64>, gm, dim3(NT), 0, s, a);

@@ -377,9 +377,7 @@ extern "C" int sdc_chan_norm(const float* x, const float* g, const float* residu
     SDC_REQUIRE(B < 65536, SDC_EINVAL, "sdc_chan_norm: B too large for grid.y");
     auto lds_bytes = [&](int pl) { return sizeof(float) * ((size_t)C * pl + 2 * (NT / pl) * pl); };
     static std::atomic<uint64_t> attr{0};
-    if (sdc::first_use_on_device(attr)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chan_norm_lds_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-    }
+    SDC_LDS_OPTIN(attr, chan_norm_lds_kernel<16>, 144 * 1024, "sdc_chan_norm");
     // 64-position tiles for long rows only; shorter rows take the 16-lane form (more, smaller workgroups: those launches
     // are latency-bound, not bandwidth-bound).  The choice depends on the row length alone, never on the batch, so a
     // trajectory's rounding does not depend on how many others share the launch.

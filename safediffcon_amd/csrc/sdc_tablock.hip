@@ -33,7 +33,12 @@ struct TaArgs {
     int inner;               // pixels per outer index (H*W)
     float eps;
     int64_t so, sc, st;      // element (o, c, pixel i, frame f) at o*so + c*sc + f*st + i
-    int dbg;                 // kernel experiments (SDC_TA_DBG): 1 no head loop, 2 no weight fetches, 4 no softmax / rotary
+#ifdef SDC_KERNEL_EXPERIMENTS
+    int dbg;                 // kernel experiments (SDC_TA_DBG; WRONG RESULTS): 1 no head loop, 2 no weight fetches, 4 no softmax / rotary
+#define TA_DBG(a) ((a).dbg)
+#else
+#define TA_DBG(a) 0         // the shipping library has no result-changing switches (build with -DSDC_KERNEL_EXPERIMENTS for them)
+#endif
 };
 
 __device__ __forceinline__ int crow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
     // head's weights are fetched before the head's chains and parked after them, one barrier per head.
     nfloat4 wreg[4];
     auto fetch_head = [&](int head) {
-        if (a.dbg & 2) return;
+        if (TA_DBG(a) & 2) return;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {                    // q, k, v: rows c = 0..63, 32 columns of this head
             const int rem = tid, c = rem >> 3, c4 = (rem & 7) * 4;
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[(2 * ks + lh) * XP + hw * 33 + l31], w[(2 * ks + lh) * 32 + l31], acc, 0, 0, 0);
     };
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every arbitration against its SIMD partner otherwise
-    for (int head = 0; head < ((a.dbg & 1) ? 0 : 4); ++head) {
+    for (int head = 0; head < ((TA_DBG(a) & 1) ? 0 : 4); ++head) {
         const float* wh = wl + (head & 1) * 8192;
         __syncthreads();                           // this head's weights are in LDS; every wave is done with the other buffer
         if (head < 3) fetch_head(head + 1);
@@ -252,13 +257,17 @@ extern "C" int sdc_tattn_block(const float* x, const float* g_pre, const float* 
     TaArgs a;
     a.x = x; a.g = g_pre; a.wqkv = wqkv; a.wo = wo; a.rot = rot; a.bias = bias; a.y = y;
     a.inner = inner; a.eps = eps; a.so = so; a.sc = sc; a.st = st;
+#ifdef SDC_KERNEL_EXPERIMENTS
     static const int dbg = getenv("SDC_TA_DBG") ? atoi(getenv("SDC_TA_DBG")) : 0;
     a.dbg = dbg;
+#endif
+    // the prologue reads the weights with 16-byte and the rotary table with 8-byte vector loads
+    SDC_REQUIRE(reinterpret_cast<uintptr_t>(wqkv) % 16 == 0 && reinterpret_cast<uintptr_t>(wo) % 16 == 0 &&
+                (!rot || reinterpret_cast<uintptr_t>(rot) % 8 == 0), SDC_EINVAL,
+                "sdc_tattn_block: wqkv / wo must be 16-byte aligned and rot 8-byte aligned");
     const size_t ldsb = sizeof(float) * (size_t)(C * XP + 4 * 32 * 33 + 2 * 32 * 16 + 1024 + 2 * 8192);
     static std::atomic<uint64_t> attr{0};
-    if (sdc::first_use_on_device(attr)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ta_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
+    SDC_LDS_OPTIN(attr, ta_block_kernel, 160 * 1024, "sdc_tattn_block");
     hipLaunchKernelGGL(ta_block_kernel, dim3((unsigned)nblk), dim3(NT), ldsb, sdc::as_stream(stream), a);
     return sdc::check_launch("sdc_tattn_block");
 }

@@ -61,8 +61,11 @@ class Plan:
     def __init__(self, device, precision=0):
         self.device = torch.device(device)
         self.lib = _lib.get_lib()
-        self.precision = int(precision)   # 0 direct fp32 MFMA | 1 split-bf16 conv | 2 fp32 Winograd F(2,3) along W | 3 (default of the
-                                          # nets) fp32 Winograd F(2x2,3x3) over (H, W) where covered, else as 2 (include/sdc.h)
+        # conv algorithm (include/sdc.h): 0 direct fp32 MFMA | 2 fp32 Winograd F(2,3) along W | 3 F(2x2,3x3) over (H, W) where
+        # covered, else as 2 | 4 (default of the nets) F(2x2x2,3x3x3) over (D, H, W) where covered, else as 3
+        self.precision = int(precision)
+        if self.precision not in (0, 2, 3, 4):
+            raise ValueError(f"precision must be 0, 2, 3 or 4 (got {precision})")
         self.calls = []          # (fn, args, keepalive)
         self.pool = Pool(self.device)
         self.keep = []           # descriptors / tensors that must outlive the plan
@@ -70,7 +73,7 @@ class Plan:
         self._stats = None
         self._ctx = None
         self._gn_parts = {}      # out.data_ptr() -> (partial-sum buffer, parts per (sample, group), groups) left by sdc_conv_gn
-        self.fuse_gn_stats = os.environ.get("SDC_NO_GNFUSE", "0") != "1"
+        self.fuse_gn_stats = True    # False: separate statistics pass after every conv (A/B checks)
 
     # ------------------------------------------------------------------ execution
     def run(self, stream):
@@ -146,18 +149,6 @@ class Plan:
                 return t4.permute(2, 3, 1, 0).reshape(-1, co).contiguous()
             t5 = as5(t)                                       # (Cout, Cin, kD, kH, kW)
             return t5.permute(2, 3, 4, 1, 0).reshape(-1, t5.shape[0]).contiguous()
-        if self.precision == 1:
-            # fp32 Wp followed by the split weights, bf16 [Cout][K] hi then lo (x = hi + lo to ~2^-17)
-            def fn3():
-                wp = fn().to(torch.float32)
-                wt = wp.t().contiguous()
-                hi = wt.to(torch.bfloat16)
-                lo = (wt - hi.to(torch.float32)).to(torch.bfloat16)
-                n = wp.numel()
-                if n % 2:
-                    return wp.reshape(-1)
-                return torch.cat([wp.reshape(-1), hi.reshape(-1).view(torch.float32), lo.reshape(-1).view(torch.float32)])
-            return self.packed(fn3)
         if self.precision in (2, 3, 4):
             # fp32 Wp followed by the Winograd F(2,3) taps along W, [(kd*kH + kh)*4 + xi][Cin][Cout]:
             # G g with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], formed in fp64 and rounded once;
@@ -207,11 +198,10 @@ class Plan:
             assert tuple(out.shape[:2]) == (B, cout) and out.dim() == 5, (out.shape, (B, cout, *o))
             o = tuple(out.shape[2:])
         nw = k[0] * k[1] * k[2] * (c0 + c1) * cout
-        split = wp.dim() == 1 and wp.numel() == 2 * nw
         wino = wp.dim() == 1 and k[2] == 3 and wp.numel() == nw + nw // 3 * 4
         wino2 = wp.dim() == 1 and k[1] == 3 and k[2] == 3 and wp.numel() == nw + nw // 3 * 4 + nw // 9 * 16
         wino3 = wp.dim() == 1 and tuple(k) == (3, 3, 3) and wp.numel() == nw + nw // 3 * 4 + nw // 9 * 16 + nw // 27 * 64
-        assert split or wino or wino2 or wino3 or wp.numel() == nw, (wp.shape, k, c0, c1, cout)
+        assert wino or wino2 or wino3 or wp.numel() == nw, (wp.shape, k, c0, c1, cout)
         d = SdcConvDesc()
         d.B, d.Cin0, d.Cin1, d.Cout = B, c0, c1, cout
         d.iD, d.iH, d.iW = iD, iH, iW
@@ -220,7 +210,7 @@ class Plan:
         d.sD, d.sH, d.sW = stride
         d.pD, d.pH, d.pW = pad
         d.uD, d.uH, d.uW = up
-        d.up_mode, d.precision = up_mode, (1 if split else 4 if wino3 else 3 if wino2 else 2 if wino else 0)
+        d.up_mode, d.precision = up_mode, (4 if wino3 else 3 if wino2 else 2 if wino else 0)
         d.x0s[:] = _s5(x)
         d.x1s[:] = _s5(x1) if x1 is not None else (0,) * 5
         d.ys[:] = _s5(out)

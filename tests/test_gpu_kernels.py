@@ -279,41 +279,6 @@ def test_conformal_scores_and_weights():
 
 
 @pytest.mark.parametrize("case", [
-    dict(nd=2, B=4, cin=64, cout=64, sp=(16, 128), k=3, pad=1),
-    dict(nd=2, B=40, cin=128, cout=192, sp=(8, 64), k=3, pad=1, cin1=64, residual=True),       # 128x128 tile, concat
-    dict(nd=3, B=2, cin=32, cout=96, sp=(4, 16, 16), k=3, pad=1),
-    dict(nd=2, B=2, cin=64, cout=384, sp=(16, 128), k=1),
-    dict(nd=1, B=3, cin=256, cout=70, sp=(64,), k=4, stride=2, pad=1),                       # ragged Cout
-])
-def test_conv_split_bf16_opt_in(plan_cls, case):
-    """precision=1 (split-bf16, 3 MFMA passes): ~16 mantissa bits -> relative error <= 2e-4 of the output scale"""
-    from safediffcon_amd.engine import as5
-    nd, B, cin, cout, sp, k = case["nd"], case["B"], case["cin"], case["cout"], case["sp"], case["k"]
-    stride, pad, cin1 = case.get("stride", 1), case.get("pad", 0), case.get("cin1", 0)
-    x, x1 = det_tensor((B, cin, *sp), 81), (det_tensor((B, cin1, *sp), 82) if cin1 else None)
-    w, b = det_tensor((cout, cin + cin1, *([k] * nd)), 83, 0.2), det_tensor((cout,), 84, 0.1)
-    xin = x if x1 is None else torch.cat((x, x1), 1)
-    ref = (F.conv1d, F.conv2d, F.conv3d)[nd - 1](xin.double(), w.double(), b.double(), stride=stride, padding=pad)
-    res = det_tensor(tuple(ref.shape), 85) if case.get("residual") else None
-    if res is not None:
-        ref = ref + res.double()
-    outs = {}
-    for prec in (0, 1):
-        plan = plan_cls(DEV, precision=prec)
-        k3, s3, p3 = (1,) * (3 - nd) + (k,) * nd, (1,) * (3 - nd) + (stride,) * nd, (0,) * (3 - nd) + (pad,) * nd
-        out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, k3,
-                        x1=None if x1 is None else as5(x1.to(DEV)), stride=s3, pad=p3,
-                        residual=None if res is None else as5(res.to(DEV)))
-        _run(plan)
-        outs[prec] = out.cpu().reshape(ref.shape).double()
-    scale = ref.abs().max().item()
-    e0 = (outs[0] - ref).abs().max().item() / scale
-    e1 = (outs[1] - ref).abs().max().item() / scale
-    assert e0 < 2e-6 and e1 < 2e-4, (e0, e1)
-    assert e1 > 0            # it really is the other kernel
-
-
-@pytest.mark.parametrize("case", [
     dict(nd=2, B=4, cin=64, cout=64, sp=(16, 128), k=3, pad=1),                                 # whole rows per tile
     dict(nd=2, B=40, cin=128, cout=192, sp=(8, 64), k=3, pad=1, cin1=64, residual=True),        # 128-row tile, concat, ragged Cout tile
     dict(nd=2, B=6, cin=32, cout=128, sp=(2, 16), k=3, pad=1),                                  # 16-wide rows: 8 segments per tile

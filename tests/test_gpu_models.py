@@ -19,14 +19,11 @@ TRAJ_GATE = 4e-4
 DDIM_GATE = 1.5e-3
 
 
-def _traj(out, ref, tag=""):
+def _traj(out, ref, tag="", gate=TRAJ_GATE):
     """trajectory parity: print the measured error, gate on the absolute maximum (the state is clipped to [-1, 1])"""
-    import inspect
     err = (out - ref).abs().max().item()
-    who = inspect.stack()[1].function
-    gate = DDIM_GATE if "ddim" in who else TRAJ_GATE
-    print(f"[measured] {who} {tag}: max|err| {err:.3e}  MSE {((out - ref) ** 2).mean().item():.3e}  (gate {gate:.1e})")
-    assert err < gate, (who, tag, err)
+    print(f"[measured] trajectory {tag}: max|err| {err:.3e}  MSE {((out - ref) ** 2).mean().item():.3e}  (gate {gate:.1e})")
+    assert err < gate, (tag, err)
 
 
 def _mse(a, b):
@@ -127,16 +124,16 @@ def test_burgers_trajectories_golden(golden):
     guid = sdc.BurgersGuidance(g.scalar("Q"), g.scalar("w_score"), g.scalar("u_bound"))
     out = gd.sample(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True, nablaJ=guid,
                     J_scheduler=lambda t: 1.0, w_scheduler=None, enable_grad=False, noise=noise).cpu()
-    _traj(out, g["out"])
+    _traj(out, g["out"], tag="burgers_trajectories_golden")
     # the same guidance passed as an opaque callable takes the split (x0 -> callable -> update) route
     out2 = gd.sample(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True,
                      nablaJ=lambda x: guid(x), J_scheduler=lambda t: 1.0, enable_grad=False, noise=noise).cpu()
-    _traj(out2, g["out"])
+    _traj(out2, g["out"], tag="burgers_trajectories_golden")
     g = golden("burgers_traj_calib")
     out = gd.sample(batch_size=2, clip_denoised=True, guidance_u0=False, u_init=g["u0"], u_final=g["uT"],
                     w_groundtruth=g["w_gt"], nablaJ=None, J_scheduler=None, w_scheduler=None, enable_grad=False,
                     noise=noise).cpu()
-    _traj(out, g["out"])
+    _traj(out, g["out"], tag="burgers_trajectories_golden")
 
 
 def test_tokamak_trajectories_golden(golden):
@@ -149,11 +146,11 @@ def test_tokamak_trajectories_golden(golden):
                                g.scalar("thr"))
     out = gd.sample(batch_size=2, clip_denoised=True, guidance_u0=True, u_init=g["u0"], u_final=g["uT"], nablaJ=guid,
                     J_scheduler=lambda t: 1.0, w_scheduler=None, enable_grad=False, noise=noise).cpu()
-    _traj(out, g["out"])
+    _traj(out, g["out"], tag="tokamak_trajectories_golden")
     g = golden("tokamak_traj_calib")
     out = gd.sample(batch_size=2, clip_denoised=True, guidance_u0=False, u_init=g["u0"], u_final=g["uT"], nablaJ=None,
                     enable_grad=False, noise=noise).cpu()
-    _traj(out, g["out"])
+    _traj(out, g["out"], tag="tokamak_trajectories_golden")
     with pytest.raises(IndexError):     # reference bug reproduced
         gd.sample(batch_size=2, guidance_u0=False, u_init=g["u0"], u_final=g["uT"], w_groundtruth=torch.zeros(2, 9, 128))
 
@@ -167,10 +164,10 @@ def test_smoke_trajectories_golden(golden):
     noise = det_noise((2, 8, 7, 16, 16), int(g.scalar("noise_seed")))
     guid = sdc.SmokeGuidance(g.scalar("Q"), g.scalar("w_safe"), g.scalar("safe_bound"))
     out = gd.sample(batch_size=2, design_fn=guid, enable_grad=False, init=g["init"], noise=noise).cpu()
-    _traj(out, g["out"])
+    _traj(out, g["out"], tag="smoke_trajectories_golden")
     g = golden("smoke_traj_calib")
     out = gd.sample(batch_size=2, design_fn=None, init=g["init"], control=g["control"], noise=noise).cpu()
-    _traj(out, g["out"])
+    _traj(out, g["out"], tag="smoke_trajectories_golden")
 
 
 def test_tokamak_mixed_guidance_and_amax_vs_oracle(golden):
@@ -189,7 +186,7 @@ def test_tokamak_mixed_guidance_and_amax_vs_oracle(golden):
     tabs = osched.make_tables("cosine", T)
     ref = osam.sample_tokamak(lambda x, t: onets.unet_tokamak(P, x, t, dim=8), tabs, B, noise, u_init=u0, u_final=uT,
                               nablaJ=osam.tokamak_guidance(target, 122, 0.1, 3.6, 0.7, 0.3, 0.5), enable_grad=False)
-    _traj(out, ref)
+    _traj(out, ref, tag="tokamak_mixed_guidance_and_amax_vs_oracle")
 
     spec = golden("burgers_unet").spec()
     P = det_params(spec, 100)
@@ -203,7 +200,7 @@ def test_tokamak_mixed_guidance_and_amax_vs_oracle(golden):
     tabs = osched.make_tables("cosine", T)
     ref = osam.sample_burgers(lambda x, t: onets.unet_burgers(P, x, t, dim=8), tabs, B, noise, u_init=u0, u_final=uT,
                               nablaJ=osam.burgers_guidance(0.01, 500.0, 0.05, False), enable_grad=False)
-    _traj(out, ref)
+    _traj(out, ref, tag="tokamak_mixed_guidance_and_amax_vs_oracle")
 
 
 def test_graph_and_eager_paths_agree_and_conditions_hold(golden):
@@ -248,14 +245,14 @@ def test_ddim_trajectories_golden(golden):
     guid = sdc.BurgersGuidance(g.scalar("Q"), g.scalar("w_score"), g.scalar("u_bound"))
     out = gd.sample(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True, nablaJ=guid,
                     J_scheduler=lambda t: 1.0, enable_grad=False, noise=noise).cpu()
-    _traj(out, g["out"])
+    _traj(out, g["out"], tag="ddim_trajectories_golden", gate=DDIM_GATE)
     out = gd.sample(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True,
                     nablaJ=lambda x: guid(x), enable_grad=False, noise=noise).cpu()          # opaque-callable route
-    _traj(out, g["out"])
+    _traj(out, g["out"], tag="ddim_trajectories_golden", gate=DDIM_GATE)
     g = golden("burgers_ddim_calib")
     out = gd.sample(batch_size=2, clip_denoised=True, guidance_u0=False, u_init=g["u0"], u_final=g["uT"],
                     w_groundtruth=g["w_gt"], nablaJ=None, enable_grad=False, noise=noise).cpu()
-    _traj(out, g["out"])
+    _traj(out, g["out"], tag="ddim_trajectories_golden", gate=DDIM_GATE)
     # Philox + hipGraph route: bit-identical to the eager call list, finite
     gd.guidance_u0 = True
     outs = []
@@ -273,11 +270,11 @@ def test_ddim_trajectories_golden(golden):
                                g.scalar("thr"))
     out = gt.sample(batch_size=2, guidance_u0=True, u_init=g["u0"], u_final=g["uT"], nablaJ=guid, enable_grad=False,
                     noise=noise).cpu()
-    _traj(out, g["out"])
+    _traj(out, g["out"], tag="ddim_trajectories_golden", gate=DDIM_GATE)
     g = golden("tokamak_ddim_calib")
     out = gt.sample(batch_size=2, guidance_u0=False, u_init=g["u0"], u_final=g["uT"], w_groundtruth=g["w_gt"], nablaJ=None,
                     enable_grad=False, noise=noise).cpu()
-    _traj(out, g["out"])
+    _traj(out, g["out"], tag="ddim_trajectories_golden", gate=DDIM_GATE)
 
     g = golden("smoke_ddim_guided")
     net = _load(sdc.Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2, 4), channels=7), golden("smoke_unet").spec(), 300)
@@ -286,10 +283,10 @@ def test_ddim_trajectories_golden(golden):
     noise = det_noise((2, 8, 7, 16, 16), int(g.scalar("noise_seed")))
     out = gs.sample(batch_size=2, design_fn=sdc.SmokeGuidance(g.scalar("Q"), g.scalar("w_safe"), g.scalar("safe_bound")),
                     init=g["init"], noise=noise).cpu()
-    _traj(out, g["out"])
+    _traj(out, g["out"], tag="ddim_trajectories_golden", gate=DDIM_GATE)
     g = golden("smoke_ddim_calib")
     out = gs.sample(batch_size=2, design_fn=None, init=g["init"], control=g["control"], noise=noise).cpu()
-    _traj(out, g["out"])
+    _traj(out, g["out"], tag="ddim_trajectories_golden", gate=DDIM_GATE)
 
 
 def test_conformal_pipelines_end_to_end(golden):
@@ -391,5 +388,6 @@ def test_full_schedule_trajectory_golden(golden, tree):
     ref = g["out"]
     err = (out - ref).abs().max().item()
     print(f"[measured] {tree} T=1000 guided DDPM vs the reference: max|err| {err:.3e}  MSE {((out - ref) ** 2).mean().item():.3e}")
-    # fp32 rounding-order differences over 1000 contracting steps; gate ~5x the error measured on MI355X
-    assert err < 2e-3 and ((out - ref) ** 2).mean().item() < 1e-7
+    # fp32 rounding-order differences over 1000 contracting steps; measured on MI355X: max|err| 2.8e-6 / 2.3e-6 / 4.0e-6,
+    # MSE 4e-14 / 7e-14 / 2e-13 (burgers / tokamak / smoke); gates ~5x that
+    assert err < 2e-5 and ((out - ref) ** 2).mean().item() < 1e-11

@@ -43,3 +43,51 @@ def test_pmc_records_carry_the_kernel_source_hash():
         if fn.startswith("r3_pmc_") and fn.endswith(".json"):
             with open(os.path.join(ROOT, "profiles", fn)) as fh:
                 assert "kernel_source_hash" in json.load(fh), fn
+
+
+def test_wg2_lane_offsets_include_the_k_row():
+    """a park lane of the F(2x2,3x3) kernel adds up to 3 channel strides (W = 128) to its 32-bit offset; the host
+    guard must count them (sdc_conv_describe launches nothing)."""
+    import ctypes as C
+    from safediffcon_amd import _lib
+    from safediffcon_amd._lib import SdcConvDesc
+    lib = _lib.get_lib()
+
+    def pick(cs):
+        d = SdcConvDesc()
+        d.B, d.Cin0, d.Cin1, d.Cout = 4096, 64, 0, 64
+        d.iD, d.iH, d.iW = d.oD, d.oH, d.oW = 1, 16, 128
+        d.kD, d.kH, d.kW = 1, 3, 3
+        d.sD = d.sH = d.sW = d.uD = d.uH = d.uW = 1
+        d.pD, d.pH, d.pW = 0, 1, 1
+        d.up_mode, d.precision = 0, 3
+        d.x0s[:] = (2048, cs, 2048, 128, 1)              # channel-outermost input: the channel stride is the big one
+        d.ys[:] = (64 * 2048, 2048, 2048, 128, 1)
+        buf = C.create_string_buffer(128)
+        assert lib.sdc_conv_describe(C.byref(d), buf, 128, None) == 0
+        return buf.value.decode()
+    span = 4095 * 2048 + 15 * 128 + 127
+    ok = ((1 << 30) - 1 - span) // 3 // 4 * 4
+    assert span + 3 * ok < (1 << 30) <= span + 3 * (ok + 4)
+    assert pick(ok).startswith("conv_wg2_kernel<128>")
+    assert not pick(ok + 4).startswith("conv_wg2")
+
+
+def test_removed_precision_1_is_refused():
+    import ctypes as C
+    import pytest
+    from safediffcon_amd import _lib
+    from safediffcon_amd._lib import SdcConvDesc
+    from safediffcon_amd.engine import Plan
+    d = SdcConvDesc()
+    d.B, d.Cin0, d.Cout = 1, 64, 64
+    d.iD, d.iH, d.iW = d.oD, d.oH, d.oW = 1, 16, 128
+    d.kD, d.kH, d.kW = 1, 3, 3
+    d.sD = d.sH = d.sW = d.uD = d.uH = d.uW = 1
+    d.pD, d.pH, d.pW = 0, 1, 1
+    d.precision = 1
+    d.x0s[:] = (64 * 2048, 2048, 2048, 128, 1)
+    d.ys[:] = (64 * 2048, 2048, 2048, 128, 1)
+    buf = C.create_string_buffer(128)
+    assert _lib.get_lib().sdc_conv_describe(C.byref(d), buf, 128, None) != 0
+    assert "precision" in _lib.last_error()
