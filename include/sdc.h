@@ -258,6 +258,56 @@ int sdc_conformal_score(const SdcStepDesc* d, const float* pred, const float* tr
 int sdc_burgers_rollout(const float* u0, const float* f, float* traj, int N, int s, int Nt, int steps, int record_every,
                         float dt, float coef_transport, float d0, float d1, float d2, void* stream);
 
+/* ------------------------------------------------- backward (fine-tuning path) */
+/* The VJP kernels of the fine-tuning loss: p_losses + loss.backward() through the U-Nets,
+ * 1D/model/diffusion.py:638-733, 2d/ddpm/diffusion_2d.py:434-452 (callers 1D/inference/inference_ft.py:183-187,
+ * tokamak/inference/pipeline.py:238-263, 2d/inference_2d.py:267-279).  Conv DATA gradients have no entry point of their
+ * own: they are convolutions with flipped / transposed taps and run on sdc_conv with re-packed weights. */
+
+/* Weight (and bias) gradient of nn.Conv1d/2d/3d, nn.Linear and nn.ConvTranspose3d:
+ *   dw[m][n][kd][kh][kw] = sum_{b, od, oh, ow} G[b][m][od][oh][ow] * X[b][n][(od sD - pD + kd) / uD][...][(ow sW - pW + kw) / uW]
+ * (terms outside X are zero; uD/uH/uW in {1,2} = nearest upsampling of X folded into the read, nn.Upsample + conv).
+ * For a conv  y = conv(x, w): G = dL/dy (M = Cout), X = x (N = Cin) -> dw in nn.Conv layout (Cout, Cin, k...).
+ * For a transposed conv y = convT(x, w): G = x (M = Cin), X = dL/dy (N = Cout), s/p of the layer -> nn.ConvTranspose layout.
+ * dbias[m] = sum G[b][m][...] or null.  oW must be a multiple of 16; (kW, sW) in {(1,1),(3,1),(7,1),(4,2),(2,2)}.
+ * fp32 MFMA; the positions are split over workgroups and summed in a fixed order (deterministic). */
+typedef struct SdcWgradDesc {
+    int32_t B, M, N;
+    int32_t oD, oH, oW;          /* positions of G */
+    int32_t iD, iH, iW;          /* stored size of X */
+    int32_t kD, kH, kW;
+    int32_t sD, sH, sW;
+    int32_t pD, pH, pW;
+    int32_t uD, uH, uW;
+    int32_t _pad;
+    int64_t gs[5], xs[5];        /* element strides (b, c, d, h, w) of G and X */
+} SdcWgradDesc;
+size_t sdc_conv_wgrad_bytes(const SdcWgradDesc* d);
+int sdc_conv_wgrad(const SdcWgradDesc* d, const float* g, const float* x, float* dw, float* dbias, void* work,
+                   size_t work_bytes, void* stream);
+
+/* Backward of sdc_gn_apply (GroupNorm -> (scale+1, shift) -> SiLU; Block, conv3d.py:189-204, 1D/model/unet.py:128-147):
+ * h = the conv output the forward normalised (contiguous (B,C,S)), stats from the forward, ss = per-sample rows
+ * [scale (C) | shift (C)] at ss + b*ss_b_stride or null.  Writes gh = dL/dh and rows[b][c] = (A1, A2) with
+ * A1 = sum_S gy silu'(v), A2 = sum_S gy silu'(v) xhat, from which the caller forms
+ * dgamma[c] = sum_b (1+scale) A2, dbeta[c] = sum_b (1+scale) A1, dscale[b][c] = gamma A2 + beta A1, dshift[b][c] = A1.
+ * (The residual the forward added passes gy through unchanged.) */
+int sdc_gn_silu_bwd(const float* h, const float* gy, const float* stats, const float* gamma, const float* beta,
+                    const float* ss, int64_t ss_b_stride, float* rows, float* gh, int B, int C, int G, int64_t S,
+                    void* stream);
+
+/* Backward of sdc_chan_norm (mode 0 channel LayerNorm, 1 RMSNorm): gx, and per-block partial sums of the gain gradient
+ * gpart[c][sdc_chan_norm_bwd_parts(B, S)] (the caller sums the last axis). */
+size_t sdc_chan_norm_bwd_parts(int B, int64_t S);
+int sdc_chan_norm_bwd(const float* x, const float* gy, const float* g, float* gx, float* gpart, int B, int C, int64_t S,
+                      int mode, float eps, void* stream);
+
+/* gx = gy * f'(x): kind 0 SiLU, 1 GELU (exact erf) -- time_mlp, 1D/model/unet.py:300-305 */
+int sdc_act_bwd(const float* x, const float* gy, float* gx, int64_t n, int kind, void* stream);
+
+/* VJP of nearest-neighbour upsampling by (fh, fw) in {1,2}^2 over the last two axes: gx (rows,H,W) from g (rows,H*fh,W*fw) */
+int sdc_sumpool2(const float* g, float* gx, int64_t rows, int H, int W, int fh, int fw, void* stream);
+
 /* ----------------------------------------------------------------- graphs */
 int sdc_graph_begin(void* stream);
 int sdc_graph_end(void* stream, void** graph_exec);

@@ -13,6 +13,7 @@ What is pinned:
     by patching torch.randn / torch.randn_like while the reference loop runs
   * guidance-gradient, weight-normalisation and conformal-quantile KATs
   * one FULL-SCHEDULE (T = 1000) guided DDPM trajectory per tree (final state), gen_long
+  * fine-tuning loss (p_losses, per sample) and gradient digests of every parameter, gen_grad
 Weights are NOT stored: both sides rebuild them with oracle.detweights.det_params
 from the (key, shape) list stored in the fixture.
 """
@@ -583,17 +584,81 @@ def gen_long(which):
              w_safe=0.9, safe_bound=-5.0, ratio=100.0)
 
 
+def _grad_summary(module, seed):
+    """per-parameter gradient digests: L2 norm and the dot product with det_tensor(shape, seed + index) for EVERY key, the
+    full gradient for the small tensors (biases, gains, time MLP rows) and a handful of conv weights"""
+    keys, norms, dots, full = [], [], [], {}
+    for i, (k, p) in enumerate(module.named_parameters()):
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        keys.append(k)
+        norms.append(g.double().norm().item())
+        dots.append((g.double() * det_tensor(tuple(g.shape), seed + i).double()).sum().item())
+        if g.numel() <= 4096 or k.endswith("block1.proj.weight") and ("downs.0.0" in k or "mid_block1" in k or "ups.0.0" in k):
+            full["grad:" + k] = g.clone()
+    return dict(grad_keys=np.array(keys), grad_norms=np.array(norms), grad_dots=np.array(dots), **full)
+
+
+def gen_grad(which):
+    """Fine-tuning loss and gradients from the REAL reference: loss_b = p_losses(x_start, t, noise, mean=False),
+    total = mean(weight_b * loss_b) as in the reference's finetune step (1D/inference/inference_ft.py:183-187,
+    2d/inference_2d.py:267-279); stored: loss_b, total, gradient digests of every parameter (see _grad_summary)."""
+    dim, B = 8, 3
+    stub_modules("h5py", "tensorboardX", "ema_pytorch", "IPython")
+    sys.modules["tensorboardX"].SummaryWriter = object
+    sys.modules["ema_pytorch"].EMA = object
+    sys.modules["IPython"].embed = None
+    wt = det_tensor((B,), 5003).abs() + 0.5
+    if which == "burgers":
+        sys.path.insert(0, os.path.join(REF, "1D"))
+        from model.unet import Unet2D
+        from model.diffusion import GaussianDiffusion
+        net = Unet2D(dim=dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+        load_det(net, seed=100)
+        gd = GaussianDiffusion(net, seq_length=(16, 128), timesteps=1000, temporal=True, use_conv2d=True, is_condition_u0=True,
+                               is_condition_uT=True, condition_idx=10, train_on_padded_locations=False)
+        x0, noise, t = det_tensor((B, 3, 16, 128), 5000, 0.3), det_tensor((B, 3, 16, 128), 5001), torch.tensor([17, 480, 933])
+        seed = 5100
+    elif which == "tokamak":
+        sys.path.insert(0, os.path.join(REF, "tokamak"))
+        from model.unet import Unet1D
+        from model.diffusion import GaussianDiffusion
+        net = Unet1D(dim=dim, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+        load_det(net, seed=200)
+        gd = GaussianDiffusion(net, seq_length=128, nt=122, timesteps=1000, use_conv2d=False, temporal=False, guidance_u0=True,
+                               is_condition_u0=True, is_condition_uT=True)
+        x0, noise, t = det_tensor((B, 12, 128), 5010, 0.3), det_tensor((B, 12, 128), 5011), torch.tensor([3, 611, 998])
+        seed = 5200
+    else:
+        sys.path.insert(0, os.path.join(HERE, "_shims"))
+        sys.path.insert(0, os.path.join(REF, "2d"))
+        from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+        from ddpm.diffusion_2d import GaussianDiffusion
+        net = Unet3D_with_Conv3D(dim=dim, dim_mults=(1, 2, 4), channels=7)
+        load_det(net, seed=300)
+        gd = GaussianDiffusion(net, image_size=16, frames=8, timesteps=1000, loss_type="l2", standard_fixed_ratio=100.0)
+        x0, noise, t = det_tensor((B, 8, 7, 16, 16), 5020, 0.3), det_tensor((B, 8, 7, 16, 16), 5021), torch.tensor([40, 500, 960])
+        seed = 5300
+    net.train()
+    loss_b = gd.p_losses(x0.clone(), t, noise=noise.clone(), mean=False)
+    total = (wt * loss_b).mean()
+    total.backward()
+    save(f"{which}_grad", loss_b=loss_b.detach(), total=total.detach(), weight=wt, t=t, x0_seed=seed - 100 + (0 if which == "burgers" else 0),
+         dim=dim, dot_seed=seed, **_grad_summary(net, seed))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which == "all":
         for w in ("burgers", "tokamak", "smoke", "burgers_wide", "tokamak_wide", "smoke_wide", "burgers_long", "tokamak_long",
-                  "smoke_long"):
+                  "smoke_long", "burgers_grad", "tokamak_grad", "smoke_grad"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     elif which.endswith("_wide"):
         gen_wide(which[:-5])
     elif which.endswith("_long"):
         gen_long(which[:-5])
+    elif which.endswith("_grad"):
+        gen_grad(which[:-5])
     else:
         {"burgers": gen_burgers, "tokamak": gen_tokamak, "smoke": gen_smoke}[which]()

@@ -30,6 +30,12 @@ class SdcStepDesc(C.Structure):
         "has_wgt", "skip_draws", "ddim")] + [("_pad", C.c_int32), ("seed", C.c_uint64)]
 
 
+class SdcWgradDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "B", "M", "N", "oD", "oH", "oW", "iD", "iH", "iW", "kD", "kH", "kW", "sD", "sH", "sW", "pD", "pH", "pW",
+        "uD", "uH", "uW", "_pad")] + [("gs", C.c_int64 * 5), ("xs", C.c_int64 * 5)]
+
+
 # name -> (restype, argtypes); every symbol include/sdc.h declares
 SIGNATURES = {
     "sdc_version": (C.c_int, []),
@@ -64,6 +70,14 @@ SIGNATURES = {
     "sdc_conformal_score": (C.c_int, [C.POINTER(SdcStepDesc), _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _stream]),
     "sdc_burgers_rollout": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                       C.c_float, C.c_float, C.c_float, _stream]),
+    "sdc_conv_wgrad_bytes": (C.c_size_t, [C.POINTER(SdcWgradDesc)]),
+    "sdc_conv_wgrad": (C.c_int, [C.POINTER(SdcWgradDesc), _f32p, _f32p, _f32p, _f32p, C.c_void_p, C.c_size_t, _stream]),
+    "sdc_gn_silu_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64,
+                                  _stream]),
+    "sdc_chan_norm_bwd_parts": (C.c_size_t, [C.c_int, _i64]),
+    "sdc_chan_norm_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, _i64, C.c_int, C.c_float, _stream]),
+    "sdc_act_bwd": (C.c_int, [_f32p, _f32p, _f32p, _i64, C.c_int, _stream]),
+    "sdc_sumpool2": (C.c_int, [_f32p, _f32p, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "sdc_graph_begin": (C.c_int, [_stream]),
     "sdc_graph_end": (C.c_int, [_stream, C.POINTER(C.c_void_p)]),
     "sdc_graph_launch": (C.c_int, [C.c_void_p, _stream]),

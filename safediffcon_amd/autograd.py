@@ -1,0 +1,514 @@
+"""Differentiable execution of the drop-in U-Nets: the fine-tuning path.
+
+``net.forward_train(x, t)`` returns eps WITH an autograd graph over the net's ``nn.Parameter``s, so that the reference's
+fine-tuning loops -- ``loss = (weight * diffusion(state, mean=False)).mean(); loss.backward(); optimizer.step()``
+(1D/inference/inference_ft.py:183-187, tokamak/inference/pipeline.py:238-263, 2d/inference_2d.py:267-279) -- run on the
+drop-in classes without a second torch copy of the network.
+
+Every node of the graph is a ``torch.autograd.Function`` whose forward launches the same libsdc_hip.so kernels the
+samplers use:
+  * convs / Linear / transposed convs (84 % of the FLOPs): forward ``sdc_conv`` (Winograd forms included); data gradient =
+    ``sdc_conv`` again with flipped / transposed taps (so it runs on the same MFMA kernels); weight and bias gradient =
+    ``sdc_conv_wgrad`` (fp32 MFMA, csrc/sdc_grad.hip);
+  * GroupNorm + scale/shift + SiLU (+ residual): ``sdc_gn_stats`` / ``sdc_gn_apply`` forward, ``sdc_gn_silu_bwd`` backward;
+  * SiLU / GELU of the time MLP: ``sdc_act`` / ``sdc_act_bwd``;
+  * the attention blocks (PreNorm + LinearAttention / temporal / full attention + residual): forward = the fused HIP block
+    kernels of the sampler (``sdc_linattn_block``, ``sdc_tattn_block``, ``sdc_attn`` ...); backward = ROUND-3 STAGE: the VJP
+    is taken by PyTorch-ROCm autograd over a torch restatement of the block (recomputed in backward from the saved block
+    input).  These blocks hold 8 % of the forward FLOPs; their HIP backward kernels are the next stage.
+PyTorch is otherwise plumbing (device memory, the current stream, the autograd tape).  There is no CPU path.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib, grad_ops
+from ._lib import SdcConvDesc, check
+from .engine import Plan, as5, pack_conv_weight
+
+HEADS, DIM_HEAD = 4, 32
+HID = HEADS * DIM_HEAD
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+# --------------------------------------------------------------------------------------------------- raw conv launch
+def conv_raw(x, wp, bias, cout, k, *, x1=None, stride=(1, 1, 1), pad=(0, 0, 0), up=(1, 1, 1), up_mode=0, out=None, residual=None):
+    """one sdc_conv launch on torch's current stream (the eager twin of engine.Plan.conv); 5-D views, any strides"""
+    lib = _lib.get_lib()
+    B, c0, iD, iH, iW = x.shape
+    c1 = 0 if x1 is None else x1.shape[1]
+
+    def osz(i, u, kk, s, p):
+        v = (i - 1) * u + 1 if up_mode else i * u
+        return (v + 2 * p - kk) // s + 1
+
+    if out is None:
+        out = torch.empty((B, cout, *(osz(i, u, kk, s, p) for i, u, kk, s, p in zip((iD, iH, iW), up, k, stride, pad))),
+                          dtype=torch.float32, device=x.device)
+    nw = k[0] * k[1] * k[2] * (c0 + c1) * cout
+    n = wp.numel()
+    prec = 0
+    if k[2] == 3 and n != nw:
+        prec = 2 if n == nw + nw // 3 * 4 else (3 if n == nw + nw // 3 * 4 + nw // 9 * 16 else 4)
+        assert prec != 4 or n == nw + nw // 3 * 4 + nw // 9 * 16 + nw // 27 * 64, (n, nw)
+    else:
+        assert n == nw, (n, nw, k, c0, c1, cout)
+    d = SdcConvDesc()
+    d.B, d.Cin0, d.Cin1, d.Cout = B, c0, c1, cout
+    d.iD, d.iH, d.iW = iD, iH, iW
+    d.oD, d.oH, d.oW = out.shape[2:]
+    d.kD, d.kH, d.kW = k
+    d.sD, d.sH, d.sW = stride
+    d.pD, d.pH, d.pW = pad
+    d.uD, d.uH, d.uW = up
+    d.up_mode, d.precision = up_mode, prec
+    d.x0s[:] = tuple(int(s) for s in x.stride())
+    d.x1s[:] = tuple(int(s) for s in x1.stride()) if x1 is not None else (0,) * 5
+    d.ys[:] = tuple(int(s) for s in out.stride())
+    d.rs[:] = tuple(int(s) for s in residual.stride()) if residual is not None else (0,) * 5
+    p = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+    check(lib.sdc_conv(C.byref(d), p(x), p(x1), p(wp), p(bias), p(residual), p(out), _stream(x)), "sdc_conv")
+    return out
+
+
+def _k5(w):
+    """kernel size of an nn.Conv weight as (kD, kH, kW)"""
+    shp = tuple(w.shape[2:])
+    return (1,) * (3 - len(shp)) + shp
+
+
+def _transposed_422(x, w, bias, cout):
+    """ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1) with weight w (Cin, Cout, 1, 4, 4) as four 2x2 sub-pixel convs"""
+    B, _, D, H, W = x.shape
+    out = torch.empty((B, cout, D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    for ph in (0, 1):
+        for pw in (0, 1):
+            conv_raw(x, pack_conv_weight(w, ("convT_sub", ph, pw)), bias, cout, (1, 2, 2), pad=(0, 1 - ph, 1 - pw),
+                     out=out[:, :, :, ph::2, pw::2])
+    return out
+
+
+class ConvFn(Function):
+    """y = conv(x [| x1], w) + b for every conv form of the three U-Nets.  cfg = (kind, stride, pad, up, precision):
+       kind 'conv'      nn.Conv1d/2d/3d / nn.Linear (1x1) with stride / pad; up = nearest upsampling of x folded into the read
+                        (nn.Upsample + conv, 1D/model/unet.py:33-37, tokamak/model/unet.py:24-28)
+       kind 'convT422'  nn.ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1) (conv3d.py:159-160)
+       kind 'unshuffle' pixel-unshuffle + 1x1 conv = 2x2 stride-2 conv (Downsample2d, 1D/model/unet.py:39-43)"""
+
+    @staticmethod
+    def forward(ctx, x, x1, w, b, cfg):
+        kind, stride, pad, up, prec = cfg
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, x1, w)
+        ctx.has_bias = b is not None
+        bb = None if b is None else b.detach().contiguous()
+        wd = w.detach()
+        if kind == "conv":
+            return conv_raw(x, pack_conv_weight(wd, "conv", prec), bb, w.shape[0], _k5(w), x1=x1, stride=stride, pad=pad, up=up)
+        if kind == "convT422":
+            return _transposed_422(x, wd, bb, w.shape[1])
+        if kind == "unshuffle":
+            return conv_raw(x, pack_conv_weight(wd, "unshuffle"), bb, w.shape[0], (1, 2, 2), stride=(1, 2, 2))
+        raise ValueError(kind)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, x1, w = ctx.saved_tensors
+        kind, stride, pad, up, prec = ctx.cfg
+        need_x, need_x1, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        wd = w.detach()
+        gx = gx1 = gw = gb = None
+        k = _k5(w)
+        c0 = x.shape[1]
+        if kind == "conv":
+            if need_w or ctx.has_bias:
+                gw, gb = grad_ops.conv_wgrad(gy, x, k, stride, pad, up, bias=ctx.has_bias)
+                if x1 is not None:
+                    gw1, _ = grad_ops.conv_wgrad(gy, x1, k, stride, pad, up, bias=False)
+                    gw = torch.cat((gw, gw1), dim=1)
+                gw = gw.reshape(w.shape)
+            if need_x or need_x1:
+                w5 = as5(wd)
+                if stride == (1, 1, 1):
+                    # correlation with the flipped, transposed taps; pad k - 1 - p restores the input size
+                    wt = w5.transpose(0, 1).flip(2, 3, 4).contiguous()
+                    ga = conv_raw(gy, pack_conv_weight(wt, "conv", prec), None, wt.shape[0], k,
+                                  pad=tuple(kk - 1 - p for kk, p in zip(k, pad)))
+                    if up != (1, 1, 1):
+                        ga = grad_ops.sumpool2(ga, up[1], up[2])       # VJP of the folded nearest upsampling
+                elif k == (1, 4, 4) and stride == (1, 2, 2) and pad == (0, 1, 1):
+                    ga = _transposed_422(gy, w5, None, w5.shape[1])    # the conv weight (Cout, Cin, k) read as a ConvTranspose weight
+                else:
+                    # generic strided conv: conv over the zero-stuffed gradient with flipped taps (engine kind 'convT')
+                    ga = conv_raw(gy, pack_conv_weight(w5, "convT"), None, w5.shape[1], k, up=stride, up_mode=1,
+                                  pad=tuple(kk - 1 - p for kk, p in zip(k, pad)),
+                                  out=torch.empty((gy.shape[0], w5.shape[1], *x.shape[2:]), dtype=torch.float32, device=gy.device))
+                gx = ga[:, :c0]
+                gx1 = ga[:, c0:] if x1 is not None else None
+        elif kind == "convT422":
+            # y[2i - 1 + k] += x[i] w[k]:  dw = wgrad(G = x, X = gy);  dx[i] = sum_k gy[2i - 1 + k] w[k] (a stride-2 conv, no flip)
+            if need_w or ctx.has_bias:
+                gw, _ = grad_ops.conv_wgrad(x, gy, (1, 4, 4), (1, 2, 2), (0, 1, 1), bias=False)
+                gw = gw.reshape(w.shape)
+                if ctx.has_bias:
+                    gb = gy.sum((0, 2, 3, 4))
+            if need_x:
+                gx = conv_raw(gy, pack_conv_weight(wd, "conv"), None, w.shape[0], (1, 4, 4), stride=(1, 2, 2), pad=(0, 1, 1))
+        elif kind == "unshuffle":
+            if need_w or ctx.has_bias:
+                gw, gb = grad_ops.conv_wgrad(gy, x, (1, 2, 2), (1, 2, 2), (0, 0, 0), bias=ctx.has_bias)
+                gw = gw.reshape(w.shape)                      # (co, c, 1, 2, 2) -> (co, c*4, 1, 1): the (c, p1, p2) order of the unshuffle
+            if need_x:
+                co, c4 = w.shape[0], w.shape[1]
+                w4 = wd.reshape(co, c4 // 4, 2, 2)
+                gx = torch.empty_like(x)
+                for p1 in (0, 1):
+                    for p2 in (0, 1):
+                        wt = w4[:, :, p1, p2].t().reshape(c4 // 4, co, 1, 1, 1).contiguous()
+                        conv_raw(gy, pack_conv_weight(wt, "conv"), None, c4 // 4, (1, 1, 1), out=gx[:, :, :, p1::2, p2::2])
+        return gx, gx1, gw, gb, None
+
+
+class GNSiLUFn(Function):
+    """SiLU(GroupNorm(h) (scale + 1) + shift) (+ residual) -- Block, conv3d.py:189-204 / 1D/model/unet.py:128-147"""
+
+    @staticmethod
+    def forward(ctx, h, gamma, beta, ss, residual, groups):
+        h = h.contiguous()
+        st = grad_ops.gn_stats(h, groups)
+        g_, b_ = gamma.detach().contiguous(), beta.detach().contiguous()
+        ssd = None if ss is None else ss.detach().contiguous()
+        ctx.save_for_backward(h, st, g_, b_, ssd)
+        ctx.groups, ctx.has_res = groups, residual is not None
+        return grad_ops.gn_apply(h, st, g_, b_, groups, ssd, None if residual is None else residual.contiguous())
+
+    @staticmethod
+    def backward(ctx, gy):
+        h, st, g_, b_, ssd = ctx.saved_tensors
+        gh, dg, db, dss = grad_ops.gn_silu_bwd(h, gy, st, g_, b_, ctx.groups, ssd)
+        return gh, dg, db, dss, (gy if ctx.has_res else None), None
+
+
+class ActFn(Function):
+    """kind 0 SiLU, 1 GELU (exact erf) -- time_mlp (1D/model/unet.py:300-305, conv3d.py:391-396)"""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        y = torch.empty_like(x)
+        check(_lib.get_lib().sdc_act(x.data_ptr(), y.data_ptr(), x.numel(), kind, _stream(x)), "sdc_act")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return grad_ops.act_bwd(x, gy, ctx.kind), None
+
+
+class BlockFn(Function):
+    """An attention block: forward through the sampler's fused HIP kernels (a cached one-block engine.Plan), backward by
+    PyTorch-ROCm autograd over the block's torch restatement, recomputed from the saved input (round-3 stage, see the
+    module docstring)."""
+
+    @staticmethod
+    def forward(ctx, hip_fwd, torch_fn, x, *params):
+        ctx.torch_fn = torch_fn
+        ctx.save_for_backward(x, *params)
+        return hip_fwd(x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, *params = ctx.saved_tensors
+        with torch.enable_grad():
+            xs = x.detach().requires_grad_()
+            ps = [p.detach().requires_grad_() for p in params]
+            y = ctx.torch_fn(xs, *ps)
+            grads = torch.autograd.grad(y, [xs, *ps], gy.contiguous(), allow_unused=True)
+        return (None, None, *grads)
+
+
+# --------------------------------------------------------------------------------------------------- block restatements (backward only)
+def _ln(x, g, eps=1e-5):
+    """channel LayerNorm, gain only (1D/model/unet.py:53-63, conv3d.py:165-174)"""
+    var = torch.var(x, dim=1, unbiased=False, keepdim=True)
+    mean = torch.mean(x, dim=1, keepdim=True)
+    return (x - mean) * (var + eps).rsqrt() * g.reshape(1, -1, *([1] * (x.dim() - 2)))
+
+
+def _rms(x, g):
+    """tokamak/model/unet.py:45-51"""
+    return F.normalize(x, dim=1) * g.reshape(1, -1, *([1] * (x.dim() - 2))) * (x.shape[1] ** 0.5)
+
+
+def _norm(x, g, mode):
+    return _ln(x, g) if mode == 0 else _rms(x, g)
+
+
+def _linattn_core(qkv, B, n):
+    q, k, v = (t.reshape(B, HEADS, DIM_HEAD, n) for t in qkv.chunk(3, dim=1))
+    q = q.softmax(dim=-2) * DIM_HEAD ** -0.5
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    return torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(B, HID, n)
+
+
+def t_linattn_lucid(mode):
+    """Residual(PreNorm(LinearAttention)) of Unet2D / Unet1D: 1D/model/unet.py:182-222, tokamak/model/unet.py:182-222"""
+    def fn(x, g_pre, wqkv, wo, bo, g_post):
+        B, Cc = x.shape[:2]
+        xf = x.reshape(B, Cc, -1)
+        qkv = torch.einsum("oc,bcn->bon", wqkv.reshape(3 * HID, Cc), _norm(xf, g_pre, mode))
+        out = torch.einsum("oc,bcn->bon", wo.reshape(Cc, HID), _linattn_core(qkv, B, xf.shape[-1])) + bo[None, :, None]
+        return (_norm(out, g_post, mode) + xf).reshape(x.shape)
+    return fn
+
+
+def t_fullattn_lucid(mode):
+    """Residual(PreNorm(Attention)) at the bottleneck: 1D/model/unet.py:224-258"""
+    def fn(x, g_pre, wqkv, wo, bo):
+        B, Cc = x.shape[:2]
+        xf = x.reshape(B, Cc, -1)
+        n = xf.shape[-1]
+        qkv = torch.einsum("oc,bcn->bon", wqkv.reshape(3 * HID, Cc), _norm(xf, g_pre, mode))
+        q, k, v = (t.reshape(B, HEADS, DIM_HEAD, n) for t in qkv.chunk(3, dim=1))
+        attn = torch.einsum("bhdi,bhdj->bhij", q * DIM_HEAD ** -0.5, k).softmax(dim=-1)
+        out = torch.einsum("bhij,bhdj->bhdi", attn, v).reshape(B, HID, n)
+        return (torch.einsum("oc,bcn->bon", wo.reshape(Cc, HID), out) + bo[None, :, None] + xf).reshape(x.shape)
+    return fn
+
+
+def t_spatial_linear(x, gamma, wqkv, wo, bo):
+    """Residual(PreNorm(SpatialLinearAttention)) of the smoke net, per frame: conv3d.py:232-258"""
+    B, Cc, Fr, H, W = x.shape
+    y = _ln(x, gamma).permute(0, 2, 1, 3, 4).reshape(B * Fr, Cc, H * W)
+    qkv = torch.einsum("oc,bcn->bon", wqkv.reshape(3 * HID, Cc), y)
+    out = torch.einsum("oc,bcn->bon", wo.reshape(Cc, HID), _linattn_core(qkv, B * Fr, H * W)) + bo[None, :, None]
+    return out.reshape(B, Fr, Cc, H, W).permute(0, 2, 1, 3, 4) + x
+
+
+def _rotary(x, freqs):
+    """rotary-embedding-torch rotate_queries_or_keys ('lang' freqs, interleaved pairs; third-party)"""
+    n = x.shape[-2]
+    ang = torch.arange(n, dtype=freqs.dtype, device=freqs.device)[:, None] * freqs[None, :]
+    ang = ang.repeat_interleave(2, dim=-1)
+    x2 = x.reshape(*x.shape[:-1], x.shape[-1] // 2, 2)
+    half = torch.stack((-x2[..., 1], x2[..., 0]), dim=-1).reshape(x.shape)
+    return x * ang.cos() + half * ang.sin()
+
+
+def _token_attention(y, wqkv, wo, freqs=None, bias=None):
+    """conv3d.py:277-353 with focus_present_mask all-False; y (..., n, c)"""
+    qkv = F.linear(y, wqkv).chunk(3, dim=-1)
+    q, k, v = (t.reshape(*t.shape[:-1], HEADS, DIM_HEAD).transpose(-2, -3) for t in qkv)
+    q = q * DIM_HEAD ** -0.5
+    if freqs is not None:
+        q, k = _rotary(q, freqs), _rotary(k, freqs)
+    sim = torch.einsum("...hid,...hjd->...hij", q, k)
+    if bias is not None:
+        sim = sim + bias
+    attn = (sim - sim.amax(dim=-1, keepdim=True).detach()).softmax(dim=-1)
+    out = torch.einsum("...hij,...hjd->...hid", attn, v).transpose(-2, -3)
+    return F.linear(out.reshape(*y.shape[:-1], HID), wo)
+
+
+def _relpos_buckets(n, device, num_buckets=32, max_distance=32):
+    """RelativePositionBias bucket indices, conv3d.py:74-112 (integer arithmetic, no gradient)"""
+    q = torch.arange(n)
+    m = -(q[None, :] - q[:, None])
+    nb = num_buckets // 2
+    ret = (m < 0).long() * nb
+    m = m.abs()
+    max_exact = nb // 2
+    large = max_exact + (torch.log(m.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    return (ret + torch.where(m < max_exact, m, large)).to(device)
+
+
+def t_temporal(x, gamma, wqkv, wo, freqs, relw):
+    """Residual(PreNorm('b c f h w -> b (h w) f c' Attention)) with rotary + relative position bias: conv3d.py:262-353"""
+    B, Cc, Fr, H, W = x.shape
+    bias = relw[_relpos_buckets(Fr, x.device)].permute(2, 0, 1)
+    y = _ln(x, gamma).permute(0, 3, 4, 2, 1).reshape(B, H * W, Fr, Cc)
+    y = _token_attention(y, wqkv, wo, freqs, bias)
+    return y.reshape(B, H, W, Fr, Cc).permute(0, 4, 3, 1, 2) + x
+
+
+def t_spatial_full(x, gamma, wqkv, wo):
+    """mid: Residual(PreNorm('b c f h w -> b f (h w) c' Attention)): conv3d.py:450-452"""
+    B, Cc, Fr, H, W = x.shape
+    y = _ln(x, gamma).permute(0, 2, 3, 4, 1).reshape(B, Fr, H * W, Cc)
+    y = _token_attention(y, wqkv, wo)
+    return y.reshape(B, Fr, H, W, Cc).permute(0, 4, 1, 2, 3) + x
+
+
+# --------------------------------------------------------------------------------------------------- the differentiable forward
+class Trainer:
+    """Walks a drop-in U-Net in the reference's forward order and records an autograd graph of HIP-backed nodes."""
+
+    def __init__(self, net):
+        self.net = net
+        self.prec = net.precision
+        self._blocks = {}          # (prefix, shape) -> one-block plan for the HIP forward of an attention block
+
+    def P(self, key):
+        return self.net.P(key)
+
+    # ---- nodes
+    def conv(self, prefix, x, x1=None, kind="conv", stride=(1, 1, 1), pad=None, up=(1, 1, 1), bias=True):
+        w = self.P(f"{prefix}.weight")
+        b = self.P(f"{prefix}.bias") if bias else None
+        if pad is None:
+            pad = tuple(kk // 2 for kk in _k5(w))
+        return ConvFn.apply(x, x1, w, b, (kind, tuple(stride), tuple(pad), tuple(up), self.prec))
+
+    def gn(self, prefix, h, ss=None, residual=None):
+        return GNSiLUFn.apply(h, self.P(f"{prefix}.weight"), self.P(f"{prefix}.bias"), ss, residual, self.net.groups)
+
+    def resnet(self, prefix, x, cond, x1=None):
+        """ResnetBlock: conv3d.py:206-230 / 1D/model/unet.py:149-180"""
+        ss = None
+        if cond is not None and self.net.has(f"{prefix}.mlp.1.weight"):
+            e = ConvFn.apply(cond, None, self.P(f"{prefix}.mlp.1.weight"), self.P(f"{prefix}.mlp.1.bias"),
+                             ("conv", (1, 1, 1), (0, 0, 0), (1, 1, 1), 0))
+            ss = e.reshape(e.shape[0], e.shape[1])
+        h = self.gn(f"{prefix}.block1.norm", self.conv(f"{prefix}.block1.proj", x, x1), ss)
+        g = self.conv(f"{prefix}.block2.proj", h)
+        if self.net.has(f"{prefix}.res_conv.weight"):
+            r = self.conv(f"{prefix}.res_conv", x, x1)
+        else:
+            r = x
+        return self.gn(f"{prefix}.block2.norm", g, None, r)
+
+    def time_cond(self, t):
+        """SinusoidalPosEmb -> Linear -> GELU -> Linear, then the SiLU every block MLP starts with"""
+        from .unet import _sinusoid
+        dim = self.net.dim
+        emb = _sinusoid(t.detach().to(self.net.device()).float(), dim).reshape(t.shape[0], dim, 1, 1, 1).contiguous()
+        cfg = ("conv", (1, 1, 1), (0, 0, 0), (1, 1, 1), 0)
+        h = ConvFn.apply(emb, None, self.P("time_mlp.1.weight").reshape(4 * dim, dim, 1, 1, 1), self.P("time_mlp.1.bias"), cfg)
+        h = ActFn.apply(h, 1)
+        h = ConvFn.apply(h, None, self.P("time_mlp.3.weight").reshape(4 * dim, 4 * dim, 1, 1, 1), self.P("time_mlp.3.bias"), cfg)
+        return ActFn.apply(h, 0)
+
+    def block(self, prefix, x, build, torch_fn, param_keys):
+        """attention block `prefix`: HIP forward through a cached one-block plan, torch VJP"""
+        from .unet import _Builder
+        key = (prefix, tuple(x.shape))
+        ent = self._blocks.get(key)
+        if ent is None:
+            plan = Plan(x.device, precision=self.prec)
+            xin = torch.zeros(tuple(x.shape), dtype=torch.float32, device=x.device)
+            y = build(_Builder(self.net, plan), prefix, xin)
+            ent = self._blocks[key] = (plan, xin, y)
+        plan, xin, yout = ent
+
+        def hip_fwd(xv):
+            xin.copy_(xv)
+            plan.refresh_weights()
+            plan.run(_stream(xv))
+            return yout.clone()
+        return BlockFn.apply(hip_fwd, torch_fn, x.contiguous(), *[self.P(k) for k in param_keys])
+
+
+def _w5(p):
+    return p.reshape(*p.shape[:2], *([1] * (5 - p.dim()))) if p.dim() < 5 else p
+
+
+def forward_train_lucid(net, x, t):
+    """Unet2D / Unet1D: 1D/model/unet.py:382-426 == tokamak/model/unet.py:359-408"""
+    T = net._trainer()
+    mode, nd = net.NORM_MODE, net.ND
+    nres = len(net.dim_mults)
+    x5 = as5(x)
+    cond = T.time_cond(t)
+    h = T.conv("init_conv", x5)
+    r = h
+    hs = []
+    la_keys = lambda p: [f"{p}.fn.norm.g", f"{p}.fn.fn.to_qkv.weight", f"{p}.fn.fn.to_out.0.weight", f"{p}.fn.fn.to_out.0.bias",  # noqa: E731
+                         f"{p}.fn.fn.to_out.1.g"]
+    for i in range(nres):
+        p = f"downs.{i}"
+        h = T.resnet(f"{p}.0", h, cond)
+        hs.append(h)
+        h = T.resnet(f"{p}.1", h, cond)
+        h = T.block(f"{p}.2", h, lambda b, pre, xin: net._lin_attn(b, pre, xin), t_linattn_lucid(mode), la_keys(f"{p}.2"))
+        hs.append(h)
+        last = i == nres - 1
+        if last:
+            h = T.conv(f"{p}.3", h)
+        elif nd == 2:
+            h = T.conv(f"{p}.3.1", h, kind="unshuffle")
+        else:
+            h = T.conv(f"{p}.3", h, stride=(1, 1, 2), pad=(0, 0, 1))
+    h = T.resnet("mid_block1", h, cond)
+    h = T.block("mid_attn", h, lambda b, pre, xin: net._full_attn(b, pre, xin), t_fullattn_lucid(mode),
+                ["mid_attn.fn.norm.g", "mid_attn.fn.fn.to_qkv.weight", "mid_attn.fn.fn.to_out.weight", "mid_attn.fn.fn.to_out.bias"])
+    h = T.resnet("mid_block2", h, cond)
+    for i in range(nres):
+        p = f"ups.{i}"
+        h = T.resnet(f"{p}.0", h, cond, x1=hs.pop())
+        h = T.resnet(f"{p}.1", h, cond, x1=hs.pop())
+        h = T.block(f"{p}.2", h, lambda b, pre, xin: net._lin_attn(b, pre, xin), t_linattn_lucid(mode), la_keys(f"{p}.2"))
+        last = i == nres - 1
+        if last:
+            h = T.conv(f"{p}.3", h)
+        else:
+            h = T.conv(f"{p}.3.1", h, up=(1, 2, 2) if nd == 2 else (1, 1, 2))
+    h = T.resnet("final_res_block", h, cond, x1=r)
+    out = T.conv("final_conv", h)
+    return out.reshape(x.shape[0], -1, *x.shape[2:])
+
+
+def forward_train_smoke(net, x, t):
+    """Unet3D_with_Conv3D: conv3d.py:487-574; x (B, F, C, H, W) frame-major"""
+    T = net._trainer()
+    nres = len(net.dim_mults)
+    x5 = x.permute(0, 2, 1, 3, 4)
+    cond = T.time_cond(t)
+    rot, rel = "init_temporal_attn.fn.fn.fn.rotary_emb.freqs", "time_rel_pos_bias.relative_attention_bias.weight"
+
+    def temporal(pre, h):
+        return T.block(pre, h, lambda b, pp, xin: net._temporal(b, pp, xin), t_temporal,
+                       [f"{pre}.fn.norm.gamma", f"{pre}.fn.fn.fn.to_qkv.weight", f"{pre}.fn.fn.fn.to_out.weight", rot, rel])
+
+    def spatial(pre, h):
+        return T.block(pre, h, lambda b, pp, xin: net._spatial_linear(b, pp, xin), t_spatial_linear,
+                       [f"{pre}.fn.norm.gamma", f"{pre}.fn.fn.to_qkv.weight", f"{pre}.fn.fn.to_out.weight", f"{pre}.fn.fn.to_out.bias"])
+
+    h = T.conv("init_conv", x5)
+    h = temporal("init_temporal_attn", h)
+    r = h
+    hs = []
+    for i in range(nres):
+        p = f"downs.{i}"
+        h = T.resnet(f"{p}.0", h, cond)
+        h = T.resnet(f"{p}.1", h, cond)
+        h = spatial(f"{p}.2", h)
+        h = temporal(f"{p}.3", h)
+        hs.append(h)
+        if i < nres - 1:
+            h = T.conv(f"{p}.4", h, stride=(1, 2, 2), pad=(0, 1, 1))
+    h = T.resnet("mid_block1", h, cond)
+    h = T.block("mid_spatial_attn", h, lambda b, pp, xin: net._spatial_full(b, pp, xin), t_spatial_full,
+                ["mid_spatial_attn.fn.norm.gamma", "mid_spatial_attn.fn.fn.fn.to_qkv.weight", "mid_spatial_attn.fn.fn.fn.to_out.weight"])
+    h = temporal("mid_temporal_attn", h)
+    h = T.resnet("mid_block2", h, cond)
+    for i in range(nres):
+        p = f"ups.{i}"
+        h = T.resnet(f"{p}.0", h, cond, x1=hs.pop())
+        h = T.resnet(f"{p}.1", h, cond)
+        h = spatial(f"{p}.2", h)
+        h = temporal(f"{p}.3", h)
+        if i < nres - 1:
+            h = T.conv(f"{p}.4", h, kind="convT422")
+    h = T.resnet("final_conv.0", h, None, x1=r)
+    out = T.conv("final_conv.1", h)
+    return out.permute(0, 2, 1, 3, 4)

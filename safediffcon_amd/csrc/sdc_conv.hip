@@ -1752,9 +1752,10 @@ int launch_wg2(const ConvArgs& a, hipStream_t s) {
 //   * At the end of pass jd the (H, W) output transform m_jd of the accumulators is folded into the two output planes,
 //        y[2 dp] = m0 + m1 + m2,      y[2 dp + 1] = m1 - m2 - m3,
 //     by read-modify-write of y by the lane that owns the element (a lane's own loads and stores of one address stay
-//     ordered): pass 0 stores plane 0, pass 1 adds to plane 0 and stores plane 1, pass 2 finishes plane 0 and subtracts
-//     from plane 1, pass 3 finishes plane 1.  The partial planes are read back from L2 / MALL; the GroupNorm sums are taken
-//     from the finished values.  The fetch pipeline of the next pass (two stages in flight) runs through
+//     ordered).  The passes run in the order m1, m2, m0, m3: m1 is parked in plane 1, the second fold reads it once and writes
+//     m1 + m2 to plane 0 and m1 - m2 to plane 1, the third finishes plane 0 with m0, the fourth plane 1 with m3 -- three plane
+//     read-backs and five plane stores (the natural order needs four and six).  The partial planes come back from L2 / MALL;
+//     the GroupNorm sums are taken from the finished values.  The fetch pipeline of the next pass (two stages in flight) runs through
 //     the fold, so only its own instructions are exposed.
 // Coverage: what the F(2x2,3x3) kernel takes, and kD = 3, even depth, W in {16, 32, 64}, Cout % 64 == 0, the row pairs of
 // a workgroup inside one plane, 8-byte aligned output rows, no fused residual (rs all zero).
@@ -1859,15 +1860,17 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
         // planes (relative to od) and signs of depth component s_jd; a plane outside the volume: plane od with factor 0
         // (integer arithmetic on the float bits: nested selects became branches, and a branch in this loop costs
         // conservative memory waits at its join)
-        const uint32_t j0 = s_jd == 0, j2 = s_jd == 2, j3 = s_jd == 3;
+        // pass s_jd (0..3) works on depth component 1, 2, 0, 3 (see the fold)
+        const uint32_t j0 = s_jd == 2, j2 = s_jd == 1, j3 = s_jd == 3;
+        const int jdc = s_jd + 1 - 3 * (int)j0 - (int)j3;
         const int da = -(int)(j0 & lo_u);                                    // -1 | 0 | 0 | 0
         const int db = 1 + (int)j3 * (hi_u ? 1 : -1);                        //  1 | 1 | 1 | 2 (0 past the volume)
         mka = __builtin_bit_cast(float, (0x3F800000u & ((j0 & (lo_u ^ 1u)) - 1u)) | (j2 << 31));       // lo_ok | 1 | -1 | 1
         mkb = __builtin_bit_cast(float, (0x3F800000u & ((j3 & (hi_u ^ 1u)) - 1u)) | ((j0 | (j3 & hi_u)) << 31));   // -1 | 1 | 1 | -hi_ok
         f_xa = uniform_ptr(bsel + da * xs2);
         f_xb = uniform_ptr(bsel + db * xs2);
-        f_w = uniform_ptr(wg3p + ((int64_t)(s_jd * cin + s_ci) * coutn) * 16);
-        f_w4 = uniform_ptr(wg3p + ((int64_t)(s_jd * cin + s_ci + 4) * coutn) * 16);
+        f_w = uniform_ptr(wg3p + ((int64_t)(jdc * cin + s_ci) * coutn) * 16);
+        f_w4 = uniform_ptr(wg3p + ((int64_t)(jdc * cin + s_ci + 4) * coutn) * 16);
         voff = first ? vp0 : vp1;
         voff0 = voff - rsel0;
         voff3 = voff + rsel3;
@@ -1932,9 +1935,11 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
     }
+    // the bias rides on component (j, xi) = (1, 1) of depth component 1 (coefficient +1 in all 8 outputs): the start value of
+    // that accumulator in the first pass.  Register r of a lane is channel m0 + 32 wm + 8 (r >> 2) + 4 lh + (r & 3).
     f32x16 zero16, biasv;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { zero16[r] = 0.0f; biasv[r] = 0.0f; }
+    for (int r = 0; r < 16; ++r) { zero16[r] = 0.0f; biasv[r] = a.bias ? a.bias[m0 + wm * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)] : 0.0f; }
 
     const int S1 = a.Cin / SK;                       // stages per depth component
     nfloat4 fa[2][4];
@@ -1985,11 +1990,16 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
     float gp[8];
     float* const gstash = ldsw + W2_NBUF * (W2_ASZ + W2_BSZ) + 64 + tid * 8;
 
-    // fold of pass jd (compile-time after unrolling) into the plane pair
-    auto fold = [&](const int jd) __attribute__((always_inline)) {
-        const bool t0 = jd <= 2, t1 = jd >= 1;                   // planes touched
-        const bool ld0 = (jd == 1 || jd == 2) && !(DBG & 2), ld1 = jd >= 2 && !(DBG & 2);      // partial plane read back
-        const bool fin0 = jd == 2, fin1 = jd == 3;               // plane finished by this pass
+    // fold of pass p (compile-time after unrolling) into the plane pair.  Pass order: depth components 1, 2, 0, 3 --
+    //   p 0 (m1): plane 1 <- m1                       (scratch: nothing read)
+    //   p 1 (m2): plane 0 <- m1 + m2,  plane 1 <- m1 - m2      (one plane read, two written)
+    //   p 2 (m0): plane 0 <- (m1 + m2) + m0  finished
+    //   p 3 (m3): plane 1 <- (m1 - m2) - m3  finished
+    // three plane read-backs and five plane stores per workgroup (the order 0, 1, 2, 3 needs four and six).
+    auto fold = [&](const int p) __attribute__((always_inline)) {
+        const bool t0 = p == 1 || p == 2, t1 = p != 2;           // planes written
+        const bool ld0 = p == 2 && !(DBG & 2), ld1 = (p == 1 || p == 3) && !(DBG & 2);      // partial plane read back
+        const bool fin0 = p == 2, fin1 = p == 3;                 // plane finished by this pass
         const bool always = d.Cout > 0;
         const int LEAD = (DBG & 8) ? 4 : 2;                      // blocks of partial sums requested ahead of their use
         const int64_t ycs4 = d.ys[1] * 4;                        // bytes per channel
@@ -1998,11 +2008,6 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
         gwchar_p s0 = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(y0p);
         gwchar_p s1 = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(y0p + d.ys[2]);
         gchar_p l0 = (gchar_p)s0, l1 = (gchar_p)s1;
-        float bias_r[16];
-        if (jd == 0 && a.bias) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bias_r[r] = a.bias[cob + 8 * (r >> 2) + 4 * lh + (r & 3)];
-        }
         w2f2 P0[4][4][2], P1[4][4][2];                           // [block][row of the block][row of the tile]
         auto load_block = [&](int g4) __attribute__((always_inline)) {
 #pragma unroll
@@ -2033,16 +2038,20 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
                 }
                 const w2f2 t0a = pk_add2(pk_add2(pa[0], pa[1]), pa[2]), t1a = pk_sub2(pk_sub2(pa[1], pa[2]), pa[3]);
                 const w2f2 t0b = pk_add2(pk_add2(pb[0], pb[1]), pb[2]), t1b = pk_sub2(pk_sub2(pb[1], pb[2]), pb[3]);
-                const w2f2 z0 = pk_addsub(pk_sumdiff_fwd(t0b), t0a);        // rows 2 hp, 2 hp + 1 of m_jd
+                const w2f2 z0 = pk_addsub(pk_sumdiff_fwd(t0b), t0a);        // rows 2 hp, 2 hp + 1 of the pass's m
                 const w2f2 z1 = pk_addsub(pk_sumdiff_fwd(t1b), t1a);
                 if (t0) {
-                    const w2f2 u0 = ld0 ? pk_add2(P0[g4][r3][0], z0) : z0, u1 = ld0 ? pk_add2(P0[g4][r3][1], z1) : z1;
+                    // p 1: m1 (read from plane 1) + m2;  p 2: (m1 + m2) + m0
+                    const bool have = p == 1 ? ld1 : ld0;
+                    const w2f2 b0 = p == 1 ? P1[g4][r3][0] : P0[g4][r3][0], b1 = p == 1 ? P1[g4][r3][1] : P0[g4][r3][1];
+                    const w2f2 u0 = have ? pk_add2(b0, z0) : z0, u1 = have ? pk_add2(b1, z1) : z1;
                     *(gwfloat2_p)(s0 + yoff) = nfloat2{u0.x, u0.y};
                     *(gwfloat2_p)(s0 + yoff1) = nfloat2{u1.x, u1.y};
                     s0 += r3 < 3 ? ycs4 : 5 * ycs4;
                     if (fin0) { bs2 = pk_add2(bs2, pk_add2(u0, u1)); bq2 = pk_sqacc(u1, pk_sqacc(u0, bq2)); }
                 }
                 if (t1) {
+                    // p 0: m1;  p 1: m1 - m2;  p 3: (m1 - m2) - m3
                     const w2f2 u0 = ld1 ? pk_sub2(P1[g4][r3][0], z0) : z0, u1 = ld1 ? pk_sub2(P1[g4][r3][1], z1) : z1;
                     *(gwfloat2_p)(s1 + yoff) = nfloat2{u0.x, u0.y};
                     *(gwfloat2_p)(s1 + yoff1) = nfloat2{u1.x, u1.y};
@@ -2057,19 +2066,13 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
             *reinterpret_cast<nfloat4*>(gstash) = nfloat4{gp[0], gp[1], gp[2], gp[3]};
             *reinterpret_cast<nfloat4*>(gstash + 4) = nfloat4{gp[4], gp[5], gp[6], gp[7]};
         }
-        // the bias rides on component (j, xi) = (1, 1) of depth component 1 (coefficient +1 in all 8 outputs): the start
-        // value of that accumulator in the next pass
-        if (jd == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) biasv[r] = a.bias ? bias_r[r] : 0.0f;
-        }
     };
     // Main loop, per depth component: stage st computes from buffer st & 1 and parks stage st+1 in the other one during its
     // k-steps 0-1, re-using each register piece for the fetch of stage st+2 as soon as it is parked; one barrier at the end of
     // k-step 2; k-step 3 reads the first fragments of stage st+1 (slots as in the kernel above, 8 row loads instead of 4).
     int rbuf = 0;
     // The first stage of a pass is a copy of the stage body whose first k-step starts the accumulators from zero (from the
-    // bias for component (1, 1) of depth component 1) in the MFMA itself: 256 register writes per pass less in the fold.
+    // bias for component (1, 1) of the first pass = depth component 1) in the MFMA itself: 256 register writes per pass less in the fold.
     auto stage = [&](auto FIRST, const int jd) __attribute__((always_inline)) {
         constexpr bool first = decltype(FIRST)::value && !(DBG & 4);     // (the no-fold experiment lets the passes accumulate on)
         {
@@ -2085,7 +2088,7 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
                 const float* Vk = ks < 3 ? Vb + (2 * (ks + 1)) * (4 * W2_TILES * 4) : Vn;
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
-                    const f32x16 cstart = (first && ks == 0) ? ((c == 5 && jd == 1) ? biasv : zero16) : acc[c];
+                    const f32x16 cstart = (first && ks == 0) ? ((c == 5 && jd == 0) ? biasv : zero16) : acc[c];
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][c >> 2][c & 3],
                                                                   fv[set][c >> 2][(c & 3) == 0 ? 2 : ((c & 3) == 3 ? 3 : (c & 3) - 1)], cstart, 0, 0, 0);
                     if (c >= 8 && c < 12) read_v(Vk, nset, c - 8);

@@ -1,0 +1,511 @@
+// Backward (VJP) kernels of the fine-tuning path (p_losses + loss.backward() of the three U-Nets,
+// 1D/model/diffusion.py:638-733, 2d/ddpm/diffusion_2d.py:434-452; callers 1D/inference/inference_ft.py:183-187,
+// tokamak/inference/pipeline.py:238-263, 2d/inference_2d.py:267-279).
+//
+//   * conv data gradients need no kernel of their own: they are convolutions with flipped / transposed taps and run on the
+//     forward kernels (sdc_conv, Winograd forms included) with re-packed weights;
+//   * sdc_conv_wgrad: the weight (and bias) gradient of every conv / Linear / transposed conv, an fp32-MFMA GEMM over the
+//     positions,  dW[m][n][tap] = sum_{b,pos} G[b][m][pos] X[b][n][pos*s - p + tap];
+//   * sdc_gn_silu_bwd: GroupNorm -> (scale + 1, shift) -> SiLU (+ residual) backward, two HBM passes;
+//   * sdc_chan_norm_bwd, sdc_act_bwd, sdc_sumpool2: channel LayerNorm / RMSNorm, SiLU / GELU and nearest-upsample VJPs.
+#include "sdc_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// GEMM  C[m][n] (per tap) = sum_k A[m][k] B[k][n]  with k = output positions: A = G rows (k contiguous), B = X rows shifted
+// by the tap.  Workgroup = 4 waves (2 x 2), 64 m x 64 n x the KW taps of one (kd, kh); the K walk covers the output rows
+// (b, od, oh) of this split in chunks of 16 positions along W.  Per chunk the G tile [64][16] and the X tile [64][15 SW + KW]
+// (one input row segment: it serves all KW taps) go through LDS; a wave issues KW MFMAs per k pair from one ds_read_b32 of A
+// and KW of B.  Chunk c+1 is fetched to registers while chunk c computes (two LDS buffers, one barrier per chunk).
+// Partial results of the splits are written to the workspace and summed in a fixed order (deterministic, no atomics).
+struct WgradArgs {
+    SdcWgradDesc d;
+    const float* g;
+    const float* x;
+    float* part;            // [nsplit][M][N][kD][kH][kW]
+    float* bpart;           // [nsplit][M] or null
+    int rows_per_split;     // output rows (b, od, oh) per split
+    int nsplit, Mt, Nt;
+    int lgD, lgH, lgW;      // log2 of the nearest-upsample factors of X
+};
+
+template <int KW, int SW>
+__global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
+    constexpr int BKP = 16;                       // positions per chunk
+    constexpr int SPAN = (BKP - 1) * SW + KW;     // input columns under a chunk
+    constexpr int AP = BKP + 1;                   // LDS pitches (odd: conflict-free column reads)
+    constexpr int BP = (SPAN | 1) + ((SPAN & 1) ? 0 : 0);
+    constexpr int NBL = (64 * SPAN + NT - 1) / NT;        // X elements per thread and chunk
+    __shared__ float As[2][64 * AP];
+    __shared__ float Bs[2][64 * BP];
+    const SdcWgradDesc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+    // tile: (m tile, n tile, kd, kh)
+    int tb = blockIdx.x;
+    const int kh = tb % d.kH; tb /= d.kH;
+    const int kd = tb % d.kD; tb /= d.kD;
+    const int nt = tb % a.Nt;
+    const int mt = tb / a.Nt;
+    const int m0 = mt * 64, n0 = nt * 64;
+    const int split = blockIdx.y;
+    const int R = d.B * d.oD * d.oH;
+    const int r_lo = split * a.rows_per_split;
+    const int r_hi = min(R, r_lo + a.rows_per_split);
+    const int chunks_per_row = d.oW / BKP;
+
+    // G fetch: thread -> (m = tid >> 2, positions 4 (tid & 3) .. + 3)
+    const int gm = tid >> 2, gq = tid & 3;
+    const bool gm_ok = m0 + gm < d.M;
+    const int64_t g_moff = (int64_t)(gm_ok ? m0 + gm : 0) * d.gs[1];
+    const bool gvec = d.gs[4] == 1 && ((d.gs[0] | d.gs[1] | d.gs[2] | d.gs[3]) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.g) & 15) == 0;
+    // X fetch: element e = tid + NT i -> (n = e / SPAN, j = e % SPAN)
+    int xn[NBL], xj[NBL];
+    int64_t x_noff[NBL];
+    bool xn_ok[NBL];
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+        const int e = tid + NT * i;
+        xn[i] = e / SPAN;
+        xj[i] = e - xn[i] * SPAN;
+        xn_ok[i] = e < 64 * SPAN && n0 + xn[i] < d.N;
+        x_noff[i] = (int64_t)(xn_ok[i] ? n0 + xn[i] : 0) * d.xs[1];
+    }
+    const int iWu = d.iW << a.lgW, iHu = d.iH << a.lgH, iDu = d.iD << a.lgD;
+
+    f32x16 acc[KW];
+#pragma unroll
+    for (int t = 0; t < KW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float bsum = 0.0f;
+    const bool want_bias = a.bpart != nullptr && nt == 0 && kd == 0 && kh == 0;
+
+    float greg[4], xreg[NBL];
+    // chunk walk: (row r, chunk c); rows whose input row (id, ih) falls outside X contribute nothing to this (kd, kh) -- but
+    // still feed the bias sum
+    int r = r_lo, c = 0;
+    auto fetch = [&](bool& valid_out) {
+        // decompose the row (uniform)
+        const int oh = r % d.oH;
+        const int q = r / d.oH;
+        const int od = q % d.oD;
+        const int b = q / d.oD;
+        const int idu = od * d.sD - d.pD + kd, ihu = oh * d.sH - d.pH + kh;
+        const bool rv = idu >= 0 && idu < iDu && ihu >= 0 && ihu < iHu;
+        valid_out = rv;
+        const int ow0 = c * BKP;
+        const float* gp = a.g + (int64_t)b * d.gs[0] + (int64_t)od * d.gs[2] + (int64_t)oh * d.gs[3] + g_moff + (int64_t)(ow0 + 4 * gq) * d.gs[4];
+        if (rv || want_bias) {
+            if (gm_ok) {
+                if (gvec) {
+                    const float4 v = *reinterpret_cast<const float4*>(gp);
+                    greg[0] = v.x; greg[1] = v.y; greg[2] = v.z; greg[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) greg[i] = gp[(int64_t)i * d.gs[4]];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) greg[i] = 0.0f;
+            }
+        }
+        if (rv) {
+            const float* xp = a.x + (int64_t)b * d.xs[0] + (int64_t)(idu >> a.lgD) * d.xs[2] + (int64_t)(ihu >> a.lgH) * d.xs[3];
+            const int iw0 = ow0 * SW - d.pW;
+#pragma unroll
+            for (int i = 0; i < NBL; ++i) {
+                const int iwu = iw0 + xj[i];
+                const bool ok = xn_ok[i] && iwu >= 0 && iwu < iWu;
+                xreg[i] = ok ? xp[x_noff[i] + (int64_t)(iwu >> a.lgW) * d.xs[4]] : 0.0f;
+            }
+        }
+    };
+    auto park = [&](int buf, bool valid) {
+        if (want_bias) bsum += (greg[0] + greg[1]) + (greg[2] + greg[3]);
+        if (!valid) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) As[buf][gm * AP + 4 * gq + i] = greg[i];
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+            if (tid + NT * i < 64 * SPAN) Bs[buf][xn[i] * BP + xj[i]] = xreg[i];
+    };
+    auto advance = [&]() { if (++c == chunks_per_row) { c = 0; ++r; } };
+
+    bool v_cur = false, v_nxt = false;
+    if (r < r_hi) {
+        fetch(v_cur);
+        park(0, v_cur);
+        advance();
+    }
+    __syncthreads();
+    int buf = 0;
+    while (true) {
+        const bool more = r < r_hi;
+        if (more) fetch(v_nxt);
+        if (v_cur) {
+            const float* Ab = As[buf] + (wm * 32 + l31) * AP + lh;
+            const float* Bb = Bs[buf] + (wn * 32 + l31) * BP + lh * SW;
+#pragma unroll
+            for (int kk = 0; kk < BKP / 2; ++kk) {
+                const float av = Ab[2 * kk];
+#pragma unroll
+                for (int t = 0; t < KW; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bb[2 * kk * SW + t], acc[t], 0, 0, 0);
+            }
+        }
+        if (!more) break;
+        park(buf ^ 1, v_nxt);
+        advance();
+        __syncthreads();
+        buf ^= 1;
+        v_cur = v_nxt;
+    }
+
+    // ---- partial sums of this split: part[split][m][n][kd][kh][kw]
+    const int taps = d.kD * d.kH * KW;
+    float* P = a.part + (int64_t)split * d.M * d.N * taps;
+    const int n = n0 + wn * 32 + l31;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const int m = m0 + wm * 32 + 8 * (rr >> 2) + 4 * lh + (rr & 3);
+        if (m < d.M && n < d.N) {
+            float* o = P + ((int64_t)m * d.N + n) * taps + (kd * d.kH + kh) * KW;
+#pragma unroll
+            for (int t = 0; t < KW; ++t) o[t] = acc[t][rr];
+        }
+    }
+    if (want_bias) {
+        // the four threads of a G row sit in adjacent lanes
+        bsum += __shfl_xor(bsum, 1, 64);
+        bsum += __shfl_xor(bsum, 2, 64);
+        if (gq == 0 && gm_ok) a.bpart[(int64_t)split * d.M + m0 + gm] = bsum;
+    }
+}
+
+// out[i] = sum_s part[s][i]  (fixed order)
+__global__ __launch_bounds__(NT) void sum_splits_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int nsplit) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        float s = 0.0f;
+        for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * n + i];
+        out[i] = s;
+    }
+}
+
+int wgrad_splits(const SdcWgradDesc& d, int* rows_per_split) {
+    const int Mt = (d.M + 63) / 64, Nt = (d.N + 63) / 64;
+    const int64_t tiles = (int64_t)Mt * Nt * d.kD * d.kH;
+    const int R = d.B * d.oD * d.oH;
+    int64_t want = (2048 + tiles - 1) / tiles;          // ~8 workgroups per CU in flight
+    if (want < 1) want = 1;
+    if (want > R) want = R;
+    const int rps = (int)((R + want - 1) / want);
+    *rows_per_split = rps;
+    return (R + rps - 1) / rps;
+}
+
+int ilog2_12(int v) { return v == 1 ? 0 : (v == 2 ? 1 : -1); }
+
+}  // namespace
+
+extern "C" size_t sdc_conv_wgrad_bytes(const SdcWgradDesc* dp) {
+    if (!dp) return 0;
+    int rps = 0;
+    const int ns = wgrad_splits(*dp, &rps);
+    const size_t taps = (size_t)dp->kD * dp->kH * dp->kW;
+    return ((size_t)ns * dp->M * dp->N * taps + (size_t)ns * dp->M) * sizeof(float);
+}
+
+extern "C" int sdc_conv_wgrad(const SdcWgradDesc* dp, const float* g, const float* x, float* dw, float* dbias, void* work,
+                              size_t work_bytes, void* stream) {
+    SDC_REQUIRE(dp && g && x && dw && work, SDC_ENULL, "sdc_conv_wgrad: null pointer");
+    const SdcWgradDesc& d = *dp;
+    SDC_REQUIRE(d.B > 0 && d.M > 0 && d.N > 0 && d.oD > 0 && d.oH > 0 && d.oW > 0 && d.iD > 0 && d.iH > 0 && d.iW > 0, SDC_EINVAL,
+                "sdc_conv_wgrad: bad sizes");
+    SDC_REQUIRE(d.oW % 16 == 0, SDC_EINVAL, "sdc_conv_wgrad: the output row length must be a multiple of 16 (got %d)", d.oW);
+    SDC_REQUIRE(work_bytes >= sdc_conv_wgrad_bytes(dp), SDC_EINVAL, "sdc_conv_wgrad: workspace too small");
+    SDC_REQUIRE((int64_t)d.B * d.oD * d.oH < (1ll << 31), SDC_EINVAL, "sdc_conv_wgrad: too many output rows");
+    WgradArgs a;
+    a.d = d; a.g = g; a.x = x;
+    a.lgD = ilog2_12(d.uD); a.lgH = ilog2_12(d.uH); a.lgW = ilog2_12(d.uW);
+    SDC_REQUIRE(a.lgD >= 0 && a.lgH >= 0 && a.lgW >= 0, SDC_EINVAL, "sdc_conv_wgrad: upsample factors must be 1 or 2");
+    a.nsplit = wgrad_splits(d, &a.rows_per_split);
+    a.Mt = (d.M + 63) / 64; a.Nt = (d.N + 63) / 64;
+    const int64_t nw = (int64_t)d.M * d.N * d.kD * d.kH * d.kW;
+    a.part = static_cast<float*>(work);
+    a.bpart = dbias ? a.part + (int64_t)a.nsplit * nw : nullptr;
+    const int64_t tiles = (int64_t)a.Mt * a.Nt * d.kD * d.kH;
+    SDC_REQUIRE(tiles < (1ll << 31) && a.nsplit < 65536, SDC_EINVAL, "sdc_conv_wgrad: grid too large");
+    dim3 grid((unsigned)tiles, (unsigned)a.nsplit);
+    hipStream_t s = sdc::as_stream(stream);
+#define WG_CASE(KWV, SWV) hipLaunchKernelGGL((wgrad_kernel<KWV, SWV>), grid, dim3(NT), 0, s, a)
+    if (d.kW == 1 && d.sW == 1) WG_CASE(1, 1);
+    else if (d.kW == 3 && d.sW == 1) WG_CASE(3, 1);
+    else if (d.kW == 7 && d.sW == 1) WG_CASE(7, 1);
+    else if (d.kW == 4 && d.sW == 2) WG_CASE(4, 2);
+    else if (d.kW == 2 && d.sW == 2) WG_CASE(2, 2);
+    else {
+        sdc::set_error("sdc_conv_wgrad: tap / stride combination (kW %d, sW %d) not built (1/1, 3/1, 7/1, 4/2, 2/2)", d.kW, d.sW);
+        return SDC_EINVAL;
+    }
+    int rc = sdc::check_launch("sdc_conv_wgrad");
+    if (rc) return rc;
+    {
+        const int blocks = (int)((nw + NT - 1) / NT < 4096 ? (nw + NT - 1) / NT : 4096);
+        hipLaunchKernelGGL(sum_splits_kernel, dim3(blocks), dim3(NT), 0, s, a.part, dw, nw, a.nsplit);
+        if (dbias) hipLaunchKernelGGL(sum_splits_kernel, dim3((d.M + NT - 1) / NT), dim3(NT), 0, s, a.bpart, dbias, (int64_t)d.M, a.nsplit);
+    }
+    return sdc::check_launch("sdc_conv_wgrad[reduce]");
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm + SiLU backward
+// forward (sdc_gn_apply):  xh = (h - mean) rstd;  u = xh gamma + beta;  v = u (1 + sc) + sh;  y = silu(v) (+ res)
+// pass 1 (per (b, c) row): A1 = sum gy silu'(v),  A2 = sum gy silu'(v) xh                        -> rows[b][c] = (A1, A2)
+// pass 2 (per (b, c) row): k = gamma (1 + sc);  m1 = sum_{c in group} k A1 / n,  m2 = sum k A2 / n;
+//                          gh = rstd (gy silu'(v) k - m1 - xh m2)
+// The parameter gradients are small sums over rows[]:  d gamma[c] = sum_b (1 + sc) A2,  d beta[c] = sum_b (1 + sc) A1,
+// d sc[b][c] = gamma A2 + beta A1,  d sh[b][c] = A1  (formed by the caller from the B x C x 2 table).
+__device__ __forceinline__ float dsilu(float v) {
+    const float s = 1.0f / (1.0f + __expf(-v));
+    return s * (1.0f + v * (1.0f - s));
+}
+
+__global__ __launch_bounds__(NT) void gn_bwd_rows_kernel(const float* __restrict__ h, const float* __restrict__ gy,
+                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ ss,
+                                                        int64_t ss_b_stride, float* __restrict__ rows, int C, int G, int64_t S) {
+    const int bc = blockIdx.x;
+    const int b = bc / C, c = bc - b * C;
+    const int g = c / (C / G);
+    const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+    float sc = 1.0f, sh = 0.0f;
+    if (ss) { sc = ss[(int64_t)b * ss_b_stride + c] + 1.0f; sh = ss[(int64_t)b * ss_b_stride + C + c]; }
+    const float ga = gamma[c], be = beta[c];
+    const int64_t base = (int64_t)bc * S;
+    double a1 = 0.0, a2 = 0.0;
+    for (int64_t i = threadIdx.x; i < S; i += NT) {
+        const float xh = (h[base + i] - mean) * rstd;
+        const float v = (xh * ga + be) * sc + sh;
+        const float gv = gy[base + i] * dsilu(v);
+        a1 += (double)gv;
+        a2 += (double)gv * (double)xh;
+    }
+    __shared__ double shm[2][NT / 64];
+    a1 = sdc::wave_sum(a1);
+    a2 = sdc::wave_sum(a2);
+    if ((threadIdx.x & 63) == 0) { shm[0][threadIdx.x >> 6] = a1; shm[1][threadIdx.x >> 6] = a2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t1 = 0, t2 = 0;
+        for (int w = 0; w < NT / 64; ++w) { t1 += shm[0][w]; t2 += shm[1][w]; }
+        rows[(int64_t)bc * 2] = (float)t1;
+        rows[(int64_t)bc * 2 + 1] = (float)t2;
+    }
+}
+
+__global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const float* __restrict__ h, const float* __restrict__ gy,
+                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ ss,
+                                                         int64_t ss_b_stride, const float* __restrict__ rows, float* __restrict__ gh,
+                                                         int C, int G, int64_t S) {
+    const int bc = blockIdx.x;
+    const int b = bc / C, c = bc - b * C;
+    const int cpg = C / G, g = c / cpg;
+    const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+    // group means of (k A1, k A2): every thread walks the group's channels (cpg <= a few thousand; L2-resident table)
+    __shared__ double gm[2];
+    {
+        double s1 = 0.0, s2 = 0.0;
+        for (int cc = threadIdx.x; cc < cpg; cc += NT) {
+            const int ch = g * cpg + cc;
+            const float k = gamma[ch] * (ss ? ss[(int64_t)b * ss_b_stride + ch] + 1.0f : 1.0f);
+            s1 += (double)k * rows[((int64_t)b * C + ch) * 2];
+            s2 += (double)k * rows[((int64_t)b * C + ch) * 2 + 1];
+        }
+        __shared__ double shm[2][NT / 64];
+        s1 = sdc::wave_sum(s1);
+        s2 = sdc::wave_sum(s2);
+        if ((threadIdx.x & 63) == 0) { shm[0][threadIdx.x >> 6] = s1; shm[1][threadIdx.x >> 6] = s2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t1 = 0, t2 = 0;
+            for (int w = 0; w < NT / 64; ++w) { t1 += shm[0][w]; t2 += shm[1][w]; }
+            const double inv = 1.0 / ((double)cpg * (double)S);
+            gm[0] = t1 * inv;
+            gm[1] = t2 * inv;
+        }
+        __syncthreads();
+    }
+    const float m1 = (float)gm[0], m2 = (float)gm[1];
+    float sc = 1.0f, sh = 0.0f;
+    if (ss) { sc = ss[(int64_t)b * ss_b_stride + c] + 1.0f; sh = ss[(int64_t)b * ss_b_stride + C + c]; }
+    const float ga = gamma[c], be = beta[c], k = ga * sc;
+    const int64_t base = (int64_t)bc * S;
+    for (int64_t i = (int64_t)blockIdx.y * NT + threadIdx.x; i < S; i += (int64_t)gridDim.y * NT) {
+        const float xh = (h[base + i] - mean) * rstd;
+        const float v = (xh * ga + be) * sc + sh;
+        const float gv = gy[base + i] * dsilu(v);
+        gh[base + i] = rstd * (gv * k - m1 - xh * m2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ channel norm backward
+// forward (sdc_chan_norm): LayerNorm over channels (mode 0): y = (x - mean) rsqrt(var + eps) g;  RMSNorm (mode 1):
+// y = x / max(||x||, 1e-12) g sqrt(C).  One thread per position, channel walk with stride S (coalesced across threads).
+__global__ __launch_bounds__(NT) void chan_norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                          const float* __restrict__ g, float* __restrict__ gx,
+                                                          float* __restrict__ gpart, int C, int64_t S, int mode, float eps) {
+    const int b = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (p >= S) return;
+    const float* xb = x + (int64_t)b * C * S + p;
+    const float* yb = gy + (int64_t)b * C * S + p;
+    float* ob = gx + (int64_t)b * C * S + p;
+    if (mode == 0) {
+        float mean = 0.0f;
+        for (int c = 0; c < C; ++c) mean += xb[(int64_t)c * S];
+        mean /= (float)C;
+        float var = 0.0f;
+        for (int c = 0; c < C; ++c) { const float dlt = xb[(int64_t)c * S] - mean; var += dlt * dlt; }
+        var /= (float)C;
+        const float rstd = rsqrtf(var + eps);
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float xh = (xb[(int64_t)c * S] - mean) * rstd;
+            const float gg = yb[(int64_t)c * S] * g[c];
+            s1 += gg;
+            s2 += gg * xh;
+        }
+        s1 /= (float)C;
+        s2 /= (float)C;
+        for (int c = 0; c < C; ++c) {
+            const float xh = (xb[(int64_t)c * S] - mean) * rstd;
+            ob[(int64_t)c * S] = rstd * (yb[(int64_t)c * S] * g[c] - s1 - xh * s2);
+        }
+    } else {
+        float n2 = 0.0f;
+        for (int c = 0; c < C; ++c) { const float v = xb[(int64_t)c * S]; n2 += v * v; }
+        const float nrm = fmaxf(sqrtf(n2), 1e-12f);
+        const float inv = 1.0f / nrm, sq = sqrtf((float)C);
+        float dot = 0.0f;
+        for (int c = 0; c < C; ++c) dot += yb[(int64_t)c * S] * g[c] * xb[(int64_t)c * S];
+        const float k = sqrtf(n2) > 1e-12f ? dot * inv * inv : 0.0f;
+        for (int c = 0; c < C; ++c) ob[(int64_t)c * S] = sq * inv * (yb[(int64_t)c * S] * g[c] - xb[(int64_t)c * S] * k);
+    }
+    (void)gpart;
+}
+
+// d g[c] = sum_{b, p} gy[b][c][p] * yhat[b][c][p]: one workgroup per channel over a (b, p) slab, partial per block row
+__global__ __launch_bounds__(NT) void chan_norm_gaing_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                            float* __restrict__ gpart, int B, int C, int64_t S, int mode, float eps) {
+    // grid.x = position blocks, grid.y = b;  each thread owns one position and walks the channels twice
+    const int b = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const bool ok = p < S;
+    const float* xb = x + (int64_t)b * C * S + (ok ? p : 0);
+    const float* yb = gy + (int64_t)b * C * S + (ok ? p : 0);
+    float mean = 0.0f, scale = 0.0f;
+    if (mode == 0) {
+        for (int c = 0; c < C; ++c) mean += xb[(int64_t)c * S];
+        mean /= (float)C;
+        float var = 0.0f;
+        for (int c = 0; c < C; ++c) { const float dlt = xb[(int64_t)c * S] - mean; var += dlt * dlt; }
+        scale = rsqrtf(var / (float)C + eps);
+    } else {
+        float n2 = 0.0f;
+        for (int c = 0; c < C; ++c) { const float v = xb[(int64_t)c * S]; n2 += v * v; }
+        scale = sqrtf((float)C) / fmaxf(sqrtf(n2), 1e-12f);
+    }
+    __shared__ float red[NT / 64];
+    const int64_t nblk = (int64_t)gridDim.x * gridDim.y;
+    const int64_t blk = (int64_t)b * gridDim.x + blockIdx.x;
+    for (int c = 0; c < C; ++c) {
+        float v = ok ? yb[(int64_t)c * S] * (xb[(int64_t)c * S] - mean) * scale : 0.0f;
+        v = sdc::wave_sum(v);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) gpart[(int64_t)c * nblk + blk] = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ small element-wise VJPs
+// kind 0: SiLU, 1: GELU (exact erf):  gx = gy * f'(x)
+__global__ __launch_bounds__(NT) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx,
+                                                    int64_t n, int kind) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float v = x[i];
+        float dv;
+        if (kind == 0) dv = dsilu(v);
+        else dv = 0.5f * (1.0f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+        gx[i] = gy[i] * dv;
+    }
+}
+
+// VJP of nearest x2 upsampling along H and W (fh, fw in {1, 2}): gx[r][h][w] = sum of the fh x fw block of g
+__global__ __launch_bounds__(NT) void sumpool_kernel(const float* __restrict__ g, float* __restrict__ gx, int64_t rows, int H, int W,
+                                                    int fh, int fw) {
+    const int64_t n = rows * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const int w = (int)(i % W);
+        const int64_t q = i / W;
+        const int hh = (int)(q % H);
+        const int64_t r = q / H;
+        const float* p = g + (r * (H * fh) + (int64_t)hh * fh) * (W * fw) + (int64_t)w * fw;
+        float s = 0.0f;
+        for (int a = 0; a < fh; ++a)
+            for (int bb = 0; bb < fw; ++bb) s += p[(int64_t)a * (W * fw) + bb];
+        gx[i] = s;
+    }
+}
+
+extern "C" int sdc_gn_silu_bwd(const float* h, const float* gy, const float* stats, const float* gamma, const float* beta,
+                               const float* ss, int64_t ss_b_stride, float* rows, float* gh, int B, int C, int G, int64_t S,
+                               void* stream) {
+    SDC_REQUIRE(h && gy && stats && gamma && beta && rows && gh, SDC_ENULL, "sdc_gn_silu_bwd: null pointer");
+    SDC_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && S > 0, SDC_EINVAL, "sdc_gn_silu_bwd: bad sizes");
+    SDC_REQUIRE((int64_t)B * C < (1ll << 31), SDC_EINVAL, "sdc_gn_silu_bwd: too many rows");
+    hipStream_t s = sdc::as_stream(stream);
+    hipLaunchKernelGGL(gn_bwd_rows_kernel, dim3((unsigned)(B * C)), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss, ss_b_stride, rows, C, G, S);
+    int ysplit = (int)((S + NT * 8 - 1) / (NT * 8));
+    if (ysplit < 1) ysplit = 1;
+    if (ysplit > 64) ysplit = 64;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(B * C), (unsigned)ysplit), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss,
+                       ss_b_stride, rows, gh, C, G, S);
+    return sdc::check_launch("sdc_gn_silu_bwd");
+}
+
+extern "C" size_t sdc_chan_norm_bwd_parts(int B, int64_t S) { return (size_t)B * (size_t)((S + NT - 1) / NT); }
+
+extern "C" int sdc_chan_norm_bwd(const float* x, const float* gy, const float* g, float* gx, float* gpart, int B, int C, int64_t S,
+                                 int mode, float eps, void* stream) {
+    SDC_REQUIRE(x && gy && g && gx && gpart, SDC_ENULL, "sdc_chan_norm_bwd: null pointer");
+    SDC_REQUIRE(B > 0 && B < 65536 && C > 0 && S > 0 && (mode == 0 || mode == 1), SDC_EINVAL, "sdc_chan_norm_bwd: bad arguments");
+    hipStream_t s = sdc::as_stream(stream);
+    dim3 grid((unsigned)((S + NT - 1) / NT), (unsigned)B);
+    hipLaunchKernelGGL(chan_norm_bwd_kernel, grid, dim3(NT), 0, s, x, gy, g, gx, gpart, C, S, mode, eps);
+    hipLaunchKernelGGL(chan_norm_gaing_kernel, grid, dim3(NT), 0, s, x, gy, gpart, B, C, S, mode, eps);
+    return sdc::check_launch("sdc_chan_norm_bwd");
+}
+
+extern "C" int sdc_act_bwd(const float* x, const float* gy, float* gx, int64_t n, int kind, void* stream) {
+    SDC_REQUIRE(x && gy && gx, SDC_ENULL, "sdc_act_bwd: null pointer");
+    SDC_REQUIRE(n >= 0 && (kind == 0 || kind == 1), SDC_EINVAL, "sdc_act_bwd: bad arguments");
+    if (n == 0) return SDC_OK;
+    const int blocks = (int)((n + NT - 1) / NT < 8192 ? (n + NT - 1) / NT : 8192);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(NT), 0, sdc::as_stream(stream), x, gy, gx, n, kind);
+    return sdc::check_launch("sdc_act_bwd");
+}
+
+extern "C" int sdc_sumpool2(const float* g, float* gx, int64_t rows, int H, int W, int fh, int fw, void* stream) {
+    SDC_REQUIRE(g && gx, SDC_ENULL, "sdc_sumpool2: null pointer");
+    SDC_REQUIRE(rows > 0 && H > 0 && W > 0 && (fh == 1 || fh == 2) && (fw == 1 || fw == 2), SDC_EINVAL, "sdc_sumpool2: bad arguments");
+    const int64_t n = rows * H * W;
+    const int blocks = (int)((n + NT - 1) / NT < 8192 ? (n + NT - 1) / NT : 8192);
+    hipLaunchKernelGGL(sumpool_kernel, dim3(blocks), dim3(NT), 0, sdc::as_stream(stream), g, gx, rows, H, W, fh, fw);
+    return sdc::check_launch("sdc_sumpool2");
+}

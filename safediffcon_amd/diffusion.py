@@ -201,6 +201,25 @@ class _SamplerBase(nn.Module):
         self._lib = _lib.get_lib()
         self.use_graph = True
 
+    # -------------------------------------------------------------- fine-tuning loss
+    def q_sample(self, x_start, t, noise=None):
+        """1D/model/diffusion.py:629-636, 2d/ddpm/diffusion_2d.py:416-423"""
+        noise = torch.randn_like(x_start) if noise is None else noise
+        bshape = (x_start.shape[0],) + (1,) * (x_start.dim() - 1)
+        return self.sqrt_alphas_cumprod[t].reshape(bshape) * x_start + self.sqrt_one_minus_alphas_cumprod[t].reshape(bshape) * noise
+
+    def _loss_tail(self, model_out, target, t, mean, kind="l2"):
+        loss = (model_out - target) ** 2 if kind == "l2" else (model_out - target).abs()
+        loss = loss.flatten(1).mean(1)                       # reduce(loss, 'b ... -> b', 'mean')
+        if self.MODEL != "smoke":                            # loss_weight = 1 for pred_noise (1D/model/diffusion.py:160-166)
+            loss = loss * self.loss_weight[t]
+        return loss.mean() if mean else loss
+
+    def forward(self, img, *args, **kwargs):
+        """diffusion(state[, mean=False]) -> loss at random timesteps: 1D/model/diffusion.py:735-747, 2d/ddpm/diffusion_2d.py:454-458"""
+        t = torch.randint(0, self.num_timesteps, (img.shape[0],), device=img.device).long()
+        return self.p_losses(img, t, *args, **kwargs)
+
     # -------------------------------------------------------------- helpers
     def _coef(self, J_scheduler, k_const=1.0):
         """[T][8] = {a, b, c1, c2, sigma, k, 0, 0}; sigma = exp(0.5*logvar) (0 at t=0: 'no noise if t == 0')."""
@@ -533,6 +552,33 @@ class GaussianDiffusionBurgers(_SamplerBase):
     def _sample_shape(self, B):
         return (B, self.channels, *self.traj_size)
 
+    def p_losses(self, x_start, t, noise=None, mean=True):
+        """1D/model/diffusion.py:638-733 for the configuration the reference builds (pred_noise, conditions on u0 / uT, padded
+        locations not trained on): eps through the differentiable HIP U-Net (safediffcon_amd.autograd), loss per sample."""
+        noise = torch.randn_like(x_start) if noise is None else noise.clone()
+        x = self.q_sample(x_start, t, noise)
+        ci = self.condition_idx
+        if self.is_condition_u0:
+            x[:, 0, 0, :] = x_start[:, 0, 0, :]
+        if self.is_condition_uT:
+            x[:, 0, ci, :] = x_start[:, 0, ci, :]
+        if not self.train_on_padded_locations:               # set_pad_condition(x): zeros
+            x[:, 0, ci + 1:, :] = 0
+            x[:, 1:3, ci:, :] = 0
+        model_out = self.model.forward_train(x, t)
+        target = noise
+        if self.is_condition_u0:                             # is_condition_u0_zero_pred_noise (default True)
+            target[:, 0, 0, :] = 0
+        if self.is_condition_uT:
+            target[:, 0, ci, :] = 0
+        if not self.train_on_padded_locations:               # set_pad_condition(model_out, origin_img=target)
+            keep = torch.ones_like(target, dtype=torch.bool)
+            keep[:, 0, ci + 1:, :] = False
+            keep[:, 1:3, ci:, :] = False
+            model_out = torch.where(keep, model_out, target)
+        return self._loss_tail(model_out, target, t, mean)
+
+
     @torch.no_grad()
     def sample(self, batch_size=16, clip_denoised=True, w_groundtruth=None, enable_grad=True, noise=None, **kwargs):
         """Reference signature (1D/model/diffusion.py:557-607) + ``noise`` (i -> tensor) for injected-noise parity."""
@@ -584,6 +630,32 @@ class GaussianDiffusionTokamak(_SamplerBase):
     def _sample_shape(self, B):
         return (B, self.channels, self.seq_length)
 
+    def p_losses(self, x_start, t, noise=None, mean=True):
+        """tokamak/model/diffusion.py:570-637 (pred_noise; conditions on u0 / uT; train_on_padded_locations as constructed)"""
+        noise = torch.randn_like(x_start) if noise is None else noise.clone()
+        x = self.q_sample(x_start, t, noise)
+        nt = self.nt
+        if self.is_condition_u0:
+            x[:, :3, 0] = x_start[:, :3, 0]
+        if self.is_condition_uT:
+            x[:, [0, 2], :nt] = x_start[:, [0, 2], :nt]
+        if not self.train_on_padded_locations:
+            x[..., :3, nt:] = x_start[..., :3, nt:]
+            x[..., 3:, nt - 1:] = x_start[..., 3:, nt - 1:]
+        model_out = self.model.forward_train(x, t)
+        target = noise
+        if self.is_condition_u0:
+            target[:, :3, 0] = 0
+        if self.is_condition_uT:
+            target[:, [0, 2], :nt] = 0
+        if not self.train_on_padded_locations:
+            keep = torch.ones_like(target, dtype=torch.bool)
+            keep[..., :3, nt:] = False
+            keep[..., 3:, nt - 1:] = False
+            model_out = torch.where(keep, model_out, target)
+        return self._loss_tail(model_out, target, t, mean)
+
+
     @torch.no_grad()
     def sample(self, batch_size=16, clip_denoised=True, w_groundtruth=None, enable_grad=True, noise=None, **kwargs):
         """Reference signature (tokamak/model/diffusion.py:498-539)."""
@@ -630,6 +702,16 @@ class GaussianDiffusionSmoke(_SamplerBase):
 
     def _sample_shape(self, B):
         return (B, self.frames, self.channels, self.image_size, self.image_size)
+
+    def p_losses(self, state_start, t, noise=None, mean=True):
+        """2d/ddpm/diffusion_2d.py:434-452: frame-0 density conditioned, its noise target zeroed; l1 / l2 per sample"""
+        noise = torch.randn_like(state_start) if noise is None else noise.clone()
+        state = self.q_sample(state_start, t, noise)
+        state[:, 0, 0] = state_start[:, 0, 0]
+        noise[:, 0, 0] = 0
+        model_out = self.model.forward_train(state, t)
+        return self._loss_tail(model_out, noise, t, mean, kind="l2" if self.loss_type == "l2" else "l1")
+
 
     @torch.no_grad()
     def sample(self, batch_size=16, design_fn=None, enable_grad=False, init=None, control=None, device=None, noise=None,

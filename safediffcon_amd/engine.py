@@ -32,6 +32,62 @@ def as5(t):
     return t
 
 
+def pack_conv_weight(t, kind="conv", precision=0):
+    """Kernel layout of a conv weight (include/sdc.h, SdcConvDesc.precision):
+    nn.Conv{1,2,3}d weight (Cout,Cin,*k) -> Wp [taps*Cin][Cout], followed for precision >= 2 by the Winograd taps;
+    kind 'convT': nn.ConvTranspose3d weight (Cin,Cout,*k) -> flipped-tap conv weight;
+    kind 'unshuffle': 1x1 conv after 'b c (h p1) (w p2) -> b (c p1 p2) h w' -> 2x2 stride-2 conv;
+    kind ('convT_sub', ph, pw) / ('up2_sub', ph, pw): the sub-pixel forms below."""
+    def base():
+        if kind == "convT":
+            t5 = as5(t)                                   # (Cin, Cout, kD, kH, kW)
+            t5 = t5.flip(2, 3, 4).permute(2, 3, 4, 0, 1)  # (kD,kH,kW,Cin,Cout)
+            return t5.reshape(-1, t5.shape[-1]).contiguous()
+        if isinstance(kind, tuple) and kind[0] == "convT_sub":
+            # sub-pixel form of ConvTranspose (1,4,4)/(1,2,2)/(0,1,1): output parity (ph, pw) is a 2x2 conv of the
+            # input with taps kh in (3,1) [ph=0] / (2,0) [ph=1] (same along W): out[2j+ph] = sum_t x[j+t-(1-ph)] W[kh_t]
+            _, ph, pw = kind
+            t5 = as5(t)                                   # (Cin, Cout, 1, 4, 4)
+            kh = (3, 1) if ph == 0 else (2, 0)
+            kw = (3, 1) if pw == 0 else (2, 0)
+            sub = t5[:, :, 0][:, :, list(kh)][:, :, :, list(kw)]       # (Cin, Cout, 2, 2)
+            return sub.permute(2, 3, 0, 1).reshape(-1, sub.shape[1]).contiguous()
+        if isinstance(kind, tuple) and kind[0] == "up2_sub":
+            # nearest x2 upsampling + 3x3 conv (pad 1), output parity (ph, pw): rows 2i+ph of the upsampled image see
+            # x[i-1], x[i], x[i] (ph = 0) or x[i], x[i], x[i+1] (ph = 1) -> a 2-tap kernel with merged weights
+            # (W0, W1+W2) on rows (i-1, i)  /  (W0+W1, W2) on rows (i, i+1); same along W.  9 taps -> 4.
+            _, ph, pw = kind
+            t5 = as5(t).to(torch.float64)                 # (Cout, Cin, 1, 3, 3)
+            mh = torch.tensor([[1, 0, 0], [0, 1, 1]] if ph == 0 else [[1, 1, 0], [0, 0, 1]], dtype=torch.float64, device=t5.device)
+            mw = torch.tensor([[1, 0, 0], [0, 1, 1]] if pw == 0 else [[1, 1, 0], [0, 0, 1]], dtype=torch.float64, device=t5.device)
+            sub = torch.einsum("ah,bw,oihw->oiab", mh, mw, t5[:, :, 0])                 # (Cout, Cin, 2, 2)
+            return sub.permute(2, 3, 1, 0).reshape(-1, sub.shape[0]).to(torch.float32).contiguous()
+        if kind == "unshuffle":
+            co, c4 = t.shape[0], t.shape[1]
+            t4 = t.reshape(co, c4 // 4, 2, 2)             # (Cout, C, p1, p2)
+            return t4.permute(2, 3, 1, 0).reshape(-1, co).contiguous()
+        t5 = as5(t)                                       # (Cout, Cin, kD, kH, kW)
+        return t5.permute(2, 3, 4, 1, 0).reshape(-1, t5.shape[0]).contiguous()
+    wp = base().to(torch.float32)
+    if precision not in (2, 3, 4) or kind != "conv" or t.shape[-1] != 3:
+        return wp
+    # fp32 Wp followed by the Winograd F(2,3) taps along W, [(kd*kH + kh)*4 + xi][Cin][Cout]:
+    # G g with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], formed in fp64 and rounded once;
+    # precision 3 appends, for 3x3 (kH = kW = 3) taps, the F(2x2,3x3) taps G g G^T over (H, W): [kd][Cin][Cout][j*4 + xi]
+    t5 = as5(t).to(torch.float64)                 # (Cout, Cin, kD, kH, 3)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64, device=t5.device)
+    u = torch.einsum("xk,oidhk->dhxio", G, t5)    # (kD, kH, 4, Cin, Cout)
+    parts = [wp.reshape(-1), u.reshape(-1).to(torch.float32)]
+    if precision >= 3 and t5.shape[3] == 3:
+        u2 = torch.einsum("jh,xk,oidhk->diojx", G, G, t5)   # (kD, Cin, Cout, 4, 4): 16 components contiguous
+        parts.append(u2.reshape(-1).to(torch.float32))
+        if precision == 4 and t5.shape[2] == 3:
+            # F(2x2x2,3x3x3) taps, G along the depth as well: [jd][Cin][Cout][j*4 + xi]
+            u3 = torch.einsum("zd,jh,xk,oidhk->ziojx", G, G, G, t5)
+            parts.append(u3.reshape(-1).to(torch.float32))
+    return torch.cat(parts)
+
+
 class Pool:
     """Size-keyed free list so that activation buffers are reused along the plan."""
 
@@ -115,63 +171,8 @@ class Plan:
         return w
 
     def conv_weight(self, w, kind="conv"):
-        """nn.Conv{1,2,3}d weight (Cout,Cin,*k) -> [taps*Cin][Cout];
-        kind 'convT': nn.ConvTranspose3d weight (Cin,Cout,*k) -> flipped-tap conv weight;
-        kind 'unshuffle': 1x1 conv after 'b c (h p1) (w p2) -> b (c p1 p2) h w' -> 2x2 stride-2 conv."""
-        def fn():
-            t = w() if callable(w) else w
-            if kind == "convT":
-                t5 = as5(t)                                   # (Cin, Cout, kD, kH, kW)
-                t5 = t5.flip(2, 3, 4).permute(2, 3, 4, 0, 1)  # (kD,kH,kW,Cin,Cout)
-                return t5.reshape(-1, t5.shape[-1]).contiguous()
-            if isinstance(kind, tuple) and kind[0] == "convT_sub":
-                # sub-pixel form of ConvTranspose (1,4,4)/(1,2,2)/(0,1,1): output parity (ph, pw) is a 2x2 conv of the
-                # input with taps kh in (3,1) [ph=0] / (2,0) [ph=1] (same along W): out[2j+ph] = sum_t x[j+t-(1-ph)] W[kh_t]
-                _, ph, pw = kind
-                t5 = as5(t)                                   # (Cin, Cout, 1, 4, 4)
-                kh = (3, 1) if ph == 0 else (2, 0)
-                kw = (3, 1) if pw == 0 else (2, 0)
-                sub = t5[:, :, 0][:, :, list(kh)][:, :, :, list(kw)]       # (Cin, Cout, 2, 2)
-                return sub.permute(2, 3, 0, 1).reshape(-1, sub.shape[1]).contiguous()
-            if isinstance(kind, tuple) and kind[0] == "up2_sub":
-                # nearest x2 upsampling + 3x3 conv (pad 1), output parity (ph, pw): rows 2i+ph of the upsampled image see
-                # x[i-1], x[i], x[i] (ph = 0) or x[i], x[i], x[i+1] (ph = 1) -> a 2-tap kernel with merged weights
-                # (W0, W1+W2) on rows (i-1, i)  /  (W0+W1, W2) on rows (i, i+1); same along W.  9 taps -> 4.
-                _, ph, pw = kind
-                t5 = as5(t).to(torch.float64)                 # (Cout, Cin, 1, 3, 3)
-                mh = torch.tensor([[1, 0, 0], [0, 1, 1]] if ph == 0 else [[1, 1, 0], [0, 0, 1]], dtype=torch.float64, device=t5.device)
-                mw = torch.tensor([[1, 0, 0], [0, 1, 1]] if pw == 0 else [[1, 1, 0], [0, 0, 1]], dtype=torch.float64, device=t5.device)
-                sub = torch.einsum("ah,bw,oihw->oiab", mh, mw, t5[:, :, 0])                 # (Cout, Cin, 2, 2)
-                return sub.permute(2, 3, 1, 0).reshape(-1, sub.shape[0]).to(torch.float32).contiguous()
-            if kind == "unshuffle":
-                co, c4 = t.shape[0], t.shape[1]
-                t4 = t.reshape(co, c4 // 4, 2, 2)             # (Cout, C, p1, p2)
-                return t4.permute(2, 3, 1, 0).reshape(-1, co).contiguous()
-            t5 = as5(t)                                       # (Cout, Cin, kD, kH, kW)
-            return t5.permute(2, 3, 4, 1, 0).reshape(-1, t5.shape[0]).contiguous()
-        if self.precision in (2, 3, 4):
-            # fp32 Wp followed by the Winograd F(2,3) taps along W, [(kd*kH + kh)*4 + xi][Cin][Cout]:
-            # G g with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], formed in fp64 and rounded once;
-            # precision 3 appends, for 3x3 (kH = kW = 3) taps, the F(2x2,3x3) taps G g G^T over (H, W): [kd][Cin][Cout][j*4 + xi]
-            def fnw():
-                wp = fn().to(torch.float32)
-                t = w() if callable(w) else w
-                if kind != "conv" or t.shape[-1] != 3:
-                    return wp
-                t5 = as5(t).to(torch.float64)                 # (Cout, Cin, kD, kH, 3)
-                G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64, device=t5.device)
-                u = torch.einsum("xk,oidhk->dhxio", G, t5)    # (kD, kH, 4, Cin, Cout)
-                parts = [wp.reshape(-1), u.reshape(-1).to(torch.float32)]
-                if self.precision >= 3 and t5.shape[3] == 3:
-                    u2 = torch.einsum("jh,xk,oidhk->diojx", G, G, t5)   # (kD, Cin, Cout, 4, 4): 16 components contiguous
-                    parts.append(u2.reshape(-1).to(torch.float32))
-                    if self.precision == 4 and t5.shape[2] == 3:
-                        # F(2x2x2,3x3x3) taps, G along the depth as well: [jd][Cin][Cout][j*4 + xi]
-                        u3 = torch.einsum("zd,jh,xk,oidhk->ziojx", G, G, G, t5)
-                        parts.append(u3.reshape(-1).to(torch.float32))
-                return torch.cat(parts)
-            return self.packed(fnw)
-        return self.packed(fn)
+        """Register the kernel layout of a conv weight (pack_conv_weight), refreshed by refresh_weights()."""
+        return self.packed(lambda: pack_conv_weight(w() if callable(w) else w, kind, self.precision))
 
     def vec(self, p):
         return self.packed(lambda: (p() if callable(p) else p).reshape(-1))

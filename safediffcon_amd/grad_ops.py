@@ -1,0 +1,126 @@
+"""Thin tensor-level wrappers of the backward (VJP) entry points of libsdc_hip.so (include/sdc.h, "backward").
+
+PyTorch is plumbing here: device memory and the current stream.  Every function takes / returns fp32 CUDA (HIP) tensors
+and launches asynchronously on torch's current stream; there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import SdcWgradDesc, check
+from .engine import as5
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("safediffcon_amd runs on MI355X only: tensors must be on a cuda (HIP) device; there is no CPU fallback")
+
+
+def conv_wgrad(g, x, k, stride=(1, 1, 1), pad=(0, 0, 0), up=(1, 1, 1), bias=True):
+    """dw[m][n][k...] = sum_{b,pos} g[b][m][pos] x[b][n][pos*s - p + tap]   (sdc_conv_wgrad)
+    g (B, M, oD, oH, oW) and x (B, N, iD, iH, iW) are 5-D views (any strides); returns (dw (M, N, kD, kH, kW), dbias (M,) | None)."""
+    _need_cuda(g, x)
+    g, x = as5(g), as5(x)
+    lib = _lib.get_lib()
+    d = SdcWgradDesc()
+    d.B, d.M, d.N = g.shape[0], g.shape[1], x.shape[1]
+    d.oD, d.oH, d.oW = g.shape[2:]
+    d.iD, d.iH, d.iW = x.shape[2:]
+    d.kD, d.kH, d.kW = k
+    d.sD, d.sH, d.sW = stride
+    d.pD, d.pH, d.pW = pad
+    d.uD, d.uH, d.uW = up
+    d.gs[:] = tuple(int(s) for s in g.stride())
+    d.xs[:] = tuple(int(s) for s in x.stride())
+    nbytes = int(lib.sdc_conv_wgrad_bytes(C.byref(d)))
+    work = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.device)
+    dw = torch.empty((d.M, d.N, *k), dtype=torch.float32, device=g.device)
+    db = torch.empty(d.M, dtype=torch.float32, device=g.device) if bias else None
+    check(lib.sdc_conv_wgrad(C.byref(d), g.data_ptr(), x.data_ptr(), dw.data_ptr(), 0 if db is None else db.data_ptr(),
+                             work.data_ptr(), nbytes, _stream(g)), "sdc_conv_wgrad")
+    return dw, db
+
+
+def gn_stats(h, groups, eps=1e-5):
+    """(mean, rstd) table of sdc_gn_stats for a contiguous (B, C, ...) tensor"""
+    _need_cuda(h)
+    lib = _lib.get_lib()
+    B, Cc = h.shape[0], h.shape[1]
+    S = h.numel() // (B * Cc)
+    st = torch.empty((int(lib.sdc_gn_stats_bytes(B, groups)) + 3) // 4, dtype=torch.float32, device=h.device)
+    check(lib.sdc_gn_stats(h.data_ptr(), st.data_ptr(), B, Cc, groups, S, eps, _stream(h)), "sdc_gn_stats")
+    return st
+
+
+def gn_apply(h, st, gamma, beta, groups, ss=None, residual=None):
+    """y = SiLU(GN(h) (scale + 1) + shift) (+ residual), out of place; ss (B, 2C) rows [scale | shift] or None"""
+    lib = _lib.get_lib()
+    B, Cc = h.shape[0], h.shape[1]
+    S = h.numel() // (B * Cc)
+    y = torch.empty_like(h)
+    check(lib.sdc_gn_apply(h.data_ptr(), st.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 0 if ss is None else ss.data_ptr(), 0,
+                           0, 0 if ss is None else ss.stride(0), 0, 0 if residual is None else residual.data_ptr(), y.data_ptr(),
+                           B, Cc, groups, S, _stream(h)), "sdc_gn_apply")
+    return y
+
+
+def gn_silu_bwd(h, gy, st, gamma, beta, groups, ss=None):
+    """-> (gh, dgamma, dbeta, dss | None): backward of gn_apply (the residual's gradient is gy itself)"""
+    _need_cuda(h, gy)
+    lib = _lib.get_lib()
+    B, Cc = h.shape[0], h.shape[1]
+    S = h.numel() // (B * Cc)
+    gy = gy.contiguous()
+    rows = torch.empty((B, Cc, 2), dtype=torch.float32, device=h.device)
+    gh = torch.empty_like(h)
+    check(lib.sdc_gn_silu_bwd(h.data_ptr(), gy.data_ptr(), st.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                              0 if ss is None else ss.data_ptr(), 0 if ss is None else ss.stride(0), rows.data_ptr(), gh.data_ptr(),
+                              B, Cc, groups, S, _stream(h)), "sdc_gn_silu_bwd")
+    # parameter gradients: O(B C) sums over the row table
+    a1, a2 = rows[..., 0], rows[..., 1]
+    if ss is None:
+        return gh, a2.sum(0), a1.sum(0), None
+    sc1 = ss[:, :Cc] + 1.0
+    dss = torch.cat((gamma[None] * a2 + beta[None] * a1, a1), dim=1)
+    return gh, (sc1 * a2).sum(0), (sc1 * a1).sum(0), dss
+
+
+def chan_norm_bwd(x, gy, g, mode, eps=1e-5):
+    """-> (gx, dgain): backward of sdc_chan_norm (mode 0 channel LayerNorm, 1 RMSNorm) for contiguous (B, C, ...) tensors"""
+    _need_cuda(x, gy)
+    lib = _lib.get_lib()
+    B, Cc = x.shape[0], x.shape[1]
+    S = x.numel() // (B * Cc)
+    gy = gy.contiguous()
+    nparts = int(lib.sdc_chan_norm_bwd_parts(B, S))
+    gpart = torch.empty((Cc, nparts), dtype=torch.float32, device=x.device)
+    gx = torch.empty_like(x)
+    gv = g.reshape(-1).contiguous()
+    check(lib.sdc_chan_norm_bwd(x.data_ptr(), gy.data_ptr(), gv.data_ptr(), gx.data_ptr(), gpart.data_ptr(), B, Cc, S, mode, eps,
+                                _stream(x)), "sdc_chan_norm_bwd")
+    return gx, gpart.sum(1)
+
+
+def act_bwd(x, gy, kind):
+    lib = _lib.get_lib()
+    gy = gy.contiguous()
+    gx = torch.empty_like(x)
+    check(lib.sdc_act_bwd(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), x.numel(), kind, _stream(x)), "sdc_act_bwd")
+    return gx
+
+
+def sumpool2(g, fh, fw):
+    """VJP of nearest upsampling by (fh, fw) over the last two axes of a contiguous tensor"""
+    lib = _lib.get_lib()
+    g = g.contiguous()
+    H, W = g.shape[-2] // fh, g.shape[-1] // fw
+    out = torch.empty((*g.shape[:-2], H, W), dtype=torch.float32, device=g.device)
+    rows = out.numel() // (H * W)
+    check(lib.sdc_sumpool2(g.data_ptr(), out.data_ptr(), rows, H, W, fh, fw, _stream(g)), "sdc_sumpool2")
+    return out

@@ -289,8 +289,26 @@ class _HipUNet(nn.Module):
         except KeyError:
             return False
 
+    def _trainer(self):
+        if getattr(self, "_train_ctx", None) is None:
+            from .autograd import Trainer
+            self._train_ctx = Trainer(self)
+        return self._train_ctx
+
+    def forward_train(self, x, time):
+        """eps = model(x, t) WITH an autograd graph over the parameters (fine-tuning path): every node runs
+        libsdc_hip.so kernels in both directions (safediffcon_amd/autograd.py).  ``forward`` stays the graph-replayed,
+        gradient-free sampler call."""
+        if not x.is_cuda:
+            raise RuntimeError("safediffcon_amd runs on MI355X only: tensors must be on a cuda (HIP) device; "
+                               "there is no CPU fallback")
+        from . import autograd
+        fn = autograd.forward_train_smoke if isinstance(self, Unet3D_with_Conv3D) else autograd.forward_train_lucid
+        return fn(self, x.to(torch.float32), time)
+
     def _drop_plans(self):
         """device moves / dtype casts invalidate bound pointers: destroy the captured graphs, forget the plans"""
+        self._train_ctx = None
         for e in self._plans.values():
             g = e.get("graph")
             if g is not None:

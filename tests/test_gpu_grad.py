@@ -1,0 +1,157 @@
+"""-m gpu: the backward (VJP) kernels of the fine-tuning path against torch autograd in fp64 (include/sdc.h "backward"):
+weight / bias gradient of every conv form the three U-Nets hold, GroupNorm + scale/shift + SiLU backward, channel
+LayerNorm / RMSNorm backward, SiLU / GELU backward, the nearest-upsample VJP.  Tolerances are relative to the gradient's
+scale (fp32 kernels, fp64 reference: summation order only)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.detweights import det_tensor
+from safediffcon_amd import grad_ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return ((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+CASES = [
+    # nd, B, cin, cout, spatial, k, stride, pad
+    dict(nd=3, B=2, cin=64, cout=64, sp=(4, 16, 32), k=3, pad=1),                      # smoke ResnetBlock conv (3 taps, 9 (kd, kh))
+    dict(nd=3, B=1, cin=7, cout=64, sp=(8, 16, 16), k=7, pad=3),                       # smoke stem, ragged Cin
+    dict(nd=3, B=2, cin=96, cout=40, sp=(2, 16, 16), k=3, pad=1),                      # ragged M and N tiles
+    dict(nd=2, B=3, cin=128, cout=64, sp=(16, 128), k=3, pad=1),                       # Burgers 3x3
+    dict(nd=2, B=2, cin=3, cout=64, sp=(16, 128), k=7, pad=3),                         # Burgers stem
+    dict(nd=1, B=5, cin=256, cout=512, sp=(32,), k=3, pad=1),                          # tokamak k3
+    dict(nd=1, B=4, cin=256, cout=512, sp=(64,), k=4, stride=2, pad=1),                # tokamak Downsample (k4 s2): oW = 32
+    dict(nd=1, B=3, cin=12, cout=256, sp=(128,), k=7, pad=3),                          # tokamak stem
+    dict(nd=2, B=2, cin=64, cout=384, sp=(16, 128), k=1),                              # 1x1 / to_qkv
+    dict(nd=3, B=2, cin=64, cout=64, sp=(2, 32, 32), k=(1, 4, 4), stride=(1, 2, 2), pad=(0, 1, 1)),   # smoke Downsample
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_wgrad_vs_autograd(case):
+    nd, B, cin, cout, sp = case["nd"], case["B"], case["cin"], case["cout"], case["sp"]
+    k = case["k"] if isinstance(case["k"], tuple) else (case["k"],) * nd
+    st = case.get("stride", 1)
+    st = st if isinstance(st, tuple) else (st,) * nd
+    pd = case.get("pad", 0)
+    pd = pd if isinstance(pd, tuple) else (pd,) * nd
+    x = det_tensor((B, cin, *sp), 91)
+    w = det_tensor((cout, cin, *k), 92, 0.1).double().requires_grad_()
+    b = det_tensor((cout,), 93, 0.1).double().requires_grad_()
+    y = (F.conv1d, F.conv2d, F.conv3d)[nd - 1](x.double(), w, b, stride=st, padding=pd)
+    gy = det_tensor(tuple(y.shape), 94)
+    y.backward(gy.double())
+    k3, s3, p3 = (1,) * (3 - nd) + k, (1,) * (3 - nd) + st, (0,) * (3 - nd) + pd
+    dw, db = grad_ops.conv_wgrad(gy.to(DEV), x.to(DEV), k3, s3, p3)
+    ew, eb = _rel(dw.reshape(w.shape), w.grad), _rel(db, b.grad)
+    print(f"[measured] wgrad {case}: rel err dw {ew:.2e} db {eb:.2e}")
+    assert ew < 2e-5 and eb < 2e-5
+
+
+def test_conv_transpose_and_upsample_wgrad():
+    """ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1) (smoke Upsample): G = x, X = dL/dy;  nn.Upsample(2) + Conv2d 3x3 (Burgers
+    Upsample2d) and Upsample + Conv1d k3 (tokamak): X read through the folded nearest upsampling; strided G views."""
+    x = det_tensor((2, 64, 2, 16, 16), 95)
+    w = det_tensor((64, 32, 1, 4, 4), 96, 0.1).double().requires_grad_()
+    y = F.conv_transpose3d(x.double(), w, None, stride=(1, 2, 2), padding=(0, 1, 1))
+    gy = det_tensor(tuple(y.shape), 97)
+    y.backward(gy.double())
+    dw, _ = grad_ops.conv_wgrad(x.to(DEV), gy.to(DEV), (1, 4, 4), (1, 2, 2), (0, 1, 1), bias=False)
+    assert _rel(dw, w.grad) < 2e-5
+
+    x = det_tensor((2, 64, 8, 32), 98)
+    w = det_tensor((32, 64, 3, 3), 99, 0.1).double().requires_grad_()
+    y = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w, None, padding=1)
+    gy = det_tensor(tuple(y.shape), 100)
+    y.backward(gy.double())
+    dw, _ = grad_ops.conv_wgrad(gy.to(DEV), x.to(DEV), (1, 3, 3), (1, 1, 1), (0, 1, 1), up=(1, 2, 2), bias=False)
+    assert _rel(dw.reshape(w.shape), w.grad) < 2e-5
+
+    x = det_tensor((3, 128, 16), 101)
+    w = det_tensor((64, 128, 3), 102, 0.1).double().requires_grad_()
+    y = F.conv1d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w, None, padding=1)
+    gy = det_tensor(tuple(y.shape), 103)
+    y.backward(gy.double())
+    dw, _ = grad_ops.conv_wgrad(gy.to(DEV), x.to(DEV), (1, 1, 3), (1, 1, 1), (0, 0, 1), up=(1, 1, 2), bias=False)
+    assert _rel(dw.reshape(w.shape), w.grad) < 2e-5
+
+    # a strided gradient view (frame-major smoke state: eps gradient arrives as (B,F,C,H,W).permute)
+    gfm = det_tensor((2, 8, 7, 16, 16), 104)
+    xin = det_tensor((2, 64, 8, 16, 16), 105)
+    w = det_tensor((7, 64, 1, 1, 1), 106, 0.1).double().requires_grad_()
+    y = F.conv3d(xin.double(), w)
+    y.backward(gfm.permute(0, 2, 1, 3, 4).double())
+    dw, db = grad_ops.conv_wgrad(gfm.to(DEV).permute(0, 2, 1, 3, 4), xin.to(DEV), (1, 1, 1))
+    assert _rel(dw, w.grad) < 2e-5 and _rel(db, gfm.double().sum((0, 1, 3, 4))) < 2e-5
+
+
+@pytest.mark.parametrize("shape,G,cond,res", [((3, 64, 4, 16, 16), 8, True, True), ((2, 128, 1, 8, 64), 1, True, False),
+                                              ((4, 256, 1, 1, 32), 1, False, True), ((2, 64, 8, 32, 32), 8, False, False)])
+def test_gn_silu_backward(shape, G, cond, res):
+    B, Cc = shape[0], shape[1]
+    h = det_tensor(shape, 110)
+    gamma, beta = 1 + 0.1 * det_tensor((Cc,), 111), 0.1 * det_tensor((Cc,), 112)
+    ss = 0.2 * det_tensor((B, 2 * Cc), 113) if cond else None
+    r = det_tensor(shape, 114) if res else None
+    gy = det_tensor(shape, 115)
+    hd = h.double().requires_grad_()
+    gd, bd = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    sd = ss.double().requires_grad_() if cond else None
+    u = F.group_norm(hd, G, gd, bd, eps=1e-5)
+    if cond:
+        bshape = (B, Cc) + (1,) * (len(shape) - 2)
+        u = u * (sd[:, :Cc].reshape(bshape) + 1) + sd[:, Cc:].reshape(bshape)
+    y = F.silu(u)
+    y.backward(gy.double())
+    hg = h.to(DEV)
+    st = grad_ops.gn_stats(hg, G)
+    y_hip = grad_ops.gn_apply(hg, st, gamma.to(DEV), beta.to(DEV), G, None if ss is None else ss.to(DEV), None if r is None else r.to(DEV))
+    want = y.detach() + (r.double() if res else 0)
+    assert _rel(y_hip, want) < 1e-5
+    gh, dg, db, dss = grad_ops.gn_silu_bwd(hg, gy.to(DEV), st, gamma.to(DEV), beta.to(DEV), G, None if ss is None else ss.to(DEV))
+    errs = dict(gh=_rel(gh, hd.grad), dgamma=_rel(dg, gd.grad), dbeta=_rel(db, bd.grad))
+    if cond:
+        errs["dss"] = _rel(dss, sd.grad)
+    print(f"[measured] gn_silu_bwd {shape} G={G}: {errs}")
+    assert max(errs.values()) < 5e-5
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("shape", [(2, 64, 4, 16, 16), (3, 256, 1, 1, 40)])
+def test_chan_norm_backward(mode, shape):
+    x = det_tensor(shape, 120)
+    g = 1 + 0.1 * det_tensor((shape[1],), 121)
+    gy = det_tensor(shape, 122)
+    xd, gd = x.double().requires_grad_(), g.double().requires_grad_()
+    gb = gd.reshape(1, -1, *([1] * (len(shape) - 2)))
+    if mode == 0:
+        var = xd.var(dim=1, unbiased=False, keepdim=True)
+        y = (xd - xd.mean(dim=1, keepdim=True)) * (var + 1e-5).rsqrt() * gb
+    else:
+        y = F.normalize(xd, dim=1) * gb * (shape[1] ** 0.5)
+    y.backward(gy.double())
+    gx, dgain = grad_ops.chan_norm_bwd(x.to(DEV), gy.to(DEV), g.to(DEV), mode)
+    e1, e2 = _rel(gx, xd.grad), _rel(dgain, gd.grad)
+    print(f"[measured] chan_norm_bwd mode {mode} {shape}: gx {e1:.2e} dgain {e2:.2e}")
+    assert e1 < 2e-5 and e2 < 2e-5
+
+
+def test_act_backward_and_sumpool():
+    x, gy = det_tensor((5, 333), 130, 2.0), det_tensor((5, 333), 131)
+    for kind, fn in ((0, F.silu), (1, F.gelu)):
+        xd = x.double().requires_grad_()
+        fn(xd).backward(gy.double())
+        assert _rel(grad_ops.act_bwd(x.to(DEV), gy.to(DEV), kind), xd.grad) < 2e-6
+    g = det_tensor((2, 3, 8, 32), 132)
+    xd = det_tensor((2, 3, 4, 16), 133).double().requires_grad_()
+    F.interpolate(xd, scale_factor=2, mode="nearest").backward(g.double())
+    assert _rel(grad_ops.sumpool2(g.to(DEV), 2, 2), xd.grad) < 1e-6
+    g1 = det_tensor((2, 3, 32), 134)
+    xd = det_tensor((2, 3, 16), 135).double().requires_grad_()
+    F.interpolate(xd, scale_factor=2, mode="nearest").backward(g1.double())
+    assert _rel(grad_ops.sumpool2(g1.to(DEV).unsqueeze(-2), 1, 2).squeeze(-2), xd.grad) < 1e-6
