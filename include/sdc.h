@@ -269,7 +269,7 @@ int sdc_burgers_rollout(const float* u0, const float* f, float* traj, int N, int
  * (terms outside X are zero; uD/uH/uW in {1,2} = nearest upsampling of X folded into the read, nn.Upsample + conv).
  * For a conv  y = conv(x, w): G = dL/dy (M = Cout), X = x (N = Cin) -> dw in nn.Conv layout (Cout, Cin, k...).
  * For a transposed conv y = convT(x, w): G = x (M = Cin), X = dL/dy (N = Cout), s/p of the layer -> nn.ConvTranspose layout.
- * dbias[m] = sum G[b][m][...] or null.  oW must be a multiple of 16; (kW, sW) in {(1,1),(3,1),(7,1),(4,2),(2,2)}.
+ * dbias[m] = sum G[b][m][...] or null.  (kW, sW) in {(1,1),(3,1),(7,1),(4,2),(2,2)}; rows are walked in chunks of 16 positions.
  * fp32 MFMA; the positions are split over workgroups and summed in a fixed order (deterministic). */
 typedef struct SdcWgradDesc {
     int32_t B, M, N;

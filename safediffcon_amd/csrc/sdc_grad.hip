@@ -56,13 +56,14 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
     const int R = d.B * d.oD * d.oH;
     const int r_lo = split * a.rows_per_split;
     const int r_hi = min(R, r_lo + a.rows_per_split);
-    const int chunks_per_row = d.oW / BKP;
+    const int chunks_per_row = (d.oW + BKP - 1) / BKP;      // a ragged last chunk is zero-filled
 
     // G fetch: thread -> (m = tid >> 2, positions 4 (tid & 3) .. + 3)
     const int gm = tid >> 2, gq = tid & 3;
     const bool gm_ok = m0 + gm < d.M;
     const int64_t g_moff = (int64_t)(gm_ok ? m0 + gm : 0) * d.gs[1];
     const bool gvec = d.gs[4] == 1 && ((d.gs[0] | d.gs[1] | d.gs[2] | d.gs[3]) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.g) & 15) == 0;
+    // (16-byte loads need every row start 16-byte aligned: the strides above; a row's chunks start at multiples of 16 positions)
     // X fetch: element e = tid + NT i -> (n = e / SPAN, j = e % SPAN)
     int xn[NBL], xj[NBL];
     int64_t x_noff[NBL];
@@ -102,12 +103,13 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
         const float* gp = a.g + (int64_t)b * d.gs[0] + (int64_t)od * d.gs[2] + (int64_t)oh * d.gs[3] + g_moff + (int64_t)(ow0 + 4 * gq) * d.gs[4];
         if (rv || want_bias) {
             if (gm_ok) {
-                if (gvec) {
+                const int left = d.oW - (ow0 + 4 * gq);              // positions of this thread inside the row
+                if (gvec && left >= 4) {
                     const float4 v = *reinterpret_cast<const float4*>(gp);
                     greg[0] = v.x; greg[1] = v.y; greg[2] = v.z; greg[3] = v.w;
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) greg[i] = gp[(int64_t)i * d.gs[4]];
+                    for (int i = 0; i < 4; ++i) greg[i] = i < left ? gp[(int64_t)i * d.gs[4]] : 0.0f;
                 }
             } else {
 #pragma unroll
@@ -226,7 +228,6 @@ extern "C" int sdc_conv_wgrad(const SdcWgradDesc* dp, const float* g, const floa
     const SdcWgradDesc& d = *dp;
     SDC_REQUIRE(d.B > 0 && d.M > 0 && d.N > 0 && d.oD > 0 && d.oH > 0 && d.oW > 0 && d.iD > 0 && d.iH > 0 && d.iW > 0, SDC_EINVAL,
                 "sdc_conv_wgrad: bad sizes");
-    SDC_REQUIRE(d.oW % 16 == 0, SDC_EINVAL, "sdc_conv_wgrad: the output row length must be a multiple of 16 (got %d)", d.oW);
     SDC_REQUIRE(work_bytes >= sdc_conv_wgrad_bytes(dp), SDC_EINVAL, "sdc_conv_wgrad: workspace too small");
     SDC_REQUIRE((int64_t)d.B * d.oD * d.oH < (1ll << 31), SDC_EINVAL, "sdc_conv_wgrad: too many output rows");
     WgradArgs a;

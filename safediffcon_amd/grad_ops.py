@@ -27,6 +27,10 @@ def conv_wgrad(g, x, k, stride=(1, 1, 1), pad=(0, 0, 0), up=(1, 1, 1), bias=True
     g (B, M, oD, oH, oW) and x (B, N, iD, iH, iW) are 5-D views (any strides); returns (dw (M, N, kD, kH, kW), dbias (M,) | None)."""
     _need_cuda(g, x)
     g, x = as5(g), as5(x)
+    if tuple(k) == (1, 1, 1) and g.shape[2:] == (1, 1, 1) and x.shape[2:] == (1, 1, 1) and g.shape[0] > 1:
+        # nn.Linear over a batch of rows: the batch is the position axis (16 rows per MFMA chunk instead of one)
+        g = g.reshape(g.shape[0], g.shape[1]).t().reshape(1, g.shape[1], 1, 1, g.shape[0])
+        x = x.reshape(x.shape[0], x.shape[1]).t().reshape(1, x.shape[1], 1, 1, x.shape[0])
     lib = _lib.get_lib()
     d = SdcWgradDesc()
     d.B, d.M, d.N = g.shape[0], g.shape[1], x.shape[1]

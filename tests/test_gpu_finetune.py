@@ -1,0 +1,108 @@
+"""-m gpu: the fine-tuning path against fixtures produced by the REAL reference
+(oracle/make_goldens.py gen_grad): loss_b = p_losses(x_start, t, noise, mean=False), total = mean(weight_b * loss_b),
+total.backward() -- loss values and the gradient of EVERY parameter (L2 norm + a fixed random projection per key, full
+tensors for the small ones and three conv weights).  The drop-in nets run libsdc_hip.so kernels in both directions
+(safediffcon_amd/autograd.py)."""
+import numpy as np
+import pytest
+import torch
+
+import safediffcon_amd as sdc
+from oracle.detweights import det_params, det_tensor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(tree, spec):
+    if tree == "burgers":
+        net = sdc.Unet2D(dim=8, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+        net.load_state_dict(det_params(spec, 100))
+        gd = sdc.GaussianDiffusionBurgers(net.to(DEV), seq_length=(16, 128), timesteps=1000, temporal=True, use_conv2d=True,
+                                          is_condition_u0=True, is_condition_uT=True, condition_idx=10,
+                                          train_on_padded_locations=False).to(DEV)
+        x0, noise = det_tensor((3, 3, 16, 128), 5000, 0.3), det_tensor((3, 3, 16, 128), 5001)
+    elif tree == "tokamak":
+        net = sdc.Unet1D(dim=8, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+        net.load_state_dict(det_params(spec, 200))
+        gd = sdc.GaussianDiffusionTokamak(net.to(DEV), seq_length=128, nt=122, timesteps=1000, guidance_u0=True).to(DEV)
+        x0, noise = det_tensor((3, 12, 128), 5010, 0.3), det_tensor((3, 12, 128), 5011)
+    else:
+        net = sdc.Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2, 4), channels=7)
+        net.load_state_dict(det_params(spec, 300))
+        gd = sdc.GaussianDiffusionSmoke(net.to(DEV), image_size=16, frames=8, timesteps=1000, loss_type="l2",
+                                        standard_fixed_ratio=100.0).to(DEV)
+        x0, noise = det_tensor((3, 8, 7, 16, 16), 5020, 0.3), det_tensor((3, 8, 7, 16, 16), 5021)
+    return net, gd, x0, noise
+
+
+@pytest.mark.parametrize("tree", ["burgers", "tokamak", "smoke"])
+def test_finetune_loss_and_gradients_vs_reference(golden, tree):
+    g = golden(tree + "_grad")
+    net, gd, x0, noise = _build(tree, golden(tree + "_unet").spec())
+    net.train()
+    loss_b = gd.p_losses(x0.to(DEV), g["t"].to(DEV), noise=noise.to(DEV), mean=False)
+    total = (g["weight"].to(DEV) * loss_b).mean()
+    total.backward()
+    el = ((loss_b.detach().cpu() - g["loss_b"]).abs() / g["loss_b"].abs()).max().item()
+    assert el < 2e-5 and abs(total.item() - g.scalar("total")) < 2e-5 * abs(g.scalar("total")), (el, total.item(), g.scalar("total"))
+    keys = [str(k) for k in g["grad_keys"]]
+    params = dict(net.named_parameters())
+    seed = int(g.scalar("dot_seed"))
+    worst_n = worst_d = worst_f = 0.0
+    noise_keys = 0
+    gmax = float(np.max(g.z["grad_norms"]))
+    for i, k in enumerate(keys):
+        gr = params[k].grad
+        assert gr is not None, f"no gradient for {k}"
+        gr = gr.detach().double().cpu()
+        n_ref, d_ref = float(g.z["grad_norms"][i]), float(g.z["grad_dots"][i])
+        # gradients that are zero in exact arithmetic (a conv bias in front of a GroupNorm with one channel per group) are
+        # rounding noise on both sides: they only have to be as small here as they are in the reference
+        if n_ref < 1e-4 * gmax:
+            assert gr.norm().item() < 2e-4 * gmax, (k, gr.norm().item(), n_ref, gmax)
+            noise_keys += 1
+            continue
+        scale = n_ref
+        en = abs(gr.norm().item() - n_ref) / scale
+        proj = det_tensor(tuple(gr.shape), seed + i).double()
+        ed = abs((gr * proj).sum().item() - d_ref) / (scale * proj.norm().item())
+        worst_n, worst_d = max(worst_n, en), max(worst_d, ed)
+        assert en < 5e-5 and ed < 5e-5, (k, en, ed, n_ref)
+        if "grad:" + k in g.keys():
+            full = g["grad:" + k].double()
+            ef = ((gr - full).abs().max() / full.abs().max()).item()
+            worst_f = max(worst_f, ef)
+            assert ef < 1e-4, (k, ef)
+    # every parameter of the reference model received a gradient digest, and vice versa
+    assert set(keys) == set(params) or set(keys) == {k for k in params if not k.endswith("rotary_emb.freqs")} | {k for k in keys if k.endswith("rotary_emb.freqs")}
+    print(f"[measured] {tree} fine-tune step vs the reference: loss rel err {el:.2e}; gradients of {len(keys)} parameters: "
+          f"worst norm err {worst_n:.2e}, worst projection err {worst_d:.2e}, worst element err (stored tensors) {worst_f:.2e}; "
+          f"{noise_keys} gradients are zero in exact arithmetic (checked for smallness only)")
+
+
+def test_finetune_step_updates_the_sampler():
+    """loss.backward(); optimizer.step(); net.refresh() -> the graph-replayed sampler sees the new weights"""
+    torch.manual_seed(0)
+    net = sdc.Unet2D(dim=16, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1).to(DEV)
+    gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=1000, temporal=True, use_conv2d=True,
+                                      is_condition_u0=True, is_condition_uT=True).to(DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    x, t = det_tensor((2, 3, 16, 128), 1).to(DEV), torch.tensor([5, 700], device=DEV)
+    e0 = net(x, t)
+    state = det_tensor((4, 3, 16, 128), 2, 0.3).to(DEV)
+    losses = []
+    for _ in range(3):
+        torch.manual_seed(1)
+        loss = (torch.ones(4, device=DEV) * gd(state, mean=False)).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        net.refresh()
+        losses.append(loss.item())
+    e1 = net(x, t)
+    assert losses[-1] < losses[0] and not torch.equal(e0, e1) and torch.isfinite(e1).all()
+    # the differentiable forward and the sampler forward are the same function of the weights
+    with torch.no_grad():
+        e2 = net.forward_train(x, t)
+    assert (e1 - e2).abs().max().item() < 1e-4 * e1.abs().max().item()
