@@ -273,6 +273,72 @@ def strawman(name, batch, steps, dim, dev):
                 value=round(batch / (T_DDPM * s), 4), unit="trajectories/s")
 
 
+def finetune_step(name, batch, dim, dev, steps=3):
+    """One fine-tuning step (loss = mean(w_b p_losses_b); loss.backward(), 2d/inference_2d.py:267-279) through the
+    drop-in net's differentiable HIP path, beside the same step of the oracle's functional net under PyTorch-ROCm autograd."""
+    import torch
+    import safediffcon_amd as sdc
+    from oracle import nets as onets
+    from oracle.detweights import det_tensor
+    torch.manual_seed(0)
+    if name == "c2":
+        net = sdc.Unet2D(dim=dim or 64, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1).to(dev)
+        gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=T_DDPM, temporal=True, use_conv2d=True,
+                                          is_condition_u0=True, is_condition_uT=True, condition_idx=10).to(dev)
+        shape, fwd, kw = (3, 16, 128), onets.unet_burgers, dict(dim=net.dim)
+    elif name == "c3":
+        net = sdc.Unet1D(dim=dim or 256, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1).to(dev)
+        gd = sdc.GaussianDiffusionTokamak(net, seq_length=128, nt=122, timesteps=T_DDPM).to(dev)
+        shape, fwd, kw = (12, 128), onets.unet_tokamak, dict(dim=net.dim)
+    else:
+        net = sdc.Unet3D_with_Conv3D(dim=dim or 64, dim_mults=(1, 2, 4), channels=7).to(dev)
+        gd = sdc.GaussianDiffusionSmoke(net, image_size=64, frames=32, timesteps=T_DDPM, loss_type="l2").to(dev)
+        shape, fwd, kw = (32, 7, 64, 64), onets.unet_smoke, dict(dim=net.dim, dim_mults=(1, 2, 4))
+    state = det_tensor((batch, *shape), 9, 0.3).to(dev)
+    w = torch.ones(batch, device=dev)
+    t = torch.randint(0, T_DDPM, (batch,), generator=torch.Generator().manual_seed(3)).to(dev)
+    noise = det_tensor((batch, *shape), 10).to(dev)
+
+    def hip_step():
+        net.zero_grad(set_to_none=True)
+        loss = (w * gd.p_losses(state, t, noise=noise, mean=False)).mean()
+        loss.backward()
+        return loss
+
+    P = {k: v.detach().clone().requires_grad_() for k, v in net.state_dict().items()}
+
+    def eager_step():
+        for v in P.values():
+            v.grad = None
+        x = gd.q_sample(state, t, noise)
+        eps = fwd(P, x, t, **kw)
+        loss = (w * ((eps - noise) ** 2).flatten(1).mean(1)).mean()
+        loss.backward()
+        return loss
+
+    def timeit(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+    ms_hip = timeit(hip_step)
+    out = dict(what="loss = mean(w_b p_losses_b(state)); loss.backward()  (U-Net forward + backward, all parameter gradients)",
+               batch=batch, hip_ms=round(ms_hip, 2), hip_ms_per_sample=round(ms_hip / batch, 2),
+               backward="convs, GroupNorm/SiLU, time MLP on libsdc_hip.so kernels in both directions; attention blocks: HIP forward, "
+                        "PyTorch-ROCm VJP (round-3 stage)")
+    try:
+        ms_eager = timeit(eager_step)
+        out.update(torch_rocm_autograd_ms=round(ms_eager, 2), speedup=round(ms_eager / ms_hip, 2))
+    except RuntimeError as e:
+        out["torch_rocm_autograd_error"] = str(e)[:160]
+    del P
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_c1_full():
     """BASELINE configs[0] ("C1") in full on the host cores: Unet2D dim 64, B=16, unguided 1000-step p_sample_loop through the
     CPU oracle ("C1 timed in full").  Minutes of CPU time: run with --cpu-c1-full, not part of the default line."""
@@ -550,6 +616,9 @@ def worker(a):
             except RuntimeError as e:                    # e.g. out of memory in the eager net: report, do not fail the line
                 extra["strawman"] = {"error": str(e)[:200]}
             torch.cuda.empty_cache()
+        if world == 1 and not a.no_extra and not a.no_finetune:
+            with torch.enable_grad():
+                extra["finetune_step"] = finetune_step(wl, a.finetune_batch or {"c2": 64, "c3": 64, "c4": 4}[wl], a.dim, dev)
         if a.full_sample and rank == 0:
             S3 = W["prep"]()
             torch.cuda.synchronize()
@@ -649,6 +718,8 @@ def main():
     ap.add_argument("--full-calibration", action="store_true", help="also run one complete calibration pass (minutes)")
     ap.add_argument("--cpu-c1-full", action="store_true", help="also run BASELINE configs[0] (C1) in full on the host cores (minutes)")
     ap.add_argument("--selftest-launcher", action="store_true", help="CPU-only check of the launcher path (tests)")
+    ap.add_argument("--no-finetune", action="store_true", help="skip the fine-tuning step timing (extra.finetune_step)")
+    ap.add_argument("--finetune-batch", type=int, default=0)
     ap.add_argument("--no-strawman", action="store_true", help="skip the PyTorch-ROCm eager timing of the oracle (extra.strawman)")
     ap.add_argument("--strawman-batch", type=int, default=0)
     ap.add_argument("--cpu-batch", type=int, default=0)

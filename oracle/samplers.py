@@ -79,7 +79,7 @@ def burgers_guidance(Q, w_score, u_bound, use_max_safety=True):
 
 def tokamak_J(x, target, nt, Q, thr, w_obj, w_safe):
     """GradientGuidance.calculate_loss, tokamak/utils/guidance.py:32-56."""
-    st = (x * TOKAMAK_SCALER)[:, :3, :nt]
+    st = (x * TOKAMAK_SCALER.to(x.device))[:, :3, :nt]
     obj = (st[:, 0] - target[:, 0]).square().mean(-1) + (st[:, 2] - target[:, 2]).square().mean(-1)
     s = st[:, 1].amin(dim=-1)                                            # utils/metrics.py:144-151
     safe = torch.maximum(thr - s + Q, torch.zeros_like(s))
@@ -97,7 +97,7 @@ def tokamak_guidance(target, nt, Q, thr, w_obj, w_safe, scaler):
 
 def smoke_J(x, Q, w_safe, safe_bound):
     """InferencePipeline.guidance, 2d/inference_2d.py:173-186."""
-    st = x * SMOKE_RESCALER
+    st = x * SMOKE_RESCALER.to(x.device)
     succ = st[:, :, 5].mean((-1, -2, -3))
     safe = torch.maximum(st[:, -1, 6].mean((-1, -2)) + Q - safe_bound, torch.zeros_like(st[:, -1, 6, 0, 0]))
     return -(1 - w_safe) * succ + w_safe * safe
@@ -239,7 +239,7 @@ def smoke_weight(state, Q, w_safe, safe_bound, ratio):
 
 
 def smoke_score(pred, state):
-    p, s = pred * SMOKE_RESCALER, state * SMOKE_RESCALER
+    p, s = pred * SMOKE_RESCALER.to(pred.device), state * SMOKE_RESCALER.to(state.device)
     return (p[:, -1, -1].mean((-1, -2)) - s[:, -1, -1, 0, 0]).abs()
 
 

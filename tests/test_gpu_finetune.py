@@ -106,3 +106,45 @@ def test_finetune_step_updates_the_sampler():
     with torch.no_grad():
         e2 = net.forward_train(x, t)
     assert (e1 - e2).abs().max().item() < 1e-4 * e1.abs().max().item()
+
+
+@pytest.mark.parametrize("tree", ["smoke", "burgers", "tokamak"])
+def test_finetune_gradients_at_production_width(tree):
+    """the production kernels (Winograd convs in both directions, the fused attention blocks, wgrad over long rows) in the
+    fine-tuning step: smoke dim 64 at 32 frames of 32x32, burgers dim 64, tokamak dim 256 -- against the oracle's functional
+    net under PyTorch-ROCm autograd on the same device (the oracle's forward is pinned by the *_unet_wide reference fixtures)"""
+    from oracle import nets as onets
+    if tree == "smoke":
+        net = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+        shape, fwd, kw, B = (32, 7, 32, 32), onets.unet_smoke, dict(dim=64, dim_mults=(1, 2, 4)), 2
+    elif tree == "burgers":
+        net = sdc.Unet2D(dim=64, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+        shape, fwd, kw, B = (3, 16, 128), onets.unet_burgers, dict(dim=64), 4
+    else:
+        net = sdc.Unet1D(dim=256, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+        shape, fwd, kw, B = (12, 128), onets.unet_tokamak, dict(dim=256), 4
+    spec = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    net.load_state_dict(det_params(spec, 77))
+    net.to(DEV).train()
+    x, t = det_tensor((B, *shape), 78).to(DEV), torch.tensor([3, 400, 777, 999][:B], device=DEV)
+    tgt, w = det_tensor((B, *shape), 79).to(DEV), (det_tensor((B,), 80).abs() + 0.5).to(DEV)
+    loss = (w * ((net.forward_train(x, t) - tgt) ** 2).flatten(1).mean(1)).mean()
+    loss.backward()
+    P = {k: v.detach().clone().requires_grad_() for k, v in net.state_dict().items()}
+    ref = (w * ((fwd(P, x, t, **kw) - tgt) ** 2).flatten(1).mean(1)).mean()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+    gmax = max(v.grad.norm().item() for v in P.values() if v.grad is not None)
+    worst, checked = 0.0, 0
+    for k, p in net.named_parameters():
+        gr, gref = p.grad, P[k].grad
+        assert gr is not None and gref is not None, k
+        n_ref = gref.norm().item()
+        if n_ref < 1e-4 * gmax:
+            assert gr.norm().item() < 2e-4 * gmax, k
+            continue
+        err = ((gr - gref).norm() / n_ref).item()
+        worst, checked = max(worst, err), checked + 1
+        assert err < 2e-4, (k, err)
+    print(f"[measured] {tree} production-width fine-tune step vs PyTorch-ROCm autograd of the oracle: loss {loss.item():.6f} vs {ref.item():.6f}; "
+          f"{checked} parameter gradients, worst relative L2 error {worst:.2e}")
