@@ -639,11 +639,15 @@ def worker(a):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             ss, ws = [], []
-            for _ in range(W["cal_batches"]):
+            for ib in range(W["cal_batches"]):
                 Sc = W["calib"](W["cal_B"])
                 Sc.init()
-                for _ in range(Sc.n_main):
+                for i_ in range(Sc.n_main):
                     Sc.step()
+                    if i_ % 250 == 249:                   # (a progress line every ~25 s: long runs must not look hung)
+                        torch.cuda.synchronize()
+                        print(f"[full-calibration] batch {ib + 1}/{W['cal_batches']} step {i_ + 1}/{Sc.n_main} "
+                              f"{time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)
                 Sc.final()
                 kind = {"c2": "burgers", "c3": "tokamak", "c4": "smoke"}[wl]
                 gpar = {"c2": [500.0, 0.64, 0.0, 10.0], "c3": [0.0, 1.0, 0.01, 4.98, 0.0], "c4": [0.9, 0.1, 0.0, 100.0]}[wl]

@@ -131,6 +131,13 @@ int sdc_gn_apply(const float* x, const float* stats, const float* gamma, const f
                  const int32_t* t_dev, int64_t ss_t_stride, int64_t ss_b_stride, int64_t ss_off,
                  const float* residual, float* y, int B, int C, int G, int64_t S, void* stream);
 
+/* GroupNorm statistics + apply in ONE launch for small groups (sdc_gn_fused_ok: (C/G)*S <= 32768, B*G >= 64): the deep levels
+ * of Unet2D / Unet1D, 1D/model/unet.py:128-147.  Arguments as sdc_gn_apply; the output bits equal sdc_gn_stats + sdc_gn_apply. */
+int sdc_gn_fused_ok(int B, int C, int G, int64_t S);
+int sdc_gn_fused(const float* x, const float* gamma, const float* beta, const float* ss, const int32_t* t_dev,
+                 int64_t ss_t_stride, int64_t ss_b_stride, int64_t ss_off, const float* residual, float* y, int B, int C, int G,
+                 int64_t S, float eps, void* stream);
+
 /* ------------------------------------------------------- channel norms */
 /* mode 0: channel LayerNorm, gain only, (x-mean)*rsqrt(var+eps)*g   1D/model/unet.py:53-63, conv3d.py:165-174
  * mode 1: RMSNorm  x / max(||x||_2,1e-12) * g * sqrt(C)            tokamak/model/unet.py:45-51
@@ -301,6 +308,17 @@ int sdc_gn_silu_bwd(const float* h, const float* gy, const float* stats, const f
 size_t sdc_chan_norm_bwd_parts(int B, int64_t S);
 int sdc_chan_norm_bwd(const float* x, const float* gy, const float* g, float* gx, float* gpart, int B, int C, int64_t S,
                       int mode, float eps, void* stream);
+
+/* Backward of the attention cores (same tensor conventions as sdc_attn / sdc_linattn: q, k, v = channel ranges of qkv, the
+ * gradients dqkv in the same layout; dout = dL/dout in the layout of `out`).
+ * sdc_attn_bwd: dbias (heads, ntok, ntok) = sum over sequences of dS, or null (built for ntok <= 32: the temporal attention's
+ * relative-position bias, conv3d.py:74-112); work = sdc_attn_bwd_bytes(...) bytes when dbias is requested. */
+size_t sdc_attn_bwd_bytes(int outer, int inner, int heads, int ntok);
+int sdc_attn_bwd(const float* qkv, const float* dout, const float* rot, const float* bias, float* dqkv, float* dbias, void* work,
+                 int outer, int inner, int heads, int ntok, int64_t q_so, int64_t q_sc, int64_t q_si, int64_t q_st,
+                 int64_t o_so, int64_t o_sc, int64_t o_si, int64_t o_st, void* stream);
+int sdc_linattn_bwd(const float* qkv, const float* dout, float* dqkv, int outer, int inner, int heads, int64_t n,
+                    int64_t q_so, int64_t q_sc, int64_t q_si, int64_t o_so, int64_t o_sc, int64_t o_si, void* stream);
 
 /* gx = gy * f'(x): kind 0 SiLU, 1 GELU (exact erf) -- time_mlp, 1D/model/unet.py:300-305 */
 int sdc_act_bwd(const float* x, const float* gy, float* gx, int64_t n, int kind, void* stream);

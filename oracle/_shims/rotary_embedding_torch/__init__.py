@@ -12,7 +12,8 @@ def _rotate_half(x):
 class RotaryEmbedding(nn.Module):
     def __init__(self, dim, theta=10000):
         super().__init__()
-        self.freqs = nn.Parameter(1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim)))
+        # (the published package: nn.Parameter(freqs, requires_grad=learned_freq) with learned_freq=False by default)
+        self.freqs = nn.Parameter(1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim)), requires_grad=False)
 
     def rotate_queries_or_keys(self, t, seq_dim=-2):
         n = t.shape[seq_dim]

@@ -49,6 +49,9 @@ SIGNATURES = {
     "sdc_gn_stats_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "sdc_gn_apply": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _i32p, _i64, _i64, _i64, _f32p, _f32p,
                                C.c_int, C.c_int, C.c_int, _i64, _stream]),
+    "sdc_gn_fused_ok": (C.c_int, [C.c_int, C.c_int, C.c_int, _i64]),
+    "sdc_gn_fused": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i32p, _i64, _i64, _i64, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64,
+                               C.c_float, _stream]),
     "sdc_chan_norm": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, _i64, C.c_int, C.c_float, _stream]),
     "sdc_linattn": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, _i64, _i64, _i64,
                               _i64, _stream]),
@@ -76,6 +79,10 @@ SIGNATURES = {
                                   _stream]),
     "sdc_chan_norm_bwd_parts": (C.c_size_t, [C.c_int, _i64]),
     "sdc_chan_norm_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, _i64, C.c_int, C.c_float, _stream]),
+    "sdc_attn_bwd_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sdc_attn_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                               _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _stream]),
+    "sdc_linattn_bwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _stream]),
     "sdc_act_bwd": (C.c_int, [_f32p, _f32p, _f32p, _i64, C.c_int, _stream]),
     "sdc_sumpool2": (C.c_int, [_f32p, _f32p, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "sdc_graph_begin": (C.c_int, [_stream]),

@@ -12,10 +12,14 @@ samplers use:
     ``sdc_conv_wgrad`` (fp32 MFMA, csrc/sdc_grad.hip);
   * GroupNorm + scale/shift + SiLU (+ residual): ``sdc_gn_stats`` / ``sdc_gn_apply`` forward, ``sdc_gn_silu_bwd`` backward;
   * SiLU / GELU of the time MLP: ``sdc_act`` / ``sdc_act_bwd``;
-  * the attention blocks (PreNorm + LinearAttention / temporal / full attention + residual): forward = the fused HIP block
-    kernels of the sampler (``sdc_linattn_block``, ``sdc_tattn_block``, ``sdc_attn`` ...); backward = ROUND-3 STAGE: the VJP
-    is taken by PyTorch-ROCm autograd over a torch restatement of the block (recomputed in backward from the saved block
-    input).  These blocks hold 8 % of the forward FLOPs; their HIP backward kernels are the next stage.
+  * the attention blocks (PreNorm + LinearAttention / temporal / full attention + residual): chains of HIP nodes -- channel
+    LayerNorm / RMSNorm (``sdc_chan_norm`` / ``sdc_chan_norm_bwd``), the 1x1 projections on the conv node above, the attention
+    cores ``sdc_linattn`` / ``sdc_attn`` (rotary + relative-position bias) with ``sdc_linattn_bwd`` / ``sdc_attn_bwd``.
+    (``Trainer.native_attention = False`` selects the first stage of this work instead: fused HIP block forward, VJP by
+    PyTorch-ROCm autograd over a torch restatement of the block -- kept as an independent check of the native backward.)
+The only torch arithmetic on the path is glue of negligible size: the residual adds, the gather of the (heads, F, F)
+relative-position bias from its 32 x 4 embedding, O(B C) parameter-gradient sums of the GroupNorm row table, and the
+element-wise loss.
 PyTorch is otherwise plumbing (device memory, the current stream, the autograd tape).  There is no CPU path.
 """
 import ctypes as C
@@ -213,6 +217,66 @@ class ActFn(Function):
         return grad_ops.act_bwd(x, gy, ctx.kind), None
 
 
+class ChanNormFn(Function):
+    """channel LayerNorm (mode 0, gain only) / RMSNorm (mode 1): 1D/model/unet.py:53-63, tokamak/model/unet.py:45-51, conv3d.py:165-174"""
+
+    @staticmethod
+    def forward(ctx, x, g, mode):
+        x = x.contiguous()
+        ctx.save_for_backward(x, g.detach())
+        ctx.mode, ctx.gshape = mode, g.shape
+        return grad_ops.chan_norm(x, g.detach(), mode)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, g = ctx.saved_tensors
+        gx, dg = grad_ops.chan_norm_bwd(x, gy, g, ctx.mode)
+        return gx, dg.reshape(ctx.gshape), None
+
+
+class AttnCoreFn(Function):
+    """softmax attention core over channel-major qkv (sdc_attn / sdc_attn_bwd); geom = (heads, outer, inner, ntok, q strides,
+    out strides, out shape); rot = [ntok][16][2] cos / sin table (no gradient), bias = (heads, ntok, ntok) or None"""
+
+    @staticmethod
+    def forward(ctx, qkv, bias, rot, geom):
+        heads, outer, inner, ntok, qs, os_, oshape = geom
+        qkv = qkv.contiguous()
+        bd = None if bias is None else bias.detach().contiguous()
+        out = torch.empty(oshape, dtype=torch.float32, device=qkv.device)
+        grad_ops.attn_core(qkv, out, heads, outer, inner, ntok, qs, os_, rot, bd)
+        ctx.save_for_backward(qkv, bd, rot)
+        ctx.geom = geom
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qkv, bd, rot = ctx.saved_tensors
+        heads, outer, inner, ntok, qs, os_, _ = ctx.geom
+        dqkv, dbias = grad_ops.attn_core_bwd(qkv, gout.contiguous(), heads, outer, inner, ntok, qs, os_, rot, bd)
+        return dqkv, dbias, None, None
+
+
+class LinAttnCoreFn(Function):
+    """linear attention core (sdc_linattn / sdc_linattn_bwd); geom = (heads, outer, inner, n, q strides, out strides, out shape)"""
+
+    @staticmethod
+    def forward(ctx, qkv, geom):
+        heads, outer, inner, n, qs, os_, oshape = geom
+        qkv = qkv.contiguous()
+        out = torch.empty(oshape, dtype=torch.float32, device=qkv.device)
+        grad_ops.linattn_core(qkv, out, heads, outer, inner, n, qs, os_)
+        ctx.save_for_backward(qkv)
+        ctx.geom = geom
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (qkv,) = ctx.saved_tensors
+        heads, outer, inner, n, qs, os_, _ = ctx.geom
+        return grad_ops.linattn_core_bwd(qkv, gout.contiguous(), heads, outer, inner, n, qs, os_), None
+
+
 class BlockFn(Function):
     """An attention block: forward through the sampler's fused HIP kernels (a cached one-block engine.Plan), backward by
     PyTorch-ROCm autograd over the block's torch restatement, recomputed from the saved input (round-3 stage, see the
@@ -357,6 +421,10 @@ class Trainer:
         self.net = net
         self.prec = net.precision
         self._blocks = {}          # (prefix, shape) -> one-block plan for the HIP forward of an attention block
+        # True (default): the attention blocks are chains of HIP nodes in both directions (channel norm, 1x1 convs, attention
+        # cores with sdc_attn_bwd / sdc_linattn_bwd).  False: the round's first stage -- fused HIP block forward, VJP by
+        # PyTorch-ROCm autograd over the block's torch restatement (kept for A/B checks of the native backward).
+        self.native_attention = True
 
     def P(self, key):
         return self.net.P(key)
@@ -397,6 +465,70 @@ class Trainer:
         h = ActFn.apply(h, 1)
         h = ConvFn.apply(h, None, self.P("time_mlp.3.weight").reshape(4 * dim, 4 * dim, 1, 1, 1), self.P("time_mlp.3.bias"), cfg)
         return ActFn.apply(h, 0)
+
+    # ---- attention blocks as chains of HIP nodes (norm -> 1x1 conv -> core -> 1x1 conv [-> norm] + x)
+    def _pw(self, key, x, bias_key=None):
+        w = self.P(key)
+        w5 = w.reshape(w.shape[0], w.shape[1], 1, 1, 1)
+        return ConvFn.apply(x, None, w5, None if bias_key is None else self.P(bias_key), ("conv", (1, 1, 1), (0, 0, 0), (1, 1, 1), 0))
+
+    def linattn_lucid(self, p, x, mode):
+        """Residual(PreNorm(LinearAttention)): 1D/model/unet.py:182-222 (LayerNorm), tokamak/model/unet.py:182-222 (RMSNorm)"""
+        B, Cc = x.shape[:2]
+        n = x.numel() // (B * Cc)
+        xn = ChanNormFn.apply(x, self.P(f"{p}.fn.norm.g"), mode)
+        qkv = self._pw(f"{p}.fn.fn.to_qkv.weight", xn)
+        o = LinAttnCoreFn.apply(qkv, (HEADS, B, 1, n, (3 * HID * n, n, 0), (HID * n, n, 0), (B, HID, *x.shape[2:])))
+        y = self._pw(f"{p}.fn.fn.to_out.0.weight", o, f"{p}.fn.fn.to_out.0.bias")
+        return ChanNormFn.apply(y, self.P(f"{p}.fn.fn.to_out.1.g"), mode) + x
+
+    def fullattn_lucid(self, p, x, mode):
+        """Residual(PreNorm(Attention)): 1D/model/unet.py:224-258"""
+        B, Cc = x.shape[:2]
+        n = x.numel() // (B * Cc)
+        xn = ChanNormFn.apply(x, self.P(f"{p}.fn.norm.g"), mode)
+        qkv = self._pw(f"{p}.fn.fn.to_qkv.weight", xn)
+        o = AttnCoreFn.apply(qkv, None, None, (HEADS, B, 1, n, (3 * HID * n, n, 0, 1), (HID * n, n, 0, 1), (B, HID, *x.shape[2:])))
+        return self._pw(f"{p}.fn.fn.to_out.weight", o, f"{p}.fn.fn.to_out.bias") + x
+
+    def spatial_linear(self, p, x):
+        """Residual(PreNorm(SpatialLinearAttention)), per frame: conv3d.py:232-258"""
+        B, Cc, Fr, H, W = x.shape
+        hw = H * W
+        xn = ChanNormFn.apply(x, self.P(f"{p}.fn.norm.gamma"), 0)
+        qkv = self._pw(f"{p}.fn.fn.to_qkv.weight", xn)
+        o = LinAttnCoreFn.apply(qkv, (HEADS, B, Fr, hw, (3 * HID * Fr * hw, Fr * hw, hw), (HID * Fr * hw, Fr * hw, hw), (B, HID, Fr, H, W)))
+        return self._pw(f"{p}.fn.fn.to_out.weight", o, f"{p}.fn.fn.to_out.bias") + x
+
+    def _temporal_tables(self, Fr, dev):
+        """rotary cos / sin table (no gradient: rotary-embedding-torch keeps freqs with requires_grad = False unless learned_freq)
+        and the relative-position bias (heads, F, F) gathered from the embedding (gradient through the gather)"""
+        fr = self.P("init_temporal_attn.fn.fn.fn.rotary_emb.freqs").detach().float()
+        ang = torch.arange(Fr, dtype=torch.float32, device=dev)[:, None] * fr[None, :]
+        rot = torch.stack((ang.cos(), ang.sin()), dim=-1).reshape(-1).contiguous()
+        bias = self.P("time_rel_pos_bias.relative_attention_bias.weight")[_relpos_buckets(Fr, dev)].permute(2, 0, 1).contiguous()
+        return rot, bias
+
+    def temporal(self, p, x, tables):
+        """Residual(PreNorm('b c f h w -> b (h w) f c' Attention)) with rotary + relative position bias: conv3d.py:262-353"""
+        B, Cc, Fr, H, W = x.shape
+        hw = H * W
+        rot, bias = tables
+        xn = ChanNormFn.apply(x, self.P(f"{p}.fn.norm.gamma"), 0)
+        qkv = self._pw(f"{p}.fn.fn.fn.to_qkv.weight", xn)
+        o = AttnCoreFn.apply(qkv, bias, rot, (HEADS, B, hw, Fr, (3 * HID * Fr * hw, Fr * hw, 1, hw), (HID * Fr * hw, Fr * hw, 1, hw),
+                                              (B, HID, Fr, H, W)))
+        return self._pw(f"{p}.fn.fn.fn.to_out.weight", o) + x
+
+    def spatial_full(self, p, x):
+        """mid: Residual(PreNorm('b c f h w -> b f (h w) c' Attention)): conv3d.py:450-452"""
+        B, Cc, Fr, H, W = x.shape
+        hw = H * W
+        xn = ChanNormFn.apply(x, self.P(f"{p}.fn.norm.gamma"), 0)
+        qkv = self._pw(f"{p}.fn.fn.fn.to_qkv.weight", xn)
+        o = AttnCoreFn.apply(qkv, None, None, (HEADS, B, Fr, hw, (3 * HID * Fr * hw, Fr * hw, hw, 1), (HID * Fr * hw, Fr * hw, hw, 1),
+                                               (B, HID, Fr, H, W)))
+        return self._pw(f"{p}.fn.fn.fn.to_out.weight", o) + x
 
     def block(self, prefix, x, build, torch_fn, param_keys):
         """attention block `prefix`: HIP forward through a cached one-block plan, torch VJP"""
@@ -439,7 +571,8 @@ def forward_train_lucid(net, x, t):
         h = T.resnet(f"{p}.0", h, cond)
         hs.append(h)
         h = T.resnet(f"{p}.1", h, cond)
-        h = T.block(f"{p}.2", h, lambda b, pre, xin: net._lin_attn(b, pre, xin), t_linattn_lucid(mode), la_keys(f"{p}.2"))
+        h = T.linattn_lucid(f"{p}.2", h, mode) if T.native_attention else \
+            T.block(f"{p}.2", h, lambda b, pre, xin: net._lin_attn(b, pre, xin), t_linattn_lucid(mode), la_keys(f"{p}.2"))
         hs.append(h)
         last = i == nres - 1
         if last:
@@ -449,14 +582,16 @@ def forward_train_lucid(net, x, t):
         else:
             h = T.conv(f"{p}.3", h, stride=(1, 1, 2), pad=(0, 0, 1))
     h = T.resnet("mid_block1", h, cond)
-    h = T.block("mid_attn", h, lambda b, pre, xin: net._full_attn(b, pre, xin), t_fullattn_lucid(mode),
+    h = T.fullattn_lucid("mid_attn", h, mode) if T.native_attention else \
+        T.block("mid_attn", h, lambda b, pre, xin: net._full_attn(b, pre, xin), t_fullattn_lucid(mode),
                 ["mid_attn.fn.norm.g", "mid_attn.fn.fn.to_qkv.weight", "mid_attn.fn.fn.to_out.weight", "mid_attn.fn.fn.to_out.bias"])
     h = T.resnet("mid_block2", h, cond)
     for i in range(nres):
         p = f"ups.{i}"
         h = T.resnet(f"{p}.0", h, cond, x1=hs.pop())
         h = T.resnet(f"{p}.1", h, cond, x1=hs.pop())
-        h = T.block(f"{p}.2", h, lambda b, pre, xin: net._lin_attn(b, pre, xin), t_linattn_lucid(mode), la_keys(f"{p}.2"))
+        h = T.linattn_lucid(f"{p}.2", h, mode) if T.native_attention else \
+            T.block(f"{p}.2", h, lambda b, pre, xin: net._lin_attn(b, pre, xin), t_linattn_lucid(mode), la_keys(f"{p}.2"))
         last = i == nres - 1
         if last:
             h = T.conv(f"{p}.3", h)
@@ -475,11 +610,17 @@ def forward_train_smoke(net, x, t):
     cond = T.time_cond(t)
     rot, rel = "init_temporal_attn.fn.fn.fn.rotary_emb.freqs", "time_rel_pos_bias.relative_attention_bias.weight"
 
+    tables = T._temporal_tables(x5.shape[2], x.device) if T.native_attention else None
+
     def temporal(pre, h):
+        if T.native_attention:
+            return T.temporal(pre, h, tables)
         return T.block(pre, h, lambda b, pp, xin: net._temporal(b, pp, xin), t_temporal,
                        [f"{pre}.fn.norm.gamma", f"{pre}.fn.fn.fn.to_qkv.weight", f"{pre}.fn.fn.fn.to_out.weight", rot, rel])
 
     def spatial(pre, h):
+        if T.native_attention:
+            return T.spatial_linear(pre, h)
         return T.block(pre, h, lambda b, pp, xin: net._spatial_linear(b, pp, xin), t_spatial_linear,
                        [f"{pre}.fn.norm.gamma", f"{pre}.fn.fn.to_qkv.weight", f"{pre}.fn.fn.to_out.weight", f"{pre}.fn.fn.to_out.bias"])
 
@@ -497,7 +638,8 @@ def forward_train_smoke(net, x, t):
         if i < nres - 1:
             h = T.conv(f"{p}.4", h, stride=(1, 2, 2), pad=(0, 1, 1))
     h = T.resnet("mid_block1", h, cond)
-    h = T.block("mid_spatial_attn", h, lambda b, pp, xin: net._spatial_full(b, pp, xin), t_spatial_full,
+    h = T.spatial_full("mid_spatial_attn", h) if T.native_attention else \
+        T.block("mid_spatial_attn", h, lambda b, pp, xin: net._spatial_full(b, pp, xin), t_spatial_full,
                 ["mid_spatial_attn.fn.norm.gamma", "mid_spatial_attn.fn.fn.fn.to_qkv.weight", "mid_spatial_attn.fn.fn.fn.to_out.weight"])
     h = temporal("mid_temporal_attn", h)
     h = T.resnet("mid_block2", h, cond)

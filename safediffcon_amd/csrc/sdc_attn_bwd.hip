@@ -1,0 +1,447 @@
+// Backward of the attention cores (fine-tuning path), heads x dim_head 32, fp32:
+//   * sdc_attn_bwd    softmax attention (mid Attention 1D/model/unet.py:224-258, smoke mid spatial attention and temporal
+//                     attention with rotary + relative-position bias, conv3d.py:277-353): dq, dk, dv and the bias gradient
+//   * sdc_linattn_bwd linear attention (1D/model/unet.py:182-222, conv3d.py:232-258): dq, dk, dv
+// Same tensor conventions as the forward cores (csrc/sdc_attn.hip): q, k, v are channel ranges of the channel-major conv
+// output, addressed through strides; the gradients are written in the same layout.  These are correctness-first fp32 VALU
+// kernels: the cores hold ~1 % of a U-Net's FLOPs, their projections run on the MFMA conv kernels.
+#include "sdc_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int DH = 32;
+constexpr float SCALE = 0.17677669529663687f;       // dim_head^-0.5
+
+// ------------------------------------------------------------------------------------------------ softmax attention
+// P = softmax(q' k'^T + bias), O = P V with q' = rot(q scale), k' = rot(k).  Given dO:
+//   D_i = sum_j P_ij dP_ij (= dO_i . O_i),  dP_ij = dO_i . v_j,  dS_ij = P_ij (dP_ij - D_i)
+//   dq'_i = sum_j dS_ij k'_j,  dk'_j = sum_i dS_ij q'_i,  dv_j = sum_i P_ij dO_i,  dbias[h][i][j] = sum over sequences dS_ij
+// A workgroup owns nseq sequences of one head (one thread per (sequence, token), nseq * ntok <= 256), q', k', v, dO in LDS.
+// Phase A: thread = query i (row statistics, D_i, dq_i);  phase B: thread = key j (dk_j, dv_j, its column of dS).  No
+// atomics: every output element has one owner.  Workgroups loop over sequence groups (fixed assignment) so that the bias
+// gradient needs one partial table per workgroup; the partials are summed in a fixed order afterwards.
+struct AttnBwdArgs {
+    const float* qkv; const float* dout; const float* rot; const float* bias;
+    float* dqkv; float* dbias_part;
+    int outer, inner, heads, ntok, nseq, tok_contig, ngrp, nslots;
+    int64_t so, sc, si, st, oso, osc, osi, ost;
+    int ls, ld, lj;   // LDS strides for (seq, d, tok)
+};
+
+__global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int ntok = a.ntok, nseq = a.nseq;
+    const int ksz = a.tok_contig ? nseq * a.ls : DH * a.ld;
+    float* Qs = lds;
+    float* Ks = lds + ksz;
+    float* Vs = lds + 2 * ksz;
+    float* Gs = lds + 3 * ksz;
+    float* Mx = lds + 4 * ksz;            // [256] row maxima, 1 / row sums, D_i
+    float* Li = Mx + NT;
+    float* Dd = Li + NT;
+    const int head = blockIdx.x % a.heads;
+    const int slot = blockIdx.x / a.heads;
+    const int nseq_tot = a.outer * a.inner;
+    const int tid = threadIdx.x;
+    const int nthr = nseq * ntok;
+    int sq, ti;
+    if (a.tok_contig) { ti = tid % ntok; sq = tid / ntok; }
+    else { sq = tid % nseq; ti = tid / nseq; }
+    const bool owner = tid < nthr;
+    const bool want_bias = a.bias != nullptr && a.dbias_part != nullptr;      // (ntok <= 32, host check)
+    float dsacc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) dsacc[i] = 0.0f;
+
+    auto seq_base = [&](int s) -> int64_t { const int o = s / a.inner, i = s - o * a.inner; return o * a.so + i * a.si; };
+    auto seq_obase = [&](int s) -> int64_t { const int o = s / a.inner, i = s - o * a.inner; return o * a.oso + i * a.osi; };
+    const int64_t qoff = (int64_t)(head * DH) * a.sc;
+    const int64_t koff = (int64_t)(a.heads * DH + head * DH) * a.sc;
+    const int64_t voff = (int64_t)(2 * a.heads * DH + head * DH) * a.sc;
+    const int64_t goff = (int64_t)(head * DH) * a.osc;
+
+    for (int grp = slot; grp < a.ngrp; grp += a.nslots) {
+        const int seq0 = grp * nseq;
+        // ---- stage q (scaled), k, v, dO
+        const int total = nseq * DH * ntok;
+        for (int e = tid; e < total; e += NT) {
+            int s_, d, j;
+            if (a.tok_contig) { j = e % ntok; d = (e / ntok) % DH; s_ = e / (ntok * DH); }
+            else { s_ = e % nseq; j = (e / nseq) % ntok; d = e / (nseq * ntok); }
+            float qv = 0.f, kv = 0.f, vv = 0.f, gv = 0.f;
+            if (seq0 + s_ < nseq_tot) {
+                const int64_t g = seq_base(seq0 + s_) + (int64_t)d * a.sc + (int64_t)j * a.st;
+                qv = a.qkv[g + qoff] * SCALE;
+                kv = a.qkv[g + koff];
+                vv = a.qkv[g + voff];
+                gv = a.dout[seq_obase(seq0 + s_) + goff + (int64_t)d * a.osc + (int64_t)j * a.ost];
+            }
+            const int li = s_ * a.ls + d * a.ld + j * a.lj;
+            Qs[li] = qv; Ks[li] = kv; Vs[li] = vv; Gs[li] = gv;
+        }
+        __syncthreads();
+        if (a.rot) {
+            // rotate q and k pairs in place: (x0, x1) -> (x0 c - x1 s, x1 c + x0 s), angle = tok * freq[pair]
+            const int npair = nseq * (DH / 2) * ntok;
+            for (int e = tid; e < npair; e += NT) {
+                int s_, m, j;
+                if (a.tok_contig) { j = e % ntok; m = (e / ntok) % (DH / 2); s_ = e / (ntok * (DH / 2)); }
+                else { s_ = e % nseq; j = (e / nseq) % ntok; m = e / (nseq * ntok); }
+                const float c = a.rot[(j * (DH / 2) + m) * 2], s = a.rot[(j * (DH / 2) + m) * 2 + 1];
+                const int l0 = s_ * a.ls + (2 * m) * a.ld + j * a.lj, l1 = l0 + a.ld;
+                float x0 = Ks[l0], x1 = Ks[l1];
+                Ks[l0] = x0 * c - x1 * s; Ks[l1] = x1 * c + x0 * s;
+                x0 = Qs[l0]; x1 = Qs[l1];
+                Qs[l0] = x0 * c - x1 * s; Qs[l1] = x1 * c + x0 * s;
+            }
+            __syncthreads();
+        }
+        const bool live = owner && seq0 + sq < nseq_tot;
+        const float* Kq = Ks + sq * a.ls;
+        const float* Vq = Vs + sq * a.ls;
+        const float* Qq = Qs + sq * a.ls;
+        const float* Gq = Gs + sq * a.ls;
+        // ---- phase A: this thread's query row
+        if (live) {
+            float q[DH], g[DH];
+#pragma unroll
+            for (int d = 0; d < DH; ++d) { q[d] = Qq[d * a.ld + ti * a.lj]; g[d] = Gq[d * a.ld + ti * a.lj]; }
+            const float* brow = a.bias ? a.bias + ((int64_t)head * ntok + ti) * ntok : nullptr;
+            float mx = -INFINITY;
+            for (int j = 0; j < ntok; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < DH; ++d) s += q[d] * Kq[d * a.ld + j * a.lj];
+                if (brow) s += brow[j];
+                mx = fmaxf(mx, s);
+            }
+            float l = 0.f, dn = 0.f, a1[DH], a2[DH];
+#pragma unroll
+            for (int d = 0; d < DH; ++d) { a1[d] = 0.f; a2[d] = 0.f; }
+            for (int j = 0; j < ntok; ++j) {
+                float s = 0.f, dp = 0.f;
+                float kk[DH];
+#pragma unroll
+                for (int d = 0; d < DH; ++d) { kk[d] = Kq[d * a.ld + j * a.lj]; s += q[d] * kk[d]; dp += g[d] * Vq[d * a.ld + j * a.lj]; }
+                if (brow) s += brow[j];
+                const float e = expf(s - mx);
+                l += e;
+                dn += e * dp;
+                const float edp = e * dp;
+#pragma unroll
+                for (int d = 0; d < DH; ++d) { a1[d] += edp * kk[d]; a2[d] += e * kk[d]; }
+            }
+            const float inv = 1.0f / l, D = dn * inv;
+            Mx[tid] = mx; Li[tid] = inv; Dd[tid] = D;
+            float dq[DH];
+#pragma unroll
+            for (int d = 0; d < DH; ++d) dq[d] = (a1[d] - D * a2[d]) * inv;
+            if (a.rot) {
+#pragma unroll
+                for (int m = 0; m < DH / 2; ++m) {       // transposed rotation
+                    const float c = a.rot[(ti * (DH / 2) + m) * 2], s = a.rot[(ti * (DH / 2) + m) * 2 + 1];
+                    const float y0 = dq[2 * m], y1 = dq[2 * m + 1];
+                    dq[2 * m] = y0 * c + y1 * s;
+                    dq[2 * m + 1] = y1 * c - y0 * s;
+                }
+            }
+            float* ob = a.dqkv + seq_base(seq0 + sq) + qoff + (int64_t)ti * a.st;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) ob[(int64_t)d * a.sc] = dq[d] * SCALE;
+        }
+        __syncthreads();
+        // ---- phase B: this thread's key column
+        if (live) {
+            float k[DH], v[DH], dk[DH], dv[DH];
+#pragma unroll
+            for (int d = 0; d < DH; ++d) { k[d] = Kq[d * a.ld + ti * a.lj]; v[d] = Vq[d * a.ld + ti * a.lj]; dk[d] = 0.f; dv[d] = 0.f; }
+            const int sbase = a.tok_contig ? sq * ntok : sq;            // tid of (sq, token i) = sbase + i * sstep
+            const int sstep = a.tok_contig ? 1 : nseq;
+            auto body = [&](int i, float& acc_ds) __attribute__((always_inline)) {
+                float s = 0.f, dp = 0.f, qq[DH], gg[DH];
+#pragma unroll
+                for (int d = 0; d < DH; ++d) { qq[d] = Qq[d * a.ld + i * a.lj]; gg[d] = Gq[d * a.ld + i * a.lj]; s += qq[d] * k[d]; dp += gg[d] * v[d]; }
+                if (a.bias) s += a.bias[((int64_t)head * ntok + i) * ntok + ti];
+                const int r = sbase + i * sstep;
+                const float p = expf(s - Mx[r]) * Li[r];
+                const float ds = p * (dp - Dd[r]);
+#pragma unroll
+                for (int d = 0; d < DH; ++d) { dk[d] += ds * qq[d]; dv[d] += p * gg[d]; }
+                acc_ds += ds;
+            };
+            if (want_bias) {
+                // (unrolled so that the per-query sums of dS stay in registers: ntok <= 32)
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    if (i < ntok) body(i, dsacc[i]);
+            } else {
+                float unused = 0.f;
+                for (int i = 0; i < ntok; ++i) body(i, unused);
+            }
+            if (a.rot) {
+#pragma unroll
+                for (int m = 0; m < DH / 2; ++m) {
+                    const float c = a.rot[(ti * (DH / 2) + m) * 2], s = a.rot[(ti * (DH / 2) + m) * 2 + 1];
+                    const float y0 = dk[2 * m], y1 = dk[2 * m + 1];
+                    dk[2 * m] = y0 * c + y1 * s;
+                    dk[2 * m + 1] = y1 * c - y0 * s;
+                }
+            }
+            float* kb = a.dqkv + seq_base(seq0 + sq) + koff + (int64_t)ti * a.st;
+            float* vb = a.dqkv + seq_base(seq0 + sq) + voff + (int64_t)ti * a.st;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) { kb[(int64_t)d * a.sc] = dk[d]; vb[(int64_t)d * a.sc] = dv[d]; }
+        }
+        __syncthreads();
+    }
+    if (want_bias) {
+        // dsacc[i] of thread (sq, key j): sum over this workgroup's sequences in a fixed order -> one partial table
+        float* tmp = lds;                                  // [nseq][ntok i][ntok j]
+        if (owner) {
+            for (int i = 0; i < ntok; ++i) tmp[(sq * ntok + i) * ntok + ti] = dsacc[i];
+        }
+        __syncthreads();
+        float* out = a.dbias_part + ((int64_t)slot * a.heads + head) * ntok * ntok;
+        for (int e = tid; e < ntok * ntok; e += NT) {
+            float s = 0.f;
+            for (int s_ = 0; s_ < nseq; ++s_) s += tmp[s_ * ntok * ntok + e];
+            out[e] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void sum_rows_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int nsplit) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * n + i];
+    out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ linear attention
+// forward:  ks[d][n] = softmax_n(k[d][:]),  ctx[d][e] = sum_n ks[d][n] v[e][n],  qs[d][n] = softmax_d(q[:][n]) scale,
+//           out[e][n] = sum_d ctx[d][e] qs[d][n]
+// backward: dctx[d][e] = sum_n qs[d][n] do[e][n];  dqs[d][n] = sum_e ctx[d][e] do[e][n];  dv[e][n] = sum_d dctx[d][e] ks[d][n];
+//           dks[d][n] = sum_e dctx[d][e] v[e][n];  dq = qsm (dqs scale - sum_d qsm dqs scale);  dk = ks (dks - sum_n ks dks)
+// One workgroup per (sequence, head); tokens contiguous.  Pass 1 (64-token tiles): row maxima / sums of k, ctx, dctx
+// (thread = 4 (d, e) pairs).  Pass 2 (thread = token): dq, dv, ks dks (parked in dk) and T_d = sum_n ks dks.  Pass 3: dk.
+struct LaBwdArgs {
+    const float* qkv; const float* dout; float* dqkv;
+    int inner, heads;
+    int64_t n, so, sc, si, oso, osc, osi;
+};
+
+__global__ __launch_bounds__(NT) void la_bwd_kernel(const LaBwdArgs a) {
+    const int head = blockIdx.x % a.heads;
+    const int seq = blockIdx.x / a.heads;
+    const int o = seq / a.inner, i = seq - o * a.inner;
+    const int64_t n = a.n;
+    const float* qb = a.qkv + o * a.so + i * a.si + (int64_t)(head * DH) * a.sc;
+    const float* kb = qb + (int64_t)(a.heads * DH) * a.sc;
+    const float* vb = kb + (int64_t)(a.heads * DH) * a.sc;
+    const float* gb = a.dout + o * a.oso + i * a.osi + (int64_t)(head * DH) * a.osc;
+    float* dqb = a.dqkv + o * a.so + i * a.si + (int64_t)(head * DH) * a.sc;
+    float* dkb = dqb + (int64_t)(a.heads * DH) * a.sc;
+    float* dvb = dkb + (int64_t)(a.heads * DH) * a.sc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    __shared__ float rmax[DH], rinv[DH], Td[DH];
+    __shared__ float t_ek[DH][65], t_v[DH][65], t_qs[DH][65], t_g[DH][65];
+    __shared__ float ctx[DH][DH + 1], dctx[DH][DH + 1];
+    __shared__ float red[NT / 64][DH];
+
+    // ---- k row maxima (wave w owns rows 8w .. 8w+7)
+    {
+        float m[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) m[r] = -INFINITY;
+        for (int64_t j = lane; j < n; j += 64) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) m[r] = fmaxf(m[r], kb[(int64_t)(wave * 8 + r) * a.sc + j]);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float mm = sdc::wave_max(m[r]);
+            if (lane == 0) rmax[wave * 8 + r] = mm;
+        }
+    }
+    __syncthreads();
+    // ---- pass 1: sums of exp(k - max), unnormalised ctx, dctx.  thread -> pairs (d = tid >> 3, e = 4 (tid & 7) .. + 3)
+    const int pd = tid >> 3, pe = 4 * (tid & 7);
+    float cu[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
+    float psum[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) psum[it] = 0.f;
+    for (int64_t t0 = 0; t0 < n; t0 += 64) {
+        const int64_t j = t0 + lane;
+        // q softmax over d for token j: every wave needs the column's max / sum -> each lane computes its own token's
+        float qmx = -INFINITY, qsum = 0.f;
+        if (j < n) {
+            for (int d = 0; d < DH; ++d) qmx = fmaxf(qmx, qb[(int64_t)d * a.sc + j]);
+            for (int d = 0; d < DH; ++d) qsum += expf(qb[(int64_t)d * a.sc + j] - qmx);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = wave + 4 * it;
+            float ek = 0.f, vv = 0.f, qs = 0.f, gg = 0.f;
+            if (j < n) {
+                ek = expf(kb[(int64_t)row * a.sc + j] - rmax[row]);
+                vv = vb[(int64_t)row * a.sc + j];
+                qs = expf(qb[(int64_t)row * a.sc + j] - qmx) / qsum * SCALE;
+                gg = gb[(int64_t)row * a.osc + j];
+            }
+            t_ek[row][lane] = ek; t_v[row][lane] = vv; t_qs[row][lane] = qs; t_g[row][lane] = gg;
+            psum[it] += ek;
+        }
+        __syncthreads();
+        for (int c = 0; c < 64; ++c) {
+            const float ekd = t_ek[pd][c], qsd = t_qs[pd][c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { cu[u] += ekd * t_v[pe + u][c]; dc[u] += qsd * t_g[pe + u][c]; }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const float t = sdc::wave_sum(psum[it]);
+        if (lane == 0) rinv[wave + 4 * it] = 1.0f / t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { ctx[pd][pe + u] = cu[u] * rinv[pd]; dctx[pd][pe + u] = dc[u]; }
+    __syncthreads();
+    // ---- pass 2: thread = token
+    float tpart[DH];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) tpart[d] = 0.f;
+    for (int64_t t0 = 0; t0 < n; t0 += NT) {
+        const int64_t j = t0 + tid;
+        if (j < n) {
+            float g[DH], ks[DH], v[DH];
+#pragma unroll
+            for (int d = 0; d < DH; ++d) {
+                g[d] = gb[(int64_t)d * a.osc + j];
+                v[d] = vb[(int64_t)d * a.sc + j];
+                ks[d] = expf(kb[(int64_t)d * a.sc + j] - rmax[d]) * rinv[d];
+            }
+            // dv[e] = sum_d dctx[d][e] ks[d];  dks[d] = sum_e dctx[d][e] v[e]
+            float dv[DH];
+#pragma unroll
+            for (int e = 0; e < DH; ++e) dv[e] = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) {
+                float dks = 0.f;
+#pragma unroll
+                for (int e = 0; e < DH; ++e) { dv[e] += dctx[d][e] * ks[d]; dks += dctx[d][e] * v[e]; }
+                const float kd = ks[d] * dks;
+                tpart[d] += kd;
+                dkb[(int64_t)d * a.sc + j] = kd;            // ks dks, finished in pass 3
+            }
+#pragma unroll
+            for (int e = 0; e < DH; ++e) dvb[(int64_t)e * a.sc + j] = dv[e];
+            // dq: qsm = softmax_d(q);  dqsm[d] = scale sum_e ctx[d][e] g[e];  dq = qsm (dqsm - sum qsm dqsm)
+            float qsm[DH], qmx = -INFINITY, qsum = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) { qsm[d] = qb[(int64_t)d * a.sc + j]; qmx = fmaxf(qmx, qsm[d]); }
+#pragma unroll
+            for (int d = 0; d < DH; ++d) { qsm[d] = expf(qsm[d] - qmx); qsum += qsm[d]; }
+            const float qi = 1.0f / qsum;
+            float dqs[DH], dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < DH; ++e) s += ctx[d][e] * g[e];
+                qsm[d] *= qi;
+                dqs[d] = s * SCALE;
+                dot += qsm[d] * dqs[d];
+            }
+#pragma unroll
+            for (int d = 0; d < DH; ++d) dqb[(int64_t)d * a.sc + j] = qsm[d] * (dqs[d] - dot);
+        }
+    }
+    // T_d = sum over all tokens of ks dks: wave sums, then the four waves in a fixed order
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+        const float t = sdc::wave_sum(tpart[d]);
+        if (lane == 0) red[wave][d] = t;
+    }
+    __syncthreads();
+    if (tid < DH) Td[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    __syncthreads();
+    // ---- pass 3: dk = ks dks - ks T_d  (each thread re-reads the elements it wrote itself)
+    for (int64_t t0 = 0; t0 < n; t0 += NT) {
+        const int64_t j = t0 + tid;
+        if (j < n) {
+#pragma unroll
+            for (int d = 0; d < DH; ++d) {
+                const float ks = expf(kb[(int64_t)d * a.sc + j] - rmax[d]) * rinv[d];
+                dkb[(int64_t)d * a.sc + j] -= ks * Td[d];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t sdc_attn_bwd_bytes(int outer, int inner, int heads, int ntok) {
+    (void)outer; (void)inner;
+    return (size_t)1024 * heads * ntok * ntok * sizeof(float);
+}
+
+extern "C" int sdc_attn_bwd(const float* qkv, const float* dout, const float* rot, const float* bias, float* dqkv, float* dbias,
+                            void* work, int outer, int inner, int heads, int ntok, int64_t q_so, int64_t q_sc, int64_t q_si,
+                            int64_t q_st, int64_t o_so, int64_t o_sc, int64_t o_si, int64_t o_st, void* stream) {
+    SDC_REQUIRE(qkv && dout && dqkv, SDC_ENULL, "sdc_attn_bwd: null pointer");
+    SDC_REQUIRE(outer > 0 && inner > 0 && heads > 0 && ntok > 0 && ntok <= 256, SDC_EINVAL, "sdc_attn_bwd: bad shape (ntok=%d, max 256)", ntok);
+    SDC_REQUIRE(!bias || !dbias || (ntok <= 32 && work), SDC_EINVAL, "sdc_attn_bwd: the bias gradient is built for ntok <= 32 and needs the workspace");
+    AttnBwdArgs a;
+    a.qkv = qkv; a.dout = dout; a.rot = rot; a.bias = bias; a.dqkv = dqkv;
+    a.dbias_part = (bias && dbias) ? static_cast<float*>(work) : nullptr;
+    a.outer = outer; a.inner = inner; a.heads = heads; a.ntok = ntok;
+    a.so = q_so; a.sc = q_sc; a.si = q_si; a.st = q_st;
+    a.oso = o_so; a.osc = o_sc; a.osi = o_si; a.ost = o_st;
+    a.tok_contig = (q_st == 1);
+    int nseq = NT / ntok;
+    if (nseq < 1) nseq = 1;
+    const int nseq_tot = outer * inner;
+    if (a.tok_contig) {
+        if (nseq > nseq_tot) nseq = nseq_tot;
+        a.ls = DH * ntok + 1; a.ld = ntok; a.lj = 1;
+    } else {
+        if (nseq > inner) nseq = inner;
+        while (inner % nseq) --nseq;
+        a.ls = 1; a.ld = ntok * nseq; a.lj = nseq;
+    }
+    a.nseq = nseq;
+    const size_t ksz = a.tok_contig ? (size_t)nseq * a.ls : (size_t)DH * a.ld;
+    size_t lds_bytes = (4 * ksz + 3 * NT) * sizeof(float);
+    const size_t bias_bytes = (size_t)nseq * ntok * ntok * sizeof(float);
+    if (a.dbias_part && bias_bytes > lds_bytes) lds_bytes = bias_bytes;
+    SDC_REQUIRE(lds_bytes <= 160 * 1024, SDC_EINVAL, "sdc_attn_bwd: LDS footprint %zu too large", lds_bytes);
+    a.ngrp = (nseq_tot + nseq - 1) / nseq;
+    a.nslots = a.ngrp < 1024 ? a.ngrp : 1024;
+    static std::atomic<uint64_t> attr{0};
+    SDC_LDS_OPTIN(attr, attn_bwd_kernel, 160 * 1024, "sdc_attn_bwd");
+    hipStream_t s = sdc::as_stream(stream);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(a.nslots * heads)), dim3(NT), lds_bytes, s, a);
+    if (a.dbias_part) {
+        const int nb = heads * ntok * ntok;
+        hipLaunchKernelGGL(sum_rows_kernel, dim3((nb + NT - 1) / NT), dim3(NT), 0, s, a.dbias_part, dbias, nb, a.nslots);
+    }
+    return sdc::check_launch("sdc_attn_bwd");
+}
+
+extern "C" int sdc_linattn_bwd(const float* qkv, const float* dout, float* dqkv, int outer, int inner, int heads, int64_t n,
+                               int64_t q_so, int64_t q_sc, int64_t q_si, int64_t o_so, int64_t o_sc, int64_t o_si, void* stream) {
+    SDC_REQUIRE(qkv && dout && dqkv, SDC_ENULL, "sdc_linattn_bwd: null pointer");
+    SDC_REQUIRE(outer > 0 && inner > 0 && heads > 0 && n > 0, SDC_EINVAL, "sdc_linattn_bwd: bad shape");
+    const int64_t nblk = (int64_t)outer * inner * heads;
+    SDC_REQUIRE(nblk < (1ll << 31), SDC_EINVAL, "sdc_linattn_bwd: too many sequences");
+    LaBwdArgs a;
+    a.qkv = qkv; a.dout = dout; a.dqkv = dqkv; a.inner = inner; a.heads = heads; a.n = n;
+    a.so = q_so; a.sc = q_sc; a.si = q_si; a.oso = o_so; a.osc = o_sc; a.osi = o_si;
+    hipLaunchKernelGGL(la_bwd_kernel, dim3((unsigned)nblk), dim3(NT), 0, sdc::as_stream(stream), a);
+    return sdc::check_launch("sdc_linattn_bwd");
+}

@@ -152,6 +152,96 @@ __global__ __launch_bounds__(NT) void gn_apply_flat_kernel(const float* x, const
     }
 }
 
+// ---------------------------------------------------------------- GroupNorm, statistics + apply in ONE launch
+// Small groups (the deep levels of the 1-D / tokamak U-Nets: (C/G) * S <= 32768 elements, 128 KB): one workgroup per
+// (b, g) sums the group exactly like gn_partial_kernel (one split) + gn_finalize_kernel, then applies
+// (scale + 1, shift), SiLU and the residual to its own channels -- the second read of the group is L2-hot.  Three launches
+// (partial, finalize, apply) become one; the arithmetic, and so every output bit, is that of the three-launch path.
+__global__ __launch_bounds__(NT) void gn_fused_kernel(const float* x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ ss, const int32_t* __restrict__ t_dev,
+                                                      int64_t ss_t_stride, int64_t ss_b_stride, int64_t ss_off, const float* res,
+                                                      float* y, int C, int G, int64_t S, float eps) {
+    extern __shared__ float coef[];                    // [cpg] mul, [cpg] add
+    const int grp = blockIdx.x;
+    const int b = grp / G, g = grp - b * G;
+    const int cpg = C / G;
+    const int64_t n = (int64_t)cpg * S;
+    const float* base = x + (int64_t)grp * n;
+    double s = 0.0, q = 0.0;
+    if ((n & 3) == 0) {
+        const float4* b4 = reinterpret_cast<const float4*>(base);
+        for (int64_t i = threadIdx.x; i < n / 4; i += NT) {
+            const float4 v = b4[i];
+            s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+            q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < n; i += NT) {
+            const double v = base[i];
+            s += v;
+            q += v * v;
+        }
+    }
+    __shared__ double sh[2][NT / 64];
+    __shared__ float st2[2];
+    s = sdc::wave_sum(s);
+    q = sdc::wave_sum(q);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0, tq = 0;
+        for (int w = 0; w < NT / 64; ++w) { ts += sh[0][w]; tq += sh[1][w]; }
+        const double inv_n = 1.0 / (double)n;
+        const double mean = ts * inv_n;
+        double var = tq * inv_n - mean * mean;
+        if (var < 0) var = 0;
+        st2[0] = (float)mean;
+        st2[1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const float mean = st2[0], rstd = st2[1];
+    const int64_t row = ss ? (t_dev ? (int64_t)(*t_dev) : 0) * ss_t_stride + (int64_t)b * ss_b_stride + ss_off : 0;
+    for (int cc = threadIdx.x; cc < cpg; cc += NT) {
+        const int c = g * cpg + cc;
+        float mul = rstd * gamma[c];
+        float add = beta[c] - mean * mul;
+        if (ss) {
+            const float sc = ss[row + c] + 1.0f, shf = ss[row + C + c];
+            mul *= sc;
+            add = add * sc + shf;
+        }
+        coef[cc] = mul;
+        coef[cpg + cc] = add;
+    }
+    __syncthreads();
+    const float* rb = res ? res + (int64_t)grp * n : nullptr;
+    float* yb = y + (int64_t)grp * n;
+    if ((S & 3) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(base);
+        const float4* r4 = reinterpret_cast<const float4*>(rb);
+        float4* y4 = reinterpret_cast<float4*>(yb);
+        const int nv_row = (int)(S >> 2);
+        for (int64_t v = threadIdx.x; v < n / 4; v += NT) {
+            const int cc = (int)(v / nv_row);
+            const float mul = coef[cc], add = coef[cpg + cc];
+            float4 w = x4[v];
+            w.x = sdc::silu_f(w.x * mul + add);
+            w.y = sdc::silu_f(w.y * mul + add);
+            w.z = sdc::silu_f(w.z * mul + add);
+            w.w = sdc::silu_f(w.w * mul + add);
+            if (rb) { const float4 r = r4[v]; w.x += r.x; w.y += r.y; w.z += r.z; w.w += r.w; }
+            y4[v] = w;
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < n; i += NT) {
+            const int cc = (int)(i / S);
+            float v = sdc::silu_f(base[i] * coef[cc] + coef[cpg + cc]);
+            if (rb) v += rb[i];
+            yb[i] = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- channel LayerNorm / RMSNorm
 // 64 positions x 4 channel slices per workgroup; positions are the contiguous axis so every
 // channel row is read in 256-byte wave-wide segments.  Two passes over C (second pass is L2-hot).
@@ -289,6 +379,26 @@ extern "C" int sdc_gn_finalize(const double* parts, float* stats, int B, int G, 
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((ngroups + 63) / 64), dim3(64), 0, sdc::as_stream(stream), parts, stats, ngroups,
                        nparts, 1.0 / (double)n_per_group, eps);
     return sdc::check_launch("sdc_gn_finalize");
+}
+
+extern "C" int sdc_gn_fused_ok(int B, int C, int G, int64_t S) {
+    if (B <= 0 || C <= 0 || G <= 0 || C % G || S <= 0) return 0;
+    const int64_t n = (int64_t)(C / G) * S;
+    // one workgroup per group: worth it while the groups are small (L2-hot second read) and numerous enough to fill the chip
+    return n <= 32768 && (int64_t)B * G >= 64 && (C / G) <= 8192;
+}
+
+extern "C" int sdc_gn_fused(const float* x, const float* gamma, const float* beta, const float* ss, const int32_t* t_dev,
+                            int64_t ss_t_stride, int64_t ss_b_stride, int64_t ss_off, const float* residual, float* y, int B, int C,
+                            int G, int64_t S, float eps, void* stream) {
+    SDC_REQUIRE(x && gamma && beta && y, SDC_ENULL, "sdc_gn_fused: null pointer");
+    SDC_REQUIRE(sdc_gn_fused_ok(B, C, G, S), SDC_EINVAL, "sdc_gn_fused: group too large or too few groups (sdc_gn_fused_ok)");
+    SDC_REQUIRE((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) % 16 == 0 ||
+                    (S & 3) != 0, SDC_EINVAL, "sdc_gn_fused: 16-byte aligned tensors required");
+    const size_t lds = (size_t)2 * (C / G) * sizeof(float);
+    hipLaunchKernelGGL(gn_fused_kernel, dim3((unsigned)(B * G)), dim3(NT), lds, sdc::as_stream(stream), x, gamma, beta, ss, t_dev,
+                       ss_t_stride, ss_b_stride, ss_off, residual, y, C, G, S, eps);
+    return sdc::check_launch("sdc_gn_fused");
 }
 
 extern "C" int sdc_gn_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* ss,

@@ -317,11 +317,12 @@ class _SamplerBase(nn.Module):
         if prepare:
             kw.setdefault("target", None)
             kw.setdefault("final_update", True)
+            kw.pop("grad_tail", None)
             return self._setup(B, dims, **kw)
         return self._reverse_loop(B, dims, **kw)
 
     def _reverse_loop(self, B, dims, *, noise, guide, J_scheduler, k_const, cond, flags, impose_last, target=None,
-                      final_update=True, ddim=False, control_at_end=False):
+                      final_update=True, ddim=False, control_at_end=False, grad_tail=False):
         """Shared DDPM loop.  `guide`: None | GuidanceSpec | callable.  `cond`: (c0, c1, c2) tensors or None.
         `noise`: None (Philox in-kernel) or callable i -> tensor (injected, parity runs)."""
         dev = self.betas.device
@@ -336,23 +337,57 @@ class _SamplerBase(nn.Module):
         with torch.cuda.stream(self._side):
             out = self._reverse_loop_on_stream(B, dims, noise=noise, guide=guide, J_scheduler=J_scheduler, k_const=k_const,
                                                cond=cond, flags=flags, impose_last=impose_last, target=target,
-                                               final_update=final_update, ddim=ddim, control_at_end=control_at_end)
+                                               final_update=final_update, ddim=ddim, control_at_end=control_at_end,
+                                               grad_tail=grad_tail)
         cur.wait_stream(self._side)
         return out
 
     def _reverse_loop_on_stream(self, B, dims, *, noise, guide, J_scheduler, k_const, cond, flags, impose_last, target,
-                                final_update, ddim, control_at_end):
+                                final_update, ddim, control_at_end, grad_tail=False):
         S = self._setup(B, dims, noise=noise, guide=guide, J_scheduler=J_scheduler, k_const=k_const, cond=cond,
                         flags=flags, impose_last=impose_last, target=target, final_update=final_update, ddim=ddim,
                         control_at_end=control_at_end)
+        # enable_grad: the reference runs its LAST step inside torch.enable_grad() so that the fine-tuning loss can be
+        # back-propagated through one U-Net evaluation (1D/model/diffusion.py:524-551, 2d/ddpm/diffusion_2d.py:314-322,:379-399)
+        grad_tail = grad_tail and any(p.requires_grad for p in self.model.parameters())
         try:
             S.init()
-            for _ in range(S.n_main):
+            n_main = S.nsteps - 1 if grad_tail else S.n_main
+            for _ in range(n_main):
                 S.step()
+            if grad_tail:
+                return self._differentiable_last_step(S, guide, cond)
             S.final()
             return S.x.clone()
         finally:
             S.close()
+
+    def _differentiable_last_step(self, S, guide, cond):
+        """the last reverse step as an autograd graph over the model parameters: eps through the differentiable HIP U-Net
+        (model.forward_train), the x0 / guidance / posterior arithmetic of sdc_step_update restated element-wise"""
+        x = S.x.clone().view(S.shape)
+        row = S.coef[S.nsteps - 1] if S.ddim else S.coef[0]
+        t_last = int(S.ttab[S.nsteps - 1].item()) if S.ddim else 0
+        a, b, k = row[0], row[1], row[5]
+        with torch.enable_grad():
+            eps = self.model.forward_train(x, torch.full((S.B,), t_last, device=x.device, dtype=torch.long))
+            x0 = (a * x - b * eps).clamp(-1.0, 1.0)
+            if guide is not None:
+                g = guide(x0.detach().clone().requires_grad_())        # (the reference differentiates J on a detached clone)
+                g = g.detach() if isinstance(g, torch.Tensor) else g
+                x0 = (a * x - b * (eps + g * k)).clamp(-1.0, 1.0)
+            if S.ddim:
+                out = x0                                               # time_next < 0: img = x_start
+            else:
+                out = row[2] * x0 + row[3] * x                         # p_sample at t = 0: posterior mean, no noise
+            out = out.clone()
+            if self.MODEL == "smoke":
+                c0, c1 = cond[0], cond[1]
+                if not S.ddim:
+                    out[:, 0, 0] = c0.to(out.device)
+                if c1 is not None:
+                    out[:, :, 3:5] = c1.to(out.device)
+        return out
 
     def _setup(self, B, dims, *, noise, guide, J_scheduler, k_const, cond, flags, impose_last, target=None,
                final_update=True, ddim=False, control_at_end=False):
@@ -584,7 +619,7 @@ class GaussianDiffusionBurgers(_SamplerBase):
         """Reference signature (1D/model/diffusion.py:557-607) + ``noise`` (i -> tensor) for injected-noise parity."""
         if "guidance_u0" in kwargs:
             self.guidance_u0 = kwargs["guidance_u0"]
-        ddim = self.is_ddim_sampling        # ddim_sample (:451-555); the enable_grad tail returns the same numbers, no autograd graph
+        ddim = self.is_ddim_sampling        # ddim_sample (:451-555); enable_grad: its last step carries an autograd graph (:524-551)
         if not (self.is_condition_u0 and self.is_condition_uT):
             raise NotImplementedError("built for is_condition_u0 = is_condition_uT = True (1D/configs/*)")
         assert kwargs.get("u_init") is not None and kwargs.get("u_final") is not None
@@ -605,7 +640,8 @@ class GaussianDiffusionBurgers(_SamplerBase):
             guide = None
         return self._dispatch(kwargs.get("_prepare", False), batch_size, (C_, H, W, 1), noise=noise, guide=guide,
                               J_scheduler=J_sched, k_const=1.0, cond=(kwargs["u_init"], kwargs["u_final"], w_groundtruth),
-                              flags=flags, impose_last=False, final_update=self.guidance_u0 or not enable_grad, ddim=ddim)
+                              flags=flags, impose_last=False, final_update=self.guidance_u0 or not enable_grad, ddim=ddim,
+                              grad_tail=bool(enable_grad and ddim and self.guidance_u0))
 
 
 class GaussianDiffusionTokamak(_SamplerBase):
@@ -684,7 +720,8 @@ class GaussianDiffusionTokamak(_SamplerBase):
         return self._dispatch(kwargs.get("_prepare", False), batch_size, (self.channels, self.seq_length, 1, 1), noise=noise,
                               guide=guide, J_scheduler=J_sched, k_const=1.0,
                               cond=(kwargs["u_init"], kwargs["u_final"], w_groundtruth), flags=flags, impose_last=False,
-                              target=target, final_update=self.guidance_u0 or not enable_grad, ddim=ddim)
+                              target=target, final_update=self.guidance_u0 or not enable_grad, ddim=ddim,
+                              grad_tail=bool(enable_grad and ddim and self.guidance_u0))
 
 
 class GaussianDiffusionSmoke(_SamplerBase):
@@ -723,7 +760,8 @@ class GaussianDiffusionSmoke(_SamplerBase):
         S = self.image_size
         return self._dispatch(_prepare, batch_size, (self.frames, self.channels, S, S), noise=noise, guide=design_fn,
                               J_scheduler=None, k_const=float(self.standard_fixed_ratio), cond=(init, control, None),
-                              flags=flags, impose_last=True, ddim=ddim, control_at_end=ddim)
+                              flags=flags, impose_last=True, ddim=ddim, control_at_end=ddim,
+                              grad_tail=bool(enable_grad and ddim))   # (the reference's DDPM p_sample is @torch.no_grad: no graph there)
 
 
 # reference-compatible alias: each reference tree calls its class ``GaussianDiffusion``

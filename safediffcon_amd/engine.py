@@ -130,6 +130,7 @@ class Plan:
         self._ctx = None
         self._gn_parts = {}      # out.data_ptr() -> (partial-sum buffer, parts per (sample, group), groups) left by sdc_conv_gn
         self.fuse_gn_stats = True    # False: separate statistics pass after every conv (A/B checks)
+        self.fuse_gn_small = True    # False: small groups take the three-launch path (partial, finalize, apply)
 
     # ------------------------------------------------------------------ execution
     def run(self, stream):
@@ -265,6 +266,12 @@ class Plan:
         fused = self._gn_parts.pop(x.data_ptr(), None)
         if fused is not None and fused[2] == groups:
             self._emit(self.lib.sdc_gn_finalize, _ptr(fused[0]), _ptr(st), B, groups, fused[1], (Cc // groups) * S, eps)
+        elif self.fuse_gn_small and self.lib.sdc_gn_fused_ok(B, Cc, groups, S):
+            # small groups without conv-epilogue sums (the deep levels of the 1-D nets): statistics + apply in one launch
+            # (argument positions 3.. match sdc_gn_apply's 4..: bind_cond patches either form)
+            self._emit(self.lib.sdc_gn_fused, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(ss), _ptr(t_dev), ss_t_stride, ss_b_stride,
+                       ss_off, _ptr(residual), _ptr(out), B, Cc, groups, S, eps)
+            return out
         else:
             self._emit(self.lib.sdc_gn_stats, _ptr(x), _ptr(st), B, Cc, groups, S, eps)
         self._emit(self.lib.sdc_gn_apply, _ptr(x), _ptr(st), _ptr(gamma), _ptr(beta), _ptr(ss), _ptr(t_dev),

@@ -128,3 +128,50 @@ def sumpool2(g, fh, fw):
     rows = out.numel() // (H * W)
     check(lib.sdc_sumpool2(g.data_ptr(), out.data_ptr(), rows, H, W, fh, fw, _stream(g)), "sdc_sumpool2")
     return out
+
+
+def chan_norm(x, g, mode, eps=1e-5):
+    """channel LayerNorm (mode 0) / RMSNorm (mode 1) of a contiguous (B, C, ...) tensor (sdc_chan_norm)"""
+    _need_cuda(x)
+    lib = _lib.get_lib()
+    B, Cc = x.shape[0], x.shape[1]
+    y = torch.empty_like(x)
+    gv = g.reshape(-1).contiguous()
+    check(lib.sdc_chan_norm(x.data_ptr(), gv.data_ptr(), 0, y.data_ptr(), B, Cc, x.numel() // (B * Cc), mode, eps, _stream(x)), "sdc_chan_norm")
+    return y
+
+
+def attn_core(qkv, out, heads, outer, inner, ntok, qs, os_, rot=None, bias=None):
+    """softmax attention core (sdc_attn): strides (so, sc, si, st) of qkv and out in elements"""
+    check(_lib.get_lib().sdc_attn(qkv.data_ptr(), out.data_ptr(), 0 if rot is None else rot.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                  outer, inner, heads, ntok, *qs, *os_, _stream(qkv)), "sdc_attn")
+    return out
+
+
+def attn_core_bwd(qkv, dout, heads, outer, inner, ntok, qs, os_, rot=None, bias=None):
+    """-> (dqkv, dbias | None)"""
+    lib = _lib.get_lib()
+    dqkv = torch.empty_like(qkv)
+    dbias = work = None
+    if bias is not None:
+        dbias = torch.empty_like(bias)
+        work = torch.empty(int(lib.sdc_attn_bwd_bytes(outer, inner, heads, ntok)) // 4, dtype=torch.float32, device=qkv.device)
+    check(lib.sdc_attn_bwd(qkv.data_ptr(), dout.data_ptr(), 0 if rot is None else rot.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                           dqkv.data_ptr(), 0 if dbias is None else dbias.data_ptr(), 0 if work is None else work.data_ptr(),
+                           outer, inner, heads, ntok, *qs, *os_, _stream(qkv)), "sdc_attn_bwd")
+    return dqkv, dbias
+
+
+def linattn_core(qkv, out, heads, outer, inner, n, qs, os_):
+    """linear attention core (sdc_linattn): strides (so, sc, si) of qkv and out"""
+    lib = _lib.get_lib()
+    ctx = torch.empty(outer * inner * heads * 32 * 32, dtype=torch.float32, device=qkv.device)
+    check(lib.sdc_linattn(qkv.data_ptr(), ctx.data_ptr(), out.data_ptr(), outer, inner, heads, n, *qs, *os_, _stream(qkv)), "sdc_linattn")
+    return out
+
+
+def linattn_core_bwd(qkv, dout, heads, outer, inner, n, qs, os_):
+    dqkv = torch.empty_like(qkv)
+    check(_lib.get_lib().sdc_linattn_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), outer, inner, heads, n, *qs, *os_,
+                                         _stream(qkv)), "sdc_linattn_bwd")
+    return dqkv

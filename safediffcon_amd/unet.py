@@ -380,10 +380,12 @@ class _HipUNet(nn.Module):
             fn, a = plan.calls[idx]
             a = list(a)
             # sdc_gn_apply(x, stats, gamma, beta, ss, t_dev, ss_t_stride, ss_b_stride, ss_off, residual, y, B, C, G, S)
+            # sdc_gn_fused(x, gamma, beta, ss, t_dev, ss_t_stride, ss_b_stride, ss_off, residual, y, B, C, G, S, eps)
+            i0 = 3 if fn is plan.lib.sdc_gn_fused else 4
             if t_dev is None:
-                a[4], a[5], a[6], a[7], a[8] = ss.data_ptr(), 0, 0, W, off
+                a[i0:i0 + 5] = ss.data_ptr(), 0, 0, W, off
             else:
-                a[4], a[5], a[6], a[7], a[8] = ss.data_ptr(), t_dev.data_ptr(), W, 0, off
+                a[i0:i0 + 5] = ss.data_ptr(), t_dev.data_ptr(), W, 0, off
             plan.calls[idx] = (fn, tuple(a))
         ent["t_dev"] = t_dev
 
@@ -597,6 +599,7 @@ class Unet3D_with_Conv3D(_HipUNet):
         # the reference shares ONE RotaryEmbedding instance between all temporal-attention layers
         # (conv3d.py:381-383): tie the eight state_dict entries to a single Parameter
         shared = self.P("init_temporal_attn.fn.fn.fn.rotary_emb.freqs")
+        shared.requires_grad_(False)      # rotary-embedding-torch: nn.Parameter(freqs, requires_grad=learned_freq), learned_freq=False
         for k, _ in self._spec:
             if k.endswith("rotary_emb.freqs"):
                 m = self

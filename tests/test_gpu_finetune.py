@@ -54,9 +54,12 @@ def test_finetune_loss_and_gradients_vs_reference(golden, tree):
     gmax = float(np.max(g.z["grad_norms"]))
     for i, k in enumerate(keys):
         gr = params[k].grad
+        n_ref, d_ref = float(g.z["grad_norms"][i]), float(g.z["grad_dots"][i])
+        if not params[k].requires_grad:                   # rotary freqs: not learnable, in the reference neither
+            assert n_ref == 0.0 and k.endswith("rotary_emb.freqs"), k
+            continue
         assert gr is not None, f"no gradient for {k}"
         gr = gr.detach().double().cpu()
-        n_ref, d_ref = float(g.z["grad_norms"][i]), float(g.z["grad_dots"][i])
         # gradients that are zero in exact arithmetic (a conv bias in front of a GroupNorm with one channel per group) are
         # rounding noise on both sides: they only have to be as small here as they are in the reference
         if n_ref < 1e-4 * gmax:
@@ -137,6 +140,8 @@ def test_finetune_gradients_at_production_width(tree):
     gmax = max(v.grad.norm().item() for v in P.values() if v.grad is not None)
     worst, checked = 0.0, 0
     for k, p in net.named_parameters():
+        if not p.requires_grad:
+            continue
         gr, gref = p.grad, P[k].grad
         assert gr is not None and gref is not None, k
         n_ref = gref.norm().item()
@@ -148,3 +153,95 @@ def test_finetune_gradients_at_production_width(tree):
         assert err < 2e-4, (k, err)
     print(f"[measured] {tree} production-width fine-tune step vs PyTorch-ROCm autograd of the oracle: loss {loss.item():.6f} vs {ref.item():.6f}; "
           f"{checked} parameter gradients, worst relative L2 error {worst:.2e}")
+
+
+def test_differentiable_ddim_tail(golden):
+    """sample(enable_grad=True) with DDIM: the last step is an autograd graph over the model parameters (1D/model/diffusion.py:
+    524-551, 2d/ddpm/diffusion_2d.py:379-399) -- the numbers equal the gradient-free sampler's, a loss on the sample
+    back-propagates into every parameter the last U-Net evaluation touches, and the gradient matches PyTorch-ROCm autograd of
+    the oracle's functional net on the same last step."""
+    from oracle import nets as onets
+    g = golden("burgers_ddim_guided")
+    T, S, eta = int(g.scalar("T")), int(g.scalar("S")), g.scalar("eta")
+    spec = golden("burgers_unet").spec()
+    net = sdc.Unet2D(dim=8, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+    net.load_state_dict(det_params(spec, 100))
+    net.to(DEV)
+    gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=T, sampling_timesteps=S, ddim_sampling_eta=eta,
+                                      temporal=True, use_conv2d=True, is_condition_u0=True, is_condition_uT=True,
+                                      condition_idx=10, train_on_padded_locations=False).to(DEV)
+    from oracle.detweights import det_noise
+    noise = det_noise((2, 3, 16, 128), int(g.scalar("noise_seed")))
+    guid = sdc.BurgersGuidance(g.scalar("Q"), g.scalar("w_score"), g.scalar("u_bound"))
+    kw = dict(batch_size=2, clip_denoised=True, u_init=g["u0"], u_final=g["uT"], guidance_u0=True, nablaJ=guid,
+              J_scheduler=lambda t: 1.0, noise=noise)
+    plain = gd.sample(enable_grad=False, **kw)
+    out = gd.sample(enable_grad=True, **kw)
+    assert out.requires_grad and not plain.requires_grad
+    err = (out.detach() - plain).abs().max().item()
+    assert err < 2e-4 and (out.detach().cpu() - g["out"]).abs().max().item() < 1.5e-3
+    # the reference's backward fine-tune loss (1D/inference/inference_ft.py:192-201)
+    s = out[:, 2, :11, :].amax(dim=(-1, -2))
+    loss = (torch.clamp(s + 0.01 - 0.05 ** 2, min=0) ** 2).mean() + 1e-3 * (out ** 2).mean()
+    loss.backward()
+    got = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    assert len(got) == len([1 for p in net.parameters() if p.requires_grad])
+    # reference arithmetic of the same last step on the oracle's functional net (PyTorch-ROCm autograd)
+    P = {k: v.detach().clone().requires_grad_() for k, v in net.state_dict().items()}
+    hooks = {}
+    orig = net.forward_train
+
+    def spy(x, t):
+        hooks["x"], hooks["t"] = x.detach().clone(), t.clone()
+        return orig(x, t)
+    net.forward_train = spy
+    net.zero_grad()
+    out2 = gd.sample(enable_grad=True, **kw)
+    net.forward_train = orig
+    x_last, t_last = hooks["x"], hooks["t"]
+    tabs = gd
+    a, b = tabs.sqrt_recip_alphas_cumprod[t_last[0]], tabs.sqrt_recipm1_alphas_cumprod[t_last[0]]
+    eps = onets.unet_burgers(P, x_last, t_last, dim=8)
+    x0 = (a * x_last - b * eps).clamp(-1, 1)
+    gg = guid(x0.detach().clone().requires_grad_()).detach()
+    ref = (a * x_last - b * (eps + gg)).clamp(-1, 1)
+    assert (ref.detach() - out2.detach()).abs().max().item() < 2e-4
+    s = ref[:, 2, :11, :].amax(dim=(-1, -2))
+    lref = (torch.clamp(s + 0.01 - 0.05 ** 2, min=0) ** 2).mean() + 1e-3 * (ref ** 2).mean()
+    lref.backward()
+    gmax = max(v.grad.norm().item() for v in P.values())
+    worst = 0.0
+    for k, gr in got.items():
+        n_ref = P[k].grad.norm().item()
+        if n_ref < 1e-4 * gmax:
+            continue
+        worst = max(worst, ((gr - P[k].grad).norm() / n_ref).item())
+    print(f"[measured] differentiable DDIM tail: sample vs gradient-free sampler {err:.2e}; loss {loss.item():.3e} vs {lref.item():.3e}; "
+          f"worst relative gradient error vs PyTorch-ROCm autograd of the oracle {worst:.2e}")
+    assert abs(loss.item() - lref.item()) < 1e-4 * abs(lref.item()) + 1e-9 and worst < 5e-4
+
+
+def test_native_attention_backward_agrees_with_the_torch_vjp_stage(golden):
+    """the attention blocks as chains of HIP nodes (default) and as fused HIP forward + PyTorch-ROCm VJP of the block's torch
+    restatement (Trainer.native_attention = False) give the same loss and gradients"""
+    spec = golden("smoke_unet").spec()
+    res = {}
+    for native in (True, False):
+        net = sdc.Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2, 4), channels=7)
+        net.load_state_dict(det_params(spec, 300))
+        net.to(DEV).train()
+        net._trainer().native_attention = native
+        x, t = det_tensor((2, 8, 7, 16, 16), 5).to(DEV), torch.tensor([10, 900], device=DEV)
+        loss = (net.forward_train(x, t) ** 2).mean()
+        loss.backward()
+        res[native] = (loss.item(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * abs(res[False][0])
+    gmax = max(v.norm().item() for v in res[False][1].values())
+    worst = 0.0
+    for k, gr in res[True][1].items():
+        ref = res[False][1][k]
+        if ref.norm().item() < 1e-4 * gmax:
+            continue
+        worst = max(worst, ((gr - ref).norm() / ref.norm()).item())
+    print(f"[measured] native attention backward vs the torch-VJP stage: worst relative gradient difference {worst:.2e}")
+    assert worst < 1e-4

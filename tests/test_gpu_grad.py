@@ -155,3 +155,93 @@ def test_act_backward_and_sumpool():
     xd = det_tensor((2, 3, 16), 135).double().requires_grad_()
     F.interpolate(xd, scale_factor=2, mode="nearest").backward(g1.double())
     assert _rel(grad_ops.sumpool2(g1.to(DEV).unsqueeze(-2), 1, 2).squeeze(-2), xd.grad) < 1e-6
+
+
+# ------------------------------------------------------------------ attention cores
+def _rot_table(F_, dev="cpu"):
+    fr = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    ang = torch.arange(F_, dtype=torch.float32)[:, None] * fr[None, :]
+    return torch.stack((ang.cos(), ang.sin()), dim=-1).reshape(-1).to(dev), ang.repeat_interleave(2, dim=-1).double()
+
+
+def _ref_attention(q, k, v, ang=None, bias=None):
+    """q, k, v (..., heads, n, 32) fp64"""
+    q = q * 32 ** -0.5
+    if ang is not None:
+        def rot(x):
+            x2 = x.reshape(*x.shape[:-1], 16, 2)
+            half = torch.stack((-x2[..., 1], x2[..., 0]), dim=-1).reshape(x.shape)
+            return x * ang.cos() + half * ang.sin()
+        q, k = rot(q), rot(k)
+    sim = torch.einsum("...id,...jd->...ij", q, k)
+    if bias is not None:
+        sim = sim + bias
+    return torch.einsum("...ij,...jd->...id", sim.softmax(-1), v)
+
+
+@pytest.mark.parametrize("Fr,H,W,B", [(32, 4, 8, 2), (8, 4, 4, 3), (32, 3, 8, 1)])
+def test_temporal_attention_core_backward(Fr, H, W, B):
+    """'b c f h w -> b (h w) f c' attention with rotary + relative-position bias (conv3d.py:277-353): sdc_attn / sdc_attn_bwd
+    on the channel-major qkv against fp64 autograd"""
+    hw = H * W
+    qkv = det_tensor((B, 384, Fr, H, W), 140)
+    bias = 0.5 * det_tensor((4, Fr, Fr), 141)
+    gout = det_tensor((B, 128, Fr, H, W), 142)
+    rot, ang = _rot_table(Fr)
+    qd, bd = qkv.double().requires_grad_(), bias.double().requires_grad_()
+    q, k, v = (t.reshape(B, 4, 32, Fr, hw).permute(0, 4, 1, 3, 2) for t in qd.chunk(3, dim=1))       # (B, hw, heads, F, 32)
+    o = _ref_attention(q, k, v, ang, bd)                                                              # (B, hw, heads, F, 32)
+    out_ref = o.permute(0, 2, 4, 3, 1).reshape(B, 128, Fr, H, W)
+    out_ref.backward(gout.double())
+    qs, os_ = (384 * Fr * hw, Fr * hw, 1, hw), (128 * Fr * hw, Fr * hw, 1, hw)
+    qg = qkv.to(DEV)
+    out = torch.empty((B, 128, Fr, H, W), device=DEV)
+    grad_ops.attn_core(qg, out, 4, B, hw, Fr, qs, os_, rot.to(DEV), bias.to(DEV))
+    assert _rel(out, out_ref.detach()) < 1e-5
+    dqkv, dbias = grad_ops.attn_core_bwd(qg, gout.to(DEV), 4, B, hw, Fr, qs, os_, rot.to(DEV), bias.to(DEV))
+    e1, e2 = _rel(dqkv, qd.grad), _rel(dbias, bd.grad)
+    print(f"[measured] temporal attention core backward F={Fr} {H}x{W} B={B}: dqkv {e1:.2e} dbias {e2:.2e}")
+    assert e1 < 2e-5 and e2 < 2e-5
+
+
+@pytest.mark.parametrize("B,inner,n", [(3, 1, 32), (2, 4, 256), (5, 1, 16), (1, 2, 100)])
+def test_full_attention_core_backward(B, inner, n):
+    """token-contiguous softmax attention (mid_attn of the 1-D nets: inner = 1; smoke mid spatial attention: inner = frames)"""
+    qkv = det_tensor((B, 384, inner, n), 150)
+    gout = det_tensor((B, 128, inner, n), 151)
+    qd = qkv.double().requires_grad_()
+    q, k, v = (t.reshape(B, 4, 32, inner, n).permute(0, 3, 1, 4, 2) for t in qd.chunk(3, dim=1))      # (B, inner, heads, n, 32)
+    out_ref = _ref_attention(q, k, v).permute(0, 2, 4, 1, 3).reshape(B, 128, inner, n)
+    out_ref.backward(gout.double())
+    qs, os_ = (384 * inner * n, inner * n, n, 1), (128 * inner * n, inner * n, n, 1)
+    qg = qkv.to(DEV)
+    out = torch.empty((B, 128, inner, n), device=DEV)
+    grad_ops.attn_core(qg, out, 4, B, inner, n, qs, os_)
+    assert _rel(out, out_ref.detach()) < 1e-5
+    dqkv, _ = grad_ops.attn_core_bwd(qg, gout.to(DEV), 4, B, inner, n, qs, os_)
+    err = _rel(dqkv, qd.grad)
+    print(f"[measured] softmax attention core backward B={B} inner={inner} n={n}: dqkv {err:.2e}")
+    assert err < 2e-5
+
+
+@pytest.mark.parametrize("B,inner,n", [(2, 1, 2048), (3, 4, 256), (2, 1, 77), (4, 1, 16)])
+def test_linear_attention_core_backward(B, inner, n):
+    """LinearAttention core (1D/model/unet.py:203-216, conv3d.py:246-256): softmax over d of q, over n of k, context, output"""
+    qkv = det_tensor((B, 384, inner, n), 160)
+    gout = det_tensor((B, 128, inner, n), 161)
+    qd = qkv.double().requires_grad_()
+    q, k, v = (t.reshape(B, 4, 32, inner, n).permute(0, 3, 1, 2, 4) for t in qd.chunk(3, dim=1))      # (B, inner, heads, 32, n)
+    qq = q.softmax(dim=-2) * 32 ** -0.5
+    kk = k.softmax(dim=-1)
+    ctx = torch.einsum("...dn,...en->...de", kk, v)
+    out_ref = torch.einsum("...de,...dn->...en", ctx, qq).permute(0, 2, 3, 1, 4).reshape(B, 128, inner, n)
+    out_ref.backward(gout.double())
+    qs, os_ = (384 * inner * n, inner * n, n), (128 * inner * n, inner * n, n)
+    qg = qkv.to(DEV)
+    out = torch.empty((B, 128, inner, n), device=DEV)
+    grad_ops.linattn_core(qg, out, 4, B, inner, n, qs, os_)
+    assert _rel(out, out_ref.detach()) < 1e-5
+    dqkv = grad_ops.linattn_core_bwd(qg, gout.to(DEV), 4, B, inner, n, qs, os_)
+    err = _rel(dqkv, qd.grad)
+    print(f"[measured] linear attention core backward B={B} inner={inner} n={n}: dqkv {err:.2e}")
+    assert err < 2e-5

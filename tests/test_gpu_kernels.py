@@ -743,3 +743,33 @@ def test_conv_direct_big_grids(plan_cls, case):
     got = out.cpu().reshape(ref.shape).double()
     scale = ref.abs().max().item()
     assert (got - ref).abs().max().item() / scale < 3e-6
+
+
+@pytest.mark.parametrize("B,Cc,G,sp,cond,res", [(128, 256, 1, (64,), True, False), (96, 256, 1, (4, 32), True, True),
+                                                 (64, 2048, 1, (16,), False, True), (80, 64, 8, (2, 8, 8), False, False),
+                                                 (70, 96, 1, (3, 7), True, True)])
+def test_gn_fused_small_groups_equal_the_three_launch_path(B, Cc, G, sp, cond, res):
+    """sdc_gn_fused (statistics + apply in one launch for small groups: the deep levels of Unet2D / Unet1D) gives the bits of
+    sdc_gn_stats + sdc_gn_apply, and both match torch in fp64"""
+    from safediffcon_amd.engine import Plan, as5
+    x = det_tensor((B, Cc, *sp), 170)
+    gamma, beta = (1 + 0.1 * det_tensor((Cc,), 171)).to(DEV), (0.1 * det_tensor((Cc,), 172)).to(DEV)
+    ss = (0.2 * det_tensor((B, 2 * Cc), 173)).to(DEV) if cond else None
+    r = det_tensor((B, Cc, *sp), 174).to(DEV) if res else None
+    outs, used = [], []
+    for small in (True, False):
+        plan = Plan(DEV)
+        plan.fuse_gn_small = small
+        xx = as5(x.to(DEV).clone())
+        y = plan.gn_silu(xx, gamma, beta, G, ss=ss, ss_b_stride=2 * Cc if cond else 0, residual=None if r is None else as5(r))
+        plan.run(torch.cuda.current_stream().cuda_stream)
+        outs.append(y.clone())
+        used.append({fn.__name__ for fn, _ in plan.calls})
+    assert used[0] == {"sdc_gn_fused"} and "sdc_gn_stats" in used[1]
+    assert torch.equal(outs[0], outs[1])
+    u = F.group_norm(x.double(), G, gamma.double().cpu(), beta.double().cpu(), eps=1e-5)
+    if cond:
+        bs = (B, Cc) + (1,) * len(sp)
+        u = u * (ss.double().cpu()[:, :Cc].reshape(bs) + 1) + ss.double().cpu()[:, Cc:].reshape(bs)
+    want = F.silu(u) + (r.double().cpu() if res else 0)
+    assert (outs[0].cpu().double().reshape(want.shape) - want).abs().max().item() < 2e-5

@@ -1,46 +1,65 @@
 #!/usr/bin/env python3
-"""Workload for the FETCH_SIZE / WRITE_SIZE / SQ PMC passes: (1) calibration launches with a KNOWN byte count in the
-same access shapes the conv uses (dword-per-lane loads: sdc_act over n floats reads 4n and writes 4n bytes),
-(2) the dominant conv of the bench workload, a few launches:
-      c4 (default): 64->64 3x3x3 at (64,64,32,64,64) + GroupNorm statistics in the epilogue (the C4 level-0 ResnetBlock conv)
-      c2:           64->64 3x3   at (256,64,16,128)
-(3) c4 only: the fused temporal-attention block at width 64 on the same tensor.
-usage: python3 tools/pmc_traffic.py [c4|c2] [batch]   (under rocprofv3 --kernel-trace --pmc ... -- python3 tools/pmc_traffic.py)"""
-import os, sys
+"""Workload for the FETCH_SIZE / WRITE_SIZE / SQ PMC passes (rocprofv3 --kernel-trace --pmc ... -- python3 tools/pmc_traffic.py):
+ (1) a calibration launch with a KNOWN byte count (sdc_act over n floats reads 4n and writes 4n bytes, dword per lane),
+ (2) the kernels of the C4 step the bench prices, a few launches each, at the C4 shapes (B = 64 by default):
+       conv_wg3<64>  64->64  3x3x3 at (B,64,32,64,64)   + GroupNorm statistics          (level-0 ResnetBlock conv)
+       conv_wg3<32>  128->128 3x3x3 at (B,128,32,32,32)
+       conv_wg3<16>  256->256 3x3x3 at (B,256,32,16,16)
+       gn_apply      GroupNorm apply + SiLU on the level-0 tensor, in place
+       ta_block      fused temporal-attention block at width 64 on the level-0 tensor
+       conv_pw       1x1x1 conv 128->384 at (B,128,32,32,32) (to_qkv of the width-128 temporal attention)
+ It writes the algorithmic bytes of every case to <out dir>/pmc_cases.json for tools/pmc_to_json.py.
+usage: python3 tools/pmc_traffic.py [batch] [cases.json]"""
+import json
+import os
+import sys
+
 import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from safediffcon_amd.engine import Plan, as5
-wl = sys.argv[1] if len(sys.argv) > 1 else "c4"
+from safediffcon_amd.engine import Plan, as5  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+cases_path = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/pmc_cases.json"
 dev = "cuda:0"
-prec = int(os.environ.get("SDC_PRECISION", "4"))
-plan = Plan(dev, precision=prec)
+plan = Plan(dev, precision=4)
 n = 64 * 1024 * 1024                       # 256 MiB in, 256 MiB out: beyond the 256 MiB Infinity Cache together
-xa = torch.randn(n, device=dev); ya = torch.empty(n, device=dev)
+xa = torch.randn(n, device=dev)
+ya = torch.empty(n, device=dev)
 plan.act(xa, 0, out=ya)
-if wl == "c2":
-    B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    x = torch.randn(B, 64, 16, 128, device=dev)
-    w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
-    k, pad = (1, 3, 3), (0, 1, 1)
-else:
-    B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-    x = torch.randn(B, 64, 32, 64, 64, device=dev)
-    w = torch.randn(64, 64, 3, 3, 3, device=dev) * 0.03
-    k, pad = (3, 3, 3), (1, 1, 1)
-b = torch.randn(64, device=dev)
-out = plan.conv(as5(x), plan.conv_weight(w), b, 64, k, pad=pad, gn_groups=8 if wl != "c2" else 1)
-if wl != "c2":
-    g = torch.ones(64, device=dev)
-    wqkv = plan.conv_weight(torch.randn(384, 64, 1, device=dev) * 0.1)
-    wo = plan.conv_weight(torch.randn(64, 128, 1, device=dev) * 0.1)
-    rot = torch.randn(32 * 16 * 2, device=dev)
-    bias = torch.randn(4 * 32 * 32, device=dev)
-    plan.tattn_block(x, g, wqkv, wo, rot, bias)
-    gm, bt = torch.ones(64, device=dev), torch.zeros(64, device=dev)
-    plan.gn_silu(out, gm, bt, 8)
+cases = {"act_kernel": dict(read=4 * n, write=4 * n, shape=f"sdc_act over {n} floats")}
+
+
+def conv3(cin, cout, sp, tag):
+    x = torch.randn(B, cin, *sp, device=dev)
+    w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.03
+    b = torch.randn(cout, device=dev)
+    out = plan.conv(as5(x), plan.conv_weight(w), b, cout, (3, 3, 3), pad=(1, 1, 1), gn_groups=8)
+    cases[tag] = dict(algorithmic=4 * (x.numel() + out.numel() + w.numel()), shape=f"{cin}->{cout} 3x3x3 at ({B},{cin},{','.join(map(str, sp))}) + GN statistics")
+    return x, out
+
+
+x0, out0 = conv3(64, 64, (32, 64, 64), "conv_wg3_kernel<64")
+conv3(128, 128, (32, 32, 32), "conv_wg3_kernel<32")
+conv3(256, 256, (32, 16, 16), "conv_wg3_kernel<16")
+gm, bt = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+plan.gn_silu(out0, gm, bt, 8)
+cases["gn_apply_kernel"] = dict(algorithmic=8 * out0.numel(), shape=f"GroupNorm apply + SiLU in place on ({B},64,32,64,64)")
+g = torch.ones(64, device=dev)
+wqkv = plan.conv_weight(torch.randn(384, 64, 1, device=dev) * 0.1)
+wo = plan.conv_weight(torch.randn(64, 128, 1, device=dev) * 0.1)
+rot = torch.randn(32 * 16 * 2, device=dev)
+bias = torch.randn(4 * 32 * 32, device=dev)
+plan.tattn_block(x0, g, wqkv, wo, rot, bias)
+cases["ta_block_kernel"] = dict(algorithmic=8 * x0.numel(), shape=f"fused temporal-attention block, width 64, on ({B},64,32,64,64)")
+x1 = torch.randn(B, 128, 32, 32, 32, device=dev)
+w1 = torch.randn(384, 128, 1, 1, 1, device=dev) * 0.1
+o1 = plan.conv(as5(x1), plan.conv_weight(w1), None, 384, (1, 1, 1))
+cases["conv_pw_kernel<128"] = dict(algorithmic=4 * (x1.numel() + o1.numel() + w1.numel()), shape=f"1x1x1 conv 128->384 at ({B},128,32,32,32)")
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
     plan.run(s)
 torch.cuda.synchronize()
-print("act bytes read/written:", 4 * n, 4 * n, "conv algorithmic bytes:", 4 * (x.numel() + out.numel() + w.numel()),
-      "x bytes:", 4 * x.numel())
+os.makedirs(os.path.dirname(cases_path) or ".", exist_ok=True)
+json.dump(dict(batch=B, cases=cases), open(cases_path, "w"), indent=1)
+print("cases:", list(cases))

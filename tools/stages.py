@@ -46,6 +46,10 @@ def classify(lib, fn, a):
         Bb, Cc, S = a[11], a[12], a[14]
         return dict(stage="groupnorm apply+SiLU(+res)", kernel="gn_apply", flops=8.0 * Bb * Cc * S, issued=0.0,
                     bytes=4.0 * Bb * Cc * S * (3 if a[9] else 2))
+    if fn is lib.sdc_gn_fused:
+        Bb, Cc, S = a[10], a[11], a[13]
+        return dict(stage="groupnorm stats+apply+SiLU(+res), one launch", kernel="gn_fused", flops=11.0 * Bb * Cc * S, issued=0.0,
+                    bytes=4.0 * Bb * Cc * S * (3 if a[8] else 2))
     if fn is lib.sdc_chan_norm:
         Bb, Cc, S = a[4], a[5], a[6]
         return dict(stage="channel LN/RMS(+res)", kernel="chan_norm", flops=8.0 * Bb * Cc * S, issued=0.0,
