@@ -18,7 +18,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------------ weight gradient
 // GEMM  C[m][n] (per tap) = sum_k A[m][k] B[k][n]  with k = output positions: A = G rows (k contiguous), B = X rows shifted
 // by the tap.  Workgroup = 4 waves (2 x 2), 64 m x 64 n x the KW taps of one (kd, kh); the K walk covers the output rows
-// (b, od, oh) of this split in chunks of 16 positions along W.  Per chunk the G tile [64][16] and the X tile [64][15 SW + KW]
+// (b, od, oh) of this split in chunks of BKP = 64 / 32 / 16 positions along W.  Per chunk the G tile [64][BKP] and the X tile
+// [64][(BKP - 1) SW + KW]
 // (one input row segment: it serves all KW taps) go through LDS; a wave issues KW MFMAs per k pair from one ds_read_b32 of A
 // and KW of B.  Chunk c+1 is fetched to registers while chunk c computes (two LDS buffers, one barrier per chunk).
 // Partial results of the splits are written to the workspace and summed in a fixed order (deterministic, no atomics).
@@ -33,15 +34,18 @@ struct WgradArgs {
     int lgD, lgH, lgW;      // log2 of the nearest-upsample factors of X
 };
 
-template <int KW, int SW>
+template <int KW, int SW, int BKP>
 __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
-    constexpr int BKP = 16;                       // positions per chunk
+    // BKP = positions per chunk (64 where the row length allows: 96 MFMAs per chunk and wave at KW = 3 cover the latency of
+    // the next chunk's global loads; 16 for the short rows of the deep levels)
     constexpr int SPAN = (BKP - 1) * SW + KW;     // input columns under a chunk
     constexpr int AP = BKP + 1;                   // LDS pitches (odd: conflict-free column reads)
-    constexpr int BP = (SPAN | 1) + ((SPAN & 1) ? 0 : 0);
+    constexpr int BP = SPAN | 1;
     constexpr int NBL = (64 * SPAN + NT - 1) / NT;        // X elements per thread and chunk
-    __shared__ float As[2][64 * AP];
-    __shared__ float Bs[2][64 * BP];
+    constexpr int GPT = BKP / 4;                  // G positions per thread (thread = row tid >> 2, quarter tid & 3)
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    float* const As = wlds;                       // [2][64 * AP]
+    float* const Bs = wlds + 2 * 64 * AP;         // [2][64 * BP]
     const SdcWgradDesc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
@@ -58,12 +62,12 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
     const int r_hi = min(R, r_lo + a.rows_per_split);
     const int chunks_per_row = (d.oW + BKP - 1) / BKP;      // a ragged last chunk is zero-filled
 
-    // G fetch: thread -> (m = tid >> 2, positions 4 (tid & 3) .. + 3)
+    // G fetch: thread -> (m = tid >> 2, positions GPT (tid & 3) .. + GPT - 1)
     const int gm = tid >> 2, gq = tid & 3;
     const bool gm_ok = m0 + gm < d.M;
     const int64_t g_moff = (int64_t)(gm_ok ? m0 + gm : 0) * d.gs[1];
+    // (16-byte loads need every row start 16-byte aligned: the strides; a thread's run starts at a multiple of 4 positions)
     const bool gvec = d.gs[4] == 1 && ((d.gs[0] | d.gs[1] | d.gs[2] | d.gs[3]) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.g) & 15) == 0;
-    // (16-byte loads need every row start 16-byte aligned: the strides above; a row's chunks start at multiples of 16 positions)
     // X fetch: element e = tid + NT i -> (n = e / SPAN, j = e % SPAN)
     int xn[NBL], xj[NBL];
     int64_t x_noff[NBL];
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
     float bsum = 0.0f;
     const bool want_bias = a.bpart != nullptr && nt == 0 && kd == 0 && kh == 0;
 
-    float greg[4], xreg[NBL];
+    float greg[GPT], xreg[NBL];
     // chunk walk: (row r, chunk c); rows whose input row (id, ih) falls outside X contribute nothing to this (kd, kh) -- but
     // still feed the bias sum
     int r = r_lo, c = 0;
@@ -100,20 +104,19 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
         const bool rv = idu >= 0 && idu < iDu && ihu >= 0 && ihu < iHu;
         valid_out = rv;
         const int ow0 = c * BKP;
-        const float* gp = a.g + (int64_t)b * d.gs[0] + (int64_t)od * d.gs[2] + (int64_t)oh * d.gs[3] + g_moff + (int64_t)(ow0 + 4 * gq) * d.gs[4];
+        const int p0 = ow0 + GPT * gq;                       // this thread's first position
+        const float* gp = a.g + (int64_t)b * d.gs[0] + (int64_t)od * d.gs[2] + (int64_t)oh * d.gs[3] + g_moff + (int64_t)p0 * d.gs[4];
         if (rv || want_bias) {
-            if (gm_ok) {
-                const int left = d.oW - (ow0 + 4 * gq);              // positions of this thread inside the row
-                if (gvec && left >= 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(gp);
-                    greg[0] = v.x; greg[1] = v.y; greg[2] = v.z; greg[3] = v.w;
-                } else {
+            const int left = gm_ok ? d.oW - p0 : 0;          // positions of this thread inside the row
+            if (gvec && left >= GPT) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) greg[i] = i < left ? gp[(int64_t)i * d.gs[4]] : 0.0f;
+                for (int i = 0; i < GPT / 4; ++i) {
+                    const float4 v = reinterpret_cast<const float4*>(gp)[i];
+                    greg[4 * i] = v.x; greg[4 * i + 1] = v.y; greg[4 * i + 2] = v.z; greg[4 * i + 3] = v.w;
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) greg[i] = 0.0f;
+                for (int i = 0; i < GPT; ++i) greg[i] = i < left ? gp[(int64_t)i * d.gs[4]] : 0.0f;
             }
         }
         if (rv) {
@@ -128,13 +131,18 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
         }
     };
     auto park = [&](int buf, bool valid) {
-        if (want_bias) bsum += (greg[0] + greg[1]) + (greg[2] + greg[3]);
-        if (!valid) return;
+        if (want_bias) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) As[buf][gm * AP + 4 * gq + i] = greg[i];
+            for (int i = 0; i < GPT; ++i) bsum += greg[i];
+        }
+        if (!valid) return;
+        float* Ab = As + buf * (64 * AP);
+        float* Bb = Bs + buf * (64 * BP);
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) Ab[gm * AP + GPT * gq + i] = greg[i];
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
-            if (tid + NT * i < 64 * SPAN) Bs[buf][xn[i] * BP + xj[i]] = xreg[i];
+            if (tid + NT * i < 64 * SPAN) Bb[xn[i] * BP + xj[i]] = xreg[i];
     };
     auto advance = [&]() { if (++c == chunks_per_row) { c = 0; ++r; } };
 
@@ -150,9 +158,9 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
         const bool more = r < r_hi;
         if (more) fetch(v_nxt);
         if (v_cur) {
-            const float* Ab = As[buf] + (wm * 32 + l31) * AP + lh;
-            const float* Bb = Bs[buf] + (wn * 32 + l31) * BP + lh * SW;
-#pragma unroll
+            const float* Ab = As + buf * (64 * AP) + (wm * 32 + l31) * AP + lh;
+            const float* Bb = Bs + buf * (64 * BP) + (wn * 32 + l31) * BP + lh * SW;
+#pragma unroll 8
             for (int kk = 0; kk < BKP / 2; ++kk) {
                 const float av = Ab[2 * kk];
 #pragma unroll
@@ -187,6 +195,23 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
         bsum += __shfl_xor(bsum, 2, 64);
         if (gq == 0 && gm_ok) a.bpart[(int64_t)split * d.M + m0 + gm] = bsum;
     }
+}
+
+template <int KW, int SW, int BKP>
+int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int SPAN = (BKP - 1) * SW + KW;
+    const size_t lds = (size_t)2 * 64 * ((BKP + 1) + (SPAN | 1)) * sizeof(float);
+    static std::atomic<uint64_t> attr{0};
+    SDC_LDS_OPTIN(attr, (wgrad_kernel<KW, SW, BKP>), 160 * 1024, "sdc_conv_wgrad");
+    hipLaunchKernelGGL((wgrad_kernel<KW, SW, BKP>), grid, dim3(NT), lds, s, a);
+    return SDC_OK;
+}
+
+template <int KW, int SW>
+int launch_wgrad_bkp(const WgradArgs& a, dim3 grid, hipStream_t s) {
+    if (a.d.oW % 64 == 0) return launch_wgrad<KW, SW, 64>(a, grid, s);
+    if (a.d.oW % 32 == 0) return launch_wgrad<KW, SW, 32>(a, grid, s);
+    return launch_wgrad<KW, SW, 16>(a, grid, s);
 }
 
 // out[i] = sum_s part[s][i]  (fixed order)
@@ -243,16 +268,17 @@ extern "C" int sdc_conv_wgrad(const SdcWgradDesc* dp, const float* g, const floa
     SDC_REQUIRE(tiles < (1ll << 31) && a.nsplit < 65536, SDC_EINVAL, "sdc_conv_wgrad: grid too large");
     dim3 grid((unsigned)tiles, (unsigned)a.nsplit);
     hipStream_t s = sdc::as_stream(stream);
-#define WG_CASE(KWV, SWV) hipLaunchKernelGGL((wgrad_kernel<KWV, SWV>), grid, dim3(NT), 0, s, a)
-    if (d.kW == 1 && d.sW == 1) WG_CASE(1, 1);
-    else if (d.kW == 3 && d.sW == 1) WG_CASE(3, 1);
-    else if (d.kW == 7 && d.sW == 1) WG_CASE(7, 1);
-    else if (d.kW == 4 && d.sW == 2) WG_CASE(4, 2);
-    else if (d.kW == 2 && d.sW == 2) WG_CASE(2, 2);
+    int lrc;
+    if (d.kW == 1 && d.sW == 1) lrc = launch_wgrad_bkp<1, 1>(a, grid, s);
+    else if (d.kW == 3 && d.sW == 1) lrc = launch_wgrad_bkp<3, 1>(a, grid, s);
+    else if (d.kW == 7 && d.sW == 1) lrc = launch_wgrad_bkp<7, 1>(a, grid, s);
+    else if (d.kW == 4 && d.sW == 2) lrc = launch_wgrad_bkp<4, 2>(a, grid, s);
+    else if (d.kW == 2 && d.sW == 2) lrc = launch_wgrad_bkp<2, 2>(a, grid, s);
     else {
         sdc::set_error("sdc_conv_wgrad: tap / stride combination (kW %d, sW %d) not built (1/1, 3/1, 7/1, 4/2, 2/2)", d.kW, d.sW);
         return SDC_EINVAL;
     }
+    if (lrc) return lrc;
     int rc = sdc::check_launch("sdc_conv_wgrad");
     if (rc) return rc;
     {
