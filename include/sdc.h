@@ -303,11 +303,20 @@ int sdc_gn_silu_bwd(const float* h, const float* gy, const float* stats, const f
                     const float* ss, int64_t ss_b_stride, float* rows, float* gh, int B, int C, int G, int64_t S,
                     void* stream);
 
-/* Backward of sdc_chan_norm (mode 0 channel LayerNorm, 1 RMSNorm): gx, and per-block partial sums of the gain gradient
- * gpart[c][sdc_chan_norm_bwd_parts(B, S)] (the caller sums the last axis). */
+/* Backward of sdc_chan_norm (mode 0 channel LayerNorm, 1 RMSNorm): gx, and partial sums of the gain gradient.
+ * gpart = sdc_chan_norm_bwd_bytes(B, C, S) bytes of scratch: [C][sdc_chan_norm_bwd_parts(B, S)] partials (the caller sums the
+ * last axis) followed by the kernel's per-position (mean, scale) table. */
 size_t sdc_chan_norm_bwd_parts(int B, int64_t S);
+size_t sdc_chan_norm_bwd_bytes(int B, int C, int64_t S);
 int sdc_chan_norm_bwd(const float* x, const float* gy, const float* g, float* gx, float* gpart, int B, int C, int64_t S,
                       int mode, float eps, void* stream);
+
+/* Kernel layout of an nn.Conv weight w (Cout, Cin, kD, kH, kW) for SdcConvDesc.precision (0, 2, 3, 4) in one launch: Wp followed
+ * by the Winograd taps the precision / tap shape call for (layouts: SdcConvDesc.precision above), transformed taps summed in fp64
+ * and rounded once.  flip != 0 packs the DATA-GRADIENT weight of the same conv instead (channels transposed, taps flipped; then the
+ * arguments Cout / Cin are those of the packed weight, i.e. swapped).  out holds sdc_pack_conv_weight_floats(...) floats. */
+size_t sdc_pack_conv_weight_floats(int Cout, int Cin, int kD, int kH, int kW, int precision);
+int sdc_pack_conv_weight(const float* w, float* out, int Cout, int Cin, int kD, int kH, int kW, int precision, int flip, void* stream);
 
 /* Backward of the attention cores (same tensor conventions as sdc_attn / sdc_linattn: q, k, v = channel ranges of qkv, the
  * gradients dqkv in the same layout; dout = dL/dout in the layout of `out`).

@@ -78,7 +78,10 @@ SIGNATURES = {
     "sdc_gn_silu_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64,
                                   _stream]),
     "sdc_chan_norm_bwd_parts": (C.c_size_t, [C.c_int, _i64]),
+    "sdc_chan_norm_bwd_bytes": (C.c_size_t, [C.c_int, C.c_int, _i64]),
     "sdc_chan_norm_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, _i64, C.c_int, C.c_float, _stream]),
+    "sdc_pack_conv_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sdc_pack_conv_weight": (C.c_int, [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "sdc_attn_bwd_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sdc_attn_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _stream]),

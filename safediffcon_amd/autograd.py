@@ -114,7 +114,7 @@ class ConvFn(Function):
         bb = None if b is None else b.detach().contiguous()
         wd = w.detach()
         if kind == "conv":
-            return conv_raw(x, pack_conv_weight(wd, "conv", prec), bb, w.shape[0], _k5(w), x1=x1, stride=stride, pad=pad, up=up)
+            return conv_raw(x, grad_ops.pack_conv_weight(wd, prec), bb, w.shape[0], _k5(w), x1=x1, stride=stride, pad=pad, up=up)
         if kind == "convT422":
             return _transposed_422(x, wd, bb, w.shape[1])
         if kind == "unshuffle":
@@ -141,8 +141,7 @@ class ConvFn(Function):
                 w5 = as5(wd)
                 if stride == (1, 1, 1):
                     # correlation with the flipped, transposed taps; pad k - 1 - p restores the input size
-                    wt = w5.transpose(0, 1).flip(2, 3, 4).contiguous()
-                    ga = conv_raw(gy, pack_conv_weight(wt, "conv", prec), None, wt.shape[0], k,
+                    ga = conv_raw(gy, grad_ops.pack_conv_weight(w5, prec, flip=True), None, w5.shape[1], k,
                                   pad=tuple(kk - 1 - p for kk, p in zip(k, pad)))
                     if up != (1, 1, 1):
                         ga = grad_ops.sumpool2(ga, up[1], up[2])       # VJP of the folded nearest upsampling

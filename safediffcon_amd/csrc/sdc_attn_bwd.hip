@@ -211,6 +211,194 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnBwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ temporal attention, MFMA
+// 32 frames x dim_head 32: every product of the backward is one 32 x 32 x 32 tile = 16 v_mfma_f32_32x32x2_f32.  A workgroup owns
+// 8 adjacent pixels (32-byte runs of the channel-major tensors) of one head, each wave two of them.  Per (pixel, head):
+//   orientation 1 (lanes = queries):  S^T = K' Q'^T,  dP^T = V dO^T  -> row statistics, D, dS^T in registers -> dQ' = dS K'
+//                                     (the dS^T registers are the A operand as they stand)
+//   orientation 2 (lanes = keys):     S = Q' K'^T,  dP = dO V^T  -> P, dS (statistics of orientation 1 through LDS)
+//                                     -> dK' = dS^T Q',  dV = P^T dO
+// 112 MFMAs per (pixel, head); q', k', v, dO live in LDS as [d][frame] images (pitch 33: conflict-free along either index); the
+// gradients go back through the same images so that global stores are 32-byte runs.  Workgroups loop over pixel groups (fixed
+// assignment): the bias gradient is accumulated in registers and leaves as one partial table per workgroup.
+constexpr int TB_NS = 8;                  // pixels per workgroup
+constexpr int TB_P = 33;                  // image pitch
+constexpr int TB_IMG = 32 * TB_P;         // floats per [d][f] image
+
+__global__ __launch_bounds__(NT) void tattn_bwd_kernel(const AttnBwdArgs a) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const img = lds;                                   // [4 tensors][8 pixels][32 d][33]
+    float* const biasT = lds + 4 * TB_NS * TB_IMG;            // [key][query]
+    float* const biasN = biasT + 32 * TB_P;                   // [query][key]
+    float* const rotc = biasN + 32 * TB_P;                    // [frame][16]
+    float* const rots = rotc + 32 * 16;
+    float* const stat = rots + 32 * 16;                       // [wave][3][32]: row max, 1 / row sum, D
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.x % a.heads;
+    const int slot = blockIdx.x / a.heads;
+    auto IMG = [&](int t, int px) -> float* { return img + (t * TB_NS + px) * TB_IMG; };
+    auto row_of = [&](int r) -> int { return 8 * (r >> 2) + 4 * lh + (r & 3); };
+
+    for (int e = tid; e < 32 * 32; e += NT) {
+        const int q = e >> 5, kk = e & 31;
+        const float bv = a.bias ? a.bias[((int64_t)head * 32 + q) * 32 + kk] : 0.0f;
+        biasT[kk * TB_P + q] = bv;
+        biasN[q * TB_P + kk] = bv;
+    }
+    for (int e = tid; e < 32 * 16; e += NT) {
+        rotc[e] = a.rot ? a.rot[e * 2] : 1.0f;
+        rots[e] = a.rot ? a.rot[e * 2 + 1] : 0.0f;
+    }
+    float dbacc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dbacc[r] = 0.0f;
+    float* const st_m = stat + wave * 96, * const st_l = st_m + 32, * const st_d = st_m + 64;
+
+    for (int grp = slot; grp < a.ngrp; grp += a.nslots) {
+        const int seq0 = grp * TB_NS;
+        const int o = seq0 / a.inner, i0 = seq0 - o * a.inner;
+        const float* qb = a.qkv + o * a.so + i0 + (int64_t)(head * DH) * a.sc;
+        const float* kb = qb + (int64_t)(a.heads * DH) * a.sc;
+        const float* vb = kb + (int64_t)(a.heads * DH) * a.sc;
+        const float* gb = a.dout + o * a.oso + i0 + (int64_t)(head * DH) * a.osc;
+        __syncthreads();                                      // the previous group's stores have read the images
+        // ---- stage q (scaled), k, v, dO: element e = tid + 256 it -> (d = e >> 8, f = (e >> 3) & 31, pixel = e & 7)
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int e = tid + it * NT;
+            const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
+            const int64_t g = (int64_t)d * a.sc + (int64_t)f * a.st + hw;
+            const int li = d * TB_P + f;
+            IMG(0, hw)[li] = qb[g] * SCALE;
+            IMG(1, hw)[li] = kb[g];
+            IMG(2, hw)[li] = vb[g];
+            IMG(3, hw)[li] = gb[(int64_t)d * a.osc + (int64_t)f * a.ost + hw];
+        }
+        __syncthreads();
+        if (a.rot) {
+            // rotate q and k pairs in place: (x0, x1) -> (x0 c - x1 s, x1 c + x0 s), angle = frame * freq[pair]
+            for (int e = tid; e < TB_NS * 16 * 32; e += NT) {
+                const int f = e & 31, m = (e >> 5) & 15, px = e >> 9;
+                const float c = rotc[f * 16 + m], sn = rots[f * 16 + m];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float* p0 = IMG(t, px) + (2 * m) * TB_P + f;
+                    const float x0 = p0[0], x1 = p0[TB_P];
+                    p0[0] = x0 * c - x1 * sn;
+                    p0[TB_P] = x1 * c + x0 * sn;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- every wave: its two pixels
+        for (int pp = 0; pp < 2; ++pp) {
+            const int px = wave * 2 + pp;
+            float* Qi = IMG(0, px);
+            float* Ki = IMG(1, px);
+            float* Vi = IMG(2, px);
+            float* Gi = IMG(3, px);
+            // orientation 1: lanes = queries
+            f32x16 sT, dpT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sT[r] = 0.f; dpT[r] = 0.f; }
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int li = (2 * s2 + lh) * TB_P + l31;
+                sT = __builtin_amdgcn_mfma_f32_32x32x2f32(Ki[li], Qi[li], sT, 0, 0, 0);
+                dpT = __builtin_amdgcn_mfma_f32_32x32x2f32(Vi[li], Gi[li], dpT, 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sT[r] += biasT[row_of(r) * TB_P + l31]; mx = fmaxf(mx, sT[r]); }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sT[r] = expf(sT[r] - mx); sum += sT[r]; }
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+            float D = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sT[r] *= inv; D += sT[r] * dpT[r]; }
+            D += __shfl_xor(D, 32, 64);
+            if (lh == 0) { st_m[l31] = mx; st_l[l31] = inv; st_d[l31] = D; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sT[r] = sT[r] * (dpT[r] - D); dbacc[r] += sT[r]; }        // dS^T[key][query]
+            // dQ'[q][d] = sum_key dS[q][key] K'[key][d]
+            f32x16 dq;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq = __builtin_amdgcn_mfma_f32_32x32x2f32(sT[r], Ki[l31 * TB_P + row_of(r)], dq, 0, 0, 0);
+            // orientation 2: lanes = keys
+            f32x16 sN, dpN;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sN[r] = 0.f; dpN[r] = 0.f; }
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int li = (2 * s2 + lh) * TB_P + l31;
+                sN = __builtin_amdgcn_mfma_f32_32x32x2f32(Qi[li], Ki[li], sN, 0, 0, 0);
+                dpN = __builtin_amdgcn_mfma_f32_32x32x2f32(Gi[li], Vi[li], dpN, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = row_of(r);
+                const float p = expf(sN[r] + biasN[q * TB_P + l31] - st_m[q]) * st_l[q];
+                sN[r] = p;                                        // P[q][key]
+                dpN[r] = p * (dpN[r] - st_d[q]);                  // dS[q][key]
+            }
+            f32x16 dk, dv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int li = l31 * TB_P + row_of(r);
+                dk = __builtin_amdgcn_mfma_f32_32x32x2f32(dpN[r], Qi[li], dk, 0, 0, 0);
+                dv = __builtin_amdgcn_mfma_f32_32x32x2f32(sN[r], Gi[li], dv, 0, 0, 0);
+            }
+            // transposed rotation of dq', dk' (pairs = adjacent lanes d, d ^ 1), the scale of q; results replace the images
+            const int m = l31 >> 1;
+            const bool odd = l31 & 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = row_of(r);
+                const float c = rotc[f * 16 + m], sn = rots[f * 16 + m];
+                const float pq = __shfl_xor(dq[r], 1, 64), pk = __shfl_xor(dk[r], 1, 64);
+                const float rq = dq[r] * c + (odd ? -pq : pq) * sn;
+                const float rk = dk[r] * c + (odd ? -pk : pk) * sn;
+                Qi[l31 * TB_P + f] = rq * SCALE;
+                Ki[l31 * TB_P + f] = rk;
+                Vi[l31 * TB_P + f] = dv[r];
+            }
+        }
+        __syncthreads();
+        // ---- gradients back to the channel-major tensor
+        float* dqb = a.dqkv + o * a.so + i0 + (int64_t)(head * DH) * a.sc;
+        float* dkb = dqb + (int64_t)(a.heads * DH) * a.sc;
+        float* dvb = dkb + (int64_t)(a.heads * DH) * a.sc;
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int e = tid + it * NT;
+            const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
+            const int64_t g = (int64_t)d * a.sc + (int64_t)f * a.st + hw;
+            const int li = d * TB_P + f;
+            dqb[g] = IMG(0, hw)[li];
+            dkb[g] = IMG(1, hw)[li];
+            dvb[g] = IMG(2, hw)[li];
+        }
+    }
+    if (a.bias != nullptr && a.dbias_part != nullptr) {
+        __syncthreads();
+        float* tmp = lds;                                     // [4 waves][32 query][32 key]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmp[(wave * 32 + l31) * 32 + row_of(r)] = dbacc[r];       // lane = query, row = key
+        __syncthreads();
+        float* out = a.dbias_part + ((int64_t)slot * a.heads + head) * 32 * 32;
+        for (int e = tid; e < 32 * 32; e += NT) out[e] = (tmp[e] + tmp[1024 + e]) + (tmp[2048 + e] + tmp[3072 + e]);
+    }
+}
+
 __global__ __launch_bounds__(NT) void sum_rows_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int nsplit) {
     const int i = blockIdx.x * NT + threadIdx.x;
     if (i >= n) return;
@@ -403,6 +591,22 @@ extern "C" int sdc_attn_bwd(const float* qkv, const float* dout, const float* ro
     a.so = q_so; a.sc = q_sc; a.si = q_si; a.st = q_st;
     a.oso = o_so; a.osc = o_sc; a.osi = o_si; a.ost = o_st;
     a.tok_contig = (q_st == 1);
+    hipStream_t s = sdc::as_stream(stream);
+    if (!a.tok_contig && ntok == 32 && inner % TB_NS == 0 && q_si == 1 && o_si == 1) {
+        // temporal attention of the smoke net: the MFMA kernel
+        a.nseq = TB_NS; a.ls = a.ld = a.lj = 0;
+        a.ngrp = outer * inner / TB_NS;
+        a.nslots = a.ngrp < 1024 ? a.ngrp : 1024;
+        const size_t ldsb = (size_t)(4 * TB_NS * TB_IMG + 2 * 32 * TB_P + 2 * 32 * 16 + 4 * 96) * sizeof(float);
+        static std::atomic<uint64_t> attr_t{0};
+        SDC_LDS_OPTIN(attr_t, tattn_bwd_kernel, 160 * 1024, "sdc_attn_bwd[mfma]");
+        hipLaunchKernelGGL(tattn_bwd_kernel, dim3((unsigned)(a.nslots * heads)), dim3(NT), ldsb, s, a);
+        if (a.dbias_part) {
+            const int nb = heads * ntok * ntok;
+            hipLaunchKernelGGL(sum_rows_kernel, dim3((nb + NT - 1) / NT), dim3(NT), 0, s, a.dbias_part, dbias, nb, a.nslots);
+        }
+        return sdc::check_launch("sdc_attn_bwd[mfma]");
+    }
     int nseq = NT / ntok;
     if (nseq < 1) nseq = 1;
     const int nseq_tot = outer * inner;
@@ -424,7 +628,6 @@ extern "C" int sdc_attn_bwd(const float* qkv, const float* dout, const float* ro
     a.nslots = a.ngrp < 1024 ? a.ngrp : 1024;
     static std::atomic<uint64_t> attr{0};
     SDC_LDS_OPTIN(attr, attn_bwd_kernel, 160 * 1024, "sdc_attn_bwd");
-    hipStream_t s = sdc::as_stream(stream);
     hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(a.nslots * heads)), dim3(NT), lds_bytes, s, a);
     if (a.dbias_part) {
         const int nb = heads * ntok * ntok;

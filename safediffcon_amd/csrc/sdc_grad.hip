@@ -227,7 +227,13 @@ int wgrad_splits(const SdcWgradDesc& d, int* rows_per_split) {
     const int Mt = (d.M + 63) / 64, Nt = (d.N + 63) / 64;
     const int64_t tiles = (int64_t)Mt * Nt * d.kD * d.kH;
     const int R = d.B * d.oD * d.oH;
-    int64_t want = (2048 + tiles - 1) / tiles;          // ~8 workgroups per CU in flight
+    int64_t want = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU in flight
+    // every split writes (and the reduction re-reads) a full copy of the gradient: keep that below the activation traffic
+    // (weight-heavy layers -- the deep levels of the 1-D nets -- get few splits, activation-heavy ones many)
+    const int64_t nw = (int64_t)d.M * d.N * d.kD * d.kH * d.kW;
+    const int64_t act = (int64_t)d.B * d.oD * d.oH * d.oW * d.M + (int64_t)d.B * d.iD * d.iH * d.iW * d.N;
+    const int64_t cap = act / (2 * nw);
+    if (want > cap) want = cap;
     if (want < 1) want = 1;
     if (want > R) want = R;
     const int rps = (int)((R + want - 1) / want);
@@ -382,82 +388,94 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------------ channel norm backward
 // forward (sdc_chan_norm): LayerNorm over channels (mode 0): y = (x - mean) rsqrt(var + eps) g;  RMSNorm (mode 1):
-// y = x / max(||x||, 1e-12) g sqrt(C).  One thread per position, channel walk with stride S (coalesced across threads).
+// y = x / max(||x||, 1e-12) g sqrt(C).  Thread layout of the forward kernel: PL position lanes x NT / PL channel slices per
+// workgroup (positions are the contiguous axis: every channel row is read in coalesced segments), channel sums through LDS.
+// The kernel also leaves (mean, scale) of every position in `pstat` for the gain-gradient kernel.
+template <int PL>
 __global__ __launch_bounds__(NT) void chan_norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                           const float* __restrict__ g, float* __restrict__ gx,
-                                                          float* __restrict__ gpart, int C, int64_t S, int mode, float eps) {
+                                                          float* __restrict__ pstat, int C, int64_t S, int mode, float eps) {
+    constexpr int NSL = NT / PL;
+    const int lane = threadIdx.x % PL, slice = threadIdx.x / PL;
     const int b = blockIdx.y;
-    const int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x;
-    if (p >= S) return;
-    const float* xb = x + (int64_t)b * C * S + p;
-    const float* yb = gy + (int64_t)b * C * S + p;
-    float* ob = gx + (int64_t)b * C * S + p;
+    const int64_t p = (int64_t)blockIdx.x * PL + lane;
+    const bool ok = p < S;
+    const int64_t base = (int64_t)b * C * S + (ok ? p : 0);
+    __shared__ float sh[3][NSL][PL];
+    auto reduce3 = [&](float& a0, float& a1, float& a2) {
+        sh[0][slice][lane] = a0; sh[1][slice][lane] = a1; sh[2][slice][lane] = a2;
+        __syncthreads();
+        a0 = a1 = a2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) { a0 += sh[0][i][lane]; a1 += sh[1][i][lane]; a2 += sh[2][i][lane]; }
+        __syncthreads();
+    };
+    // pass 1: sum x, sum x^2
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (ok)
+        for (int c = slice; c < C; c += NSL) { const float v = x[base + (int64_t)c * S]; s1 += v; s2 += v * v; }
+    reduce3(s1, s2, s3);
+    float mean = 0.f, scale;
     if (mode == 0) {
-        float mean = 0.0f;
-        for (int c = 0; c < C; ++c) mean += xb[(int64_t)c * S];
-        mean /= (float)C;
-        float var = 0.0f;
-        for (int c = 0; c < C; ++c) { const float dlt = xb[(int64_t)c * S] - mean; var += dlt * dlt; }
-        var /= (float)C;
-        const float rstd = rsqrtf(var + eps);
-        float s1 = 0.0f, s2 = 0.0f;
-        for (int c = 0; c < C; ++c) {
-            const float xh = (xb[(int64_t)c * S] - mean) * rstd;
-            const float gg = yb[(int64_t)c * S] * g[c];
-            s1 += gg;
-            s2 += gg * xh;
+        mean = s1 / (float)C;
+        float q2 = 0.f, z0 = 0.f, z1 = 0.f;               // centred second pass, like the forward kernel
+        if (ok)
+            for (int c = slice; c < C; c += NSL) { const float dv = x[base + (int64_t)c * S] - mean; q2 += dv * dv; }
+        reduce3(q2, z0, z1);
+        scale = rsqrtf(q2 / (float)C + eps);
+    } else {
+        scale = 1.0f / fmaxf(sqrtf(s2), 1e-12f);          // (the sqrt(C) factor is applied below)
+    }
+    // pass 2: sums of gy g and gy g xhat
+    float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    if (ok)
+        for (int c = slice; c < C; c += NSL) {
+            const float gg = gy[base + (int64_t)c * S] * g[c];
+            const float xv = x[base + (int64_t)c * S];
+            t1 += gg;
+            t2 += gg * (mode == 0 ? (xv - mean) * scale : xv);
         }
-        s1 /= (float)C;
-        s2 /= (float)C;
-        for (int c = 0; c < C; ++c) {
-            const float xh = (xb[(int64_t)c * S] - mean) * rstd;
-            ob[(int64_t)c * S] = rstd * (yb[(int64_t)c * S] * g[c] - s1 - xh * s2);
+    reduce3(t1, t2, t3);
+    if (!ok) return;
+    if (slice == 0) {
+        pstat[((int64_t)b * S + p) * 2] = mean;
+        pstat[((int64_t)b * S + p) * 2 + 1] = mode == 0 ? scale : scale * sqrtf((float)C);
+    }
+    if (mode == 0) {
+        const float m1 = t1 / (float)C, m2 = t2 / (float)C;
+        for (int c = slice; c < C; c += NSL) {
+            const int64_t o = base + (int64_t)c * S;
+            const float xh = (x[o] - mean) * scale;
+            gx[o] = scale * (gy[o] * g[c] - m1 - xh * m2);
         }
     } else {
-        float n2 = 0.0f;
-        for (int c = 0; c < C; ++c) { const float v = xb[(int64_t)c * S]; n2 += v * v; }
-        const float nrm = fmaxf(sqrtf(n2), 1e-12f);
-        const float inv = 1.0f / nrm, sq = sqrtf((float)C);
-        float dot = 0.0f;
-        for (int c = 0; c < C; ++c) dot += yb[(int64_t)c * S] * g[c] * xb[(int64_t)c * S];
-        const float k = sqrtf(n2) > 1e-12f ? dot * inv * inv : 0.0f;
-        for (int c = 0; c < C; ++c) ob[(int64_t)c * S] = sq * inv * (yb[(int64_t)c * S] * g[c] - xb[(int64_t)c * S] * k);
+        const float sq = sqrtf((float)C);
+        const float k = sqrtf(s2) > 1e-12f ? t2 * scale * scale : 0.f;
+        for (int c = slice; c < C; c += NSL) {
+            const int64_t o = base + (int64_t)c * S;
+            gx[o] = sq * scale * (gy[o] * g[c] - x[o] * k);
+        }
     }
-    (void)gpart;
 }
 
-// d g[c] = sum_{b, p} gy[b][c][p] * yhat[b][c][p]: one workgroup per channel over a (b, p) slab, partial per block row
+// d g[c] = sum_{b, p} gy[b][c][p] (x[b][c][p] - mean[b][p]) scale[b][p]: one workgroup per (channel, batch slab), fixed order
 __global__ __launch_bounds__(NT) void chan_norm_gaing_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                            float* __restrict__ gpart, int B, int C, int64_t S, int mode, float eps) {
-    // grid.x = position blocks, grid.y = b;  each thread owns one position and walks the channels twice
-    const int b = blockIdx.y;
-    const int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x;
-    const bool ok = p < S;
-    const float* xb = x + (int64_t)b * C * S + (ok ? p : 0);
-    const float* yb = gy + (int64_t)b * C * S + (ok ? p : 0);
-    float mean = 0.0f, scale = 0.0f;
-    if (mode == 0) {
-        for (int c = 0; c < C; ++c) mean += xb[(int64_t)c * S];
-        mean /= (float)C;
-        float var = 0.0f;
-        for (int c = 0; c < C; ++c) { const float dlt = xb[(int64_t)c * S] - mean; var += dlt * dlt; }
-        scale = rsqrtf(var / (float)C + eps);
-    } else {
-        float n2 = 0.0f;
-        for (int c = 0; c < C; ++c) { const float v = xb[(int64_t)c * S]; n2 += v * v; }
-        scale = sqrtf((float)C) / fmaxf(sqrtf(n2), 1e-12f);
+                                                            const float* __restrict__ pstat, float* __restrict__ gpart, int B, int C,
+                                                            int64_t S, int nslab) {
+    const int c = blockIdx.x, slab = blockIdx.y;
+    const int b_lo = (int)((int64_t)B * slab / nslab), b_hi = (int)((int64_t)B * (slab + 1) / nslab);
+    float acc = 0.f;
+    for (int b = b_lo; b < b_hi; ++b) {
+        const float* xb = x + ((int64_t)b * C + c) * S;
+        const float* yb = gy + ((int64_t)b * C + c) * S;
+        const float* st = pstat + (int64_t)b * S * 2;
+        for (int64_t p = threadIdx.x; p < S; p += NT) acc += yb[p] * (xb[p] - st[2 * p]) * st[2 * p + 1];
     }
     __shared__ float red[NT / 64];
-    const int64_t nblk = (int64_t)gridDim.x * gridDim.y;
-    const int64_t blk = (int64_t)b * gridDim.x + blockIdx.x;
-    for (int c = 0; c < C; ++c) {
-        float v = ok ? yb[(int64_t)c * S] * (xb[(int64_t)c * S] - mean) * scale : 0.0f;
-        v = sdc::wave_sum(v);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) gpart[(int64_t)c * nblk + blk] = (red[0] + red[1]) + (red[2] + red[3]);
-        __syncthreads();
-    }
+    acc = sdc::wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) gpart[(int64_t)c * B + slab] = (red[0] + red[1]) + (red[2] + red[3]);      // [C][B], slabs >= nslab stay 0
 }
 
 // ------------------------------------------------------------------------------------------------ small element-wise VJPs
@@ -506,16 +524,36 @@ extern "C" int sdc_gn_silu_bwd(const float* h, const float* gy, const float* sta
     return sdc::check_launch("sdc_gn_silu_bwd");
 }
 
-extern "C" size_t sdc_chan_norm_bwd_parts(int B, int64_t S) { return (size_t)B * (size_t)((S + NT - 1) / NT); }
+// gain-gradient partials per channel (the caller sums them) followed by the (mean, scale) table of every position
+static int cn_slabs(int B, int C) {
+    int ns = 1;
+    while (ns < B && (int64_t)C * ns < 1024) ns *= 2;      // enough workgroups to fill the chip
+    return ns < B ? ns : B;
+}
+
+extern "C" size_t sdc_chan_norm_bwd_parts(int B, int64_t S) { (void)S; return (size_t)B; }
+
+extern "C" size_t sdc_chan_norm_bwd_bytes(int B, int C, int64_t S) {
+    return ((size_t)C * B + (size_t)B * S * 2) * sizeof(float);
+}
 
 extern "C" int sdc_chan_norm_bwd(const float* x, const float* gy, const float* g, float* gx, float* gpart, int B, int C, int64_t S,
                                  int mode, float eps, void* stream) {
     SDC_REQUIRE(x && gy && g && gx && gpart, SDC_ENULL, "sdc_chan_norm_bwd: null pointer");
     SDC_REQUIRE(B > 0 && B < 65536 && C > 0 && S > 0 && (mode == 0 || mode == 1), SDC_EINVAL, "sdc_chan_norm_bwd: bad arguments");
     hipStream_t s = sdc::as_stream(stream);
-    dim3 grid((unsigned)((S + NT - 1) / NT), (unsigned)B);
-    hipLaunchKernelGGL(chan_norm_bwd_kernel, grid, dim3(NT), 0, s, x, gy, g, gx, gpart, C, S, mode, eps);
-    hipLaunchKernelGGL(chan_norm_gaing_kernel, grid, dim3(NT), 0, s, x, gy, gpart, B, C, S, mode, eps);
+    float* pstat = gpart + (size_t)C * B;                  // gpart = sdc_chan_norm_bwd_bytes(B, C, S): [C][B] partials, then the table
+    if (S >= 1024) {
+        dim3 grid((unsigned)((S + 63) / 64), (unsigned)B);
+        hipLaunchKernelGGL(chan_norm_bwd_kernel<64>, grid, dim3(NT), 0, s, x, gy, g, gx, pstat, C, S, mode, eps);
+    } else {
+        dim3 grid((unsigned)((S + 15) / 16), (unsigned)B);
+        hipLaunchKernelGGL(chan_norm_bwd_kernel<16>, grid, dim3(NT), 0, s, x, gy, g, gx, pstat, C, S, mode, eps);
+    }
+    const int ns = cn_slabs(B, C);
+    // partial layout [C][B]: slabs beyond ns stay zero
+    (void)hipMemsetAsync(gpart, 0, (size_t)C * B * sizeof(float), s);
+    hipLaunchKernelGGL(chan_norm_gaing_kernel, dim3((unsigned)C, (unsigned)ns), dim3(NT), 0, s, x, gy, pstat, gpart, B, C, S, ns);
     return sdc::check_launch("sdc_chan_norm_bwd");
 }
 
@@ -535,4 +573,112 @@ extern "C" int sdc_sumpool2(const float* g, float* gx, int64_t rows, int H, int 
     const int blocks = (int)((n + NT - 1) / NT < 8192 ? (n + NT - 1) / NT : 8192);
     hipLaunchKernelGGL(sumpool_kernel, dim3(blocks), dim3(NT), 0, sdc::as_stream(stream), g, gx, rows, H, W, fh, fw);
     return sdc::check_launch("sdc_sumpool2");
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// Kernel layout of an nn.Conv weight (include/sdc.h, SdcConvDesc.precision) in ONE launch: Wp[(kd, kh, kw, ci)][co], then for
+// 3-wide taps the Winograd F(2,3) taps Wg[(kd kH + kh) 4 + xi][ci][co], for 3x3 taps the F(2x2,3x3) taps Wg2[kd][ci][co][j 4 + xi]
+// and for 3x3x3 taps the F(2x2x2,3x3x3) taps Wg3[jd][ci][co][j 4 + xi] -- every transformed tap summed in fp64 and rounded once,
+// like the host packing (engine.pack_conv_weight).  flip != 0 packs the data-gradient weight instead: w'[co'][ci'][k] =
+// w[ci'][co'][K - 1 - k] (transposed channels, flipped taps).  A fine-tuning step re-packs every conv twice; as torch ops that
+// was ~12 launches per conv.
+namespace {
+__device__ __forceinline__ double wino_g(int row, int tap) {
+    // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+    if (row == 0) return tap == 0 ? 1.0 : 0.0;
+    if (row == 3) return tap == 2 ? 1.0 : 0.0;
+    return (row == 2 && tap == 1) ? -0.5 : 0.5;
+}
+
+struct PackArgs {
+    const float* w; float* out;
+    int Cout, Cin, kD, kH, kW, flip;       // logical (packed) channel counts
+    int64_t n0, n1, n2, n3;                // floats of the four sections
+};
+
+__global__ __launch_bounds__(NT) void pack_weight_kernel(const PackArgs a) {
+    const int64_t total = a.n0 + a.n1 + a.n2 + a.n3;
+    const int taps = a.kD * a.kH * a.kW;
+    auto wv = [&](int co, int ci, int kd, int kh, int kw) -> double {
+        if (a.flip) return (double)a.w[((int64_t)ci * a.Cout + co) * taps + ((a.kD - 1 - kd) * a.kH + (a.kH - 1 - kh)) * a.kW + (a.kW - 1 - kw)];
+        return (double)a.w[((int64_t)co * a.Cin + ci) * taps + (kd * a.kH + kh) * a.kW + kw];
+    };
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        double v;
+        if (i < a.n0) {                                   // Wp[(kd, kh, kw, ci)][co]
+            const int co = (int)(i % a.Cout);
+            int64_t r = i / a.Cout;
+            const int ci = (int)(r % a.Cin); r /= a.Cin;
+            const int kw = (int)(r % a.kW); r /= a.kW;
+            const int kh = (int)(r % a.kH);
+            const int kd = (int)(r / a.kH);
+            v = wv(co, ci, kd, kh, kw);
+        } else if (i < a.n0 + a.n1) {                     // Wg[(kd kH + kh) 4 + xi][ci][co]
+            int64_t r = i - a.n0;
+            const int co = (int)(r % a.Cout); r /= a.Cout;
+            const int ci = (int)(r % a.Cin); r /= a.Cin;
+            const int xi = (int)(r % 4); r /= 4;
+            const int kh = (int)(r % a.kH);
+            const int kd = (int)(r / a.kH);
+            v = 0.0;
+            for (int kw = 0; kw < 3; ++kw) v += wino_g(xi, kw) * wv(co, ci, kd, kh, kw);
+        } else if (i < a.n0 + a.n1 + a.n2) {              // Wg2[kd][ci][co][j 4 + xi]
+            int64_t r = i - a.n0 - a.n1;
+            const int xi = (int)(r % 4); r /= 4;
+            const int j = (int)(r % 4); r /= 4;
+            const int co = (int)(r % a.Cout); r /= a.Cout;
+            const int ci = (int)(r % a.Cin);
+            const int kd = (int)(r / a.Cin);
+            v = 0.0;
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw) v += wino_g(j, kh) * wino_g(xi, kw) * wv(co, ci, kd, kh, kw);
+        } else {                                          // Wg3[jd][ci][co][j 4 + xi]
+            int64_t r = i - a.n0 - a.n1 - a.n2;
+            const int xi = (int)(r % 4); r /= 4;
+            const int j = (int)(r % 4); r /= 4;
+            const int co = (int)(r % a.Cout); r /= a.Cout;
+            const int ci = (int)(r % a.Cin);
+            const int jd = (int)(r / a.Cin);
+            v = 0.0;
+            for (int kd = 0; kd < 3; ++kd)
+                for (int kh = 0; kh < 3; ++kh)
+                    for (int kw = 0; kw < 3; ++kw) v += wino_g(jd, kd) * wino_g(j, kh) * wino_g(xi, kw) * wv(co, ci, kd, kh, kw);
+        }
+        a.out[i] = (float)v;
+    }
+}
+
+void pack_sections(int Cout, int Cin, int kD, int kH, int kW, int precision, int64_t* n) {
+    const int64_t nw = (int64_t)Cout * Cin * kD * kH * kW;
+    n[0] = nw; n[1] = n[2] = n[3] = 0;
+    if (precision >= 2 && kW == 3) {
+        n[1] = nw / 3 * 4;
+        if (precision >= 3 && kH == 3) {
+            n[2] = nw / 9 * 16;
+            if (precision == 4 && kD == 3) n[3] = nw / 27 * 64;
+        }
+    }
+}
+}  // namespace
+
+extern "C" size_t sdc_pack_conv_weight_floats(int Cout, int Cin, int kD, int kH, int kW, int precision) {
+    int64_t n[4];
+    pack_sections(Cout, Cin, kD, kH, kW, precision, n);
+    return (size_t)(n[0] + n[1] + n[2] + n[3]);
+}
+
+extern "C" int sdc_pack_conv_weight(const float* w, float* out, int Cout, int Cin, int kD, int kH, int kW, int precision, int flip,
+                                    void* stream) {
+    SDC_REQUIRE(w && out, SDC_ENULL, "sdc_pack_conv_weight: null pointer");
+    SDC_REQUIRE(Cout > 0 && Cin > 0 && kD > 0 && kH > 0 && kW > 0 && (precision == 0 || (precision >= 2 && precision <= 4)), SDC_EINVAL,
+                "sdc_pack_conv_weight: bad arguments");
+    PackArgs a;
+    a.w = w; a.out = out; a.Cout = Cout; a.Cin = Cin; a.kD = kD; a.kH = kH; a.kW = kW; a.flip = flip;
+    int64_t n[4];
+    pack_sections(Cout, Cin, kD, kH, kW, precision, n);
+    a.n0 = n[0]; a.n1 = n[1]; a.n2 = n[2]; a.n3 = n[3];
+    const int64_t total = n[0] + n[1] + n[2] + n[3];
+    const int blocks = (int)((total + NT - 1) / NT < 16384 ? (total + NT - 1) / NT : 16384);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(NT), 0, sdc::as_stream(stream), a);
+    return sdc::check_launch("sdc_pack_conv_weight");
 }

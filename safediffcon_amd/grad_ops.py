@@ -103,12 +103,12 @@ def chan_norm_bwd(x, gy, g, mode, eps=1e-5):
     S = x.numel() // (B * Cc)
     gy = gy.contiguous()
     nparts = int(lib.sdc_chan_norm_bwd_parts(B, S))
-    gpart = torch.empty((Cc, nparts), dtype=torch.float32, device=x.device)
+    gpart = torch.empty(int(lib.sdc_chan_norm_bwd_bytes(B, Cc, S)) // 4, dtype=torch.float32, device=x.device)
     gx = torch.empty_like(x)
     gv = g.reshape(-1).contiguous()
     check(lib.sdc_chan_norm_bwd(x.data_ptr(), gy.data_ptr(), gv.data_ptr(), gx.data_ptr(), gpart.data_ptr(), B, Cc, S, mode, eps,
                                 _stream(x)), "sdc_chan_norm_bwd")
-    return gx, gpart.sum(1)
+    return gx, gpart[: Cc * nparts].view(Cc, nparts).sum(1)
 
 
 def act_bwd(x, gy, kind):
@@ -175,3 +175,18 @@ def linattn_core_bwd(qkv, dout, heads, outer, inner, n, qs, os_):
     check(_lib.get_lib().sdc_linattn_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), outer, inner, heads, n, *qs, *os_,
                                          _stream(qkv)), "sdc_linattn_bwd")
     return dqkv
+
+
+def pack_conv_weight(w, precision, flip=False):
+    """kernel layout of a contiguous nn.Conv weight (Cout, Cin, *k) on the device in one launch (sdc_pack_conv_weight);
+    flip: the data-gradient weight (transposed channels, flipped taps)"""
+    _need_cuda(w)
+    lib = _lib.get_lib()
+    w5 = as5(w.detach()).contiguous()
+    co, ci, kD, kH, kW = w5.shape
+    if flip:
+        co, ci = ci, co
+    out = torch.empty(int(lib.sdc_pack_conv_weight_floats(co, ci, kD, kH, kW, precision)), dtype=torch.float32, device=w.device)
+    check(lib.sdc_pack_conv_weight(w5.data_ptr(), out.data_ptr(), co, ci, kD, kH, kW, precision, 1 if flip else 0, _stream(w)),
+          "sdc_pack_conv_weight")
+    return out

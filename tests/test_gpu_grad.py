@@ -179,7 +179,7 @@ def _ref_attention(q, k, v, ang=None, bias=None):
     return torch.einsum("...ij,...jd->...id", sim.softmax(-1), v)
 
 
-@pytest.mark.parametrize("Fr,H,W,B", [(32, 4, 8, 2), (8, 4, 4, 3), (32, 3, 8, 1)])
+@pytest.mark.parametrize("Fr,H,W,B", [(32, 4, 8, 2), (8, 4, 4, 3), (32, 3, 8, 1), (32, 3, 5, 2), (32, 16, 16, 3)])
 def test_temporal_attention_core_backward(Fr, H, W, B):
     """'b c f h w -> b (h w) f c' attention with rotary + relative-position bias (conv3d.py:277-353): sdc_attn / sdc_attn_bwd
     on the channel-major qkv against fp64 autograd"""
@@ -245,3 +245,20 @@ def test_linear_attention_core_backward(B, inner, n):
     err = _rel(dqkv, qd.grad)
     print(f"[measured] linear attention core backward B={B} inner={inner} n={n}: dqkv {err:.2e}")
     assert err < 2e-5
+
+
+@pytest.mark.parametrize("shape,prec", [((64, 48, 3, 3, 3), 4), ((40, 64, 1, 3, 3), 4), ((96, 32, 3), 4), ((64, 7, 7, 7, 7), 4),
+                                        ((128, 64, 1, 1), 4), ((32, 16, 3, 3, 3), 3), ((32, 16, 3, 3), 2), ((8, 8, 3, 3, 3), 0)])
+def test_pack_conv_weight_kernel_equals_host_packing(shape, prec):
+    """sdc_pack_conv_weight (one launch) against engine.pack_conv_weight (torch, fp64 einsums): Wp and every Winograd section,
+    forward and data-gradient (transposed, flipped) forms"""
+    from safediffcon_amd.engine import as5, pack_conv_weight
+    w = det_tensor(shape, 180, 0.3).to(DEV)
+    got, want = grad_ops.pack_conv_weight(w, prec), pack_conv_weight(w, "conv", prec).reshape(-1)
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 1e-7 * want.abs().max().item()
+    w5 = as5(w)
+    wt = w5.transpose(0, 1).flip(2, 3, 4).contiguous()
+    got, want = grad_ops.pack_conv_weight(w, prec, flip=True), pack_conv_weight(wt, "conv", prec).reshape(-1)
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 1e-7 * want.abs().max().item()

@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""time one fine-tuning step (bench.finetune_step) of a workload: python tools/ft_time.py [c2|c3|c4] [batch]"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c4"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else {"c2": 64, "c3": 64, "c4": 4}[wl]
+print(json.dumps(bench.finetune_step(wl, B, 0, torch.device("cuda:0"))))
