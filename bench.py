@@ -273,7 +273,7 @@ def strawman(name, batch, steps, dim, dev):
                 value=round(batch / (T_DDPM * s), 4), unit="trajectories/s")
 
 
-def finetune_step(name, batch, dim, dev, steps=3):
+def finetune_step(name, batch, dim, dev, steps=3, eager=True):
     """One fine-tuning step (loss = mean(w_b p_losses_b); loss.backward(), 2d/inference_2d.py:267-279) through the
     drop-in net's differentiable HIP path, beside the same step of the oracle's functional net under PyTorch-ROCm autograd."""
     import torch
@@ -327,8 +327,10 @@ def finetune_step(name, batch, dim, dev, steps=3):
     ms_hip = timeit(hip_step)
     out = dict(what="loss = mean(w_b p_losses_b(state)); loss.backward()  (U-Net forward + backward, all parameter gradients)",
                batch=batch, hip_ms=round(ms_hip, 2), hip_ms_per_sample=round(ms_hip / batch, 2),
-               backward="convs, GroupNorm/SiLU, time MLP on libsdc_hip.so kernels in both directions; attention blocks: HIP forward, "
-                        "PyTorch-ROCm VJP (round-3 stage)")
+               backward="every node on libsdc_hip.so kernels in both directions (conv data gradient on the forward Winograd kernels, "
+                        "sdc_conv_wgrad, sdc_gn_silu_bwd, sdc_chan_norm_bwd, sdc_attn_bwd, sdc_linattn_bwd, sdc_act_bwd)")
+    if not eager:
+        return out
     try:
         ms_eager = timeit(eager_step)
         out.update(torch_rocm_autograd_ms=round(ms_eager, 2), speedup=round(ms_eager / ms_hip, 2))

@@ -232,7 +232,7 @@ int wgrad_splits(const SdcWgradDesc& d, int* rows_per_split) {
     // (weight-heavy layers -- the deep levels of the 1-D nets -- get few splits, activation-heavy ones many)
     const int64_t nw = (int64_t)d.M * d.N * d.kD * d.kH * d.kW;
     const int64_t act = (int64_t)d.B * d.oD * d.oH * d.oW * d.M + (int64_t)d.B * d.iD * d.iH * d.iW * d.N;
-    const int64_t cap = act / (2 * nw);
+    const int64_t cap = act / (4 * nw);
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     if (want > R) want = R;
@@ -268,8 +268,9 @@ extern "C" int sdc_conv_wgrad(const SdcWgradDesc* dp, const float* g, const floa
     a.nsplit = wgrad_splits(d, &a.rows_per_split);
     a.Mt = (d.M + 63) / 64; a.Nt = (d.N + 63) / 64;
     const int64_t nw = (int64_t)d.M * d.N * d.kD * d.kH * d.kW;
-    a.part = static_cast<float*>(work);
-    a.bpart = dbias ? a.part + (int64_t)a.nsplit * nw : nullptr;
+    // one split: the workgroups write the gradient itself (no partial copy, no reduction pass)
+    a.part = a.nsplit == 1 ? dw : static_cast<float*>(work);
+    a.bpart = dbias ? (a.nsplit == 1 ? dbias : static_cast<float*>(work) + (int64_t)a.nsplit * nw) : nullptr;
     const int64_t tiles = (int64_t)a.Mt * a.Nt * d.kD * d.kH;
     SDC_REQUIRE(tiles < (1ll << 31) && a.nsplit < 65536, SDC_EINVAL, "sdc_conv_wgrad: grid too large");
     dim3 grid((unsigned)tiles, (unsigned)a.nsplit);
@@ -286,7 +287,7 @@ extern "C" int sdc_conv_wgrad(const SdcWgradDesc* dp, const float* g, const floa
     }
     if (lrc) return lrc;
     int rc = sdc::check_launch("sdc_conv_wgrad");
-    if (rc) return rc;
+    if (rc || a.nsplit == 1) return rc;
     {
         const int blocks = (int)((nw + NT - 1) / NT < 4096 ? (nw + NT - 1) / NT : 4096);
         hipLaunchKernelGGL(sum_splits_kernel, dim3(blocks), dim3(NT), 0, s, a.part, dw, nw, a.nsplit);

@@ -2,7 +2,9 @@
 # rocprofv3 kernel statistics of one fine-tuning step workload: bash tools/ft_prof.sh c2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/ftprof_$1; rm -rf $O; mkdir -p $O
+export FT_NO_EAGER=1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O --output-format csv -- python3 tools/ft_time.py $1 > $O/run.log 2>&1
+find $O -name "*kernel_trace.csv" -delete
 f=$(find $O -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

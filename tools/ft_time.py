@@ -11,4 +11,4 @@ import bench  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c4"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else {"c2": 64, "c3": 64, "c4": 4}[wl]
-print(json.dumps(bench.finetune_step(wl, B, 0, torch.device("cuda:0"))))
+print(json.dumps(bench.finetune_step(wl, B, 0, torch.device("cuda:0"), eager=os.environ.get("FT_NO_EAGER") != "1")))
