@@ -132,7 +132,7 @@ int sdc_gn_apply(const float* x, const float* stats, const float* gamma, const f
                  const float* residual, float* y, int B, int C, int G, int64_t S, void* stream);
 
 /* GroupNorm statistics + apply in ONE launch for small groups (sdc_gn_fused_ok: (C/G)*S <= 32768, B*G >= 64): the deep levels
- * of Unet2D / Unet1D, 1D/model/unet.py:128-147.  Arguments as sdc_gn_apply; the output bits equal sdc_gn_stats + sdc_gn_apply. */
+ * of Unet2D / Unet1D, 1D/model/unet.py:128-147.  Arguments as sdc_gn_apply (fp64 statistics like sdc_gn_stats). */
 int sdc_gn_fused_ok(int B, int C, int G, int64_t S);
 int sdc_gn_fused(const float* x, const float* gamma, const float* beta, const float* ss, const int32_t* t_dev,
                  int64_t ss_t_stride, int64_t ss_b_stride, int64_t ss_off, const float* residual, float* y, int B, int C, int G,

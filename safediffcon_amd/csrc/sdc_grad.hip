@@ -227,12 +227,11 @@ int wgrad_splits(const SdcWgradDesc& d, int* rows_per_split) {
     const int Mt = (d.M + 63) / 64, Nt = (d.N + 63) / 64;
     const int64_t tiles = (int64_t)Mt * Nt * d.kD * d.kH;
     const int R = d.B * d.oD * d.oH;
-    int64_t want = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU in flight
-    // every split writes (and the reduction re-reads) a full copy of the gradient: keep that below the activation traffic
-    // (weight-heavy layers -- the deep levels of the 1-D nets -- get few splits, activation-heavy ones many)
+    // splits: ~3 workgroups per CU in flight (a layer with few tiles and long rows is otherwise a handful of workgroups); every
+    // split writes, and the reduction re-reads, a full copy of the gradient, at HBM rate: cheap beside idle CUs, bounded at 256 MB
+    int64_t want = (768 + tiles - 1) / tiles;
     const int64_t nw = (int64_t)d.M * d.N * d.kD * d.kH * d.kW;
-    const int64_t act = (int64_t)d.B * d.oD * d.oH * d.oW * d.M + (int64_t)d.B * d.iD * d.iH * d.iW * d.N;
-    const int64_t cap = act / (4 * nw);
+    const int64_t cap = (64ll << 20) / nw;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     if (want > R) want = R;

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(NT) void gn_apply_flat_kernel(const float* x, const
 // (b, g) sums the group exactly like gn_partial_kernel (one split) + gn_finalize_kernel, then applies
 // (scale + 1, shift), SiLU and the residual to its own channels -- the second read of the group is L2-hot.  Three launches
 // (partial, finalize, apply) become one; the arithmetic, and so every output bit, is that of the three-launch path.
-__global__ __launch_bounds__(NT) void gn_fused_kernel(const float* x, const float* __restrict__ gamma, const float* __restrict__ beta,
+constexpr int NTF = 1024;            // one workgroup per group: 16 waves keep the two sweeps short
+__global__ __launch_bounds__(NTF) void gn_fused_kernel(const float* x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ ss, const int32_t* __restrict__ t_dev,
                                                       int64_t ss_t_stride, int64_t ss_b_stride, int64_t ss_off, const float* res,
                                                       float* y, int C, int G, int64_t S, float eps) {
@@ -170,19 +171,19 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const float* x, const floa
     double s = 0.0, q = 0.0;
     if ((n & 3) == 0) {
         const float4* b4 = reinterpret_cast<const float4*>(base);
-        for (int64_t i = threadIdx.x; i < n / 4; i += NT) {
+        for (int64_t i = threadIdx.x; i < n / 4; i += NTF) {
             const float4 v = b4[i];
             s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
             q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
         }
     } else {
-        for (int64_t i = threadIdx.x; i < n; i += NT) {
+        for (int64_t i = threadIdx.x; i < n; i += NTF) {
             const double v = base[i];
             s += v;
             q += v * v;
         }
     }
-    __shared__ double sh[2][NT / 64];
+    __shared__ double sh[2][NTF / 64];
     __shared__ float st2[2];
     s = sdc::wave_sum(s);
     q = sdc::wave_sum(q);
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const float* x, const floa
     __syncthreads();
     if (threadIdx.x == 0) {
         double ts = 0, tq = 0;
-        for (int w = 0; w < NT / 64; ++w) { ts += sh[0][w]; tq += sh[1][w]; }
+        for (int w = 0; w < NTF / 64; ++w) { ts += sh[0][w]; tq += sh[1][w]; }
         const double inv_n = 1.0 / (double)n;
         const double mean = ts * inv_n;
         double var = tq * inv_n - mean * mean;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const float* x, const floa
     __syncthreads();
     const float mean = st2[0], rstd = st2[1];
     const int64_t row = ss ? (t_dev ? (int64_t)(*t_dev) : 0) * ss_t_stride + (int64_t)b * ss_b_stride + ss_off : 0;
-    for (int cc = threadIdx.x; cc < cpg; cc += NT) {
+    for (int cc = threadIdx.x; cc < cpg; cc += NTF) {
         const int c = g * cpg + cc;
         float mul = rstd * gamma[c];
         float add = beta[c] - mean * mul;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const float* x, const floa
         const float4* r4 = reinterpret_cast<const float4*>(rb);
         float4* y4 = reinterpret_cast<float4*>(yb);
         const int nv_row = (int)(S >> 2);
-        for (int64_t v = threadIdx.x; v < n / 4; v += NT) {
+        for (int64_t v = threadIdx.x; v < n / 4; v += NTF) {
             const int cc = (int)(v / nv_row);
             const float mul = coef[cc], add = coef[cpg + cc];
             float4 w = x4[v];
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const float* x, const floa
             y4[v] = w;
         }
     } else {
-        for (int64_t i = threadIdx.x; i < n; i += NT) {
+        for (int64_t i = threadIdx.x; i < n; i += NTF) {
             const int cc = (int)(i / S);
             float v = sdc::silu_f(base[i] * coef[cc] + coef[cpg + cc]);
             if (rb) v += rb[i];
@@ -396,7 +397,7 @@ extern "C" int sdc_gn_fused(const float* x, const float* gamma, const float* bet
     SDC_REQUIRE((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) % 16 == 0 ||
                     (S & 3) != 0, SDC_EINVAL, "sdc_gn_fused: 16-byte aligned tensors required");
     const size_t lds = (size_t)2 * (C / G) * sizeof(float);
-    hipLaunchKernelGGL(gn_fused_kernel, dim3((unsigned)(B * G)), dim3(NT), lds, sdc::as_stream(stream), x, gamma, beta, ss, t_dev,
+    hipLaunchKernelGGL(gn_fused_kernel, dim3((unsigned)(B * G)), dim3(NTF), lds, sdc::as_stream(stream), x, gamma, beta, ss, t_dev,
                        ss_t_stride, ss_b_stride, ss_off, residual, y, C, G, S, eps);
     return sdc::check_launch("sdc_gn_fused");
 }

@@ -749,8 +749,8 @@ def test_conv_direct_big_grids(plan_cls, case):
                                                  (64, 2048, 1, (16,), False, True), (80, 64, 8, (2, 8, 8), False, False),
                                                  (70, 96, 1, (3, 7), True, True)])
 def test_gn_fused_small_groups_equal_the_three_launch_path(B, Cc, G, sp, cond, res):
-    """sdc_gn_fused (statistics + apply in one launch for small groups: the deep levels of Unet2D / Unet1D) gives the bits of
-    sdc_gn_stats + sdc_gn_apply, and both match torch in fp64"""
+    """sdc_gn_fused (statistics + apply in one launch for small groups: the deep levels of Unet2D / Unet1D) against
+    sdc_gn_stats + sdc_gn_apply and against torch in fp64"""
     from safediffcon_amd.engine import Plan, as5
     x = det_tensor((B, Cc, *sp), 170)
     gamma, beta = (1 + 0.1 * det_tensor((Cc,), 171)).to(DEV), (0.1 * det_tensor((Cc,), 172)).to(DEV)
@@ -766,7 +766,7 @@ def test_gn_fused_small_groups_equal_the_three_launch_path(B, Cc, G, sp, cond, r
         outs.append(y.clone())
         used.append({fn.__name__ for fn, _ in plan.calls})
     assert used[0] == {"sdc_gn_fused"} and "sdc_gn_stats" in used[1]
-    assert torch.equal(outs[0], outs[1])
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-6          # fp64 statistics on both sides, summed in another order
     u = F.group_norm(x.double(), G, gamma.double().cpu(), beta.double().cpu(), eps=1e-5)
     if cond:
         bs = (B, Cc) + (1,) * len(sp)
