@@ -28,7 +28,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("SDC_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")     # (override: regeneration checks)
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
 
