@@ -42,23 +42,27 @@ def build_experiments(verbose=True):
     return out
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, jobs=4):
+    """compile the translation units (up to `jobs` hipcc processes at a time) and link libsdc_hip.so"""
+    from concurrent.futures import ThreadPoolExecutor
     hdrs = [os.path.join(CSRC, "sdc_common.h"), os.path.join(HERE, "..", "include", "sdc.h")]
-    objs = []
+    objs, todo = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC, *FLAGS, "-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            todo.append([HIPCC, *FLAGS, "-c", s, "-o", o])
         objs.append(o)
-    if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    if todo:
+        with ThreadPoolExecutor(max_workers=max(1, min(jobs, len(todo)))) as ex:
+            list(ex.map(run, todo))
+    if force or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
     return LIB
 
 
