@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsdc_hip.so")
-SOURCES = ["sdc_api.hip", "sdc_conv.hip", "sdc_norm.hip", "sdc_attn.hip", "sdc_lablock.hip", "sdc_tablock.hip", "sdc_step.hip", "sdc_solver.hip", "sdc_grad.hip", "sdc_attn_bwd.hip"]
+SOURCES = ["sdc_api.hip", "sdc_conv.hip", "sdc_conv_wino.hip", "sdc_norm.hip", "sdc_attn.hip", "sdc_lablock.hip", "sdc_tablock.hip", "sdc_step.hip", "sdc_solver.hip", "sdc_grad.hip", "sdc_attn_bwd.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -16,7 +16,7 @@ def source_hash():
     bench.py can tell a record collected on other kernels from a current one (no git on the GPU box)"""
     import hashlib
     h = hashlib.sha256()
-    for f in SOURCES + ["sdc_common.h"]:
+    for f in SOURCES + ["sdc_common.h", "sdc_conv.h"]:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     with open(os.path.join(HERE, "..", "include", "sdc.h"), "rb") as fh:
@@ -45,7 +45,7 @@ def build_experiments(verbose=True):
 def build(force=False, verbose=True, jobs=4):
     """compile the translation units (up to `jobs` hipcc processes at a time) and link libsdc_hip.so"""
     from concurrent.futures import ThreadPoolExecutor
-    hdrs = [os.path.join(CSRC, "sdc_common.h"), os.path.join(HERE, "..", "include", "sdc.h")]
+    hdrs = [os.path.join(CSRC, "sdc_common.h"), os.path.join(CSRC, "sdc_conv.h"), os.path.join(HERE, "..", "include", "sdc.h")]
     objs, todo = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

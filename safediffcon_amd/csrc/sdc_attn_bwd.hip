@@ -50,9 +50,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnBwdArgs a) {
     else { sq = tid % nseq; ti = tid / nseq; }
     const bool owner = tid < nthr;
     const bool want_bias = a.bias != nullptr && a.dbias_part != nullptr;      // (ntok <= 32, host check)
-    float dsacc[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) dsacc[i] = 0.0f;
+    float* Db = Dd + NT;                  // [nseq][query][key] sums of dS over this workgroup's groups (bias gradient)
+    if (want_bias) {
+        for (int e = tid; e < nseq * ntok * ntok; e += NT) Db[e] = 0.0f;
+    }
 
     auto seq_base = [&](int s) -> int64_t { const int o = s / a.inner, i = s - o * a.inner; return o * a.so + i * a.si; };
     auto seq_obase = [&](int s) -> int64_t { const int o = s / a.inner, i = s - o * a.inner; return o * a.oso + i * a.osi; };
@@ -158,7 +159,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnBwdArgs a) {
             for (int d = 0; d < DH; ++d) { k[d] = Kq[d * a.ld + ti * a.lj]; v[d] = Vq[d * a.ld + ti * a.lj]; dk[d] = 0.f; dv[d] = 0.f; }
             const int sbase = a.tok_contig ? sq * ntok : sq;            // tid of (sq, token i) = sbase + i * sstep
             const int sstep = a.tok_contig ? 1 : nseq;
-            auto body = [&](int i, float& acc_ds) __attribute__((always_inline)) {
+            float* dbcol = Db + sq * ntok * ntok + ti;                     // this thread's column: element i at dbcol[i * ntok]
+            for (int i = 0; i < ntok; ++i) {
                 float s = 0.f, dp = 0.f, qq[DH], gg[DH];
 #pragma unroll
                 for (int d = 0; d < DH; ++d) { qq[d] = Qq[d * a.ld + i * a.lj]; gg[d] = Gq[d * a.ld + i * a.lj]; s += qq[d] * k[d]; dp += gg[d] * v[d]; }
@@ -168,16 +170,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnBwdArgs a) {
                 const float ds = p * (dp - Dd[r]);
 #pragma unroll
                 for (int d = 0; d < DH; ++d) { dk[d] += ds * qq[d]; dv[d] += p * gg[d]; }
-                acc_ds += ds;
-            };
-            if (want_bias) {
-                // (unrolled so that the per-query sums of dS stay in registers: ntok <= 32)
-#pragma unroll
-                for (int i = 0; i < 32; ++i)
-                    if (i < ntok) body(i, dsacc[i]);
-            } else {
-                float unused = 0.f;
-                for (int i = 0; i < ntok; ++i) body(i, unused);
+                if (want_bias) dbcol[i * ntok] += ds;
             }
             if (a.rot) {
 #pragma unroll
@@ -196,17 +189,13 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnBwdArgs a) {
         __syncthreads();
     }
     if (want_bias) {
-        // dsacc[i] of thread (sq, key j): sum over this workgroup's sequences in a fixed order -> one partial table
-        float* tmp = lds;                                  // [nseq][ntok i][ntok j]
-        if (owner) {
-            for (int i = 0; i < ntok; ++i) tmp[(sq * ntok + i) * ntok + ti] = dsacc[i];
-        }
+        // Db[sq][i][j]: sum over this workgroup's sequences in a fixed order -> one partial table
         __syncthreads();
         float* out = a.dbias_part + ((int64_t)slot * a.heads + head) * ntok * ntok;
         for (int e = tid; e < ntok * ntok; e += NT) {
-            float s = 0.f;
-            for (int s_ = 0; s_ < nseq; ++s_) s += tmp[s_ * ntok * ntok + e];
-            out[e] = s;
+            float sacc = 0.f;
+            for (int s_ = 0; s_ < nseq; ++s_) sacc += Db[s_ * ntok * ntok + e];
+            out[e] = sacc;
         }
     }
 }
@@ -618,11 +607,13 @@ extern "C" int sdc_attn_bwd(const float* qkv, const float* dout, const float* ro
         while (inner % nseq) --nseq;
         a.ls = 1; a.ld = ntok * nseq; a.lj = nseq;
     }
+    if (a.dbias_part && nseq > 4) {          // room for the [nseq][ntok][ntok] bias-gradient table
+        nseq = 4;
+        if (!a.tok_contig) { while (inner % nseq) --nseq; a.ld = ntok * nseq; a.lj = nseq; }
+    }
     a.nseq = nseq;
     const size_t ksz = a.tok_contig ? (size_t)nseq * a.ls : (size_t)DH * a.ld;
-    size_t lds_bytes = (4 * ksz + 3 * NT) * sizeof(float);
-    const size_t bias_bytes = (size_t)nseq * ntok * ntok * sizeof(float);
-    if (a.dbias_part && bias_bytes > lds_bytes) lds_bytes = bias_bytes;
+    const size_t lds_bytes = (4 * ksz + 3 * NT + (a.dbias_part ? (size_t)nseq * ntok * ntok : 0)) * sizeof(float);
     SDC_REQUIRE(lds_bytes <= 160 * 1024, SDC_EINVAL, "sdc_attn_bwd: LDS footprint %zu too large", lds_bytes);
     a.ngrp = (nseq_tot + nseq - 1) / nseq;
     a.nslots = a.ngrp < 1024 ? a.ngrp : 1024;

@@ -1,0 +1,1050 @@
+// Winograd F(2x2,3x3) and F(2x2x2,3x3x3) conv kernels on the gfx950 fp32 matrix cores (precision 3 / 4 of SdcConvDesc).
+#include "sdc_conv.h"
+
+namespace sdcconv {
+
+// ------------------------------------------------------------------------------------------------
+// precision = 3: fp32 Winograd F(2x2, 3x3) over (H, W) for the 3x3 (Conv2d) / 3x3x3 (Conv3d, direct along D) stride-1
+// convs: per 2x2 output tile and its 4x4 input patch d,  Y = A^T [ (G g G^T) . (B^T d B) ] A  with the same G, B^T, A^T as
+// the 1-D form above applied along H and along W -- 16 products per 4 outputs instead of 36: 4/9 of the direct fp32 MFMA
+// work (the 1-D form: 2/3).  The caller stores U[kd][ci][co][j*4+xi] = sum_{kh,kw} G[j][kh] G[xi][kw] w[co][ci][kd][kh][kw]
+// (fp64, rounded once; the 16 components of one (ci, co) contiguous) behind the 1-D taps.  16 GEMMs over K = kD*Cin, N = tiles:
+//   * workgroup = 4 waves, ONE per SIMD (16 components x 32x32 accumulators = 256 registers per wave), 64 output
+//     channels x 64 tiles (= RP whole row pairs of W/2 tiles, 256 output positions); K stages of 8 channels.
+//   * What decides the speed (tools/mfma_fill.hip, tools/wg_probe.py with parts of the loop switched off): the fp32 MFMA runs
+//     at the fp32 VALU rate and a VALU instruction issued between two MFMAs of the wave is NOT hidden behind them (~7-11
+//     cycles each, a global load ~14); ds_read_b128 / ds_write_b32 are nearly free up to two per MFMA, SALU is free.  So
+//     the loop is built to need few VALU and VMEM instructions per MFMA:
+//   * B: the whole input transform V = B^T d B happens ONCE per workgroup, when a stage is parked in LDS -- not per wave at
+//     fragment-read time.  A lane owns CPL adjacent columns of one row pair (CPL = W/16, so a 16-lane DPP row is one image
+//     row; W = 16: two rows interleaved): it loads the 4 input rows with one vector load each, applies the H transform in
+//     registers, then the W transform with the neighbour columns taken through DPP row shifts (bound_ctrl supplies the zero
+//     padding at the row ends), and stores V[k][j][tile][xi] with ds_write_b128.  A wave then reads its B fragments with four
+//     ds_read_b128 per k-step and feeds them to the MFMAs as they are.
+//   * A: U tile [8][64][16] per stage with 16-byte loads (scalar base + fixed lane offset), parked with one ds_write_b128
+//     and read back as four ds_read_b128 per k-step (16-byte chunks XOR-swizzled by (row >> 2) & 3: conflict-free).
+//   * two LDS stage buffers, ONE barrier per stage (end of k-step 2: every park of stage st+1 is done and every read of the
+//     buffer that stage st+2's parks will overwrite has returned); stage st+2 is fetched while stage st computes; the last
+//     k-step of a stage already reads the first fragments of the next one.
+//   * all LDS offsets and the row taps are immediates (W is a template parameter, input rows contiguous); the padding masks
+//     are skipped by whole waves whose rows are all inside the image.
+// Results differ from the direct form by rounding order (measured 2-6e-7 of the output scale vs fp64; direct form 1-2e-6).
+namespace {
+
+// single fp32 VALU ops the SLP vectoriser cannot pack (v_pk_add_f32 beside MFMAs is slower than two v_add_f32)
+__device__ __forceinline__ float vsub1(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vadd1(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// Packed / DPP forms of the park-time transform (a VALU instruction between two fp32 MFMAs costs the same whether it
+// produces one result or two, and a DPP operand is free):
+typedef float w2f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ w2f2 pk_add2(w2f2 a, w2f2 b) { w2f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ w2f2 pk_sub2(w2f2 a, w2f2 b) { w2f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ w2f2 pk_mul2(w2f2 a, w2f2 b) { w2f2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// a * b - c ;  c - a * b
+__device__ __forceinline__ w2f2 pk_fms2(w2f2 a, w2f2 b, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ w2f2 pk_fnma2(w2f2 a, w2f2 b, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// (c1, c2) -> (c1 + c2, c2 - c1)
+__device__ __forceinline__ w2f2 pk_sumdiff(w2f2 c) {
+    w2f2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(c));
+    return r;
+}
+// (c1, c2) -> (c1 + c2, c1 - c2);  (s.x + a.x, s.y - a.y);  a * a + c
+__device__ __forceinline__ w2f2 pk_sumdiff_fwd(w2f2 c) {
+    w2f2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(c));
+    return r;
+}
+__device__ __forceinline__ w2f2 pk_addsub(w2f2 s, w2f2 a) { w2f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(s), "v"(a)); return r; }
+__device__ __forceinline__ w2f2 pk_sqacc(w2f2 a, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(r) : "v"(a), "v"(c)); return r; }
+// Sums over the 64 lanes of eight fp64 values per lane with 10 exchanges instead of 48: halve the value set at the xor-32,
+// -16 and -8 levels (each lane keeps the half its lane bit selects), then an all-reduce of the one value left over xor 4, 2, 1.
+// Afterwards every lane holds the wave total of value (lane >> 3).  Fixed order: the result does not depend on anything but
+// the 512 inputs.
+__device__ __forceinline__ double wave_sum8(const double (&v)[8], int lane) {
+    double w[4], u[2];
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (b5 ? v[4 + i] : v[i]) + __shfl_xor(b5 ? v[i] : v[4 + i], 32, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) u[i] = (b4 ? w[2 + i] : w[i]) + __shfl_xor(b4 ? w[i] : w[2 + i], 16, 64);
+    double t = (b3 ? u[1] : u[0]) + __shfl_xor(b3 ? u[0] : u[1], 8, 64);
+    t += __shfl_xor(t, 4, 64);
+    t += __shfl_xor(t, 2, 64);
+    t += __shfl_xor(t, 1, 64);
+    return t;
+}
+// value of lane - S of the same 16-lane row (0 past the row end) minus b;  a minus the value of lane + S
+template <int S>
+__device__ __forceinline__ float sub_prev(float x, float b) {
+    float r;
+    if (S == 1) asm("v_sub_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(x), "v"(b));
+    else asm("v_sub_f32_dpp %0, %1, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(x), "v"(b));
+    return r;
+}
+template <int S>
+__device__ __forceinline__ float sub_next(float a, float x) {
+    float r;
+    if (S == 1) asm("v_subrev_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(x), "v"(a));
+    else asm("v_subrev_f32_dpp %0, %1, %2 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(x), "v"(a));
+    return r;
+}
+
+template <int OW, int DBG>
+__global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
+    constexpr int SK = W2_SK, BM = W2_BM, NTH = 256;
+    constexpr int TW = OW / 2, RP = W2_TILES / TW;
+    constexpr int LGW = OW == 128 ? 7 : (OW == 64 ? 6 : (OW == 32 ? 5 : 4));
+    constexpr int CPL = OW == 16 ? 2 : OW / 16;          // adjacent columns per lane
+    constexpr int SH = OW == 16 ? 2 : 1;                 // DPP lane distance of the neighbouring column group
+    constexpr int LPK = 128 / CPL;                       // lanes per staged channel (k row)
+    constexpr int NIT = CPL == 2 ? 2 : 1;                // park items per thread and stage
+    constexpr int KPW = CPL == 8 ? 4 : 2;                // k rows per (parking) wave
+    constexpr int TPL = CPL / 2;                         // tiles per lane and row pair
+    typedef float nfloat4 __attribute__((ext_vector_type(4)));
+    typedef float nfloat2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) char* gchar_p;
+    typedef const __attribute__((address_space(1))) nfloat4* gfloat4_p;
+    typedef const __attribute__((address_space(1))) nfloat2* gfloat2_p;
+    extern __shared__ __attribute__((aligned(16))) float ldsw[];
+    float* const As = ldsw;                          // [2][SK][BM][16]  (chunk q of row m at slot q ^ ((m >> 2) & 3))
+    float* const Vs = ldsw + W2_NBUF * W2_ASZ;       // [2][SK][4 j][64 tiles][4 xi]
+
+    const SdcConvDesc& d = a.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = SDC_UNIFORM(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int MT = (d.Cout + BM - 1) / BM;
+    // consecutive logical blocks (one XCD, dispatched back to back) share an input tile: m fastest
+    const int lb = xcd_tile(blockIdx.x, gridDim.x);
+    const int m0 = (lb % MT) * BM;
+    const int tile0 = (lb / MT) * W2_TILES;
+    const int H2 = d.oH >> 1;
+    const int RPtot = d.B * d.oD * H2;
+    const int rp0 = tile0 >> (LGW - 1);
+    const bool two = d.Cin1 > 0;
+    const float r_H2 = 1.0f / (float)H2, r_oD = 1.0f / (float)d.oD;
+    auto split_rp = [&](int rp, int& ob, int& od, int& hp) {      // rp < 2^20 (host check): float quotients are exact
+        const int q = (int)(((float)rp + 0.5f) * r_H2);
+        hp = rp - q * H2;
+        ob = (int)(((float)q + 0.5f) * r_oD);
+        od = q - ob * d.oD;
+    };
+
+    // ---- park geometry of this thread: k row inside the stage, row pair r, first column c0 (CPL columns c0 .. c0+CPL-1)
+    const bool parker = CPL != 8 || wave < 2;                      // W = 128: 128 items per stage, waves 0 and 1 park
+    const int ksub = CPL == 4 ? (lane >> 5) : (CPL == 8 ? (lane >> 4) : 0);        // k row inside the wave's group (CPL = 2: the item)
+    const int lik = lane & (LPK - 1);
+    int pr, pc0;
+    if (OW == 16) { pr = 2 * (lik >> 4) + (lik & 1); pc0 = 2 * ((lik & 15) >> 1); }
+    else { pr = lik >> 4; pc0 = (lik & 15) * CPL; }
+    // byte offset of (b, od, 2hp, c0) inside one channel of x0 / x1 plus this lane's k-row offset; the depth-tap shift
+    // (kd - pD) planes is added once per stage.  Zero padding without per-element masks: the row above / below the row pair
+    // is fetched from a clamped (valid) row and multiplied by a 0 / 1 factor inside the H transform (one fused op, no extra
+    // instruction); a depth tap outside the volume reads the lane's own plane and is multiplied by 0 the same way.
+    uint32_t vp0 = 0, vp1 = 0, dmsk = 0, rsel0 = 0, rsel3 = 0;
+    float m0f = 0.0f, m3f = 0.0f;
+    {
+        const int rp = rp0 + pr;
+        if (parker && rp < RPtot) {
+            int ob, od, hp;
+            split_rp(rp, ob, od, hp);
+            if (hp > 0) { m0f = 1.0f; rsel0 = OW * 4; }                       // row 2hp - 1 exists
+            if (2 * hp + 2 < d.iH) { m3f = 1.0f; rsel3 = 2 * OW * 4; }        // row 2hp + 2 exists
+            for (int kd = 0; kd < d.kD; ++kd) dmsk |= (od - d.pD + kd >= 0 && od - d.pD + kd < d.iD) ? (1u << kd) : 0u;
+            vp0 = (uint32_t)(ksub * d.x0s[1] + ob * d.x0s[0] + od * d.x0s[2] + (2 * hp) * OW + pc0) * 4u;
+            if (two) vp1 = (uint32_t)(ksub * d.x1s[1] + ob * d.x1s[0] + od * d.x1s[2] + (2 * hp) * OW + pc0) * 4u;
+        }
+    }
+    // park position: V[k][j][tile][4]; k = wave * KPW + ksub (+ item for CPL = 2), tile = pr * TW + c0 / 2 (+ t)
+    const int vpark = ((wave * KPW + ksub) * 4 * W2_TILES + pr * TW + (pc0 >> 1)) * 4;          // floats; + j * 256, + item * 1024
+    // B fragments: tile n = wn * 32 + l31 of k row 2ks + lh: four 16-byte reads (j = 0..3)
+    const int boff = (lh * 4 * W2_TILES + wn * 32 + l31) * 4;
+    // A fragments: row (k = 2ks + lh, m): four 16-byte chunks, chunk q at slot q ^ ((m >> 2) & 3)
+    const int arow = wm * 32 + l31;
+    int aoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) aoff[q] = (lh * BM + arow) * 16 + 4 * (q ^ ((arow >> 2) & 3));
+    // weight fetch / park: float4 f = tid + 256 i: k = i, m = tid >> 2, chunk = tid & 3
+    const int pm = tid >> 2, pq = tid & 3;
+    const int apark = pm * 16 + 4 * (pq ^ ((pm >> 2) & 3));                        // + i * BM * 16 floats
+    const int pmc = (m0 + pm) < d.Cout ? (m0 + pm) : d.Cout - 1;                   // rows beyond Cout: any valid row (never stored)
+    uint32_t a_voff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a_voff[i] = (uint32_t)(((int64_t)i * d.Cout + pmc) * 16 + 4 * pq) * 4u;
+
+    w2f2 braw[NIT][4][TPL];       // [item][source row j][column pair]
+    nfloat4 areg[8];
+    int s_kd = 0, s_ci = 0;
+    const int64_t xs1_0 = d.x0s[1], xs1_1 = d.x1s[1];
+    const int xs2_0 = (int)d.x0s[2], xs2_1 = (int)d.x1s[2];
+    const int cin0 = d.Cin0, cin = a.Cin, kDn = d.kD, coutn = d.Cout, pDn = d.pD;
+    const float* const wg2p = a.wg2;
+    const float* const x0p = a.x0;
+    const float* const x1p = two ? a.x1 : a.x0;
+    // stage fetch state: scalar bases (weights; the first channel row of this wave), the lane offsets of the selected input
+    // (rows 2hp / 2hp+1 at voff / voff + W*4, the clamped rows above / below at voff0 / voff3), the stage's 0 / 1 factors
+    gfloat_p f_w = uniform_ptr(wg2p), f_x = uniform_ptr(x0p);
+    int64_t f_sc = 0;
+    uint32_t voff = 0, voff0 = 0, voff3 = 0;
+    w2f2 mk0 = {0.f, 0.f}, mk3 = {0.f, 0.f}, mk12 = {0.f, 0.f};
+    auto fetch_begin = [&]() {
+        const bool first = s_ci < cin0;
+        f_sc = first ? xs1_0 : xs1_1;
+        const float* bsel = first ? x0p : x1p;
+        const int cbase = (first ? s_ci : s_ci - cin0) + wave * KPW;
+        const uint32_t dsb = (uint32_t)((s_kd - pDn) * (first ? xs2_0 : xs2_1) * 4);   // bytes, two's complement
+        f_x = uniform_ptr(bsel + (int64_t)cbase * f_sc);
+        f_w = uniform_ptr(wg2p + ((int64_t)(s_kd * cin + s_ci) * coutn) * 16);
+        const bool dv = (dmsk >> s_kd) & 1u;
+        voff = (first ? vp0 : vp1) + (dv ? dsb : 0u);
+        voff0 = voff - rsel0;
+        voff3 = voff + rsel3;
+        const float md = dv ? 1.0f : 0.0f, a0 = dv ? m0f : 0.0f, a3 = dv ? m3f : 0.0f;
+        mk12 = w2f2{md, md};
+        mk0 = w2f2{a0, a0};
+        mk3 = w2f2{a3, a3};
+        s_ci += SK;
+        // (past the last stage the walk wraps to the first one: the extra fetches of the pipeline tail stay in bounds and are
+        // never consumed)
+        if (s_ci >= cin) { s_ci = 0; if (++s_kd == kDn) s_kd = 0; }
+    };
+    // (the offset passes through an empty asm so that its zero-extension is not hoisted out of the loop as a 64-bit
+    // register pair: the load then takes the scalar base + 32-bit lane offset form)
+    auto fetch_a = [&](int i, nfloat4 (&ar)[8]) { uint32_t o = a_voff[i]; asm volatile("" : "+v"(o)); ar[i] = *(gfloat4_p)((gchar_p)f_w + o); };
+    // the 4 input rows under the row pair, CPL adjacent columns each: one vector load per row, row tap (j - 1) as an immediate.
+    // A lane whose row is outside the image reads the first elements of the channel instead and is zeroed when parked.
+    auto fetch_b_row = [&](int it, int j, w2f2 (&br)[NIT][4][TPL]) {
+        const gchar_p rb = (gchar_p)f_x + (CPL == 2 ? (int64_t)it * f_sc * 4 : 0);
+        const gchar_p p = j == 0 ? rb + voff0 : (j == 3 ? rb + voff3 : (j == 1 ? rb + voff : rb + voff + OW * 4));
+        if (CPL == 2) { const nfloat2 v = *(gfloat2_p)p; br[it][j][0] = w2f2{v.x, v.y}; }
+        else {
+#pragma unroll
+            for (int h = 0; h < CPL / 4; ++h) {
+                const nfloat4 v = *(gfloat4_p)(p + 16 * h);
+                br[it][j][2 * h] = w2f2{v.x, v.y};
+                br[it][j][2 * h + 1] = w2f2{v.z, v.w};
+            }
+        }
+    };
+    auto fetch_b = [&](int it, w2f2 (&br)[NIT][4][TPL]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fetch_b_row(it, j, br);
+    };
+    auto park_a = [&](int buf, int i, const nfloat4 (&ar)[8]) {
+        *reinterpret_cast<nfloat4*>(As + buf * W2_ASZ + i * (BM * 16) + apark) = ar[i];
+    };
+    // input transform of one item: H transform per column pair (packed), then per transformed row j the W transform of the
+    // lane's TPL tiles -- V0 = c0 - c2, (V1, V2) = (c1 + c2, c2 - c1) packed, V3 = c1 - c3, the neighbour columns c0 / c3 of the
+    // edge tiles through DPP -- and one 16-byte store per tile, slot order (V1, V2, V0, V3)
+    w2f2 hrow[4][TPL];
+    auto park_b_h = [&](int it, const w2f2 (&br)[NIT][4][TPL], w2f2 k0, w2f2 k12, w2f2 k3) {
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) {
+            const w2f2 t1 = pk_mul2(br[it][1][t], k12), t2 = pk_mul2(br[it][2][t], k12);
+            hrow[0][t] = pk_fms2(br[it][0][t], k0, t2);          // d0 - d2
+            hrow[1][t] = pk_add2(t1, t2);                        // d1 + d2
+            hrow[2][t] = pk_sub2(t2, t1);                        // d2 - d1
+            hrow[3][t] = pk_fnma2(br[it][3][t], k3, t1);         // d1 - d3
+        }
+    };
+    auto park_b_w = [&](int buf, int it, int j) {
+        float* dst = Vs + buf * W2_BSZ + vpark + (CPL == 2 ? it * (4 * W2_TILES * 4) : 0) + j * (W2_TILES * 4);
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) {
+            const w2f2 cc = hrow[j][t];
+            const w2f2 sd = pk_sumdiff(cc);
+            const float v0 = t == 0 ? sub_prev<SH>(hrow[j][TPL - 1].y, cc.y) : vsub1(hrow[j][t - 1].y, cc.y);
+            const float v3 = t == TPL - 1 ? sub_next<SH>(cc.x, hrow[j][0].x) : vsub1(cc.x, hrow[j][t + 1].x);
+            nfloat4 v;
+            v.x = sd.x; v.y = sd.y; v.z = v0; v.w = v3;
+            *reinterpret_cast<nfloat4*>(dst + t * 4) = v;
+        }
+    };
+    auto park_b = [&](int buf, int it, const w2f2 (&br)[NIT][4][TPL], w2f2 k0, w2f2 k12, w2f2 k3) {
+        park_b_h(it, br, k0, k12, k3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) park_b_w(buf, it, j);
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+    // The bias is the start value of component (j, xi) = (1, 1): A^T M A hands that component to each of the 2x2 outputs with
+    // coefficient +1.  Register r of a lane is channel m0 + 32 wm + 8 (r >> 2) + 4 lh + (r & 3).
+    if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m0 + wm * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+            acc[5][r] = a.bias[co < d.Cout ? co : d.Cout - 1];
+        }
+    }
+
+    const int nstages = d.kD * (a.Cin / SK);
+    nfloat4 fa[2][4];             // [set][chunk j]: U components (j, xi = 0..3) of this lane's (k, m)
+    nfloat4 fv[2][4];             // [set][j]:       V components (j, xi = 0..3) of this lane's (k, tile)
+    auto read_a = [&](const float* Ak, int set, int q) { fa[set][q] = *reinterpret_cast<const nfloat4*>(Ak + aoff[q]); };
+    auto read_v = [&](const float* Vk, int set, int j) { fv[set][j] = *reinterpret_cast<const nfloat4*>(Vk + boff + j * (W2_TILES * 4)); };
+    w2f2 pk0, pk12, pk3, nk0 = {0.f, 0.f}, nk12 = {0.f, 0.f}, nk3 = {0.f, 0.f};     // 0 / 1 factors of the items still in registers
+    {   // prologue: the fetches of the first two stages travel together; stage 0 is parked in buffer 0
+        w2f2 braw0[NIT][4][TPL];
+        nfloat4 areg0[8];
+        fetch_begin();
+        const w2f2 q0 = mk0, q12 = mk12, q3 = mk3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fetch_a(i, areg0);
+        if (parker) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) fetch_b(it, braw0);
+        }
+        fetch_begin();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fetch_a(i, areg);
+        if (parker) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) fetch_b(it, braw);
+        }
+        pk0 = mk0; pk12 = mk12; pk3 = mk3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) park_a(0, i, areg0);
+        if (parker) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) park_b(0, it, braw0, q0, q12, q3);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) read_a(As, 0, q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) read_v(Vs, 0, j);
+
+    // Main loop: stage st computes from buffer st & 1 and parks stage st+1 in the other one during its k-steps 0-1, re-using
+    // each register piece for the fetch of stage st+2 as soon as it is parked (a fetch then has four k-steps to arrive); the
+    // one barrier sits at the end of k-step 2; k-step 3 reads the first fragments of stage st+1, so the MFMA stream runs
+    // through the stage boundary.  The non-MFMA work of a k-step sits in 16 slots, one behind each MFMA, in source order;
+    // no branch inside the loop (a per-slot fast / masked choice cost conservative vmcnt waits at every join).
+    int rbuf = 0;
+    for (int st = 0; st < nstages; ++st) {
+        const int wbuf = rbuf ^ 1;
+        const float* Ab = As + rbuf * W2_ASZ;
+        const float* Vb = Vs + rbuf * W2_BSZ;
+        const float* An = As + wbuf * W2_ASZ;
+        const float* Vn = Vs + wbuf * W2_BSZ;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int set = ks & 1, nset = set ^ 1;
+            const float* Ak = ks < 3 ? Ab + (2 * (ks + 1)) * (BM * 16) : An;               // fragments of the next k-step
+            const float* Vk = ks < 3 ? Vb + (2 * (ks + 1)) * (4 * W2_TILES * 4) : Vn;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                // component (j = c >> 2, xi = c & 3): V slot order in LDS is (V1, V2, V0, V3)
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][c >> 2][c & 3],
+                                                              fv[set][c >> 2][(c & 3) == 0 ? 2 : ((c & 3) == 3 ? 3 : (c & 3) - 1)], acc[c], 0, 0, 0);
+                // -- fragments of the next k-step: eight 16-byte LDS reads
+                if (DBG & 2) {}
+                else if (c >= 8 && c < 12) read_v(Vk, nset, c - 8);
+                else if (c >= 12) read_a(Ak, nset, c - 12);
+                // -- staging: k-step p = 0, 1 parks piece p of stage st+1 and re-fetches it for stage st+2
+                if (ks < 2 && !(DBG & 1)) {
+                    const int p = ks;
+                    const bool bwork = parker && p < NIT;
+                    if (c < 4) { if (!(DBG & 32)) park_a(wbuf, 2 * c + p, areg); }
+                    else if (c == 4) { if (bwork && !(DBG & 8)) park_b_h(p, braw, pk0, pk12, pk3); }
+                    else if (c < 9) { if (bwork && !(DBG & 8)) park_b_w(wbuf, p, c - 5); }
+                    else if (c == 9) { if (p == 0) { fetch_begin(); nk0 = mk0; nk12 = mk12; nk3 = mk3; } }
+                    else if (c < 14) {
+                        if (bwork && !(DBG & 16)) fetch_b_row(p, c - 10, braw);
+                        if (c >= 12 && !(DBG & 64)) fetch_a(2 * (c - 12) + p, areg);
+                    }
+                    else { if (!(DBG & 64)) fetch_a(2 * (c - 12) + p, areg); if (c == 15 && p == 1) { pk0 = nk0; pk12 = nk12; pk3 = nk3; } }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ks == 2 && !(DBG & 4)) __syncthreads();
+        }
+        rbuf = wbuf;
+    }
+
+    if (DBG & 128) {      // experiment: no epilogue (keeps the accumulators alive through one store)
+        float sdbg = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sdbg += acc[c][0];
+        if (sdbg == 12345.678f) a.y[0] = sdbg;
+        return;
+    }
+    // ---- epilogue: output transform Y = A^T M A on the accumulators, residual, GroupNorm partial sums.
+    // Every instruction here is exposed (nothing else runs on the CU), so the common case -- all 64 channels and all 64
+    // tiles of the workgroup exist, 8-byte stores allowed, no residual -- is straight-line code: per channel row 16
+    // accumulator reads, 12 packed adds (the H stage on the component pairs (xi 0, 3) and (1, 2), which hands the W stage
+    // its operands already paired; its results are the two adjacent outputs of a row), two 8-byte stores from a scalar
+    // channel base stepped by the channel stride, 4 packed ops for the GroupNorm sums.
+    const bool v2 = a.vec2;
+    const bool gn = a.gn_part != nullptr;
+    double gv[8];                                           // 8-row block g4: gv[2 g4] = sum, gv[2 g4 + 1] = sum of squares
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gv[i] = 0.0;
+    {
+        const int cob = m0 + wm * 32;                       // wave-uniform; this lane's rows: cob + 4 lh + (rr & 3) + 8 (rr >> 2)
+        const int n = tile0 + wn * 32 + l31;
+        const int rp = n >> (LGW - 1), tw = n & (TW - 1);
+        const bool pok = rp < RPtot;
+        int ob = 0, od = 0, hp = 0;
+        if (pok) split_rp(rp, ob, od, hp);
+        // lane offsets in bytes (host check: the y / residual spans stay below 2^32 bytes), the 4 lh rows folded in
+        const uint32_t yoff = (uint32_t)(ob * d.ys[0] + od * d.ys[2] + (2 * hp) * d.ys[3] + (2 * tw) * d.ys[4] + (4 * lh) * d.ys[1]) * 4u;
+        const uint32_t roff = a.res ? (uint32_t)(ob * d.rs[0] + od * d.rs[2] + (2 * hp) * d.rs[3] + (2 * tw) * d.rs[4] + (4 * lh) * d.rs[1]) * 4u : 0u;
+        const int64_t ycs = d.ys[1], rcs = d.rs[1];
+        const uint32_t yrow = (uint32_t)d.ys[3] * 4u, rrow = (uint32_t)d.rs[3] * 4u, ycol = (uint32_t)d.ys[4] * 4u, rcol = (uint32_t)d.rs[4] * 4u;
+        const bool full = m0 + BM <= d.Cout;                // all 64 rows of the workgroup exist
+        typedef __attribute__((address_space(1))) char* gwchar_p;
+        typedef __attribute__((address_space(1))) float* gwfloat_p;
+        typedef __attribute__((address_space(1))) nfloat2* gwfloat2_p;
+        if (full && v2 && !a.res && rp0 + RP <= RPtot) {
+            gwchar_p yb = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(a.y + (int64_t)cob * ycs);
+            const int64_t rstep = ycs * 4, gstep = ycs * 20;                // bytes: the next row, the first row of the next block
+            const uint32_t yoff1 = yoff + yrow;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                w2f2 bs2 = {0.f, 0.f}, bq2 = {0.f, 0.f};
+#pragma unroll
+                for (int r3 = 0; r3 < 4; ++r3) {
+                    const int rr = g4 * 4 + r3;
+                    w2f2 pa[4], pb[4];                      // per j: (M[j][0], M[j][3]), (M[j][1], M[j][2])
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        pa[j] = w2f2{acc[4 * j][rr], acc[4 * j + 3][rr]};
+                        pb[j] = w2f2{acc[4 * j + 1][rr], acc[4 * j + 2][rr]};
+                    }
+                    const w2f2 t0a = pk_add2(pk_add2(pa[0], pa[1]), pa[2]), t1a = pk_sub2(pk_sub2(pa[1], pa[2]), pa[3]);
+                    const w2f2 t0b = pk_add2(pk_add2(pb[0], pb[1]), pb[2]), t1b = pk_sub2(pk_sub2(pb[1], pb[2]), pb[3]);
+                    const w2f2 z0 = pk_addsub(pk_sumdiff_fwd(t0b), t0a);    // (y00, y01)
+                    const w2f2 z1 = pk_addsub(pk_sumdiff_fwd(t1b), t1a);    // (y10, y11)
+                    *(gwfloat2_p)(yb + yoff) = nfloat2{z0.x, z0.y};
+                    *(gwfloat2_p)(yb + yoff1) = nfloat2{z1.x, z1.y};
+                    bs2 = pk_add2(bs2, pk_add2(z0, z1));
+                    bq2 = pk_sqacc(z1, pk_sqacc(z0, bq2));
+                    yb += r3 < 3 ? rstep : gstep;
+                }
+                gv[2 * g4] = (double)(bs2.x + bs2.y);
+                gv[2 * g4 + 1] = (double)(bq2.x + bq2.y);
+            }
+        } else {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {                // 8-row blocks: rows cob + 8 g4 + 4 lh + (0..3)
+                float bsx = 0.0f, bsy = 0.0f, bqx = 0.0f, bqy = 0.0f;      // the two halves of the packed path's sums
+#pragma unroll
+                for (int r3 = 0; r3 < 4; ++r3) {
+                    const int rr = g4 * 4 + r3;
+                    const int cou = cob + 8 * g4 + r3;      // wave-uniform part of the row
+                    const bool rok = full || (cou + 4 * lh) < d.Cout;
+                    const int coc = full ? cou : (cou < d.Cout - 4 ? cou : d.Cout - 8);       // clamped: in-bounds addresses for the tail
+                    float t0[4], t1[4];
+#pragma unroll
+                    for (int xi = 0; xi < 4; ++xi) {
+                        const float M0 = acc[0 + xi][rr], M1 = acc[4 + xi][rr], M2 = acc[8 + xi][rr], M3 = acc[12 + xi][rr];
+                        t0[xi] = (M0 + M1) + M2;
+                        t1[xi] = (M1 - M2) - M3;
+                    }
+                    // (the same association as the packed path above: a sample must come out bit-identical whichever path
+                    // the workgroup that holds it takes -- that depends on the batch it is launched with)
+                    float y00 = (t0[1] + t0[2]) + t0[0];
+                    float y01 = (t0[1] - t0[2]) - t0[3];
+                    float y10 = (t1[1] + t1[2]) + t1[0];
+                    float y11 = (t1[1] - t1[2]) - t1[3];
+                    if (a.res) {
+                        const gchar_p rb = (gchar_p)uniform_ptr(a.res + (int64_t)coc * rcs);
+                        if (v2) {
+                            const nfloat2 u0 = *(gfloat2_p)(rb + roff), u1 = *(gfloat2_p)(rb + roff + rrow);
+                            y00 += u0.x; y01 += u0.y; y10 += u1.x; y11 += u1.y;
+                        } else {
+                            y00 += *(gfloat_p)(rb + roff); y01 += *(gfloat_p)(rb + roff + rcol);
+                            y10 += *(gfloat_p)(rb + roff + rrow); y11 += *(gfloat_p)(rb + roff + rrow + rcol);
+                        }
+                    }
+                    if (pok && rok) {
+                        const gwchar_p yb = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(a.y + (int64_t)coc * ycs);
+                        if (v2) {
+                            *(gwfloat2_p)(yb + yoff) = nfloat2{y00, y01};
+                            *(gwfloat2_p)(yb + yoff + yrow) = nfloat2{y10, y11};
+                        } else {
+                            *(gwfloat_p)(yb + yoff) = y00; *(gwfloat_p)(yb + yoff + ycol) = y01;
+                            *(gwfloat_p)(yb + yoff + yrow) = y10; *(gwfloat_p)(yb + yoff + yrow + ycol) = y11;
+                        }
+                        // GroupNorm sums: the 2x2 tile and the 4 rows of the block in fp32 (1e-7 relative on a 16-element partial
+                        // sum), fp64 from there on -- independent of the batch a trajectory is launched with (the tile grid cuts
+                        // every sample alike)
+                        bsx += y00 + y10; bsy += y01 + y11;
+                        bqx = fmaf(y10, y10, fmaf(y00, y00, bqx)); bqy = fmaf(y11, y11, fmaf(y01, y01, bqy));
+                    }
+                }
+                gv[2 * g4] = (double)(bsx + bsy);
+                gv[2 * g4 + 1] = (double)(bqx + bqy);
+            }
+        }
+    }
+    if (gn) {
+        // scr[wave][4][2] behind the stage buffers (a wave may get here while another still reads its last fragments);
+        // 8-row block t of the workgroup's 64 rows = (wm = t / 4, k = t % 4)
+        double* scr = reinterpret_cast<double*>(ldsw + W2_NBUF * (W2_ASZ + W2_BSZ));
+        const double tot = wave_sum8(gv, lane);
+        if ((lane & 7) == 0) scr[wave * 8 + (lane >> 3)] = tot;
+        __syncthreads();
+        const int ngl = a.gn_cpg >= BM ? 1 : BM / a.gn_cpg;       // groups inside this workgroup's rows
+        if (tid < ngl) {
+            const int r0 = a.gn_cpg >= BM ? 0 : tid * a.gn_cpg, r1 = a.gn_cpg >= BM ? BM : r0 + a.gn_cpg;   // local rows
+            double sum = 0.0, sq = 0.0;
+            for (int blk = r0 / 8; blk < r1 / 8; ++blk) {
+                const int wmi = blk >> 2, k = blk & 3;
+                for (int wni = 0; wni < 2; ++wni) {
+                    sum += scr[((wmi * 2 + wni) * 4 + k) * 2];
+                    sq += scr[((wmi * 2 + wni) * 4 + k) * 2 + 1];
+                }
+            }
+            if (m0 + r0 < d.Cout) {
+                const int g = (m0 + r0) / a.gn_cpg;
+                const int p0 = tile0 * 4;                          // first output position of the workgroup (whole row pairs)
+                const int b = p0 / a.gn_S, ntl = (p0 - b * a.gn_S) / (W2_TILES * 4);
+                const int idx = a.gn_cpg >= BM ? ntl * (a.gn_cpg / BM) + (m0 - g * a.gn_cpg) / BM : ntl;
+                double* pp = a.gn_part + (((int64_t)b * a.gn_G + g) * a.gn_nparts + idx) * 2;
+                pp[0] = sum; pp[1] = sq;
+            }
+        }
+    }
+}
+
+
+}  // namespace
+
+// coverage of the F(2x2,3x3) kernel (precision 3)
+bool wg2_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
+    const int64_t rptot = (int64_t)d.B * d.oD * (d.oH / 2);
+    return d.precision >= 3 && rowhalo && small && d.kH == 3 && d.kW == 3 && (d.kD == 1 || d.kD == 3) &&
+           d.sD == 1 && d.sH == 1 && d.sW == 1 && d.uD == 1 && d.uH == 1 && d.uW == 1 && d.up_mode == 0 &&
+           d.pH == 1 && d.pW == 1 && d.pD == d.kD / 2 && d.oH == d.iH && d.oW == d.iW && d.oD == d.iD &&
+           (d.oW == 16 || d.oW == 32 || d.oW == 64 || d.oW == 128) && d.oH % 2 == 0 &&
+           d.Cin0 % W2_SK == 0 && d.Cin1 % W2_SK == 0 && d.Cout % 4 == 0 && d.Cout > 32 && rptot < (1 << 20) &&
+           ((int64_t)d.kD * 9 * (d.Cin0 + d.Cin1) * d.Cout) % 4 == 0 &&
+           // input rows contiguous (the row taps are instruction immediates)
+           d.x0s[4] == 1 && d.x0s[3] == d.iW && (d.Cin1 == 0 || (d.x1s[4] == 1 && d.x1s[3] == d.iW)) &&
+           // the park lanes add their k row (up to 3 channel strides at W = 128, 1 otherwise) to the 32-bit byte offset of the
+           // (batch, depth, row, column) part, and the depth-tap shift is formed in 32 bits
+           span5(d.x0s, d.B, 1, d.iD, d.iH, d.iW) + 3 * d.x0s[1] < (1ll << 30) && d.x0s[2] < (1ll << 29) &&
+           (d.Cin1 == 0 || (span5(d.x1s, d.B, 1, d.iD, d.iH, d.iW) + 3 * d.x1s[1] < (1ll << 30) && d.x1s[2] < (1ll << 29))) &&
+           // the epilogue addresses y / the residual with 32-bit byte offsets from per-channel scalar bases
+           span5(d.ys, d.B, 8, d.oD, d.oH, d.oW) < (1ll << 30) && span5(d.rs, d.B, 8, d.oD, d.oH, d.oW) < (1ll << 30) &&
+           // ... and read with 8 / 16-byte vector loads
+           d.x0s[0] % 4 == 0 && d.x0s[1] % 4 == 0 && d.x0s[2] % 4 == 0 &&
+           (d.Cin1 == 0 || (d.x1s[0] % 4 == 0 && d.x1s[1] % 4 == 0 && d.x1s[2] % 4 == 0));
+}
+
+int launch_wg2(const ConvArgs& a, hipStream_t s) {
+    const SdcConvDesc& d = a.d;
+    const int64_t tiles = (int64_t)d.B * d.oD * (d.oH / 2) * (d.oW / 2);
+    const int MT = (d.Cout + W2_BM - 1) / W2_BM;
+    dim3 grid((unsigned)(((tiles + W2_TILES - 1) / W2_TILES) * MT));
+    const size_t lds = (size_t)W2_NBUF * (W2_ASZ + W2_BSZ) * sizeof(float) + 4 * 8 * sizeof(double);     // stage buffers + GroupNorm scratch
+#define W2_LAUNCH(OWV, D)                                                                                                        \
+    do {                                                                                                                         \
+        static std::atomic<uint64_t> attr{0};                                                                                    \
+        SDC_LDS_OPTIN(attr, (conv_wg2_kernel<OWV, D>), 160 * 1024, "sdc_conv[winograd 2x2]");                                    \
+        hipLaunchKernelGGL((conv_wg2_kernel<OWV, D>), grid, dim3(256), lds, s, a);                                               \
+    } while (0)
+#ifdef SDC_KERNEL_EXPERIMENTS
+    // parts of the loop switched off (WRONG RESULTS): never compiled into the shipping library
+    static const int dbg = exp_env("SDC_WG2_DBG");
+    if (d.oW == 64 && dbg) {
+        switch (dbg) {
+            case 1: W2_LAUNCH(64, 1); break; case 2: W2_LAUNCH(64, 2); break; case 3: W2_LAUNCH(64, 3); break;
+            case 128: W2_LAUNCH(64, 128); break; default: W2_LAUNCH(64, 3 + 128); break;
+        }
+        return SDC_OK;
+    }
+#endif
+    if (d.oW == 16) W2_LAUNCH(16, 0);
+    else if (d.oW == 32) W2_LAUNCH(32, 0);
+    else if (d.oW == 64) W2_LAUNCH(64, 0);
+    else W2_LAUNCH(128, 0);
+    return SDC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// precision = 4: fp32 Winograd F(2x2x2, 3x3x3) for the 3x3x3 stride-1 convs -- the F(2x2,3x3) kernel above with the same
+// transform applied along the depth as well: 64 products per 8 outputs instead of 216, i.e. 2/3 of the MFMA work of the
+// (H, W)-only form and 8/27 of the direct form.  The caller stores U3[jd][ci][co][j*4+xi] = sum G[jd][kd] G[j][kh] G[xi][kw] w
+// behind the F(2x2,3x3) taps.
+//   * A workgroup owns 64 output channels x 64 (h, w) tiles x ONE PAIR of output planes (2 dp, 2 dp + 1) and walks the four
+//     depth components jd one after the other with the 16 (j, xi) accumulators of the kernel above.  The K loop of pass jd
+//     runs over the input channels only; its B operand is the (H, W) transform of the depth combination
+//        jd 0: s[-1] - s[1],   jd 1: s[0] + s[1],   jd 2: s[1] - s[0],   jd 3: s[0] - s[2]      (s[i] = input plane 2 dp + i)
+//     which costs two row loads and one packed multiply-add more per row than the plain slice (the signs, the zero planes
+//     past the volume and the zero rows above / below the image are factors of the same fused ops).
+//   * At the end of pass jd the (H, W) output transform m_jd of the accumulators is folded into the two output planes,
+//        y[2 dp] = m0 + m1 + m2,      y[2 dp + 1] = m1 - m2 - m3,
+//     by read-modify-write of y by the lane that owns the element (a lane's own loads and stores of one address stay
+//     ordered).  The passes run in the order m1, m2, m0, m3: m1 is parked in plane 1, the second fold reads it once and writes
+//     m1 + m2 to plane 0 and m1 - m2 to plane 1, the third finishes plane 0 with m0, the fourth plane 1 with m3 -- three plane
+//     read-backs and five plane stores (the natural order needs four and six).  The partial planes come back from L2 / MALL;
+//     the GroupNorm sums are taken from the finished values.  The fetch pipeline of the next pass (two stages in flight) runs through
+//     the fold, so only its own instructions are exposed.
+// Coverage: what the F(2x2,3x3) kernel takes, and kD = 3, even depth, W in {16, 32, 64}, Cout % 64 == 0, the row pairs of
+// a workgroup inside one plane, 8-byte aligned output rows, no fused residual (rs all zero).
+namespace {
+__device__ __forceinline__ uint64_t lo64(float k) { return (uint64_t)__builtin_bit_cast(uint32_t, k); }
+// a * k, a * k + c with a wave-uniform factor k (both halves)
+__device__ __forceinline__ w2f2 pks_mul(w2f2 a, float k) { w2f2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "s"(lo64(k))); return r; }
+__device__ __forceinline__ w2f2 pks_fma(w2f2 a, float k, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "s"(lo64(k)), "v"(c)); return r; }
+__device__ __forceinline__ w2f2 pk_fma2(w2f2 a, w2f2 b, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+template <int OW, int DBG>
+__global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
+    constexpr int SK = W2_SK, BM = W2_BM;
+    constexpr int TW = OW / 2, RP = W2_TILES / TW;
+    constexpr int LGW = OW == 64 ? 6 : (OW == 32 ? 5 : 4);
+    constexpr int CPL = OW == 16 ? 2 : OW / 16;          // adjacent columns per lane
+    constexpr int SH = OW == 16 ? 2 : 1;                 // DPP lane distance of the neighbouring column group
+    constexpr int LPK = 128 / CPL;                       // lanes per staged channel (k row)
+    constexpr int NIT = CPL == 2 ? 2 : 1;                // park items per thread and stage
+    constexpr int KPW = 2;                               // k rows per (parking) wave
+    constexpr int TPL = CPL / 2;                         // tiles per lane and row pair
+    typedef float nfloat4 __attribute__((ext_vector_type(4)));
+    typedef float nfloat2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) char* gchar_p;
+    typedef const __attribute__((address_space(1))) nfloat4* gfloat4_p;
+    typedef const __attribute__((address_space(1))) nfloat2* gfloat2_p;
+    typedef __attribute__((address_space(1))) char* gwchar_p;
+    typedef __attribute__((address_space(1))) nfloat2* gwfloat2_p;
+    extern __shared__ __attribute__((aligned(16))) float ldsw[];
+    float* const As = ldsw;                          // [2][SK][BM][16]  (chunk q of row m at slot q ^ ((m >> 2) & 3))
+    float* const Vs = ldsw + W2_NBUF * W2_ASZ;       // [2][SK][4 j][64 tiles][4 xi]
+
+    const SdcConvDesc& d = a.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = SDC_UNIFORM(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int MT = d.Cout / BM;
+    const int lb = xcd_tile(blockIdx.x, gridDim.x);
+    const int m0 = (lb % MT) * BM;
+    const int tile0 = (lb / MT) * W2_TILES;
+    const int H2 = d.oH >> 1, D2 = d.oD >> 1;
+    // the workgroup's RP row pairs lie in one plane pair (host check: H2 % RP == 0): (sample ob, planes od, od + 1, first row pair hp0)
+    int ob, od, hp0;
+    {
+        const int rp0 = tile0 >> (LGW - 1);          // < 2^20 (host check): the float quotients are exact
+        const int q = (int)(((float)rp0 + 0.5f) * (1.0f / (float)H2));
+        const int b = (int)(((float)q + 0.5f) * (1.0f / (float)D2));
+        hp0 = SDC_UNIFORM(rp0 - q * H2);
+        ob = SDC_UNIFORM(b);
+        od = SDC_UNIFORM(2 * (q - b * D2));
+    }
+    const bool two = d.Cin1 > 0;
+
+    // ---- park geometry of this thread: k row inside the stage, row pair, first column (CPL columns)
+    const int ksub = CPL == 4 ? (lane >> 5) : 0;                    // k row inside the wave's pair (CPL = 2: the item)
+    const int lik = lane & (LPK - 1);
+    int pr, pc0;
+    if (OW == 16) { pr = 2 * (lik >> 4) + (lik & 1); pc0 = 2 * ((lik & 15) >> 1); }
+    else { pr = lik >> 4; pc0 = (lik & 15) * CPL; }
+    // lane part of the input addresses (bytes): k row, row 2 hp, column; the rows above / below the pair are fetched from a
+    // clamped (valid) row and multiplied by 0 where they fall outside the image.  Sample, plane and channel are scalar.
+    const int hp = hp0 + pr;
+    const bool up_ok = hp > 0, dn_ok = 2 * hp + 2 < d.iH;
+    const w2f2 m0p = {up_ok ? 1.0f : 0.0f, up_ok ? 1.0f : 0.0f}, m3p = {dn_ok ? 1.0f : 0.0f, dn_ok ? 1.0f : 0.0f};
+    const uint32_t rsel0 = up_ok ? OW * 4 : 0, rsel3 = dn_ok ? 2 * OW * 4 : 0;
+    const uint32_t vp0 = (uint32_t)(ksub * d.x0s[1] + (2 * hp) * OW + pc0) * 4u;
+    const uint32_t vp1 = two ? (uint32_t)(ksub * d.x1s[1] + (2 * hp) * OW + pc0) * 4u : 0u;
+    const int vpark = ((wave * KPW + ksub) * 4 * W2_TILES + pr * TW + (pc0 >> 1)) * 4;          // floats; + j * 256, + item * 1024
+    const int boff = (lh * 4 * W2_TILES + wn * 32 + l31) * 4;
+    const int arow = wm * 32 + l31;
+    int aoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) aoff[q] = (lh * BM + arow) * 16 + 4 * (q ^ ((arow >> 2) & 3));
+    const int pm = tid >> 2, pq = tid & 3;
+    const int apark = pm * 16 + 4 * (pq ^ ((pm >> 2) & 3));                        // + i * BM * 16 floats
+    uint32_t a_voff[4];                                  // k rows 0..3 of a stage; rows 4..7 from a second scalar base
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_voff[i] = (uint32_t)(((int64_t)i * d.Cout + m0 + pm) * 16 + 4 * pq) * 4u;
+
+    w2f2 braw[NIT][2][4][TPL];    // [item][depth slice a / b][source row j][column pair]
+    nfloat4 areg[8];
+    int s_jd = 0, s_ci = 0;
+    const int64_t xs1_0 = d.x0s[1], xs1_1 = d.x1s[1];
+    const int cin0 = d.Cin0, cin = a.Cin, coutn = d.Cout;
+    const float* const wg3p = a.wg2;
+    // sample and plane folded into the bases
+    const float* const x0p = a.x0 + (int64_t)ob * d.x0s[0] + (int64_t)od * d.x0s[2];
+    const float* const x1p = two ? a.x1 + (int64_t)ob * d.x1s[0] + (int64_t)od * d.x1s[2] : x0p;
+    const int64_t xs2_0 = d.x0s[2], xs2_1 = two ? d.x1s[2] : d.x0s[2];
+    const uint32_t lo_u = od > 0, hi_u = od + 2 < d.iD;          // planes od - 1 / od + 2 exist
+    gfloat_p f_w = uniform_ptr(wg3p), f_w4 = f_w, f_xa = uniform_ptr(x0p), f_xb = f_xa;
+    int64_t f_sc = 0;
+    uint32_t voff = 0, voff0 = 0, voff3 = 0;
+    float mka = 0.f, mkb = 0.f;
+    auto fetch_begin = [&]() __attribute__((always_inline)) {
+        const bool first = s_ci < cin0;
+        f_sc = first ? xs1_0 : xs1_1;
+        const int64_t xs2 = first ? xs2_0 : xs2_1;
+        const int cbase = (first ? s_ci : s_ci - cin0) + wave * KPW;
+        const float* bsel = (first ? x0p : x1p) + (int64_t)cbase * f_sc;
+        // planes (relative to od) and signs of depth component s_jd; a plane outside the volume: plane od with factor 0
+        // (integer arithmetic on the float bits: nested selects became branches, and a branch in this loop costs
+        // conservative memory waits at its join)
+        // pass s_jd (0..3) works on depth component 1, 2, 0, 3 (see the fold)
+        const uint32_t j0 = s_jd == 2, j2 = s_jd == 1, j3 = s_jd == 3;
+        const int jdc = s_jd + 1 - 3 * (int)j0 - (int)j3;
+        const int da = -(int)(j0 & lo_u);                                    // -1 | 0 | 0 | 0
+        const int db = 1 + (int)j3 * (hi_u ? 1 : -1);                        //  1 | 1 | 1 | 2 (0 past the volume)
+        mka = __builtin_bit_cast(float, (0x3F800000u & ((j0 & (lo_u ^ 1u)) - 1u)) | (j2 << 31));       // lo_ok | 1 | -1 | 1
+        mkb = __builtin_bit_cast(float, (0x3F800000u & ((j3 & (hi_u ^ 1u)) - 1u)) | ((j0 | (j3 & hi_u)) << 31));   // -1 | 1 | 1 | -hi_ok
+        f_xa = uniform_ptr(bsel + da * xs2);
+        f_xb = uniform_ptr(bsel + db * xs2);
+        f_w = uniform_ptr(wg3p + ((int64_t)(jdc * cin + s_ci) * coutn) * 16);
+        f_w4 = uniform_ptr(wg3p + ((int64_t)(jdc * cin + s_ci + 4) * coutn) * 16);
+        voff = first ? vp0 : vp1;
+        voff0 = voff - rsel0;
+        voff3 = voff + rsel3;
+        s_ci += SK;
+        // (past the last stage the walk wraps to the first one: the extra fetches of the pipeline tail stay in bounds and are
+        // never consumed)
+        if (s_ci >= cin) { s_ci = 0; if (++s_jd == 4) s_jd = 0; }
+    };
+    // (the offset passes through an empty asm so that its zero-extension is not hoisted out of the loop as a 64-bit
+    // register pair: the load then takes the scalar base + 32-bit lane offset form)
+    auto fetch_a = [&](int i, nfloat4 (&ar)[8]) { uint32_t o = a_voff[i & 3]; asm volatile("" : "+v"(o)); ar[i] = *(gfloat4_p)((gchar_p)(i < 4 ? f_w : f_w4) + o); };
+    auto fetch_b_row = [&](int it, int sl, int j, w2f2 (&br)[NIT][2][4][TPL]) __attribute__((always_inline)) {
+        const gchar_p rb = (gchar_p)(sl ? f_xb : f_xa) + (CPL == 2 ? (int64_t)it * f_sc * 4 : 0);
+        const gchar_p p = j == 0 ? rb + voff0 : (j == 3 ? rb + voff3 : (j == 1 ? rb + voff : rb + voff + OW * 4));
+        if (CPL == 2) { const nfloat2 v = *(gfloat2_p)p; br[it][sl][j][0] = w2f2{v.x, v.y}; }
+        else {
+            const nfloat4 v = *(gfloat4_p)p;
+            br[it][sl][j][0] = w2f2{v.x, v.y};
+            br[it][sl][j][1] = w2f2{v.z, v.w};
+        }
+    };
+    auto fetch_b = [&](int it, w2f2 (&br)[NIT][2][4][TPL]) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) fetch_b_row(it, r >> 2, r & 3, br);
+    };
+    auto park_a = [&](int buf, int i, const nfloat4 (&ar)[8]) {
+        *reinterpret_cast<nfloat4*>(As + buf * W2_ASZ + i * (BM * 16) + apark) = ar[i];
+    };
+    // depth combination e_j = ca a_j + cb b_j of the two planes fused with the H transform (packed, per column pair), then
+    // the W transform as in the kernel above
+    w2f2 hrow[4][TPL];
+    auto park_b_h = [&](int it, const w2f2 (&br)[NIT][2][4][TPL], float ca, float cb) __attribute__((always_inline)) {
+        const w2f2 ka0 = pks_mul(m0p, ca), kb0 = pks_mul(m0p, cb), ka3 = pks_mul(m3p, ca), kb3 = pks_mul(m3p, cb);
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) {
+            const w2f2 e1 = pks_fma(br[it][1][1][t], cb, pks_mul(br[it][0][1][t], ca));
+            const w2f2 e2 = pks_fma(br[it][1][2][t], cb, pks_mul(br[it][0][2][t], ca));
+            hrow[0][t] = pk_fma2(br[it][1][0][t], kb0, pk_fms2(br[it][0][0][t], ka0, e2));       // e0 - e2
+            hrow[1][t] = pk_add2(e1, e2);
+            hrow[2][t] = pk_sub2(e2, e1);
+            hrow[3][t] = pk_fnma2(br[it][1][3][t], kb3, pk_fnma2(br[it][0][3][t], ka3, e1));     // e1 - e3
+        }
+    };
+    auto park_b_w = [&](int buf, int it, int j) __attribute__((always_inline)) {
+        float* dst = Vs + buf * W2_BSZ + vpark + (CPL == 2 ? it * (4 * W2_TILES * 4) : 0) + j * (W2_TILES * 4);
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) {
+            const w2f2 cc = hrow[j][t];
+            const w2f2 sd = pk_sumdiff(cc);
+            const float v0 = t == 0 ? sub_prev<SH>(hrow[j][TPL - 1].y, cc.y) : vsub1(hrow[j][t - 1].y, cc.y);
+            const float v3 = t == TPL - 1 ? sub_next<SH>(cc.x, hrow[j][0].x) : vsub1(cc.x, hrow[j][t + 1].x);
+            nfloat4 v;
+            v.x = sd.x; v.y = sd.y; v.z = v0; v.w = v3;
+            *reinterpret_cast<nfloat4*>(dst + t * 4) = v;
+        }
+    };
+
+    f32x16 acc[16];                                  // (started from zero by the first MFMAs of each pass)
+    if (DBG & 4) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+    }
+    // the bias rides on component (j, xi) = (1, 1) of depth component 1 (coefficient +1 in all 8 outputs): the start value of
+    // that accumulator in the first pass.  Register r of a lane is channel m0 + 32 wm + 8 (r >> 2) + 4 lh + (r & 3).
+    f32x16 zero16, biasv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { zero16[r] = 0.0f; biasv[r] = a.bias ? a.bias[m0 + wm * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)] : 0.0f; }
+
+    const int S1 = a.Cin / SK;                       // stages per depth component
+    nfloat4 fa[2][4];
+    nfloat4 fv[2][4];
+    auto read_a = [&](const float* Ak, int set, int q) { fa[set][q] = *reinterpret_cast<const nfloat4*>(Ak + aoff[q]); };
+    auto read_v = [&](const float* Vk, int set, int j) { fv[set][j] = *reinterpret_cast<const nfloat4*>(Vk + boff + j * (W2_TILES * 4)); };
+    float pka, pkb, nka = 0.f, nkb = 0.f;            // factors of the items still in registers
+    {   // prologue: the fetches of the first two stages travel together; stage 0 is parked in buffer 0
+        w2f2 braw0[NIT][2][4][TPL];
+        nfloat4 areg0[8];
+        fetch_begin();
+        const float qa = mka, qb = mkb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fetch_a(i, areg0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) fetch_b(it, braw0);
+        fetch_begin();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fetch_a(i, areg);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) fetch_b(it, braw);
+        pka = mka; pkb = mkb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) park_a(0, i, areg0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            park_b_h(it, braw0, qa, qb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) park_b_w(0, it, j);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) read_a(As, 0, q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) read_v(Vs, 0, j);
+
+    // ---- output geometry: this lane's tile n (row pair hp0 + n / TW of the plane pair, tile column n % TW), channel rows
+    // cob + 8 (rr >> 2) + 4 lh + (rr & 3); lane offsets in bytes with the 4 lh rows folded in, channel bases scalar
+    const int cob = m0 + wm * 32;
+    const int nloc = wn * 32 + l31;
+    const int ohp = hp0 + (nloc >> (LGW - 1)), otw = nloc & (TW - 1);
+    const uint32_t yoff = (uint32_t)((2 * ohp) * d.ys[3] + (2 * otw) * d.ys[4] + (4 * lh) * d.ys[1]) * 4u;
+    const uint32_t yoff1 = yoff + (uint32_t)d.ys[3] * 4u;
+    const bool gn = a.gn_part != nullptr;
+    // GroupNorm sums of this lane: 8-row block g4 -> (sum, sum of squares) over the 4 rows x 2x2 tile in fp32, per finished
+    // plane; the plane-0 values wait in LDS (behind the stage buffers and the reduction scratch) for those of plane 1
+    float gp[8];
+    float* const gstash = ldsw + W2_NBUF * (W2_ASZ + W2_BSZ) + 64 + tid * 8;
+
+    // fold of pass p (compile-time after unrolling) into the plane pair.  Pass order: depth components 1, 2, 0, 3 --
+    //   p 0 (m1): plane 1 <- m1                       (scratch: nothing read)
+    //   p 1 (m2): plane 0 <- m1 + m2,  plane 1 <- m1 - m2      (one plane read, two written)
+    //   p 2 (m0): plane 0 <- (m1 + m2) + m0  finished
+    //   p 3 (m3): plane 1 <- (m1 - m2) - m3  finished
+    // three plane read-backs and five plane stores per workgroup (the order 0, 1, 2, 3 needs four and six).
+    auto fold = [&](const int p) __attribute__((always_inline)) {
+        const bool t0 = p == 1 || p == 2, t1 = p != 2;           // planes written
+        const bool ld0 = p == 2 && !(DBG & 2), ld1 = (p == 1 || p == 3) && !(DBG & 2);      // partial plane read back
+        const bool fin0 = p == 2, fin1 = p == 3;                 // plane finished by this pass
+        const bool always = d.Cout > 0;
+        const int LEAD = (DBG & 8) ? 4 : 2;                      // blocks of partial sums requested ahead of their use
+        const int64_t ycs4 = d.ys[1] * 4;                        // bytes per channel
+        // plane od (+1) of sample ob, channel cob: scalar cursors, one for the reads and one for the writes of each plane
+        float* const y0p = a.y + (int64_t)ob * d.ys[0] + (int64_t)od * d.ys[2] + (int64_t)cob * d.ys[1];
+        gwchar_p s0 = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(y0p);
+        gwchar_p s1 = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(y0p + d.ys[2]);
+        gchar_p l0 = (gchar_p)s0, l1 = (gchar_p)s1;
+        w2f2 P0[4][4][2], P1[4][4][2];                           // [block][row of the block][row of the tile]
+        auto load_block = [&](int g4) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r3 = 0; r3 < 4; ++r3) {
+                if (ld0) { P0[g4][r3][0] = *(gfloat2_p)(l0 + yoff); P0[g4][r3][1] = *(gfloat2_p)(l0 + yoff1); l0 += r3 < 3 ? ycs4 : 5 * ycs4; }
+                if (ld1) { P1[g4][r3][0] = *(gfloat2_p)(l1 + yoff); P1[g4][r3][1] = *(gfloat2_p)(l1 + yoff1); l1 += r3 < 3 ? ycs4 : 5 * ycs4; }
+            }
+        };
+        if (ld0 || ld1) {
+#pragma unroll
+            for (int g = 0; g < LEAD; ++g) load_block(g);
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            if (g4 + LEAD < 4 && (ld0 || ld1)) load_block(g4 + LEAD);
+            // Each 8-row block is its own basic block (the condition always holds): in one block the compiler hoists all 256
+            // accumulator reads to the top of the fold, beside the fetch pipeline's registers, and spills.
+            if (!always) continue;
+            w2f2 bs2 = {0.f, 0.f}, bq2 = {0.f, 0.f};
+#pragma unroll
+            for (int r3 = 0; r3 < 4; ++r3) {
+                const int rr = g4 * 4 + r3;
+                w2f2 pa[4], pb[4];                               // per j: (M[j][0], M[j][3]), (M[j][1], M[j][2])
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pa[j] = w2f2{acc[4 * j][rr], acc[4 * j + 3][rr]};
+                    pb[j] = w2f2{acc[4 * j + 1][rr], acc[4 * j + 2][rr]};
+                }
+                const w2f2 t0a = pk_add2(pk_add2(pa[0], pa[1]), pa[2]), t1a = pk_sub2(pk_sub2(pa[1], pa[2]), pa[3]);
+                const w2f2 t0b = pk_add2(pk_add2(pb[0], pb[1]), pb[2]), t1b = pk_sub2(pk_sub2(pb[1], pb[2]), pb[3]);
+                const w2f2 z0 = pk_addsub(pk_sumdiff_fwd(t0b), t0a);        // rows 2 hp, 2 hp + 1 of the pass's m
+                const w2f2 z1 = pk_addsub(pk_sumdiff_fwd(t1b), t1a);
+                if (t0) {
+                    // p 1: m1 (read from plane 1) + m2;  p 2: (m1 + m2) + m0
+                    const bool have = p == 1 ? ld1 : ld0;
+                    const w2f2 b0 = p == 1 ? P1[g4][r3][0] : P0[g4][r3][0], b1 = p == 1 ? P1[g4][r3][1] : P0[g4][r3][1];
+                    const w2f2 u0 = have ? pk_add2(b0, z0) : z0, u1 = have ? pk_add2(b1, z1) : z1;
+                    *(gwfloat2_p)(s0 + yoff) = nfloat2{u0.x, u0.y};
+                    *(gwfloat2_p)(s0 + yoff1) = nfloat2{u1.x, u1.y};
+                    s0 += r3 < 3 ? ycs4 : 5 * ycs4;
+                    if (fin0) { bs2 = pk_add2(bs2, pk_add2(u0, u1)); bq2 = pk_sqacc(u1, pk_sqacc(u0, bq2)); }
+                }
+                if (t1) {
+                    // p 0: m1;  p 1: m1 - m2;  p 3: (m1 - m2) - m3
+                    const w2f2 u0 = ld1 ? pk_sub2(P1[g4][r3][0], z0) : z0, u1 = ld1 ? pk_sub2(P1[g4][r3][1], z1) : z1;
+                    *(gwfloat2_p)(s1 + yoff) = nfloat2{u0.x, u0.y};
+                    *(gwfloat2_p)(s1 + yoff1) = nfloat2{u1.x, u1.y};
+                    s1 += r3 < 3 ? ycs4 : 5 * ycs4;
+                    if (fin1) { bs2 = pk_add2(bs2, pk_add2(u0, u1)); bq2 = pk_sqacc(u1, pk_sqacc(u0, bq2)); }
+                }
+            }
+            // GroupNorm sums: the 2x2 tile and the 4 rows of the block in fp32, fp64 from there on
+            if (fin0 || fin1) { gp[2 * g4] = bs2.x + bs2.y; gp[2 * g4 + 1] = bq2.x + bq2.y; }
+        }
+        if (fin0 && gn) {
+            *reinterpret_cast<nfloat4*>(gstash) = nfloat4{gp[0], gp[1], gp[2], gp[3]};
+            *reinterpret_cast<nfloat4*>(gstash + 4) = nfloat4{gp[4], gp[5], gp[6], gp[7]};
+        }
+    };
+    // Main loop, per depth component: stage st computes from buffer st & 1 and parks stage st+1 in the other one during its
+    // k-steps 0-1, re-using each register piece for the fetch of stage st+2 as soon as it is parked; one barrier at the end of
+    // k-step 2; k-step 3 reads the first fragments of stage st+1 (slots as in the kernel above, 8 row loads instead of 4).
+    int rbuf = 0;
+    // The first stage of a pass is a copy of the stage body whose first k-step starts the accumulators from zero (from the
+    // bias for component (1, 1) of the first pass = depth component 1) in the MFMA itself: 256 register writes per pass less in the fold.
+    auto stage = [&](auto FIRST, const int jd) __attribute__((always_inline)) {
+        constexpr bool first = decltype(FIRST)::value && !(DBG & 4);     // (the no-fold experiment lets the passes accumulate on)
+        {
+            const int wbuf = rbuf ^ 1;
+            const float* Ab = As + rbuf * W2_ASZ;
+            const float* Vb = Vs + rbuf * W2_BSZ;
+            const float* An = As + wbuf * W2_ASZ;
+            const float* Vn = Vs + wbuf * W2_BSZ;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int set = ks & 1, nset = set ^ 1;
+                const float* Ak = ks < 3 ? Ab + (2 * (ks + 1)) * (BM * 16) : An;
+                const float* Vk = ks < 3 ? Vb + (2 * (ks + 1)) * (4 * W2_TILES * 4) : Vn;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const f32x16 cstart = (first && ks == 0) ? ((c == 5 && jd == 0) ? biasv : zero16) : acc[c];
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][c >> 2][c & 3],
+                                                                  fv[set][c >> 2][(c & 3) == 0 ? 2 : ((c & 3) == 3 ? 3 : (c & 3) - 1)], cstart, 0, 0, 0);
+                    if (c >= 8 && c < 12) read_v(Vk, nset, c - 8);
+                    else if (c >= 12) read_a(Ak, nset, c - 12);
+                    if (ks < 2) {
+                        const int p = ks;
+                        const bool bwork = p < NIT;
+                        if (c < 4) park_a(wbuf, 2 * c + p, areg);
+                        else if (c == 4) { if (bwork) park_b_h(p, braw, pka, pkb); }
+                        else if (c < 8) { if (bwork) park_b_w(wbuf, p, c - 5); if (c == 7 && p == 0) { fetch_begin(); nka = mka; nkb = mkb; } }
+                        else {
+                            if (c == 8 && bwork) park_b_w(wbuf, p, 3);
+                            if (bwork) fetch_b_row(p, (c - 8) >> 2, (c - 8) & 3, braw);
+                            if (c >= 12) fetch_a(2 * (c - 12) + p, areg);
+                            if (c == 15 && p == 1) { pka = nka; pkb = nkb; }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ks == 2) __syncthreads();
+            }
+            rbuf = wbuf;
+        }
+    };
+    auto run_pass = [&](auto JD) __attribute__((always_inline)) {
+        constexpr int jd = decltype(JD)::value;
+        stage(std::true_type{}, jd);
+        for (int st = 1; st < S1; ++st) stage(std::false_type{}, jd);
+        if (!(DBG & 4)) {
+            fold(jd);
+            // (the first fragments of the next stage, read again: carried across the fold they cost 32 registers there)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) read_a(As + rbuf * W2_ASZ, 0, q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) read_v(Vs + rbuf * W2_BSZ, 0, j);
+        }
+    };
+    run_pass(std::integral_constant<int, 0>{});
+    run_pass(std::integral_constant<int, 1>{});
+    run_pass(std::integral_constant<int, 2>{});
+    run_pass(std::integral_constant<int, 3>{});
+
+    if (DBG & 4) {      // experiment: no folds (keeps the accumulators alive through one store)
+        float sdbg = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sdbg += acc[c][0];
+        if (sdbg == 12345.678f) a.y[0] = sdbg;
+        return;
+    }
+    if (gn) {
+        double* scr = reinterpret_cast<double*>(ldsw + W2_NBUF * (W2_ASZ + W2_BSZ));
+        double gv[8];                                // fp64 from here on
+        {
+            const nfloat4 s0 = *reinterpret_cast<const nfloat4*>(gstash), s1 = *reinterpret_cast<const nfloat4*>(gstash + 4);
+            const float g0[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gv[i] = (double)g0[i] + (double)gp[i];
+        }
+        const double tot = wave_sum8(gv, lane);
+        if ((lane & 7) == 0) scr[wave * 8 + (lane >> 3)] = tot;
+        __syncthreads();
+        const int ngl = a.gn_cpg >= BM ? 1 : BM / a.gn_cpg;       // groups inside this workgroup's rows
+        if (tid < ngl) {
+            const int r0 = a.gn_cpg >= BM ? 0 : tid * a.gn_cpg, r1 = a.gn_cpg >= BM ? BM : r0 + a.gn_cpg;   // local rows
+            double sum = 0.0, sq = 0.0;
+            for (int blk = r0 / 8; blk < r1 / 8; ++blk) {
+                const int wmi = blk >> 2, k = blk & 3;
+                for (int wni = 0; wni < 2; ++wni) {
+                    sum += scr[((wmi * 2 + wni) * 4 + k) * 2];
+                    sq += scr[((wmi * 2 + wni) * 4 + k) * 2 + 1];
+                }
+            }
+            const int g = (m0 + r0) / a.gn_cpg;
+            const int ntl = tile0 / W2_TILES - ob * (D2 * H2 * TW / W2_TILES);      // part of the sample (512 positions each)
+            const int idx = a.gn_cpg >= BM ? ntl * (a.gn_cpg / BM) + (m0 - g * a.gn_cpg) / BM : ntl;
+            double* pp = a.gn_part + (((int64_t)ob * a.gn_G + g) * a.gn_nparts + idx) * 2;
+            pp[0] = sum; pp[1] = sq;
+        }
+    }
+}
+
+}  // namespace
+
+// coverage of the F(2x2x2,3x3x3) kernel (precision 4): the F(2x2,3x3) shapes with kD = 3, an even depth, whole 64-channel
+// blocks, the row pairs of a workgroup inside one plane, 8-byte aligned rows of y (and of the residual)
+bool wg3_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
+    auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
+    if (!(d.precision == 4 && d.kD == 3 && d.oD % 2 == 0 && (d.oW == 16 || d.oW == 32 || d.oW == 64) && d.Cout % W2_BM == 0)) return false;
+    SdcConvDesc e = d;
+    e.precision = 3;
+    if (!wg2_ok(e, small, rowhalo)) return false;
+    const int rp = W2_TILES / (d.oW / 2);
+    const bool nores = d.rs[0] == 0 && d.rs[1] == 0 && d.rs[2] == 0 && d.rs[3] == 0 && d.rs[4] == 0;     // (a fused residual: the F(2x2,3x3) kernel)
+    return (d.oH / 2) % rp == 0 && even(d.ys) && nores;
+}
+
+int launch_wg3(const ConvArgs& a, hipStream_t s) {
+    const SdcConvDesc& d = a.d;
+    const int64_t tiles = (int64_t)d.B * (d.oD / 2) * (d.oH / 2) * (d.oW / 2);
+    dim3 grid((unsigned)((tiles / W2_TILES) * (d.Cout / W2_BM)));
+    const size_t lds = (size_t)W2_NBUF * (W2_ASZ + W2_BSZ) * sizeof(float) + 4 * 8 * sizeof(double) + 256 * 8 * sizeof(float);
+#define W3_LAUNCH(OWV, D)                                                                                                        \
+    do {                                                                                                                         \
+        static std::atomic<uint64_t> attr{0};                                                                                    \
+        SDC_LDS_OPTIN(attr, (conv_wg3_kernel<OWV, D>), 160 * 1024, "sdc_conv[winograd 2x2x2]");                                  \
+        hipLaunchKernelGGL((conv_wg3_kernel<OWV, D>), grid, dim3(256), lds, s, a);                                               \
+    } while (0)
+#ifdef SDC_KERNEL_EXPERIMENTS
+    // kernel experiments (2, 4: WRONG RESULTS): 2 no read-back, 4 no folds, 8 all read-backs of a fold up front
+    static const int dbg = exp_env("SDC_WG3_DBG");
+    if (d.oW == 64 && dbg) {
+        switch (dbg) {
+            case 2: W3_LAUNCH(64, 2); break; case 8: W3_LAUNCH(64, 8); break;
+            default: W3_LAUNCH(64, 4); break;
+        }
+        return SDC_OK;
+    }
+#endif
+    if (d.oW == 16) W3_LAUNCH(16, 0);
+    else if (d.oW == 32) W3_LAUNCH(32, 0);
+    else W3_LAUNCH(64, 0);
+    return SDC_OK;
+}
+
+}  // namespace sdcconv
