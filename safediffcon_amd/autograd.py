@@ -15,8 +15,6 @@ samplers use:
   * the attention blocks (PreNorm + LinearAttention / temporal / full attention + residual): chains of HIP nodes -- channel
     LayerNorm / RMSNorm (``sdc_chan_norm`` / ``sdc_chan_norm_bwd``), the 1x1 projections on the conv node above, the attention
     cores ``sdc_linattn`` / ``sdc_attn`` (rotary + relative-position bias) with ``sdc_linattn_bwd`` / ``sdc_attn_bwd``.
-    (``Trainer.native_attention = False`` selects the first stage of this work instead: fused HIP block forward, VJP by
-    PyTorch-ROCm autograd over a torch restatement of the block -- kept as an independent check of the native backward.)
 The only torch arithmetic on the path is glue of negligible size: the residual adds, the gather of the (heads, F, F)
 relative-position bias from its 32 x 4 embedding, O(B C) parameter-gradient sums of the GroupNorm row table, and the
 element-wise loss.
@@ -26,12 +24,11 @@ import ctypes as C
 import math
 
 import torch
-import torch.nn.functional as F
 from torch.autograd import Function
 
 from . import _lib, grad_ops
 from ._lib import SdcConvDesc, check
-from .engine import Plan, as5, pack_conv_weight
+from .engine import as5, pack_conv_weight
 
 HEADS, DIM_HEAD = 4, 32
 HID = HEADS * DIM_HEAD
@@ -276,112 +273,7 @@ class LinAttnCoreFn(Function):
         return grad_ops.linattn_core_bwd(qkv, gout.contiguous(), heads, outer, inner, n, qs, os_), None
 
 
-class BlockFn(Function):
-    """An attention block: forward through the sampler's fused HIP kernels (a cached one-block engine.Plan), backward by
-    PyTorch-ROCm autograd over the block's torch restatement, recomputed from the saved input (round-3 stage, see the
-    module docstring)."""
-
-    @staticmethod
-    def forward(ctx, hip_fwd, torch_fn, x, *params):
-        ctx.torch_fn = torch_fn
-        ctx.save_for_backward(x, *params)
-        return hip_fwd(x)
-
-    @staticmethod
-    def backward(ctx, gy):
-        x, *params = ctx.saved_tensors
-        with torch.enable_grad():
-            xs = x.detach().requires_grad_()
-            ps = [p.detach().requires_grad_() for p in params]
-            y = ctx.torch_fn(xs, *ps)
-            grads = torch.autograd.grad(y, [xs, *ps], gy.contiguous(), allow_unused=True)
-        return (None, None, *grads)
-
-
-# --------------------------------------------------------------------------------------------------- block restatements (backward only)
-def _ln(x, g, eps=1e-5):
-    """channel LayerNorm, gain only (1D/model/unet.py:53-63, conv3d.py:165-174)"""
-    var = torch.var(x, dim=1, unbiased=False, keepdim=True)
-    mean = torch.mean(x, dim=1, keepdim=True)
-    return (x - mean) * (var + eps).rsqrt() * g.reshape(1, -1, *([1] * (x.dim() - 2)))
-
-
-def _rms(x, g):
-    """tokamak/model/unet.py:45-51"""
-    return F.normalize(x, dim=1) * g.reshape(1, -1, *([1] * (x.dim() - 2))) * (x.shape[1] ** 0.5)
-
-
-def _norm(x, g, mode):
-    return _ln(x, g) if mode == 0 else _rms(x, g)
-
-
-def _linattn_core(qkv, B, n):
-    q, k, v = (t.reshape(B, HEADS, DIM_HEAD, n) for t in qkv.chunk(3, dim=1))
-    q = q.softmax(dim=-2) * DIM_HEAD ** -0.5
-    k = k.softmax(dim=-1)
-    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
-    return torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(B, HID, n)
-
-
-def t_linattn_lucid(mode):
-    """Residual(PreNorm(LinearAttention)) of Unet2D / Unet1D: 1D/model/unet.py:182-222, tokamak/model/unet.py:182-222"""
-    def fn(x, g_pre, wqkv, wo, bo, g_post):
-        B, Cc = x.shape[:2]
-        xf = x.reshape(B, Cc, -1)
-        qkv = torch.einsum("oc,bcn->bon", wqkv.reshape(3 * HID, Cc), _norm(xf, g_pre, mode))
-        out = torch.einsum("oc,bcn->bon", wo.reshape(Cc, HID), _linattn_core(qkv, B, xf.shape[-1])) + bo[None, :, None]
-        return (_norm(out, g_post, mode) + xf).reshape(x.shape)
-    return fn
-
-
-def t_fullattn_lucid(mode):
-    """Residual(PreNorm(Attention)) at the bottleneck: 1D/model/unet.py:224-258"""
-    def fn(x, g_pre, wqkv, wo, bo):
-        B, Cc = x.shape[:2]
-        xf = x.reshape(B, Cc, -1)
-        n = xf.shape[-1]
-        qkv = torch.einsum("oc,bcn->bon", wqkv.reshape(3 * HID, Cc), _norm(xf, g_pre, mode))
-        q, k, v = (t.reshape(B, HEADS, DIM_HEAD, n) for t in qkv.chunk(3, dim=1))
-        attn = torch.einsum("bhdi,bhdj->bhij", q * DIM_HEAD ** -0.5, k).softmax(dim=-1)
-        out = torch.einsum("bhij,bhdj->bhdi", attn, v).reshape(B, HID, n)
-        return (torch.einsum("oc,bcn->bon", wo.reshape(Cc, HID), out) + bo[None, :, None] + xf).reshape(x.shape)
-    return fn
-
-
-def t_spatial_linear(x, gamma, wqkv, wo, bo):
-    """Residual(PreNorm(SpatialLinearAttention)) of the smoke net, per frame: conv3d.py:232-258"""
-    B, Cc, Fr, H, W = x.shape
-    y = _ln(x, gamma).permute(0, 2, 1, 3, 4).reshape(B * Fr, Cc, H * W)
-    qkv = torch.einsum("oc,bcn->bon", wqkv.reshape(3 * HID, Cc), y)
-    out = torch.einsum("oc,bcn->bon", wo.reshape(Cc, HID), _linattn_core(qkv, B * Fr, H * W)) + bo[None, :, None]
-    return out.reshape(B, Fr, Cc, H, W).permute(0, 2, 1, 3, 4) + x
-
-
-def _rotary(x, freqs):
-    """rotary-embedding-torch rotate_queries_or_keys ('lang' freqs, interleaved pairs; third-party)"""
-    n = x.shape[-2]
-    ang = torch.arange(n, dtype=freqs.dtype, device=freqs.device)[:, None] * freqs[None, :]
-    ang = ang.repeat_interleave(2, dim=-1)
-    x2 = x.reshape(*x.shape[:-1], x.shape[-1] // 2, 2)
-    half = torch.stack((-x2[..., 1], x2[..., 0]), dim=-1).reshape(x.shape)
-    return x * ang.cos() + half * ang.sin()
-
-
-def _token_attention(y, wqkv, wo, freqs=None, bias=None):
-    """conv3d.py:277-353 with focus_present_mask all-False; y (..., n, c)"""
-    qkv = F.linear(y, wqkv).chunk(3, dim=-1)
-    q, k, v = (t.reshape(*t.shape[:-1], HEADS, DIM_HEAD).transpose(-2, -3) for t in qkv)
-    q = q * DIM_HEAD ** -0.5
-    if freqs is not None:
-        q, k = _rotary(q, freqs), _rotary(k, freqs)
-    sim = torch.einsum("...hid,...hjd->...hij", q, k)
-    if bias is not None:
-        sim = sim + bias
-    attn = (sim - sim.amax(dim=-1, keepdim=True).detach()).softmax(dim=-1)
-    out = torch.einsum("...hij,...hjd->...hid", attn, v).transpose(-2, -3)
-    return F.linear(out.reshape(*y.shape[:-1], HID), wo)
-
-
+# --------------------------------------------------------------------------------------------------- helpers
 def _relpos_buckets(n, device, num_buckets=32, max_distance=32):
     """RelativePositionBias bucket indices, conv3d.py:74-112 (integer arithmetic, no gradient)"""
     q = torch.arange(n)
@@ -395,23 +287,6 @@ def _relpos_buckets(n, device, num_buckets=32, max_distance=32):
     return (ret + torch.where(m < max_exact, m, large)).to(device)
 
 
-def t_temporal(x, gamma, wqkv, wo, freqs, relw):
-    """Residual(PreNorm('b c f h w -> b (h w) f c' Attention)) with rotary + relative position bias: conv3d.py:262-353"""
-    B, Cc, Fr, H, W = x.shape
-    bias = relw[_relpos_buckets(Fr, x.device)].permute(2, 0, 1)
-    y = _ln(x, gamma).permute(0, 3, 4, 2, 1).reshape(B, H * W, Fr, Cc)
-    y = _token_attention(y, wqkv, wo, freqs, bias)
-    return y.reshape(B, H, W, Fr, Cc).permute(0, 4, 3, 1, 2) + x
-
-
-def t_spatial_full(x, gamma, wqkv, wo):
-    """mid: Residual(PreNorm('b c f h w -> b f (h w) c' Attention)): conv3d.py:450-452"""
-    B, Cc, Fr, H, W = x.shape
-    y = _ln(x, gamma).permute(0, 2, 3, 4, 1).reshape(B, Fr, H * W, Cc)
-    y = _token_attention(y, wqkv, wo)
-    return y.reshape(B, Fr, H, W, Cc).permute(0, 4, 1, 2, 3) + x
-
-
 # --------------------------------------------------------------------------------------------------- the differentiable forward
 class Trainer:
     """Walks a drop-in U-Net in the reference's forward order and records an autograd graph of HIP-backed nodes."""
@@ -419,11 +294,6 @@ class Trainer:
     def __init__(self, net):
         self.net = net
         self.prec = net.precision
-        self._blocks = {}          # (prefix, shape) -> one-block plan for the HIP forward of an attention block
-        # True (default): the attention blocks are chains of HIP nodes in both directions (channel norm, 1x1 convs, attention
-        # cores with sdc_attn_bwd / sdc_linattn_bwd).  False: the round's first stage -- fused HIP block forward, VJP by
-        # PyTorch-ROCm autograd over the block's torch restatement (kept for A/B checks of the native backward).
-        self.native_attention = True
 
     def P(self, key):
         return self.net.P(key)
@@ -529,25 +399,6 @@ class Trainer:
                                                (B, HID, Fr, H, W)))
         return self._pw(f"{p}.fn.fn.fn.to_out.weight", o) + x
 
-    def block(self, prefix, x, build, torch_fn, param_keys):
-        """attention block `prefix`: HIP forward through a cached one-block plan, torch VJP"""
-        from .unet import _Builder
-        key = (prefix, tuple(x.shape))
-        ent = self._blocks.get(key)
-        if ent is None:
-            plan = Plan(x.device, precision=self.prec)
-            xin = torch.zeros(tuple(x.shape), dtype=torch.float32, device=x.device)
-            y = build(_Builder(self.net, plan), prefix, xin)
-            ent = self._blocks[key] = (plan, xin, y)
-        plan, xin, yout = ent
-
-        def hip_fwd(xv):
-            xin.copy_(xv)
-            plan.refresh_weights()
-            plan.run(_stream(xv))
-            return yout.clone()
-        return BlockFn.apply(hip_fwd, torch_fn, x.contiguous(), *[self.P(k) for k in param_keys])
-
 
 def _w5(p):
     return p.reshape(*p.shape[:2], *([1] * (5 - p.dim()))) if p.dim() < 5 else p
@@ -563,15 +414,12 @@ def forward_train_lucid(net, x, t):
     h = T.conv("init_conv", x5)
     r = h
     hs = []
-    la_keys = lambda p: [f"{p}.fn.norm.g", f"{p}.fn.fn.to_qkv.weight", f"{p}.fn.fn.to_out.0.weight", f"{p}.fn.fn.to_out.0.bias",  # noqa: E731
-                         f"{p}.fn.fn.to_out.1.g"]
     for i in range(nres):
         p = f"downs.{i}"
         h = T.resnet(f"{p}.0", h, cond)
         hs.append(h)
         h = T.resnet(f"{p}.1", h, cond)
-        h = T.linattn_lucid(f"{p}.2", h, mode) if T.native_attention else \
-            T.block(f"{p}.2", h, lambda b, pre, xin: net._lin_attn(b, pre, xin), t_linattn_lucid(mode), la_keys(f"{p}.2"))
+        h = T.linattn_lucid(f"{p}.2", h, mode)
         hs.append(h)
         last = i == nres - 1
         if last:
@@ -581,16 +429,13 @@ def forward_train_lucid(net, x, t):
         else:
             h = T.conv(f"{p}.3", h, stride=(1, 1, 2), pad=(0, 0, 1))
     h = T.resnet("mid_block1", h, cond)
-    h = T.fullattn_lucid("mid_attn", h, mode) if T.native_attention else \
-        T.block("mid_attn", h, lambda b, pre, xin: net._full_attn(b, pre, xin), t_fullattn_lucid(mode),
-                ["mid_attn.fn.norm.g", "mid_attn.fn.fn.to_qkv.weight", "mid_attn.fn.fn.to_out.weight", "mid_attn.fn.fn.to_out.bias"])
+    h = T.fullattn_lucid("mid_attn", h, mode)
     h = T.resnet("mid_block2", h, cond)
     for i in range(nres):
         p = f"ups.{i}"
         h = T.resnet(f"{p}.0", h, cond, x1=hs.pop())
         h = T.resnet(f"{p}.1", h, cond, x1=hs.pop())
-        h = T.linattn_lucid(f"{p}.2", h, mode) if T.native_attention else \
-            T.block(f"{p}.2", h, lambda b, pre, xin: net._lin_attn(b, pre, xin), t_linattn_lucid(mode), la_keys(f"{p}.2"))
+        h = T.linattn_lucid(f"{p}.2", h, mode)
         last = i == nres - 1
         if last:
             h = T.conv(f"{p}.3", h)
@@ -607,21 +452,56 @@ def forward_train_smoke(net, x, t):
     nres = len(net.dim_mults)
     x5 = x.permute(0, 2, 1, 3, 4)
     cond = T.time_cond(t)
-    rot, rel = "init_temporal_attn.fn.fn.fn.rotary_emb.freqs", "time_rel_pos_bias.relative_attention_bias.weight"
 
-    tables = T._temporal_tables(x5.shape[2], x.device) if T.native_attention else None
+    tables = T._temporal_tables(x5.shape[2], x.device)
+    temporal = lambda pre, h: T.temporal(pre, h, tables)        # noqa: E731
+    spatial = T.spatial_linear
 
-    def temporal(pre, h):
-        if T.native_attention:
-            return T.temporal(pre, h, tables)
-        return T.block(pre, h, lambda b, pp, xin: net._temporal(b, pp, xin), t_temporal,
-                       [f"{pre}.fn.norm.gamma", f"{pre}.fn.fn.fn.to_qkv.weight", f"{pre}.fn.fn.fn.to_out.weight", rot, rel])
+    h = T.conv("init_conv", x5)
+    r = h
+    hs = []
+    for i in range(nres):
+        p = f"downs.{i}"
+        h = T.resnet(f"{p}.0", h, cond)
+        hs.append(h)
+        h = T.resnet(f"{p}.1", h, cond)
+        h = T.linattn_lucid(f"{p}.2", h, mode)
+        hs.append(h)
+        last = i == nres - 1
+        if last:
+            h = T.conv(f"{p}.3", h)
+        elif nd == 2:
+            h = T.conv(f"{p}.3.1", h, kind="unshuffle")
+        else:
+            h = T.conv(f"{p}.3", h, stride=(1, 1, 2), pad=(0, 0, 1))
+    h = T.resnet("mid_block1", h, cond)
+    h = T.fullattn_lucid("mid_attn", h, mode)
+    h = T.resnet("mid_block2", h, cond)
+    for i in range(nres):
+        p = f"ups.{i}"
+        h = T.resnet(f"{p}.0", h, cond, x1=hs.pop())
+        h = T.resnet(f"{p}.1", h, cond, x1=hs.pop())
+        h = T.linattn_lucid(f"{p}.2", h, mode)
+        last = i == nres - 1
+        if last:
+            h = T.conv(f"{p}.3", h)
+        else:
+            h = T.conv(f"{p}.3.1", h, up=(1, 2, 2) if nd == 2 else (1, 1, 2))
+    h = T.resnet("final_res_block", h, cond, x1=r)
+    out = T.conv("final_conv", h)
+    return out.reshape(x.shape[0], -1, *x.shape[2:])
 
-    def spatial(pre, h):
-        if T.native_attention:
-            return T.spatial_linear(pre, h)
-        return T.block(pre, h, lambda b, pp, xin: net._spatial_linear(b, pp, xin), t_spatial_linear,
-                       [f"{pre}.fn.norm.gamma", f"{pre}.fn.fn.to_qkv.weight", f"{pre}.fn.fn.to_out.weight", f"{pre}.fn.fn.to_out.bias"])
+
+def forward_train_smoke(net, x, t):
+    """Unet3D_with_Conv3D: conv3d.py:487-574; x (B, F, C, H, W) frame-major"""
+    T = net._trainer()
+    nres = len(net.dim_mults)
+    x5 = x.permute(0, 2, 1, 3, 4)
+    cond = T.time_cond(t)
+
+    tables = T._temporal_tables(x5.shape[2], x.device)
+    temporal = lambda pre, h: T.temporal(pre, h, tables)        # noqa: E731
+    spatial = T.spatial_linear
 
     h = T.conv("init_conv", x5)
     h = temporal("init_temporal_attn", h)
@@ -637,9 +517,7 @@ def forward_train_smoke(net, x, t):
         if i < nres - 1:
             h = T.conv(f"{p}.4", h, stride=(1, 2, 2), pad=(0, 1, 1))
     h = T.resnet("mid_block1", h, cond)
-    h = T.spatial_full("mid_spatial_attn", h) if T.native_attention else \
-        T.block("mid_spatial_attn", h, lambda b, pp, xin: net._spatial_full(b, pp, xin), t_spatial_full,
-                ["mid_spatial_attn.fn.norm.gamma", "mid_spatial_attn.fn.fn.fn.to_qkv.weight", "mid_spatial_attn.fn.fn.fn.to_out.weight"])
+    h = T.spatial_full("mid_spatial_attn", h)
     h = temporal("mid_temporal_attn", h)
     h = T.resnet("mid_block2", h, cond)
     for i in range(nres):

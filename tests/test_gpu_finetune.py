@@ -219,29 +219,3 @@ def test_differentiable_ddim_tail(golden):
     print(f"[measured] differentiable DDIM tail: sample vs gradient-free sampler {err:.2e}; loss {loss.item():.3e} vs {lref.item():.3e}; "
           f"worst relative gradient error vs PyTorch-ROCm autograd of the oracle {worst:.2e}")
     assert abs(loss.item() - lref.item()) < 1e-4 * abs(lref.item()) + 1e-9 and worst < 5e-4
-
-
-def test_native_attention_backward_agrees_with_the_torch_vjp_stage(golden):
-    """the attention blocks as chains of HIP nodes (default) and as fused HIP forward + PyTorch-ROCm VJP of the block's torch
-    restatement (Trainer.native_attention = False) give the same loss and gradients"""
-    spec = golden("smoke_unet").spec()
-    res = {}
-    for native in (True, False):
-        net = sdc.Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2, 4), channels=7)
-        net.load_state_dict(det_params(spec, 300))
-        net.to(DEV).train()
-        net._trainer().native_attention = native
-        x, t = det_tensor((2, 8, 7, 16, 16), 5).to(DEV), torch.tensor([10, 900], device=DEV)
-        loss = (net.forward_train(x, t) ** 2).mean()
-        loss.backward()
-        res[native] = (loss.item(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
-    assert abs(res[True][0] - res[False][0]) < 1e-5 * abs(res[False][0])
-    gmax = max(v.norm().item() for v in res[False][1].values())
-    worst = 0.0
-    for k, gr in res[True][1].items():
-        ref = res[False][1][k]
-        if ref.norm().item() < 1e-4 * gmax:
-            continue
-        worst = max(worst, ((gr - ref).norm() / ref.norm()).item())
-    print(f"[measured] native attention backward vs the torch-VJP stage: worst relative gradient difference {worst:.2e}")
-    assert worst < 1e-4
