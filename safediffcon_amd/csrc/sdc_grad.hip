@@ -34,8 +34,10 @@ struct WgradArgs {
     int lgD, lgH, lgW;      // log2 of the nearest-upsample factors of X
 };
 
-template <int KW, int SW, int BKP>
+template <int KW, int SW, int BKP, bool FOLD = false>
 __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
+    // FOLD (stem convs: N * KW <= 64, e.g. 7 input channels x 7 taps): the GEMM column is the pair (input channel, tap kw), so a
+    // k pair costs ONE MFMA per wave instead of KW mostly-empty ones
     // BKP = positions per chunk (64 where the row length allows: 96 MFMAs per chunk and wave at KW = 3 cover the latency of
     // the next chunk's global loads; 16 for the short rows of the deep levels)
     constexpr int SPAN = (BKP - 1) * SW + KW;     // input columns under a chunk
@@ -82,11 +84,15 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
     }
     const int iWu = d.iW << a.lgW, iHu = d.iH << a.lgH, iDu = d.iD << a.lgD;
 
-    f32x16 acc[KW];
+    constexpr int NACC = FOLD ? 1 : KW;
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < KW; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    // FOLD: this lane's column n' = wn 32 + l31 -> (channel fci, tap fkw)
+    const int fcol = wn * 32 + l31, fci = fcol / KW, fkw = fcol - fci * KW;
+    const bool fok = fci < d.N;
     float bsum = 0.0f;
     const bool want_bias = a.bpart != nullptr && nt == 0 && kd == 0 && kh == 0;
 
@@ -159,13 +165,20 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
         if (more) fetch(v_nxt);
         if (v_cur) {
             const float* Ab = As + buf * (64 * AP) + (wm * 32 + l31) * AP + lh;
-            const float* Bb = Bs + buf * (64 * BP) + (wn * 32 + l31) * BP + lh * SW;
+            if constexpr (FOLD) {
+                const float* Bb = Bs + buf * (64 * BP) + (fok ? fci : 0) * BP + fkw + lh * SW;
 #pragma unroll 8
-            for (int kk = 0; kk < BKP / 2; ++kk) {
-                const float av = Ab[2 * kk];
+                for (int kk = 0; kk < BKP / 2; ++kk)
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ab[2 * kk], fok ? Bb[2 * kk * SW] : 0.0f, acc[0], 0, 0, 0);
+            } else {
+                const float* Bb = Bs + buf * (64 * BP) + (wn * 32 + l31) * BP + lh * SW;
+#pragma unroll 8
+                for (int kk = 0; kk < BKP / 2; ++kk) {
+                    const float av = Ab[2 * kk];
 #pragma unroll
-                for (int t = 0; t < KW; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bb[2 * kk * SW + t], acc[t], 0, 0, 0);
+                    for (int t = 0; t < KW; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bb[2 * kk * SW + t], acc[t], 0, 0, 0);
+                }
             }
         }
         if (!more) break;
@@ -183,7 +196,9 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
         const int m = m0 + wm * 32 + 8 * (rr >> 2) + 4 * lh + (rr & 3);
-        if (m < d.M && n < d.N) {
+        if constexpr (FOLD) {
+            if (m < d.M && fok) P[((int64_t)m * d.N + fci) * taps + (kd * d.kH + kh) * KW + fkw] = acc[0][rr];
+        } else if (m < d.M && n < d.N) {
             float* o = P + ((int64_t)m * d.N + n) * taps + (kd * d.kH + kh) * KW;
 #pragma unroll
             for (int t = 0; t < KW; ++t) o[t] = acc[t][rr];
@@ -197,18 +212,25 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
-template <int KW, int SW, int BKP>
+template <int KW, int SW, int BKP, bool FOLD = false>
 int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t s) {
     constexpr int SPAN = (BKP - 1) * SW + KW;
     const size_t lds = (size_t)2 * 64 * ((BKP + 1) + (SPAN | 1)) * sizeof(float);
     static std::atomic<uint64_t> attr{0};
-    SDC_LDS_OPTIN(attr, (wgrad_kernel<KW, SW, BKP>), 160 * 1024, "sdc_conv_wgrad");
-    hipLaunchKernelGGL((wgrad_kernel<KW, SW, BKP>), grid, dim3(NT), lds, s, a);
+    SDC_LDS_OPTIN(attr, (wgrad_kernel<KW, SW, BKP, FOLD>), 160 * 1024, "sdc_conv_wgrad");
+    hipLaunchKernelGGL((wgrad_kernel<KW, SW, BKP, FOLD>), grid, dim3(NT), lds, s, a);
     return SDC_OK;
 }
 
 template <int KW, int SW>
 int launch_wgrad_bkp(const WgradArgs& a, dim3 grid, hipStream_t s) {
+    if constexpr (KW == 7) {
+        if (a.d.N * KW <= 64) {                 // stem convs (7 or 3 input channels)
+            if (a.d.oW % 64 == 0) return launch_wgrad<KW, SW, 64, true>(a, grid, s);
+            if (a.d.oW % 32 == 0) return launch_wgrad<KW, SW, 32, true>(a, grid, s);
+            return launch_wgrad<KW, SW, 16, true>(a, grid, s);
+        }
+    }
     if (a.d.oW % 64 == 0) return launch_wgrad<KW, SW, 64>(a, grid, s);
     if (a.d.oW % 32 == 0) return launch_wgrad<KW, SW, 32>(a, grid, s);
     return launch_wgrad<KW, SW, 16>(a, grid, s);
