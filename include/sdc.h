@@ -326,7 +326,8 @@ size_t sdc_attn_bwd_bytes(int outer, int inner, int heads, int ntok);
 int sdc_attn_bwd(const float* qkv, const float* dout, const float* rot, const float* bias, float* dqkv, float* dbias, void* work,
                  int outer, int inner, int heads, int ntok, int64_t q_so, int64_t q_sc, int64_t q_si, int64_t q_st,
                  int64_t o_so, int64_t o_sc, int64_t o_si, int64_t o_st, void* stream);
-int sdc_linattn_bwd(const float* qkv, const float* dout, float* dqkv, int outer, int inner, int heads, int64_t n,
+size_t sdc_linattn_bwd_bytes(int outer, int inner, int heads, int64_t n);      /* scratch of sdc_linattn_bwd */
+int sdc_linattn_bwd(const float* qkv, const float* dout, float* dqkv, void* work, int outer, int inner, int heads, int64_t n,
                     int64_t q_so, int64_t q_sc, int64_t q_si, int64_t o_so, int64_t o_sc, int64_t o_si, void* stream);
 
 /* gx = gy * f'(x): kind 0 SiLU, 1 GELU (exact erf) -- time_mlp, 1D/model/unet.py:300-305 */

@@ -85,7 +85,9 @@ SIGNATURES = {
     "sdc_attn_bwd_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sdc_attn_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _stream]),
-    "sdc_linattn_bwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _stream]),
+    "sdc_linattn_bwd_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, _i64]),
+    "sdc_linattn_bwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                  _stream]),
     "sdc_act_bwd": (C.c_int, [_f32p, _f32p, _f32p, _i64, C.c_int, _stream]),
     "sdc_sumpool2": (C.c_int, [_f32p, _f32p, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "sdc_graph_begin": (C.c_int, [_stream]),

@@ -401,15 +401,18 @@ __global__ __launch_bounds__(NT) void sum_rows_kernel(const float* __restrict__ 
 //           out[e][n] = sum_d ctx[d][e] qs[d][n]
 // backward: dctx[d][e] = sum_n qs[d][n] do[e][n];  dqs[d][n] = sum_e ctx[d][e] do[e][n];  dv[e][n] = sum_d dctx[d][e] ks[d][n];
 //           dks[d][n] = sum_e dctx[d][e] v[e][n];  dq = qsm (dqs scale - sum_d qsm dqs scale);  dk = ks (dks - sum_n ks dks)
-// One workgroup per (sequence, head); tokens contiguous.  Pass 1 (64-token tiles): row maxima / sums of k, ctx, dctx
-// (thread = 4 (d, e) pairs).  Pass 2 (thread = token): dq, dv, ks dks (parked in dk) and T_d = sum_n ks dks.  Pass 3: dk.
+// Tokens contiguous.  Three kernels, the first with one workgroup per (sequence, head), the others with one per 256 tokens:
+//   la_bwd_red   row maxima / sums of k, ctx, dctx (64-token tiles; thread = 4 (d, e) pairs)       -> scratch[blk][2112]
+//   la_bwd_tok   thread = token: dq, dv, ks dks (parked in dk), partial T_d = sum ks dks per tile  -> tpart[blk][tile][32]
+//   la_bwd_fin   T_d (fixed order over the tiles), dk = ks dks - ks T_d
 struct LaBwdArgs {
-    const float* qkv; const float* dout; float* dqkv;
-    int inner, heads;
+    const float* qkv; const float* dout; float* dqkv; float* scratch;
+    int inner, heads, ntile;
     int64_t n, so, sc, si, oso, osc, osi;
 };
+constexpr int LA_SCR = 32 + 32 + 1024 + 1024;        // rmax, rinv, ctx, dctx per (sequence, head)
 
-__global__ __launch_bounds__(NT) void la_bwd_kernel(const LaBwdArgs a) {
+__global__ __launch_bounds__(NT) void la_bwd_red_kernel(const LaBwdArgs a) {
     const int head = blockIdx.x % a.heads;
     const int seq = blockIdx.x / a.heads;
     const int o = seq / a.inner, i = seq - o * a.inner;
@@ -418,16 +421,9 @@ __global__ __launch_bounds__(NT) void la_bwd_kernel(const LaBwdArgs a) {
     const float* kb = qb + (int64_t)(a.heads * DH) * a.sc;
     const float* vb = kb + (int64_t)(a.heads * DH) * a.sc;
     const float* gb = a.dout + o * a.oso + i * a.osi + (int64_t)(head * DH) * a.osc;
-    float* dqb = a.dqkv + o * a.so + i * a.si + (int64_t)(head * DH) * a.sc;
-    float* dkb = dqb + (int64_t)(a.heads * DH) * a.sc;
-    float* dvb = dkb + (int64_t)(a.heads * DH) * a.sc;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    __shared__ float rmax[DH], rinv[DH], Td[DH];
+    __shared__ float rmax[DH], rinv[DH];
     __shared__ float t_ek[DH][65], t_v[DH][65], t_qs[DH][65], t_g[DH][65];
-    __shared__ float ctx[DH][DH + 1], dctx[DH][DH + 1];
-    __shared__ float red[NT / 64][DH];
-
     // ---- k row maxima (wave w owns rows 8w .. 8w+7)
     {
         float m[8];
@@ -444,7 +440,7 @@ __global__ __launch_bounds__(NT) void la_bwd_kernel(const LaBwdArgs a) {
         }
     }
     __syncthreads();
-    // ---- pass 1: sums of exp(k - max), unnormalised ctx, dctx.  thread -> pairs (d = tid >> 3, e = 4 (tid & 7) .. + 3)
+    // ---- sums of exp(k - max), unnormalised ctx, dctx.  thread -> pairs (d = tid >> 3, e = 4 (tid & 7) .. + 3)
     const int pd = tid >> 3, pe = 4 * (tid & 7);
     float cu[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
     float psum[8];
@@ -452,8 +448,7 @@ __global__ __launch_bounds__(NT) void la_bwd_kernel(const LaBwdArgs a) {
     for (int it = 0; it < 8; ++it) psum[it] = 0.f;
     for (int64_t t0 = 0; t0 < n; t0 += 64) {
         const int64_t j = t0 + lane;
-        // q softmax over d for token j: every wave needs the column's max / sum -> each lane computes its own token's
-        float qmx = -INFINITY, qsum = 0.f;
+        float qmx = -INFINITY, qsum = 0.f;                 // q softmax over d of token j (every wave computes its lanes' tokens)
         if (j < n) {
             for (int d = 0; d < DH; ++d) qmx = fmaxf(qmx, qb[(int64_t)d * a.sc + j]);
             for (int d = 0; d < DH; ++d) qsum += expf(qb[(int64_t)d * a.sc + j] - qmx);
@@ -485,78 +480,113 @@ __global__ __launch_bounds__(NT) void la_bwd_kernel(const LaBwdArgs a) {
         if (lane == 0) rinv[wave + 4 * it] = 1.0f / t;
     }
     __syncthreads();
+    float* scr = a.scratch + (int64_t)blockIdx.x * LA_SCR;
+    if (tid < DH) { scr[tid] = rmax[tid]; scr[32 + tid] = rinv[tid]; }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { ctx[pd][pe + u] = cu[u] * rinv[pd]; dctx[pd][pe + u] = dc[u]; }
-    __syncthreads();
-    // ---- pass 2: thread = token
-    float tpart[DH];
-#pragma unroll
-    for (int d = 0; d < DH; ++d) tpart[d] = 0.f;
-    for (int64_t t0 = 0; t0 < n; t0 += NT) {
-        const int64_t j = t0 + tid;
-        if (j < n) {
-            float g[DH], ks[DH], v[DH];
-#pragma unroll
-            for (int d = 0; d < DH; ++d) {
-                g[d] = gb[(int64_t)d * a.osc + j];
-                v[d] = vb[(int64_t)d * a.sc + j];
-                ks[d] = expf(kb[(int64_t)d * a.sc + j] - rmax[d]) * rinv[d];
-            }
-            // dv[e] = sum_d dctx[d][e] ks[d];  dks[d] = sum_e dctx[d][e] v[e]
-            float dv[DH];
-#pragma unroll
-            for (int e = 0; e < DH; ++e) dv[e] = 0.f;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) {
-                float dks = 0.f;
-#pragma unroll
-                for (int e = 0; e < DH; ++e) { dv[e] += dctx[d][e] * ks[d]; dks += dctx[d][e] * v[e]; }
-                const float kd = ks[d] * dks;
-                tpart[d] += kd;
-                dkb[(int64_t)d * a.sc + j] = kd;            // ks dks, finished in pass 3
-            }
-#pragma unroll
-            for (int e = 0; e < DH; ++e) dvb[(int64_t)e * a.sc + j] = dv[e];
-            // dq: qsm = softmax_d(q);  dqsm[d] = scale sum_e ctx[d][e] g[e];  dq = qsm (dqsm - sum qsm dqsm)
-            float qsm[DH], qmx = -INFINITY, qsum = 0.f;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) { qsm[d] = qb[(int64_t)d * a.sc + j]; qmx = fmaxf(qmx, qsm[d]); }
-#pragma unroll
-            for (int d = 0; d < DH; ++d) { qsm[d] = expf(qsm[d] - qmx); qsum += qsm[d]; }
-            const float qi = 1.0f / qsum;
-            float dqs[DH], dot = 0.f;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) {
-                float s = 0.f;
-#pragma unroll
-                for (int e = 0; e < DH; ++e) s += ctx[d][e] * g[e];
-                qsm[d] *= qi;
-                dqs[d] = s * SCALE;
-                dot += qsm[d] * dqs[d];
-            }
-#pragma unroll
-            for (int d = 0; d < DH; ++d) dqb[(int64_t)d * a.sc + j] = qsm[d] * (dqs[d] - dot);
-        }
+    for (int u = 0; u < 4; ++u) { scr[64 + pd * 32 + pe + u] = cu[u] * rinv[pd]; scr[64 + 1024 + pd * 32 + pe + u] = dc[u]; }
+}
+
+__global__ __launch_bounds__(NT) void la_bwd_tok_kernel(const LaBwdArgs a, float* __restrict__ tpart) {
+    const int blk = blockIdx.y;
+    const int head = blk % a.heads;
+    const int seq = blk / a.heads;
+    const int o = seq / a.inner, i = seq - o * a.inner;
+    const int64_t n = a.n;
+    const float* qb = a.qkv + o * a.so + i * a.si + (int64_t)(head * DH) * a.sc;
+    const float* kb = qb + (int64_t)(a.heads * DH) * a.sc;
+    const float* vb = kb + (int64_t)(a.heads * DH) * a.sc;
+    const float* gb = a.dout + o * a.oso + i * a.osi + (int64_t)(head * DH) * a.osc;
+    float* dqb = a.dqkv + o * a.so + i * a.si + (int64_t)(head * DH) * a.sc;
+    float* dkb = dqb + (int64_t)(a.heads * DH) * a.sc;
+    float* dvb = dkb + (int64_t)(a.heads * DH) * a.sc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float rmax[DH], rinv[DH];
+    __shared__ float ctx[DH][DH + 1], dctx[DH][DH + 1];
+    __shared__ float red[NT / 64][DH];
+    {
+        const float* scr = a.scratch + (int64_t)blk * LA_SCR;
+        if (tid < DH) { rmax[tid] = scr[tid]; rinv[tid] = scr[32 + tid]; }
+        for (int e = tid; e < 1024; e += NT) { ctx[e >> 5][e & 31] = scr[64 + e]; dctx[e >> 5][e & 31] = scr[64 + 1024 + e]; }
     }
-    // T_d = sum over all tokens of ks dks: wave sums, then the four waves in a fixed order
+    __syncthreads();
+    float tp[DH];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) tp[d] = 0.f;
+    const int64_t j = (int64_t)blockIdx.x * NT + tid;
+    if (j < n) {
+        float g[DH], ks[DH], v[DH];
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+            g[d] = gb[(int64_t)d * a.osc + j];
+            v[d] = vb[(int64_t)d * a.sc + j];
+            ks[d] = expf(kb[(int64_t)d * a.sc + j] - rmax[d]) * rinv[d];
+        }
+        float dv[DH];
+#pragma unroll
+        for (int e = 0; e < DH; ++e) dv[e] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+            float dks = 0.f;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) { dv[e] += dctx[d][e] * ks[d]; dks += dctx[d][e] * v[e]; }
+            tp[d] = ks[d] * dks;
+            dkb[(int64_t)d * a.sc + j] = tp[d];               // ks dks, finished by la_bwd_fin
+        }
+#pragma unroll
+        for (int e = 0; e < DH; ++e) dvb[(int64_t)e * a.sc + j] = dv[e];
+        float qsm[DH], qmx = -INFINITY, qsum = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) { qsm[d] = qb[(int64_t)d * a.sc + j]; qmx = fmaxf(qmx, qsm[d]); }
+#pragma unroll
+        for (int d = 0; d < DH; ++d) { qsm[d] = expf(qsm[d] - qmx); qsum += qsm[d]; }
+        const float qi = 1.0f / qsum;
+        float dqs[DH], dot = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) sacc += ctx[d][e] * g[e];
+            qsm[d] *= qi;
+            dqs[d] = sacc * SCALE;
+            dot += qsm[d] * dqs[d];
+        }
+#pragma unroll
+        for (int d = 0; d < DH; ++d) dqb[(int64_t)d * a.sc + j] = qsm[d] * (dqs[d] - dot);
+    }
+    // this tile's part of T_d = sum_n ks dks: wave sums, then the four waves in a fixed order
 #pragma unroll
     for (int d = 0; d < DH; ++d) {
-        const float t = sdc::wave_sum(tpart[d]);
+        const float t = sdc::wave_sum(tp[d]);
         if (lane == 0) red[wave][d] = t;
     }
     __syncthreads();
-    if (tid < DH) Td[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tid < DH) tpart[((int64_t)blk * a.ntile + blockIdx.x) * DH + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+__global__ __launch_bounds__(NT) void la_bwd_fin_kernel(const LaBwdArgs a, const float* __restrict__ tpart) {
+    const int blk = blockIdx.y;
+    const int head = blk % a.heads;
+    const int seq = blk / a.heads;
+    const int o = seq / a.inner, i = seq - o * a.inner;
+    const float* kb = a.qkv + o * a.so + i * a.si + (int64_t)(a.heads * DH + head * DH) * a.sc;
+    float* dkb = a.dqkv + o * a.so + i * a.si + (int64_t)(a.heads * DH + head * DH) * a.sc;
+    __shared__ float Td[DH], rmax[DH], rinv[DH];
+    const int tid = threadIdx.x;
+    if (tid < DH) {
+        float t = 0.f;
+        for (int k = 0; k < a.ntile; ++k) t += tpart[((int64_t)blk * a.ntile + k) * DH + tid];
+        Td[tid] = t;
+        const float* scr = a.scratch + (int64_t)blk * LA_SCR;
+        rmax[tid] = scr[tid];
+        rinv[tid] = scr[32 + tid];
+    }
     __syncthreads();
-    // ---- pass 3: dk = ks dks - ks T_d  (each thread re-reads the elements it wrote itself)
-    for (int64_t t0 = 0; t0 < n; t0 += NT) {
-        const int64_t j = t0 + tid;
-        if (j < n) {
+    const int64_t j = (int64_t)blockIdx.x * NT + tid;
+    if (j >= a.n) return;
 #pragma unroll
-            for (int d = 0; d < DH; ++d) {
-                const float ks = expf(kb[(int64_t)d * a.sc + j] - rmax[d]) * rinv[d];
-                dkb[(int64_t)d * a.sc + j] -= ks * Td[d];
-            }
-        }
+    for (int d = 0; d < DH; ++d) {
+        const float ks = expf(kb[(int64_t)d * a.sc + j] - rmax[d]) * rinv[d];
+        dkb[(int64_t)d * a.sc + j] -= ks * Td[d];
     }
 }
 
@@ -627,15 +657,26 @@ extern "C" int sdc_attn_bwd(const float* qkv, const float* dout, const float* ro
     return sdc::check_launch("sdc_attn_bwd");
 }
 
-extern "C" int sdc_linattn_bwd(const float* qkv, const float* dout, float* dqkv, int outer, int inner, int heads, int64_t n,
+extern "C" size_t sdc_linattn_bwd_bytes(int outer, int inner, int heads, int64_t n) {
+    const size_t nblk = (size_t)outer * inner * heads, ntile = (size_t)((n + NT - 1) / NT);
+    return nblk * (LA_SCR + ntile * DH) * sizeof(float);
+}
+
+extern "C" int sdc_linattn_bwd(const float* qkv, const float* dout, float* dqkv, void* work, int outer, int inner, int heads, int64_t n,
                                int64_t q_so, int64_t q_sc, int64_t q_si, int64_t o_so, int64_t o_sc, int64_t o_si, void* stream) {
-    SDC_REQUIRE(qkv && dout && dqkv, SDC_ENULL, "sdc_linattn_bwd: null pointer");
+    SDC_REQUIRE(qkv && dout && dqkv && work, SDC_ENULL, "sdc_linattn_bwd: null pointer");
     SDC_REQUIRE(outer > 0 && inner > 0 && heads > 0 && n > 0, SDC_EINVAL, "sdc_linattn_bwd: bad shape");
     const int64_t nblk = (int64_t)outer * inner * heads;
-    SDC_REQUIRE(nblk < (1ll << 31), SDC_EINVAL, "sdc_linattn_bwd: too many sequences");
+    SDC_REQUIRE(nblk < 65536, SDC_EINVAL, "sdc_linattn_bwd: outer*inner*heads must be < 65536");
     LaBwdArgs a;
     a.qkv = qkv; a.dout = dout; a.dqkv = dqkv; a.inner = inner; a.heads = heads; a.n = n;
     a.so = q_so; a.sc = q_sc; a.si = q_si; a.oso = o_so; a.osc = o_sc; a.osi = o_si;
-    hipLaunchKernelGGL(la_bwd_kernel, dim3((unsigned)nblk), dim3(NT), 0, sdc::as_stream(stream), a);
+    a.ntile = (int)((n + NT - 1) / NT);
+    a.scratch = static_cast<float*>(work);
+    float* tpart = a.scratch + nblk * LA_SCR;
+    hipStream_t s = sdc::as_stream(stream);
+    hipLaunchKernelGGL(la_bwd_red_kernel, dim3((unsigned)nblk), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL(la_bwd_tok_kernel, dim3((unsigned)a.ntile, (unsigned)nblk), dim3(NT), 0, s, a, tpart);
+    hipLaunchKernelGGL(la_bwd_fin_kernel, dim3((unsigned)a.ntile, (unsigned)nblk), dim3(NT), 0, s, a, (const float*)tpart);
     return sdc::check_launch("sdc_linattn_bwd");
 }

@@ -171,9 +171,11 @@ def linattn_core(qkv, out, heads, outer, inner, n, qs, os_):
 
 
 def linattn_core_bwd(qkv, dout, heads, outer, inner, n, qs, os_):
+    lib = _lib.get_lib()
     dqkv = torch.empty_like(qkv)
-    check(_lib.get_lib().sdc_linattn_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), outer, inner, heads, n, *qs, *os_,
-                                         _stream(qkv)), "sdc_linattn_bwd")
+    work = torch.empty(int(lib.sdc_linattn_bwd_bytes(outer, inner, heads, n)) // 4, dtype=torch.float32, device=qkv.device)
+    check(lib.sdc_linattn_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), work.data_ptr(), outer, inner, heads, n, *qs, *os_,
+                              _stream(qkv)), "sdc_linattn_bwd")
     return dqkv
 
 
