@@ -262,3 +262,77 @@ def test_pack_conv_weight_kernel_equals_host_packing(shape, prec):
     got, want = grad_ops.pack_conv_weight(w, prec, flip=True), pack_conv_weight(wt, "conv", prec).reshape(-1)
     assert got.shape == want.shape
     assert (got - want).abs().max().item() <= 1e-7 * want.abs().max().item()
+
+
+def test_conv_node_gradients_seeded_sweep():
+    """autograd.ConvFn (forward sdc_conv, data gradient sdc_conv with flipped taps, weight / bias gradient sdc_conv_wgrad) over a
+    seeded sweep of the conv forms the three nets hold -- 1-D / 2-D / 3-D, 1 / 3 / 7 taps, stride-1 'same' convs with ragged
+    channel counts and row lengths, two concatenated inputs, the strided / transposed / unshuffle / upsample forms -- against
+    torch autograd in fp64"""
+    import random
+    from safediffcon_amd.autograd import ConvFn
+    from safediffcon_amd.engine import as5
+    rng = random.Random(1234)
+    worst = {}
+    for case in range(36):
+        nd = rng.choice([1, 2, 3])
+        k = rng.choice([1, 3, 3, 3, 7]) if nd < 3 else rng.choice([1, 3, 3])
+        cin, cout = rng.choice([3, 7, 8, 12, 16, 24, 40, 64, 96]), rng.choice([7, 8, 16, 32, 40, 64, 72, 128])
+        cin1 = rng.choice([0, 0, 8, 16]) if k == 3 else 0
+        B = rng.choice([1, 2, 3])
+        sp = tuple(rng.choice([4, 6, 8, 16, 20, 32, 64] if i == nd - 1 else [1, 2, 4, 6, 8]) for i in range(nd))
+        x = det_tensor((B, cin, *sp), 2000 + case, 0.5)
+        x1 = det_tensor((B, cin1, *sp), 2100 + case, 0.5) if cin1 else None
+        w = det_tensor((cout, cin + cin1, *([k] * nd)), 2200 + case, 0.2)
+        b = det_tensor((cout,), 2300 + case, 0.1)
+        xd = x.double().requires_grad_()
+        x1d = x1.double().requires_grad_() if cin1 else None
+        wd, bd = w.double().requires_grad_(), b.double().requires_grad_()
+        xin = xd if x1d is None else torch.cat((xd, x1d), 1)
+        ref = (F.conv1d, F.conv2d, F.conv3d)[nd - 1](xin, wd, bd, padding=k // 2)
+        gy = det_tensor(tuple(ref.shape), 2400 + case)
+        ref.backward(gy.double())
+        xg = as5(x.to(DEV)).requires_grad_()
+        x1g = as5(x1.to(DEV)).requires_grad_() if cin1 else None
+        wg, bg = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        k3 = (1,) * (3 - nd) + (k,) * nd
+        y = ConvFn.apply(xg, x1g, wg, bg, ("conv", (1, 1, 1), tuple(kk // 2 for kk in k3), (1, 1, 1), 4))
+        y.backward(as5(gy.to(DEV)))
+        errs = dict(y=_rel(y.detach().reshape(ref.shape), ref.detach()), gx=_rel(xg.grad.reshape(x.shape), xd.grad),
+                    gw=_rel(wg.grad, wd.grad), gb=_rel(bg.grad, bd.grad))
+        if cin1:
+            errs["gx1"] = _rel(x1g.grad.reshape(x1.shape), x1d.grad)
+        for kk, v in errs.items():
+            worst[kk] = max(worst.get(kk, 0.0), v)
+            assert v < 3e-5, (case, nd, k, cin, cin1, cout, B, sp, kk, v)
+    print(f"[measured] conv node sweep (36 shapes): worst relative errors {worst}")
+    # the strided / transposed / resampling forms
+    forms = [
+        ("conv", (2, 64, 2, 16, 16), (32, 64, 1, 4, 4), dict(stride=(1, 2, 2), pad=(0, 1, 1)),
+         lambda x_, w_, b_: F.conv3d(x_, w_, b_, stride=(1, 2, 2), padding=(0, 1, 1))),
+        ("convT422", (2, 48, 2, 8, 8), (48, 24, 1, 4, 4), dict(),
+         lambda x_, w_, b_: F.conv_transpose3d(x_, w_, b_, stride=(1, 2, 2), padding=(0, 1, 1))),
+        ("unshuffle", (2, 16, 1, 8, 32), (40, 64, 1, 1), dict(),
+         lambda x_, w_, b_: F.conv2d(x_[:, :, 0].reshape(2, 16, 4, 2, 16, 2).permute(0, 1, 3, 5, 2, 4).reshape(2, 64, 4, 16), w_, b_).unsqueeze(2)),
+        ("conv", (3, 24, 1, 1, 32), (16, 24, 4), dict(stride=(1, 1, 2), pad=(0, 0, 1)),
+         lambda x_, w_, b_: F.conv1d(x_[:, :, 0, 0], w_, b_, stride=2, padding=1).unsqueeze(2).unsqueeze(2)),
+        ("conv", (2, 32, 1, 4, 16), (24, 32, 3, 3), dict(up=(1, 2, 2), pad=(0, 1, 1)),
+         lambda x_, w_, b_: F.conv2d(F.interpolate(x_[:, :, 0], scale_factor=2, mode="nearest"), w_, b_, padding=1).unsqueeze(2)),
+        ("conv", (2, 40, 1, 1, 16), (24, 40, 3), dict(up=(1, 1, 2), pad=(0, 0, 1)),
+         lambda x_, w_, b_: F.conv1d(F.interpolate(x_[:, :, 0, 0], scale_factor=2, mode="nearest"), w_, b_, padding=1).unsqueeze(2).unsqueeze(2)),
+    ]
+    for i, (kind, xs, ws, kw, fn) in enumerate(forms):
+        x, w = det_tensor(xs, 2500 + i, 0.5), det_tensor(ws, 2600 + i, 0.2)
+        nb = ws[1] if kind == "convT422" else ws[0]
+        b = det_tensor((nb,), 2700 + i, 0.1)
+        xd, wd, bd = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+        ref = fn(xd, wd, bd)
+        gy = det_tensor(tuple(ref.shape), 2800 + i)
+        ref.backward(gy.double())
+        xg, wg, bg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        w5 = wg if kind == "convT422" else wg
+        cfg = (kind, kw.get("stride", (1, 1, 1)), kw.get("pad", (0, 0, 0)), kw.get("up", (1, 1, 1)), 4)
+        y = ConvFn.apply(xg, None, w5, bg, cfg)
+        assert _rel(y.detach(), ref.detach()) < 3e-5, (kind, i)
+        y.backward(gy.to(DEV))
+        assert _rel(xg.grad, xd.grad) < 3e-5 and _rel(wg.grad, wd.grad) < 3e-5 and _rel(bg.grad, bd.grad) < 3e-5, (kind, i)
