@@ -282,3 +282,59 @@ def test_c4_batch64_every_sample_vs_eager_oracle():
             del ref, d
     print(f"[measured] C4 B=64, all 64 samples vs the eager-GPU oracle: worst per-sample eps-MSE {worst_mse:.3e}, max|err| {worst_abs:.3e}")
     assert worst_mse <= 1e-9 and worst_abs < 6e-5
+
+
+# ------------------------------------------------------------------ DDIM (what the shipped scripts run) at production width
+@pytest.mark.parametrize("tree", ["smoke", "burgers", "tokamak"])
+def test_ddim_sampler_at_production_width_vs_oracle(tree):
+    """ddim_sample (eta = 1) of the three trees at the production net widths -- 1D/model/diffusion.py:451-555,
+    tokamak/model/diffusion.py:374-496, 2d/ddpm/diffusion_2d.py:324-404 -- guided, injected noise, HIP sampler against the
+    oracle's DDIM loop on the CPU (the dim-8 DDIM fixtures of the real reference pin the oracle's loop)."""
+    T, S = 20, 4
+    if tree == "smoke":
+        net = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+        P = det_params(_spec(net), 31)
+        net.load_state_dict(P)
+        gd = sdc.GaussianDiffusionSmoke(net.to(DEV), image_size=64, frames=32, timesteps=T, sampling_timesteps=S, ddim_sampling_eta=1.0,
+                                        standard_fixed_ratio=100.0).to(DEV)
+        B = 1
+        init, control = det_tensor((B, 64, 64), 43, 0.2).abs(), det_tensor((B, 32, 2, 64, 64), 44, 0.3)
+        noise = det_noise((B, 32, 7, 64, 64), 7300)
+        out = gd.sample(batch_size=B, design_fn=sdc.SmokeGuidance(0.01, 0.9, -5.0), init=init.to(DEV), control=control.to(DEV),
+                        noise=noise).cpu()
+        ref = osam.ddim_smoke(lambda a, b: onets.unet_smoke(P, a, b, dim=64, dim_mults=(1, 2, 4)), osched.make_tables("sigmoid", T), B,
+                              noise, S=S, eta=1.0, init=init, control=control, design_fn=osam.smoke_guidance(0.01, 0.9, -5.0), ratio=100.0)
+        gate = 4e-3      # measured 1.0e-3 (one element; the re-derived eps of DDIM divides by sqrt(1/abar - 1)), MSE 5.7e-11
+    elif tree == "burgers":
+        net = sdc.Unet2D(dim=64, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+        P = det_params(_spec(net), 11)
+        net.load_state_dict(P)
+        gd = sdc.GaussianDiffusionBurgers(net.to(DEV), seq_length=(16, 128), timesteps=T, sampling_timesteps=S, ddim_sampling_eta=1.0,
+                                          temporal=True, use_conv2d=True, is_condition_u0=True, is_condition_uT=True, condition_idx=10,
+                                          train_on_padded_locations=False).to(DEV)
+        B = 4
+        u0, uT = det_tensor((B, 128), 61, 0.1, -0.1, 0.3), det_tensor((B, 128), 62, 0.1, -0.1, 0.3)
+        noise = det_noise((B, 3, 16, 128), 7400)
+        out = gd.sample(batch_size=B, clip_denoised=True, u_init=u0, u_final=uT, guidance_u0=True,
+                        nablaJ=sdc.BurgersGuidance(0.01, 500.0, 0.05), J_scheduler=lambda t: 1.0, enable_grad=False, noise=noise).cpu()
+        ref = osam.ddim_burgers(lambda a, b: onets.unet_burgers(P, a, b, dim=64), osched.make_tables("cosine", T), B, noise, S=S, eta=1.0,
+                                u_init=u0, u_final=uT, nablaJ=osam.burgers_guidance(0.01, 500.0, 0.05))
+        gate = 1.5e-3
+    else:
+        net = sdc.Unet1D(dim=256, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+        P = det_params(_spec(net), 21)
+        net.load_state_dict(P)
+        gd = sdc.GaussianDiffusionTokamak(net.to(DEV), seq_length=128, nt=122, timesteps=T, sampling_timesteps=S,
+                                          ddim_sampling_eta=1.0).to(DEV)
+        B = 4
+        u0, uT = det_tensor((B, 3), 51, 0.1) + 0.6, det_tensor((B, 2, 122), 52, 0.1) + 0.6
+        target = det_tensor((B, 3, 122), 53, 0.3) + 1.0
+        noise = det_noise((B, 12, 128), 7500)
+        args = dict(w_obj=0.3, w_safe=1.0, guidance_scaler=0.5, Q=0.05, safety_threshold=4.98)
+        out = gd.sample(batch_size=B, u_init=u0, u_final=uT, nablaJ=sdc.TokamakGuidance(target, 122, **args), enable_grad=False,
+                        noise=noise).cpu()
+        ref = osam.ddim_tokamak(lambda a, b: onets.unet_tokamak(P, a, b, dim=256), osched.make_tables("cosine", T), B, noise, S=S, eta=1.0,
+                                u_init=u0, u_final=uT, nablaJ=osam.tokamak_guidance(target, 122, 0.05, 4.98, 0.3, 1.0, 0.5))
+        gate = 3e-3      # measured 7.8e-4, MSE 5.0e-10
+    assert torch.isfinite(out).all()
+    assert _report(f"{tree} production-width DDIM ({S} of {T} steps, eta 1) vs oracle", out, ref) < gate and _mse(out, ref) <= 1e-8
