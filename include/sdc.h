@@ -295,7 +295,7 @@ int sdc_conv_wgrad(const SdcWgradDesc* d, const float* g, const float* x, float*
 
 /* Backward of sdc_gn_apply (GroupNorm -> (scale+1, shift) -> SiLU; Block, conv3d.py:189-204, 1D/model/unet.py:128-147):
  * h = the conv output the forward normalised (contiguous (B,C,S)), stats from the forward, ss = per-sample rows
- * [scale (C) | shift (C)] at ss + b*ss_b_stride or null.  Writes gh = dL/dh and rows[b][c] = (A1, A2) with
+ * [scale (C) | shift (C)] at ss + b*ss_b_stride or null.  rows holds (B*C + B*G) * 2 floats.  Writes gh = dL/dh and rows[b][c] = (A1, A2) with
  * A1 = sum_S gy silu'(v), A2 = sum_S gy silu'(v) xhat, from which the caller forms
  * dgamma[c] = sum_b (1+scale) A2, dbeta[c] = sum_b (1+scale) A1, dscale[b][c] = gamma A2 + beta A1, dshift[b][c] = A1.
  * (The residual the forward added passes gy through unchanged.) */

@@ -401,35 +401,41 @@ __global__ __launch_bounds__(NT) void sum_rows_kernel(const float* __restrict__ 
 //           out[e][n] = sum_d ctx[d][e] qs[d][n]
 // backward: dctx[d][e] = sum_n qs[d][n] do[e][n];  dqs[d][n] = sum_e ctx[d][e] do[e][n];  dv[e][n] = sum_d dctx[d][e] ks[d][n];
 //           dks[d][n] = sum_e dctx[d][e] v[e][n];  dq = qsm (dqs scale - sum_d qsm dqs scale);  dk = ks (dks - sum_n ks dks)
-// Tokens contiguous.  Three kernels, the first with one workgroup per (sequence, head), the others with one per 256 tokens:
-//   la_bwd_red   row maxima / sums of k, ctx, dctx (64-token tiles; thread = 4 (d, e) pairs)       -> scratch[blk][2112]
-//   la_bwd_tok   thread = token: dq, dv, ks dks (parked in dk), partial T_d = sum ks dks per tile  -> tpart[blk][tile][32]
-//   la_bwd_fin   T_d (fixed order over the tiles), dk = ks dks - ks T_d
+// Tokens contiguous.  Four kernels:
+//   la_bwd_red    one workgroup per (256-token chunk, sequence, head): the chunk's k row maxima, sums of exp(k - max), unnormalised
+//                 ctx and dctx (64-token tiles; thread = 4 (d, e) pairs)                            -> cpart[blk][chunk][2112]
+//   la_bwd_merge  per (sequence, head): the chunks merged in a fixed order (maxima, rescaled sums)  -> scratch[blk][2112]
+//   la_bwd_tok    thread = token: dq, dv, ks dks (parked in dk), partial T_d = sum ks dks per tile  -> tpart[blk][tile][32]
+//   la_bwd_fin    T_d (fixed order over the tiles), dk = ks dks - ks T_d
 struct LaBwdArgs {
-    const float* qkv; const float* dout; float* dqkv; float* scratch;
-    int inner, heads, ntile;
+    const float* qkv; const float* dout; float* dqkv; float* scratch; float* cpart;
+    int inner, heads, ntile, nchunk;
     int64_t n, so, sc, si, oso, osc, osi;
 };
-constexpr int LA_SCR = 32 + 32 + 1024 + 1024;        // rmax, rinv, ctx, dctx per (sequence, head)
+constexpr int LA_SCR = 32 + 32 + 1024 + 1024;        // rmax, rinv (chunks: sum), ctx, dctx per (sequence, head)
+constexpr int LA_CHUNK = 256;
 
 __global__ __launch_bounds__(NT) void la_bwd_red_kernel(const LaBwdArgs a) {
-    const int head = blockIdx.x % a.heads;
-    const int seq = blockIdx.x / a.heads;
+    const int blk = blockIdx.y;
+    const int head = blk % a.heads;
+    const int seq = blk / a.heads;
     const int o = seq / a.inner, i = seq - o * a.inner;
-    const int64_t n = a.n;
+    const int64_t c0 = (int64_t)blockIdx.x * LA_CHUNK;
+    const int64_t c1 = c0 + LA_CHUNK < a.n ? c0 + LA_CHUNK : a.n;
     const float* qb = a.qkv + o * a.so + i * a.si + (int64_t)(head * DH) * a.sc;
     const float* kb = qb + (int64_t)(a.heads * DH) * a.sc;
     const float* vb = kb + (int64_t)(a.heads * DH) * a.sc;
     const float* gb = a.dout + o * a.oso + i * a.osi + (int64_t)(head * DH) * a.osc;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ float rmax[DH], rinv[DH];
+    __shared__ float rmax[DH];
     __shared__ float t_ek[DH][65], t_v[DH][65], t_qs[DH][65], t_g[DH][65];
-    // ---- k row maxima (wave w owns rows 8w .. 8w+7)
+    __shared__ float qpm[4][64], qps[4][64];
+    // ---- k row maxima of the chunk (wave w owns rows 8w .. 8w+7)
     {
         float m[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) m[r] = -INFINITY;
-        for (int64_t j = lane; j < n; j += 64) {
+        for (int64_t j = c0 + lane; j < c1; j += 64) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) m[r] = fmaxf(m[r], kb[(int64_t)(wave * 8 + r) * a.sc + j]);
         }
@@ -446,21 +452,33 @@ __global__ __launch_bounds__(NT) void la_bwd_red_kernel(const LaBwdArgs a) {
     float psum[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) psum[it] = 0.f;
-    for (int64_t t0 = 0; t0 < n; t0 += 64) {
+    for (int64_t t0 = c0; t0 < c1; t0 += 64) {
         const int64_t j = t0 + lane;
-        float qmx = -INFINITY, qsum = 0.f;                 // q softmax over d of token j (every wave computes its lanes' tokens)
-        if (j < n) {
-            for (int d = 0; d < DH; ++d) qmx = fmaxf(qmx, qb[(int64_t)d * a.sc + j]);
-            for (int d = 0; d < DH; ++d) qsum += expf(qb[(int64_t)d * a.sc + j] - qmx);
+        const bool live = j < c1;
+        // q softmax over d of token j: every wave holds 8 of the 32 rows (row = wave + 4 it), maxima and sums meet in LDS
+        float qv[8], pm = -INFINITY;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            qv[it] = live ? qb[(int64_t)(wave + 4 * it) * a.sc + j] : 0.f;
+            pm = fmaxf(pm, qv[it]);
         }
+        qpm[wave][lane] = pm;
+        __syncthreads();
+        const float qmx = fmaxf(fmaxf(qpm[0][lane], qpm[1][lane]), fmaxf(qpm[2][lane], qpm[3][lane]));
+        float ps = 0.f;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) { qv[it] = expf(qv[it] - qmx); ps += qv[it]; }
+        qps[wave][lane] = ps;
+        __syncthreads();
+        const float qinv = SCALE / ((qps[0][lane] + qps[1][lane]) + (qps[2][lane] + qps[3][lane]));
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row = wave + 4 * it;
             float ek = 0.f, vv = 0.f, qs = 0.f, gg = 0.f;
-            if (j < n) {
+            if (live) {
                 ek = expf(kb[(int64_t)row * a.sc + j] - rmax[row]);
                 vv = vb[(int64_t)row * a.sc + j];
-                qs = expf(qb[(int64_t)row * a.sc + j] - qmx) / qsum * SCALE;
+                qs = qv[it] * qinv;
                 gg = gb[(int64_t)row * a.osc + j];
             }
             t_ek[row][lane] = ek; t_v[row][lane] = vv; t_qs[row][lane] = qs; t_g[row][lane] = gg;
@@ -474,13 +492,38 @@ __global__ __launch_bounds__(NT) void la_bwd_red_kernel(const LaBwdArgs a) {
         }
         __syncthreads();
     }
+    float* cp = a.cpart + ((int64_t)blk * a.nchunk + blockIdx.x) * LA_SCR;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const float t = sdc::wave_sum(psum[it]);
-        if (lane == 0) rinv[wave + 4 * it] = 1.0f / t;
+        if (lane == 0) cp[32 + wave + 4 * it] = t;
+    }
+    if (tid < DH) cp[tid] = rmax[tid];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { cp[64 + pd * 32 + pe + u] = cu[u]; cp[64 + 1024 + pd * 32 + pe + u] = dc[u]; }
+}
+
+__global__ __launch_bounds__(NT) void la_bwd_merge_kernel(const LaBwdArgs a) {
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    const float* cp = a.cpart + (int64_t)blk * a.nchunk * LA_SCR;
+    __shared__ float rmax[DH], rinv[DH];
+    if (tid < DH) {
+        float m = -INFINITY;
+        for (int c = 0; c < a.nchunk; ++c) m = fmaxf(m, cp[(int64_t)c * LA_SCR + tid]);
+        float s = 0.f;
+        for (int c = 0; c < a.nchunk; ++c) s += cp[(int64_t)c * LA_SCR + 32 + tid] * expf(cp[(int64_t)c * LA_SCR + tid] - m);
+        rmax[tid] = m; rinv[tid] = 1.0f / s;
     }
     __syncthreads();
-    float* scr = a.scratch + (int64_t)blockIdx.x * LA_SCR;
+    const int pd = tid >> 3, pe = 4 * (tid & 7);
+    float cu[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < a.nchunk; ++c) {
+        const float* q = cp + (int64_t)c * LA_SCR;
+        const float f = expf(q[pd] - rmax[pd]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { cu[u] += q[64 + pd * 32 + pe + u] * f; dc[u] += q[64 + 1024 + pd * 32 + pe + u]; }
+    }
+    float* scr = a.scratch + (int64_t)blk * LA_SCR;
     if (tid < DH) { scr[tid] = rmax[tid]; scr[32 + tid] = rinv[tid]; }
 #pragma unroll
     for (int u = 0; u < 4; ++u) { scr[64 + pd * 32 + pe + u] = cu[u] * rinv[pd]; scr[64 + 1024 + pd * 32 + pe + u] = dc[u]; }
@@ -658,8 +701,8 @@ extern "C" int sdc_attn_bwd(const float* qkv, const float* dout, const float* ro
 }
 
 extern "C" size_t sdc_linattn_bwd_bytes(int outer, int inner, int heads, int64_t n) {
-    const size_t nblk = (size_t)outer * inner * heads, ntile = (size_t)((n + NT - 1) / NT);
-    return nblk * (LA_SCR + ntile * DH) * sizeof(float);
+    const size_t nblk = (size_t)outer * inner * heads, ntile = (size_t)((n + NT - 1) / NT), nchunk = (size_t)((n + LA_CHUNK - 1) / LA_CHUNK);
+    return nblk * (LA_SCR + ntile * DH + nchunk * LA_SCR) * sizeof(float);
 }
 
 extern "C" int sdc_linattn_bwd(const float* qkv, const float* dout, float* dqkv, void* work, int outer, int inner, int heads, int64_t n,
@@ -673,9 +716,12 @@ extern "C" int sdc_linattn_bwd(const float* qkv, const float* dout, float* dqkv,
     a.so = q_so; a.sc = q_sc; a.si = q_si; a.oso = o_so; a.osc = o_sc; a.osi = o_si;
     a.ntile = (int)((n + NT - 1) / NT);
     a.scratch = static_cast<float*>(work);
+    a.nchunk = (int)((n + LA_CHUNK - 1) / LA_CHUNK);
     float* tpart = a.scratch + nblk * LA_SCR;
+    a.cpart = tpart + nblk * a.ntile * DH;
     hipStream_t s = sdc::as_stream(stream);
-    hipLaunchKernelGGL(la_bwd_red_kernel, dim3((unsigned)nblk), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL(la_bwd_red_kernel, dim3((unsigned)a.nchunk, (unsigned)nblk), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL(la_bwd_merge_kernel, dim3((unsigned)nblk), dim3(NT), 0, s, a);
     hipLaunchKernelGGL(la_bwd_tok_kernel, dim3((unsigned)a.ntile, (unsigned)nblk), dim3(NT), 0, s, a, tpart);
     hipLaunchKernelGGL(la_bwd_fin_kernel, dim3((unsigned)a.ntile, (unsigned)nblk), dim3(NT), 0, s, a, (const float*)tpart);
     return sdc::check_launch("sdc_linattn_bwd");

@@ -236,13 +236,42 @@ int launch_wgrad_bkp(const WgradArgs& a, dim3 grid, hipStream_t s) {
     return launch_wgrad<KW, SW, 16>(a, grid, s);
 }
 
-// out[i] = sum_s part[s][i]  (fixed order)
+// out[i] = sum_s part[s][i] in a fixed order.  KG = 1: a thread per element, splits in sequence (loads four deep).  KG = 4 (many
+// splits over a small gradient): wave g of the workgroup sums the splits s = g (mod 4) of 64 elements, wave 0 adds the four
+// partial sums in order -- the chain of dependent HBM latencies is what this reduction costs, not its bytes.
+template <int KG>
 __global__ __launch_bounds__(NT) void sum_splits_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int nsplit) {
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
-        float s = 0.0f;
-        for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * n + i];
-        out[i] = s;
+    const int g = KG == 1 ? 0 : (int)(threadIdx.x >> 6);
+    const int64_t i = KG == 1 ? (int64_t)blockIdx.x * NT + threadIdx.x : (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    float s = 0.0f;
+    if (i < n) {
+        int k = g;
+        for (; k + 3 * KG < nsplit; k += 4 * KG) {
+            const float v0 = part[(int64_t)k * n + i], v1 = part[(int64_t)(k + KG) * n + i];
+            const float v2 = part[(int64_t)(k + 2 * KG) * n + i], v3 = part[(int64_t)(k + 3 * KG) * n + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < nsplit; k += KG) s += part[(int64_t)k * n + i];
     }
+    if (KG == 1) {
+        if (i < n) out[i] = s;
+    } else {
+        __shared__ float sh[KG][64];
+        sh[g][threadIdx.x & 63] = s;
+        __syncthreads();
+        if (g == 0 && i < n) {
+            float t = sh[0][threadIdx.x];
+            for (int q = 1; q < KG; ++q) t += sh[q][threadIdx.x];
+            out[i] = t;
+        }
+    }
+}
+
+void launch_sum_splits(const float* part, float* out, int64_t n, int nsplit, hipStream_t s) {
+    if (nsplit >= 8)
+        hipLaunchKernelGGL(sum_splits_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(NT), 0, s, part, out, n, nsplit);
+    else
+        hipLaunchKernelGGL(sum_splits_kernel<1>, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, s, part, out, n, nsplit);
 }
 
 int wgrad_splits(const SdcWgradDesc& d, int* rows_per_split) {
@@ -310,9 +339,8 @@ extern "C" int sdc_conv_wgrad(const SdcWgradDesc* dp, const float* g, const floa
     int rc = sdc::check_launch("sdc_conv_wgrad");
     if (rc || a.nsplit == 1) return rc;
     {
-        const int blocks = (int)((nw + NT - 1) / NT < 4096 ? (nw + NT - 1) / NT : 4096);
-        hipLaunchKernelGGL(sum_splits_kernel, dim3(blocks), dim3(NT), 0, s, a.part, dw, nw, a.nsplit);
-        if (dbias) hipLaunchKernelGGL(sum_splits_kernel, dim3((d.M + NT - 1) / NT), dim3(NT), 0, s, a.bpart, dbias, (int64_t)d.M, a.nsplit);
+        launch_sum_splits(a.part, dw, nw, a.nsplit, s);
+        if (dbias) launch_sum_splits(a.bpart, dbias, (int64_t)d.M, a.nsplit, s);
     }
     return sdc::check_launch("sdc_conv_wgrad[reduce]");
 }
@@ -329,82 +357,115 @@ __device__ __forceinline__ float dsilu(float v) {
     return s * (1.0f + v * (1.0f - s));
 }
 
+// rows kernel: a workgroup owns RPB (b, c) rows -- one for long rows (all 256 threads sweep it), four (one per wave) for the short
+// rows of the 1-D nets (S < 1024: a workgroup per 16-element row would be 130 k nearly empty workgroups)
+template <int RPB>
 __global__ __launch_bounds__(NT) void gn_bwd_rows_kernel(const float* __restrict__ h, const float* __restrict__ gy,
                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ ss,
-                                                        int64_t ss_b_stride, float* __restrict__ rows, int C, int G, int64_t S) {
-    const int bc = blockIdx.x;
-    const int b = bc / C, c = bc - b * C;
-    const int g = c / (C / G);
-    const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
-    float sc = 1.0f, sh = 0.0f;
-    if (ss) { sc = ss[(int64_t)b * ss_b_stride + c] + 1.0f; sh = ss[(int64_t)b * ss_b_stride + C + c]; }
-    const float ga = gamma[c], be = beta[c];
-    const int64_t base = (int64_t)bc * S;
+                                                        int64_t ss_b_stride, float* __restrict__ rows, int nrows, int C, int G, int64_t S) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bc = RPB == 1 ? blockIdx.x : blockIdx.x * RPB + wave;
+    const bool live = bc < nrows;
     double a1 = 0.0, a2 = 0.0;
-    for (int64_t i = threadIdx.x; i < S; i += NT) {
-        const float xh = (h[base + i] - mean) * rstd;
-        const float v = (xh * ga + be) * sc + sh;
-        const float gv = gy[base + i] * dsilu(v);
-        a1 += (double)gv;
-        a2 += (double)gv * (double)xh;
+    if (live) {
+        const int b = bc / C, c = bc - b * C;
+        const int g = c / (C / G);
+        const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+        float sc = 1.0f, sh = 0.0f;
+        if (ss) { sc = ss[(int64_t)b * ss_b_stride + c] + 1.0f; sh = ss[(int64_t)b * ss_b_stride + C + c]; }
+        const float ga = gamma[c], be = beta[c];
+        const int64_t base = (int64_t)bc * S;
+        const int i0 = RPB == 1 ? threadIdx.x : lane, step = RPB == 1 ? NT : 64;
+        for (int64_t i = i0; i < S; i += step) {
+            const float xh = (h[base + i] - mean) * rstd;
+            const float v = (xh * ga + be) * sc + sh;
+            const float gv = gy[base + i] * dsilu(v);
+            a1 += (double)gv;
+            a2 += (double)gv * (double)xh;
+        }
     }
-    __shared__ double shm[2][NT / 64];
     a1 = sdc::wave_sum(a1);
     a2 = sdc::wave_sum(a2);
-    if ((threadIdx.x & 63) == 0) { shm[0][threadIdx.x >> 6] = a1; shm[1][threadIdx.x >> 6] = a2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t1 = 0, t2 = 0;
-        for (int w = 0; w < NT / 64; ++w) { t1 += shm[0][w]; t2 += shm[1][w]; }
-        rows[(int64_t)bc * 2] = (float)t1;
-        rows[(int64_t)bc * 2 + 1] = (float)t2;
-    }
-}
-
-__global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const float* __restrict__ h, const float* __restrict__ gy,
-                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, const float* __restrict__ ss,
-                                                         int64_t ss_b_stride, const float* __restrict__ rows, float* __restrict__ gh,
-                                                         int C, int G, int64_t S) {
-    const int bc = blockIdx.x;
-    const int b = bc / C, c = bc - b * C;
-    const int cpg = C / G, g = c / cpg;
-    const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
-    // group means of (k A1, k A2): every thread walks the group's channels (cpg <= a few thousand; L2-resident table)
-    __shared__ double gm[2];
-    {
-        double s1 = 0.0, s2 = 0.0;
-        for (int cc = threadIdx.x; cc < cpg; cc += NT) {
-            const int ch = g * cpg + cc;
-            const float k = gamma[ch] * (ss ? ss[(int64_t)b * ss_b_stride + ch] + 1.0f : 1.0f);
-            s1 += (double)k * rows[((int64_t)b * C + ch) * 2];
-            s2 += (double)k * rows[((int64_t)b * C + ch) * 2 + 1];
-        }
+    if (RPB == 1) {
         __shared__ double shm[2][NT / 64];
-        s1 = sdc::wave_sum(s1);
-        s2 = sdc::wave_sum(s2);
-        if ((threadIdx.x & 63) == 0) { shm[0][threadIdx.x >> 6] = s1; shm[1][threadIdx.x >> 6] = s2; }
+        if (lane == 0) { shm[0][wave] = a1; shm[1][wave] = a2; }
         __syncthreads();
         if (threadIdx.x == 0) {
             double t1 = 0, t2 = 0;
             for (int w = 0; w < NT / 64; ++w) { t1 += shm[0][w]; t2 += shm[1][w]; }
-            const double inv = 1.0 / ((double)cpg * (double)S);
-            gm[0] = t1 * inv;
-            gm[1] = t2 * inv;
+            rows[(int64_t)bc * 2] = (float)t1;
+            rows[(int64_t)bc * 2 + 1] = (float)t2;
         }
-        __syncthreads();
+    } else if (live && lane == 0) {
+        rows[(int64_t)bc * 2] = (float)a1;
+        rows[(int64_t)bc * 2 + 1] = (float)a2;
     }
-    const float m1 = (float)gm[0], m2 = (float)gm[1];
-    float sc = 1.0f, sh = 0.0f;
-    if (ss) { sc = ss[(int64_t)b * ss_b_stride + c] + 1.0f; sh = ss[(int64_t)b * ss_b_stride + C + c]; }
-    const float ga = gamma[c], be = beta[c], k = ga * sc;
-    const int64_t base = (int64_t)bc * S;
-    for (int64_t i = (int64_t)blockIdx.y * NT + threadIdx.x; i < S; i += (int64_t)gridDim.y * NT) {
-        const float xh = (h[base + i] - mean) * rstd;
-        const float v = (xh * ga + be) * sc + sh;
-        const float gv = gy[base + i] * dsilu(v);
-        gh[base + i] = rstd * (gv * k - m1 - xh * m2);
+}
+
+// group means of (k A1, k A2), k = gamma (1 + sc): one workgroup per (b, g) -> gstat[b][g] = (m1, m2)
+__global__ __launch_bounds__(NT) void gn_bwd_group_kernel(const float* __restrict__ rows, const float* __restrict__ gamma,
+                                                         const float* __restrict__ ss, int64_t ss_b_stride, float* __restrict__ gstat,
+                                                         int C, int G, int64_t S) {
+    const int bg = blockIdx.x;
+    const int b = bg / G, g = bg - b * G;
+    const int cpg = C / G;
+    double s1 = 0.0, s2 = 0.0;
+    for (int cc = threadIdx.x; cc < cpg; cc += NT) {
+        const int ch = g * cpg + cc;
+        const float k = gamma[ch] * (ss ? ss[(int64_t)b * ss_b_stride + ch] + 1.0f : 1.0f);
+        s1 += (double)k * rows[((int64_t)b * C + ch) * 2];
+        s2 += (double)k * rows[((int64_t)b * C + ch) * 2 + 1];
+    }
+    __shared__ double shm[2][NT / 64];
+    s1 = sdc::wave_sum(s1);
+    s2 = sdc::wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { shm[0][threadIdx.x >> 6] = s1; shm[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t1 = 0, t2 = 0;
+        for (int w = 0; w < NT / 64; ++w) { t1 += shm[0][w]; t2 += shm[1][w]; }
+        const double inv = 1.0 / ((double)cpg * (double)S);
+        gstat[bg * 2] = (float)(t1 * inv);
+        gstat[bg * 2 + 1] = (float)(t2 * inv);
+    }
+}
+
+// apply: gh = rstd (gy silu'(v) k - m1 - xh m2).  FLAT: threads walk a flat element index and look the row constants up
+// (short rows); otherwise grid.x = (b, c) row, grid.y walks the row.
+template <bool FLAT>
+__global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const float* __restrict__ h, const float* __restrict__ gy,
+                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ ss,
+                                                         int64_t ss_b_stride, const float* __restrict__ gstat, float* __restrict__ gh,
+                                                         int C, int G, int64_t S, int64_t total) {
+    auto row_consts = [&](int bc, float& mean, float& rstd, float& ga, float& be, float& sc, float& sh, float& m1, float& m2) {
+        const int b = bc / C, c = bc - b * C;
+        const int g = c / (C / G);
+        mean = stats[(b * G + g) * 2]; rstd = stats[(b * G + g) * 2 + 1];
+        m1 = gstat[(b * G + g) * 2]; m2 = gstat[(b * G + g) * 2 + 1];
+        sc = 1.0f; sh = 0.0f;
+        if (ss) { sc = ss[(int64_t)b * ss_b_stride + c] + 1.0f; sh = ss[(int64_t)b * ss_b_stride + C + c]; }
+        ga = gamma[c]; be = beta[c];
+    };
+    float mean, rstd, ga, be, sc, sh, m1, m2;
+    if (FLAT) {
+        for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+            row_consts((int)(i / S), mean, rstd, ga, be, sc, sh, m1, m2);
+            const float xh = (h[i] - mean) * rstd;
+            const float v = (xh * ga + be) * sc + sh;
+            gh[i] = rstd * (gy[i] * dsilu(v) * (ga * sc) - m1 - xh * m2);
+        }
+    } else {
+        const int bc = blockIdx.x;
+        row_consts(bc, mean, rstd, ga, be, sc, sh, m1, m2);
+        const float k = ga * sc;
+        const int64_t base = (int64_t)bc * S;
+        for (int64_t i = (int64_t)blockIdx.y * NT + threadIdx.x; i < S; i += (int64_t)gridDim.y * NT) {
+            const float xh = (h[base + i] - mean) * rstd;
+            const float v = (xh * ga + be) * sc + sh;
+            gh[base + i] = rstd * (gy[base + i] * dsilu(v) * k - m1 - xh * m2);
+        }
     }
 }
 
@@ -537,12 +598,24 @@ extern "C" int sdc_gn_silu_bwd(const float* h, const float* gy, const float* sta
     SDC_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && S > 0, SDC_EINVAL, "sdc_gn_silu_bwd: bad sizes");
     SDC_REQUIRE((int64_t)B * C < (1ll << 31), SDC_EINVAL, "sdc_gn_silu_bwd: too many rows");
     hipStream_t s = sdc::as_stream(stream);
-    hipLaunchKernelGGL(gn_bwd_rows_kernel, dim3((unsigned)(B * C)), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss, ss_b_stride, rows, C, G, S);
-    int ysplit = (int)((S + NT * 8 - 1) / (NT * 8));
-    if (ysplit < 1) ysplit = 1;
-    if (ysplit > 64) ysplit = 64;
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(B * C), (unsigned)ysplit), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss,
-                       ss_b_stride, rows, gh, C, G, S);
+    const int nrows = B * C;
+    float* gstat = rows + (int64_t)nrows * 2;             // rows = [B][C][2] row sums, then [B][G][2] group means
+    if (S >= 1024)
+        hipLaunchKernelGGL(gn_bwd_rows_kernel<1>, dim3((unsigned)nrows), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss, ss_b_stride, rows, nrows, C, G, S);
+    else
+        hipLaunchKernelGGL(gn_bwd_rows_kernel<4>, dim3((unsigned)((nrows + 3) / 4)), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss, ss_b_stride, rows, nrows, C, G, S);
+    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((unsigned)(B * G)), dim3(NT), 0, s, rows, gamma, ss, ss_b_stride, gstat, C, G, S);
+    const int64_t total = (int64_t)nrows * S;
+    if (S >= 1024) {
+        int ysplit = (int)((S + NT * 8 - 1) / (NT * 8));
+        if (ysplit > 64) ysplit = 64;
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3((unsigned)nrows, (unsigned)ysplit), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss,
+                           ss_b_stride, gstat, gh, C, G, S, total);
+    } else {
+        const int blocks = (int)((total + NT - 1) / NT < 8192 ? (total + NT - 1) / NT : 8192);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3((unsigned)blocks), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss, ss_b_stride,
+                           gstat, gh, C, G, S, total);
+    }
     return sdc::check_launch("sdc_gn_silu_bwd");
 }
 
@@ -618,55 +691,80 @@ struct PackArgs {
     int64_t n0, n1, n2, n3;                // floats of the four sections
 };
 
-__global__ __launch_bounds__(NT) void pack_weight_kernel(const PackArgs a) {
-    const int64_t total = a.n0 + a.n1 + a.n2 + a.n3;
+// One workgroup stages a (co_t co) x (ci_t ci) x taps block of the weight through LDS -- read along the source's contiguous axis
+// ([co][ci, taps] rows, or [ci][co, taps] rows when flipped), written along co, the packed layouts' contiguous axis -- and emits
+// that block of every section.
+__global__ __launch_bounds__(NT) void pack_weight_kernel(const PackArgs a, const int co_sh, const int ci_sh, const unsigned tap_magic) {
+    extern __shared__ float tile[];                       // [co_t][ci_t * taps + 1], element (co, ci, logical tap)
+    const int co_t = 1 << co_sh, ci_t = 1 << ci_sh;
     const int taps = a.kD * a.kH * a.kW;
-    auto wv = [&](int co, int ci, int kd, int kh, int kw) -> double {
-        if (a.flip) return (double)a.w[((int64_t)ci * a.Cout + co) * taps + ((a.kD - 1 - kd) * a.kH + (a.kH - 1 - kh)) * a.kW + (a.kW - 1 - kw)];
-        return (double)a.w[((int64_t)co * a.Cin + ci) * taps + (kd * a.kH + kh) * a.kW + kw];
-    };
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
-        double v;
-        if (i < a.n0) {                                   // Wp[(kd, kh, kw, ci)][co]
-            const int co = (int)(i % a.Cout);
-            int64_t r = i / a.Cout;
-            const int ci = (int)(r % a.Cin); r /= a.Cin;
-            const int kw = (int)(r % a.kW); r /= a.kW;
-            const int kh = (int)(r % a.kH);
-            const int kd = (int)(r / a.kH);
-            v = wv(co, ci, kd, kh, kw);
-        } else if (i < a.n0 + a.n1) {                     // Wg[(kd kH + kh) 4 + xi][ci][co]
-            int64_t r = i - a.n0;
-            const int co = (int)(r % a.Cout); r /= a.Cout;
-            const int ci = (int)(r % a.Cin); r /= a.Cin;
-            const int xi = (int)(r % 4); r /= 4;
-            const int kh = (int)(r % a.kH);
-            const int kd = (int)(r / a.kH);
-            v = 0.0;
-            for (int kw = 0; kw < 3; ++kw) v += wino_g(xi, kw) * wv(co, ci, kd, kh, kw);
-        } else if (i < a.n0 + a.n1 + a.n2) {              // Wg2[kd][ci][co][j 4 + xi]
-            int64_t r = i - a.n0 - a.n1;
-            const int xi = (int)(r % 4); r /= 4;
-            const int j = (int)(r % 4); r /= 4;
-            const int co = (int)(r % a.Cout); r /= a.Cout;
-            const int ci = (int)(r % a.Cin);
-            const int kd = (int)(r / a.Cin);
-            v = 0.0;
-            for (int kh = 0; kh < 3; ++kh)
-                for (int kw = 0; kw < 3; ++kw) v += wino_g(j, kh) * wino_g(xi, kw) * wv(co, ci, kd, kh, kw);
-        } else {                                          // Wg3[jd][ci][co][j 4 + xi]
-            int64_t r = i - a.n0 - a.n1 - a.n2;
-            const int xi = (int)(r % 4); r /= 4;
-            const int j = (int)(r % 4); r /= 4;
-            const int co = (int)(r % a.Cout); r /= a.Cout;
-            const int ci = (int)(r % a.Cin);
-            const int jd = (int)(r / a.Cin);
-            v = 0.0;
-            for (int kd = 0; kd < 3; ++kd)
-                for (int kh = 0; kh < 3; ++kh)
-                    for (int kw = 0; kw < 3; ++kw) v += wino_g(jd, kd) * wino_g(j, kh) * wino_g(xi, kw) * wv(co, ci, kd, kh, kw);
+    const int pitch = ci_t * taps + 1;
+    const int co0 = blockIdx.x << co_sh, ci0 = blockIdx.y << ci_sh;
+    const int nco = a.Cout - co0 < co_t ? a.Cout - co0 : co_t;
+    const int nci = a.Cin - ci0 < ci_t ? a.Cin - ci0 : ci_t;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (!a.flip) {
+        const int len = nci * taps;
+        for (int r = wave; r < nco; r += NT / 64) {
+            const float* src = a.w + ((int64_t)(co0 + r) * a.Cin + ci0) * taps;
+            for (int c = lane; c < len; c += 64) tile[r * pitch + c] = src[c];
         }
-        a.out[i] = (float)v;
+    } else {                                              // w[ci][co][taps], taps reversed
+        const int len = nco * taps;
+        for (int r = wave; r < nci; r += NT / 64) {
+            const float* src = a.w + ((int64_t)(ci0 + r) * a.Cout + co0) * taps;
+            for (int c = lane; c < len; c += 64) {
+                const int co = (int)(((unsigned)c * tap_magic) >> 24), t = c - co * taps;     // c / taps (exact: c * taps < 2^24)
+                tile[co * pitch + r * taps + (taps - 1 - t)] = src[c];
+            }
+        }
+    }
+    __syncthreads();
+    auto wv = [&](int co, int ci, int kd, int kh, int kw) -> double { return (double)tile[co * pitch + ci * taps + (kd * a.kH + kh) * a.kW + kw]; };
+    const int cell = co_t * ci_t;
+    // Wp[(kd, kh, kw, ci)][co]
+    for (int tap = 0; tap < taps; ++tap)
+        for (int e = threadIdx.x; e < cell; e += NT) {
+            const int co = e & (co_t - 1), ci = e >> co_sh;
+            if (co < nco && ci < nci) a.out[((int64_t)tap * a.Cin + ci0 + ci) * a.Cout + co0 + co] = tile[co * pitch + ci * taps + tap];
+        }
+    if (a.n1) {                                           // Wg[(kd kH + kh) 4 + xi][ci][co]
+        float* o = a.out + a.n0;
+        for (int kd = 0; kd < a.kD; ++kd)
+            for (int kh = 0; kh < a.kH; ++kh)
+                for (int xi = 0; xi < 4; ++xi)
+                    for (int e = threadIdx.x; e < cell; e += NT) {
+                        const int co = e & (co_t - 1), ci = e >> co_sh;
+                        if (co >= nco || ci >= nci) continue;
+                        double v = 0.0;
+                        for (int kw = 0; kw < 3; ++kw) v += wino_g(xi, kw) * wv(co, ci, kd, kh, kw);
+                        o[((int64_t)((kd * a.kH + kh) * 4 + xi) * a.Cin + ci0 + ci) * a.Cout + co0 + co] = (float)v;
+                    }
+    }
+    if (a.n2) {                                           // Wg2[kd][ci][co][j 4 + xi]
+        float* o = a.out + a.n0 + a.n1;
+        for (int kd = 0; kd < a.kD; ++kd)
+            for (int e = threadIdx.x; e < cell * 16; e += NT) {
+                const int xi = e & 3, j = (e >> 2) & 3, co = (e >> 4) & (co_t - 1), ci = e >> (4 + co_sh);
+                if (co >= nco || ci >= nci) continue;
+                double v = 0.0;
+                for (int kh = 0; kh < 3; ++kh)
+                    for (int kw = 0; kw < 3; ++kw) v += wino_g(j, kh) * wino_g(xi, kw) * wv(co, ci, kd, kh, kw);
+                o[(((int64_t)kd * a.Cin + ci0 + ci) * a.Cout + co0 + co) * 16 + j * 4 + xi] = (float)v;
+            }
+    }
+    if (a.n3) {                                           // Wg3[jd][ci][co][j 4 + xi]
+        float* o = a.out + a.n0 + a.n1 + a.n2;
+        for (int jd = 0; jd < 4; ++jd)
+            for (int e = threadIdx.x; e < cell * 16; e += NT) {
+                const int xi = e & 3, j = (e >> 2) & 3, co = (e >> 4) & (co_t - 1), ci = e >> (4 + co_sh);
+                if (co >= nco || ci >= nci) continue;
+                double v = 0.0;
+                for (int kd = 0; kd < 3; ++kd)
+                    for (int kh = 0; kh < 3; ++kh)
+                        for (int kw = 0; kw < 3; ++kw) v += wino_g(jd, kd) * wino_g(j, kh) * wino_g(xi, kw) * wv(co, ci, kd, kh, kw);
+                o[(((int64_t)jd * a.Cin + ci0 + ci) * a.Cout + co0 + co) * 16 + j * 4 + xi] = (float)v;
+            }
     }
 }
 
@@ -699,8 +797,17 @@ extern "C" int sdc_pack_conv_weight(const float* w, float* out, int Cout, int Ci
     int64_t n[4];
     pack_sections(Cout, Cin, kD, kH, kW, precision, n);
     a.n0 = n[0]; a.n1 = n[1]; a.n2 = n[2]; a.n3 = n[3];
-    const int64_t total = n[0] + n[1] + n[2] + n[3];
-    const int blocks = (int)((total + NT - 1) / NT < 16384 ? (total + NT - 1) / NT : 16384);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(NT), 0, sdc::as_stream(stream), a);
+    const int taps = kD * kH * kW;
+    int ci_sh = 4, co_sh = 6;
+    while (ci_sh > 0 && (taps << ci_sh) > 128) --ci_sh;
+    while (co_sh > 0 && ((size_t)((taps << ci_sh) + 1) << co_sh) * sizeof(float) > 48u * 1024u) --co_sh;
+    // at least ~4 workgroups per CU: a tile's emit loops are a few thousand fp64 sums per thread
+    while (ci_sh > 1 && (int64_t)((Cout + (1 << co_sh) - 1) >> co_sh) * ((Cin + (1 << ci_sh) - 1) >> ci_sh) < 1024) --ci_sh;
+    const size_t lds = ((size_t)((taps << ci_sh) + 1) << co_sh) * sizeof(float);
+    SDC_REQUIRE(lds <= 64u * 1024u && ((int64_t)taps * taps << co_sh) < (1 << 24), SDC_EINVAL, "sdc_pack_conv_weight: too many taps");
+    const dim3 grid((unsigned)((Cout + (1 << co_sh) - 1) >> co_sh), (unsigned)((Cin + (1 << ci_sh) - 1) >> ci_sh));
+    SDC_REQUIRE(grid.y < 65536u, SDC_EINVAL, "sdc_pack_conv_weight: too many input channels");
+    const unsigned tap_magic = (unsigned)(((1u << 24) + taps - 1) / taps);
+    hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(NT), lds, sdc::as_stream(stream), a, co_sh, ci_sh, tap_magic);
     return sdc::check_launch("sdc_pack_conv_weight");
 }

@@ -81,10 +81,11 @@ def gn_silu_bwd(h, gy, st, gamma, beta, groups, ss=None):
     B, Cc = h.shape[0], h.shape[1]
     S = h.numel() // (B * Cc)
     gy = gy.contiguous()
-    rows = torch.empty((B, Cc, 2), dtype=torch.float32, device=h.device)
+    buf = torch.empty((B * Cc + B * groups) * 2, dtype=torch.float32, device=h.device)     # row sums, then the kernel's group means
+    rows = buf[: B * Cc * 2].view(B, Cc, 2)
     gh = torch.empty_like(h)
     check(lib.sdc_gn_silu_bwd(h.data_ptr(), gy.data_ptr(), st.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                              0 if ss is None else ss.data_ptr(), 0 if ss is None else ss.stride(0), rows.data_ptr(), gh.data_ptr(),
+                              0 if ss is None else ss.data_ptr(), 0 if ss is None else ss.stride(0), buf.data_ptr(), gh.data_ptr(),
                               B, Cc, groups, S, _stream(h)), "sdc_gn_silu_bwd")
     # parameter gradients: O(B C) sums over the row table
     a1, a2 = rows[..., 0], rows[..., 1]
