@@ -92,7 +92,7 @@ __device__ __forceinline__ float sub_next(float a, float x) {
 
 template <int OW, int DBG>
 __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
-    constexpr int SK = W2_SK, BM = W2_BM, NTH = 256;
+    constexpr int SK = W2_SK, BM = W2_BM;
     constexpr int TW = OW / 2, RP = W2_TILES / TW;
     constexpr int LGW = OW == 128 ? 7 : (OW == 64 ? 6 : (OW == 32 ? 5 : 4));
     constexpr int CPL = OW == 16 ? 2 : OW / 16;          // adjacent columns per lane
@@ -602,7 +602,7 @@ __device__ __forceinline__ w2f2 pk_fma2(w2f2 a, w2f2 b, w2f2 c) { w2f2 r; asm("v
 template <int OW, int DBG>
 __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
     constexpr int SK = W2_SK, BM = W2_BM;
-    constexpr int TW = OW / 2, RP = W2_TILES / TW;
+    constexpr int TW = OW / 2;
     constexpr int LGW = OW == 64 ? 6 : (OW == 32 ? 5 : 4);
     constexpr int CPL = OW == 16 ? 2 : OW / 16;          // adjacent columns per lane
     constexpr int SH = OW == 16 ? 2 : 1;                 // DPP lane distance of the neighbouring column group

@@ -591,10 +591,41 @@ __global__ __launch_bounds__(NT) void sumpool_kernel(const float* __restrict__ g
     }
 }
 
+// parameter gradients from the row table: a workgroup owns 64 channels, wave g the samples b = g (mod 4) (fixed order, the four
+// partial sums added in order):  dgamma[c] = sum_b (1 + sc) A2, dbeta[c] = sum_b (1 + sc) A1, dss[b] = [gamma A2 + beta A1 (C) | A1 (C)]
+__global__ __launch_bounds__(NT) void gn_bwd_param_kernel(const float* __restrict__ rows, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ ss,
+                                                         int64_t ss_b_stride, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                         float* __restrict__ dss, int B, int C) {
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool live = c < C;
+    float sg = 0.0f, sb = 0.0f;
+    if (live) {
+        const float ga = gamma[c], be = beta[c];
+        for (int b = g; b < B; b += NT / 64) {
+            const float2 r = *reinterpret_cast<const float2*>(rows + ((int64_t)b * C + c) * 2);
+            const float k = ss ? ss[(int64_t)b * ss_b_stride + c] + 1.0f : 1.0f;
+            sg += k * r.y;
+            sb += k * r.x;
+            if (dss) { dss[(int64_t)b * 2 * C + c] = ga * r.y + be * r.x; dss[(int64_t)b * 2 * C + C + c] = r.x; }
+        }
+    }
+    __shared__ float sh[2][NT / 64][64];
+    sh[0][g][lane] = sg; sh[1][g][lane] = sb;
+    __syncthreads();
+    if (g == 0 && live) {
+        dgamma[c] = (sh[0][0][lane] + sh[0][1][lane]) + (sh[0][2][lane] + sh[0][3][lane]);
+        dbeta[c] = (sh[1][0][lane] + sh[1][1][lane]) + (sh[1][2][lane] + sh[1][3][lane]);
+    }
+}
+
 extern "C" int sdc_gn_silu_bwd(const float* h, const float* gy, const float* stats, const float* gamma, const float* beta,
-                               const float* ss, int64_t ss_b_stride, float* rows, float* gh, int B, int C, int G, int64_t S,
-                               void* stream) {
+                               const float* ss, int64_t ss_b_stride, float* rows, float* gh, float* dgamma, float* dbeta, float* dss,
+                               int B, int C, int G, int64_t S, void* stream) {
     SDC_REQUIRE(h && gy && stats && gamma && beta && rows && gh, SDC_ENULL, "sdc_gn_silu_bwd: null pointer");
+    SDC_REQUIRE((dgamma != nullptr) == (dbeta != nullptr) && (!dss || (dgamma && ss)), SDC_EINVAL,
+                "sdc_gn_silu_bwd: dgamma and dbeta come together, dss with them and with ss");
     SDC_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && S > 0, SDC_EINVAL, "sdc_gn_silu_bwd: bad sizes");
     SDC_REQUIRE((int64_t)B * C < (1ll << 31), SDC_EINVAL, "sdc_gn_silu_bwd: too many rows");
     hipStream_t s = sdc::as_stream(stream);
@@ -616,6 +647,9 @@ extern "C" int sdc_gn_silu_bwd(const float* h, const float* gy, const float* sta
         hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3((unsigned)blocks), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss, ss_b_stride,
                            gstat, gh, C, G, S, total);
     }
+    if (dgamma)
+        hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)((C + 63) / 64)), dim3(NT), 0, s, rows, gamma, beta, ss, ss_b_stride,
+                           dgamma, dbeta, dss, B, C);
     return sdc::check_launch("sdc_gn_silu_bwd");
 }
 
@@ -674,7 +708,7 @@ extern "C" int sdc_sumpool2(const float* g, float* gx, int64_t rows, int H, int 
 // Kernel layout of an nn.Conv weight (include/sdc.h, SdcConvDesc.precision) in ONE launch: Wp[(kd, kh, kw, ci)][co], then for
 // 3-wide taps the Winograd F(2,3) taps Wg[(kd kH + kh) 4 + xi][ci][co], for 3x3 taps the F(2x2,3x3) taps Wg2[kd][ci][co][j 4 + xi]
 // and for 3x3x3 taps the F(2x2x2,3x3x3) taps Wg3[jd][ci][co][j 4 + xi] -- every transformed tap summed in fp64 and rounded once,
-// like the host packing (engine.pack_conv_weight).  flip != 0 packs the data-gradient weight instead: w'[co'][ci'][k] =
+// like the host packing (engine.pack_conv_weight; equal to it to the last bit or two of fp32, the fp64 sums are ordered differently).  flip != 0 packs the data-gradient weight instead: w'[co'][ci'][k] =
 // w[ci'][co'][K - 1 - k] (transposed channels, flipped taps).  A fine-tuning step re-packs every conv twice; as torch ops that
 // was ~12 launches per conv.
 namespace {
@@ -741,29 +775,43 @@ __global__ __launch_bounds__(NT) void pack_weight_kernel(const PackArgs a, const
                         o[((int64_t)((kd * a.kH + kh) * 4 + xi) * a.Cin + ci0 + ci) * a.Cout + co0 + co] = (float)v;
                     }
     }
+    // the 2-D / 3-D Winograd taps: a thread forms the (kd, kh)-weighted sums of the three kw taps once (rows 0 and 3 of G pick one
+    // tap, rows 1 and 2 weigh all three by +-1/2) and writes the four xi taps of its (jd, j) as one 16-byte store
+    auto g_lo = [](int r) { return r == 3 ? 2 : 0; };
+    auto g_hi = [](int r) { return r == 0 ? 0 : 2; };
+    auto g_cf = [](int r, int t) -> double { return (r == 0 || r == 3) ? 1.0 : ((r == 2 && t == 1) ? -0.5 : 0.5); };
+    auto emit4 = [](float* o, double s0, double s1, double s2) {
+        const float4 v = make_float4((float)s0, (float)(0.5 * ((s0 + s2) + s1)), (float)(0.5 * ((s0 + s2) - s1)), (float)s2);
+        if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) *reinterpret_cast<float4*>(o) = v;       // odd channel products shift the sections
+        else { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    };
     if (a.n2) {                                           // Wg2[kd][ci][co][j 4 + xi]
         float* o = a.out + a.n0 + a.n1;
         for (int kd = 0; kd < a.kD; ++kd)
-            for (int e = threadIdx.x; e < cell * 16; e += NT) {
-                const int xi = e & 3, j = (e >> 2) & 3, co = (e >> 4) & (co_t - 1), ci = e >> (4 + co_sh);
+            for (int e = threadIdx.x; e < cell * 4; e += NT) {
+                const int j = e & 3, co = (e >> 2) & (co_t - 1), ci = e >> (2 + co_sh);
                 if (co >= nco || ci >= nci) continue;
-                double v = 0.0;
-                for (int kh = 0; kh < 3; ++kh)
-                    for (int kw = 0; kw < 3; ++kw) v += wino_g(j, kh) * wino_g(xi, kw) * wv(co, ci, kd, kh, kw);
-                o[(((int64_t)kd * a.Cin + ci0 + ci) * a.Cout + co0 + co) * 16 + j * 4 + xi] = (float)v;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                for (int kh = g_lo(j); kh <= g_hi(j); ++kh) {
+                    const double c = g_cf(j, kh);
+                    s0 += c * wv(co, ci, kd, kh, 0); s1 += c * wv(co, ci, kd, kh, 1); s2 += c * wv(co, ci, kd, kh, 2);
+                }
+                emit4(o + (((int64_t)kd * a.Cin + ci0 + ci) * a.Cout + co0 + co) * 16 + j * 4, s0, s1, s2);
             }
     }
     if (a.n3) {                                           // Wg3[jd][ci][co][j 4 + xi]
         float* o = a.out + a.n0 + a.n1 + a.n2;
         for (int jd = 0; jd < 4; ++jd)
-            for (int e = threadIdx.x; e < cell * 16; e += NT) {
-                const int xi = e & 3, j = (e >> 2) & 3, co = (e >> 4) & (co_t - 1), ci = e >> (4 + co_sh);
+            for (int e = threadIdx.x; e < cell * 4; e += NT) {
+                const int j = e & 3, co = (e >> 2) & (co_t - 1), ci = e >> (2 + co_sh);
                 if (co >= nco || ci >= nci) continue;
-                double v = 0.0;
-                for (int kd = 0; kd < 3; ++kd)
-                    for (int kh = 0; kh < 3; ++kh)
-                        for (int kw = 0; kw < 3; ++kw) v += wino_g(jd, kd) * wino_g(j, kh) * wino_g(xi, kw) * wv(co, ci, kd, kh, kw);
-                o[(((int64_t)jd * a.Cin + ci0 + ci) * a.Cout + co0 + co) * 16 + j * 4 + xi] = (float)v;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                for (int kd = g_lo(jd); kd <= g_hi(jd); ++kd)
+                    for (int kh = g_lo(j); kh <= g_hi(j); ++kh) {
+                        const double c = g_cf(jd, kd) * g_cf(j, kh);
+                        s0 += c * wv(co, ci, kd, kh, 0); s1 += c * wv(co, ci, kd, kh, 1); s2 += c * wv(co, ci, kd, kh, 2);
+                    }
+                emit4(o + (((int64_t)jd * a.Cin + ci0 + ci) * a.Cout + co0 + co) * 16 + j * 4, s0, s1, s2);
             }
     }
 }

@@ -82,18 +82,14 @@ def gn_silu_bwd(h, gy, st, gamma, beta, groups, ss=None):
     S = h.numel() // (B * Cc)
     gy = gy.contiguous()
     buf = torch.empty((B * Cc + B * groups) * 2, dtype=torch.float32, device=h.device)     # row sums, then the kernel's group means
-    rows = buf[: B * Cc * 2].view(B, Cc, 2)
     gh = torch.empty_like(h)
+    dgb = torch.empty((2, Cc), dtype=torch.float32, device=h.device)
+    dss = None if ss is None else torch.empty((B, 2 * Cc), dtype=torch.float32, device=h.device)
     check(lib.sdc_gn_silu_bwd(h.data_ptr(), gy.data_ptr(), st.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                               0 if ss is None else ss.data_ptr(), 0 if ss is None else ss.stride(0), buf.data_ptr(), gh.data_ptr(),
+                              dgb[0].data_ptr(), dgb[1].data_ptr(), 0 if dss is None else dss.data_ptr(),
                               B, Cc, groups, S, _stream(h)), "sdc_gn_silu_bwd")
-    # parameter gradients: O(B C) sums over the row table
-    a1, a2 = rows[..., 0], rows[..., 1]
-    if ss is None:
-        return gh, a2.sum(0), a1.sum(0), None
-    sc1 = ss[:, :Cc] + 1.0
-    dss = torch.cat((gamma[None] * a2 + beta[None] * a1, a1), dim=1)
-    return gh, (sc1 * a2).sum(0), (sc1 * a1).sum(0), dss
+    return gh, dgb[0], dgb[1], dss
 
 
 def chan_norm_bwd(x, gy, g, mode, eps=1e-5):

@@ -248,7 +248,8 @@ def test_linear_attention_core_backward(B, inner, n):
 
 
 @pytest.mark.parametrize("shape,prec", [((64, 48, 3, 3, 3), 4), ((40, 64, 1, 3, 3), 4), ((96, 32, 3), 4), ((64, 7, 7, 7, 7), 4),
-                                        ((128, 64, 1, 1), 4), ((32, 16, 3, 3, 3), 3), ((32, 16, 3, 3), 2), ((8, 8, 3, 3, 3), 0)])
+                                        ((128, 64, 1, 1), 4), ((32, 16, 3, 3, 3), 3), ((32, 16, 3, 3), 2), ((8, 8, 3, 3, 3), 0),
+                                        ((7, 5, 3, 3, 3), 4), ((70, 33, 3, 3), 4), ((2048, 24, 3), 4)])
 def test_pack_conv_weight_kernel_equals_host_packing(shape, prec):
     """sdc_pack_conv_weight (one launch) against engine.pack_conv_weight (torch, fp64 einsums): Wp and every Winograd section,
     forward and data-gradient (transposed, flipped) forms"""

@@ -11,7 +11,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"total kernel time {tot/1e6:.1f} ms over {sum(int(r['Calls']) for r in rows)} launches")
-for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:22]:
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:int(__import__("os").environ.get("FT_TOP", "22"))]:
     print(f"{float(r['TotalDurationNs'])/1e6:9.2f} ms {int(r['Calls']):6d}  {r['Name'][:110]}")
 PY
 tail -1 $O/run.log | cut -c100-330
