@@ -348,6 +348,39 @@ int sdc_event_record(void* ev, void* stream);
 int sdc_event_elapsed_ms(void* ev0, void* ev1, float* ms);   /* synchronises on ev1 */
 int sdc_event_destroy(void* ev);
 
+/* ---- Tokamak score check: the KSTAR surrogate rollout (tokamak/kstar_solver.py:163-428 KSTARSolver.control / predict_0d /
+ * simulate; the Keras networks of tokamak/common/model_structure.py:69-152; called per sample by control_trajectories,
+ * tokamak/utils/metrics.py:60-85).  Replaces the 122 x B serial single-sample Keras predict() calls with one launch. */
+#define SDC_KSTAR_SEQ 10      /* window rows (seq_len, kstar_solver.py:34) */
+#define SDC_KSTAR_NIN 18      /* window columns: 4 fed-back outputs + 13 inputs + year */
+#define SDC_KSTAR_UNITS 100   /* LSTM units of kstar_v220505 (model_structure.py:108) */
+typedef struct {
+    int nlayers;              /* BatchNormalization -> Dense blocks (Dropout is the identity at inference) */
+    int width[7];             /* width[0] inputs ... width[nlayers] outputs, each <= 256 */
+    int act[6];               /* per block: 0 linear, 1 sigmoid */
+    const float* params;      /* per network, per block: inv[in], off[in] (BatchNorm folded: x*inv + off), kernel[in][out], bias[out] */
+    int64_t stride;           /* floats between consecutive networks of an ensemble */
+} SdcKstarMlp;
+typedef struct {
+    int n_lstm, n_bpw;        /* networks averaged (the reference's n_model_box, kstar_solver.py:156-162) */
+    const float* lstm;        /* per network: bn0 inv, off [18]; K0 [18][400]; R0 [100][400]; b0 [400]; bn1 inv, off [100];
+                                 K1 [100][400]; R1 [100][400]; b1 [400]   (Keras gate order i, f, c, o) */
+    int64_t lstm_stride;      /* floats between networks, >= sdc_kstar_lstm_floats() */
+    SdcKstarMlp head;         /* 100 -> ... -> 4 after the second LSTM (BatchNorm, Dense(50, sigmoid), BatchNorm, Dense(4)) */
+    SdcKstarMlp steady;       /* kstar_nn, 17 -> 4: the steady-state first row */
+    SdcKstarMlp bpw;          /* bpw_nn, 8 -> 2: (beta_p, W_mhd) */
+    double lstm_ystd[4], lstm_ymean[4], nn_ystd[4], nn_ymean[4], bpw_ystd[2], bpw_ymean[2];
+    double scale;             /* 10 ** np.log10(1000) as the host evaluates it (f2i / i2f, kstar_solver.py:35,107-113) */
+    double inputs0[15];       /* i2f(f2i(input_init)), kstar_solver.py:84,150-152 */
+    double low_action[9], high_action[9];
+    double year_in;
+} SdcKstarModel;
+size_t sdc_kstar_lstm_floats(void);
+/* actions: element (b, t, i) at actions[b*act_b_stride + t*act_t_stride + i*act_c_stride], t < nsteps, i < 9 (so a (B, C, T)
+ * sample tensor is read in place).  out (B, nsteps + 1, 8) fp64 rows [bn, bp, h89, h98, q95, q0, li, wmhd]; work: 4 doubles. */
+int sdc_kstar_rollout(const SdcKstarModel* m, const float* actions, int64_t act_b_stride, int64_t act_t_stride,
+                      int64_t act_c_stride, double* out, double* work, int B, int nsteps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

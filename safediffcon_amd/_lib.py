@@ -36,6 +36,18 @@ class SdcWgradDesc(C.Structure):
         "uD", "uH", "uW", "_pad")] + [("gs", C.c_int64 * 5), ("xs", C.c_int64 * 5)]
 
 
+class SdcKstarMlp(C.Structure):
+    _fields_ = [("nlayers", C.c_int32), ("width", C.c_int32 * 7), ("act", C.c_int32 * 6), ("params", C.c_void_p), ("stride", C.c_int64)]
+
+
+class SdcKstarModel(C.Structure):
+    _fields_ = [("n_lstm", C.c_int32), ("n_bpw", C.c_int32), ("lstm", C.c_void_p), ("lstm_stride", C.c_int64),
+                ("head", SdcKstarMlp), ("steady", SdcKstarMlp), ("bpw", SdcKstarMlp),
+                ("lstm_ystd", C.c_double * 4), ("lstm_ymean", C.c_double * 4), ("nn_ystd", C.c_double * 4), ("nn_ymean", C.c_double * 4),
+                ("bpw_ystd", C.c_double * 2), ("bpw_ymean", C.c_double * 2), ("scale", C.c_double), ("inputs0", C.c_double * 15),
+                ("low_action", C.c_double * 9), ("high_action", C.c_double * 9), ("year_in", C.c_double)]
+
+
 # name -> (restype, argtypes); every symbol include/sdc.h declares
 SIGNATURES = {
     "sdc_version": (C.c_int, []),
@@ -90,6 +102,8 @@ SIGNATURES = {
                                   _stream]),
     "sdc_act_bwd": (C.c_int, [_f32p, _f32p, _f32p, _i64, C.c_int, _stream]),
     "sdc_sumpool2": (C.c_int, [_f32p, _f32p, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "sdc_kstar_lstm_floats": (C.c_size_t, []),
+    "sdc_kstar_rollout": (C.c_int, [C.POINTER(SdcKstarModel), _f32p, _i64, _i64, _i64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _stream]),
     "sdc_graph_begin": (C.c_int, [_stream]),
     "sdc_graph_end": (C.c_int, [_stream, C.POINTER(C.c_void_p)]),
     "sdc_graph_launch": (C.c_int, [C.c_void_p, _stream]),
