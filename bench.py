@@ -273,6 +273,34 @@ def strawman(name, batch, steps, dim, dev):
                 value=round(batch / (T_DDPM * s), 4), unit="trajectories/s")
 
 
+def kstar_score_check(batch, dev):
+    """the tokamak score check that follows a C3 sampling pass (BASELINE config 3; tokamak/utils/metrics.py:60-85): the batch's
+    control sequences through the KSTAR surrogate, sdc_kstar_rollout against the CPU restatement timed on two trajectories"""
+    import numpy as np
+    from oracle import kstar as okstar                 # cpu_baseline leg only
+    from safediffcon_amd import kstar
+    w = kstar.unflatten_weights(dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "kstar_weights.npz"))))
+    model = kstar.KSTARModel(w, dev)
+    lo, hi = torch.tensor(kstar.LOW_ACTION), torch.tensor(kstar.HIGH_ACTION)
+    g = torch.Generator().manual_seed(0)
+    acts = (lo + (hi - lo) * torch.rand(batch, kstar.N_STEPS, 9, generator=g)).float().to(dev)
+    rows = model.rollout(acts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        rows = model.rollout(acts)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    t0 = time.perf_counter()
+    want = [okstar.KSTARSolver(w).simulate(acts[i].cpu().numpy()) for i in range(2)]
+    cpu_ms = (time.perf_counter() - t0) / 2 * 1e3
+    err = max(float(np.max(np.abs(rows[i].cpu().numpy() - want[i]) / np.abs(want[i]).max(axis=0))) for i in range(2))
+    return {"what": "control_trajectories: 122-row KSTAR surrogate rollout of every sampled control sequence (one launch)",
+            "batch": batch, "hip_ms": round(ms, 2), "trajectories_per_s": round(batch / ms * 1e3, 1),
+            "cpu_restatement_ms_per_trajectory": round(cpu_ms, 1), "max_rel_err_vs_cpu_restatement": float(f"{err:.2e}"),
+            "parity": "unpinned: the reference's simulator needs TensorFlow (DESIGN.md section 9)"}
+
+
 def finetune_step(name, batch, dim, dev, steps=3, eager=True):
     """One fine-tuning step (loss = mean(w_b p_losses_b); loss.backward(), 2d/inference_2d.py:267-279) through the
     drop-in net's differentiable HIP path, beside the same step of the oracle's functional net under PyTorch-ROCm autograd."""
@@ -621,6 +649,8 @@ def worker(a):
         if world == 1 and not a.no_extra and not a.no_finetune:
             with torch.enable_grad():
                 extra["finetune_step"] = finetune_step(wl, a.finetune_batch or {"c2": 64, "c3": 64, "c4": 4}[wl], a.dim, dev)
+        if world == 1 and not a.no_extra and wl == "c3":
+            extra["kstar_score_check"] = kstar_score_check(B, dev)
         if a.full_sample and rank == 0:
             S3 = W["prep"]()
             torch.cuda.synchronize()

@@ -4,8 +4,8 @@
 //   kstar_v220505 / kstar_nn / bpw_nn               tokamak/common/model_structure.py:69-152   (Keras LSTM(100,100) + Dense nets)
 //   control_trajectories                            tokamak/utils/metrics.py:60-85             (serial over samples there)
 // The reference makes 122 single-sample Keras predict() calls per trajectory, one trajectory after the other.  Here one
-// workgroup carries NS trajectories through all 122 rows: thread t < 400 owns gate column t of the LSTM kernels (the weight
-// element it loads serves the NS samples), the 10-row input window, the hidden / cell states and the small dense nets live in
+// workgroup carries NS trajectories through all 122 rows: thread t < 400 owns gate column t of the LSTM kernels (held in
+// registers for the ten window rows of a call, serving the NS samples), the 10-row input window, the hidden / cell states and the small dense nets live in
 // LDS, and the integer quantisation of the actions (f2i / i2f) and the output de-normalisation run in fp64 like the Python.
 //
 // Per step (kstar_solver.py:236-350):  control: inputs <- f2i(clip(action));  window rows shift (inputs part), new last row;
@@ -63,31 +63,53 @@ __device__ const float (*mlp(const SdcKstarMlp& d, int net, Lds<NS>& s))[MAXW] {
     return cur;
 }
 
-// one LSTM layer over the T window rows; xin row t of sample sm at xin + (sm * T + t) * xstride
-template <int NS, int NI, bool SEQ>
-__device__ void lstm_layer(Lds<NS>& s, const float* xin, int xstride, const float* K, const float* R, const float* b,
-                           const float* inv_next, const float* off_next) {
-    const int col = threadIdx.x;
+// one LSTM layer over the T window rows.  FIRST: input = s.xb (NIN wide), output sequence -> s.seq through the next
+// BatchNormalization; otherwise input = s.seq (U wide) and only the final state is kept.  Thread col < 400 holds its column of
+// the recurrent kernel (and of the input kernel) in registers for the ten rows: the weights are read once per layer call.
+template <int NS, bool FIRST>
+__device__ void lstm_layer(Lds<NS>& s, const float* __restrict__ K, const float* __restrict__ R, const float* __restrict__ b,
+                           const float* __restrict__ inv_next, const float* __restrict__ off_next) {
+    constexpr int NI = FIRST ? NIN : U;
+    constexpr bool KREG = FIRST || NS == 1;              // the input kernel's column in registers too (register budget: 256)
+    const int col = threadIdx.x < G ? threadIdx.x : G - 1;
+    float wk[KREG ? NI : 1], wr[U];
+    if (KREG) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) wk[k] = K[k * G + col];
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) wr[k] = R[k * G + col];
+    const float bias = b[col];
     for (int e = threadIdx.x; e < NS * U; e += KT) { (&s.h[0][0])[e] = 0.f; (&s.c[0][0])[e] = 0.f; }
     __syncthreads();
     for (int t = 0; t < T; ++t) {
-        if (col < G) {
-            float acc[NS];
-            const float bias = b[col];
+        // even / odd input index into two partial sums, the same order whichever way the input kernel is held
+        float acc0[NS], acc1[NS];
 #pragma unroll
-            for (int sm = 0; sm < NS; ++sm) acc[sm] = bias;
-#pragma unroll 6
-            for (int k = 0; k < NI; ++k) {
-                const float w = K[k * G + col];
+        for (int sm = 0; sm < NS; ++sm) { acc0[sm] = bias; acc1[sm] = 0.f; }
+        if (!KREG) {
+#pragma unroll 5
+            for (int k = 0; k < NI; k += 2) {
+                const float w0 = K[k * G + col], w1 = K[(k + 1) * G + col];
 #pragma unroll
-                for (int sm = 0; sm < NS; ++sm) acc[sm] += xin[(sm * T + t) * xstride + k] * w;
+                for (int sm = 0; sm < NS; ++sm) { acc0[sm] += s.seq[sm][t][k] * w0; acc1[sm] += s.seq[sm][t][k + 1] * w1; }
             }
-#pragma unroll 10
-            for (int k = 0; k < U; ++k) {
-                const float w = R[k * G + col];
+        }
+        float acc[NS];
 #pragma unroll
-                for (int sm = 0; sm < NS; ++sm) acc[sm] += s.h[sm][k] * w;
+        for (int sm = 0; sm < NS; ++sm) {
+            float a0 = acc0[sm], a1 = acc1[sm];
+            if (KREG) {
+                const float* x = FIRST ? &s.xb[sm][t][0] : &s.seq[sm][t][0];
+#pragma unroll
+                for (int k = 0; k + 1 < NI; k += 2) { a0 += x[k] * wk[k]; a1 += x[k + 1] * wk[k + 1]; }
             }
+            const float* hh = &s.h[sm][0];
+#pragma unroll
+            for (int k = 0; k < U; k += 2) { a0 += hh[k] * wr[k]; a1 += hh[k + 1] * wr[k + 1]; }
+            acc[sm] = a0 + a1;
+        }
+        if (threadIdx.x < G) {
 #pragma unroll
             for (int sm = 0; sm < NS; ++sm) s.z[sm][col] = acc[sm];
         }
@@ -99,7 +121,7 @@ __device__ void lstm_layer(Lds<NS>& s, const float* xin, int xstride, const floa
             const float hn = sigmoidf(zo) * tanhf(cn);
             s.c[sm][u] = cn;
             s.h[sm][u] = hn;
-            if (SEQ) s.seq[sm][t][u] = hn * inv_next[u] + off_next[u];
+            if (FIRST) s.seq[sm][t][u] = hn * inv_next[u] + off_next[u];
         }
         __syncthreads();
     }
@@ -215,8 +237,8 @@ __global__ __launch_bounds__(KT) void kstar_rollout_kernel(const SdcKstarModel m
             const float* R1 = K1 + U * G; const float* bb1 = R1 + U * G;
             for (int e = tid; e < NS * T * NIN; e += KT) { const int j = e % NIN; (&s.xb[0][0][0])[e] = (&s.win[0][0][0])[e] * inv0[j] + off0[j]; }
             __syncthreads();
-            lstm_layer<NS, NIN, true>(s, &s.xb[0][0][0], NIN, K0, R0, bb0, inv1, off1);
-            lstm_layer<NS, U, false>(s, &s.seq[0][0][0], U, K1, R1, bb1, nullptr, nullptr);
+            lstm_layer<NS, true>(s, K0, R0, bb0, inv1, off1);
+            lstm_layer<NS, false>(s, K1, R1, bb1, nullptr, nullptr);
             for (int e = tid; e < NS * U; e += KT) s.va[e / U][e % U] = s.h[e / U][e % U];
             __syncthreads();
             const float (*r)[MAXW] = mlp<NS>(m.head, net, s);
@@ -287,6 +309,9 @@ extern "C" int sdc_kstar_rollout(const SdcKstarModel* mp, const float* actions, 
     if (B <= 256)
         hipLaunchKernelGGL(kstar_rollout_kernel<1>, dim3((unsigned)B), dim3(KT), 0, s, m, actions, act_b_stride, act_t_stride, act_c_stride,
                            out, (const double*)work, B, nsteps);
+    else if (B <= 512)
+        hipLaunchKernelGGL(kstar_rollout_kernel<2>, dim3((unsigned)((B + 1) / 2)), dim3(KT), 0, s, m, actions, act_b_stride, act_t_stride,
+                           act_c_stride, out, (const double*)work, B, nsteps);
     else
         hipLaunchKernelGGL(kstar_rollout_kernel<4>, dim3((unsigned)((B + 3) / 4)), dim3(KT), 0, s, m, actions, act_b_stride, act_t_stride,
                            act_c_stride, out, (const double*)work, B, nsteps);

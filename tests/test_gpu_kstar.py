@@ -84,19 +84,19 @@ def test_action_quantisation_clip_and_truncation():
     assert (got[2] == got[3]).all() and not (got[0] == got[2]).all()
 
 
-def test_both_kernel_shapes_and_ragged_batches_agree():
-    """B <= 256 runs one trajectory per workgroup, larger batches four: the same trajectories must come out bit-identical, with a
-    batch that is not a multiple of four"""
+def test_all_kernel_shapes_and_ragged_batches_agree():
+    """B <= 256 runs one trajectory per workgroup, B <= 512 two, larger batches four: the same trajectories must come out
+    bit-identical whatever the batch they ride in, with batches that are not multiples of the group size"""
     w = _weights()
     model = kstar.KSTARModel(w, DEV)
-    acts = torch.from_numpy(_actions(259, 3)).to(DEV)
-    big = model.rollout(acts)
-    small = model.rollout(acts[:7])
-    assert torch.equal(big[:7], small)
-    last = model.rollout(acts[256:259])
-    assert torch.equal(big[256:], last)
-    want = okstar.KSTARSolver(w).simulate(acts[258].cpu().numpy())
-    assert _rel(big[258].cpu().numpy(), want) < 2e-4
+    acts = torch.from_numpy(_actions(515, 3)).to(DEV)
+    big = model.rollout(acts)                      # four per workgroup, 3 trajectories in the last one
+    mid = model.rollout(acts[:301])                # two per workgroup, 1 in the last one
+    small = model.rollout(acts[:7])                # one per workgroup
+    assert torch.equal(big[:301], mid) and torch.equal(big[:7], small)
+    assert torch.equal(big[512:], model.rollout(acts[512:515]))
+    want = okstar.KSTARSolver(w).simulate(acts[514].cpu().numpy())
+    assert _rel(big[514].cpu().numpy(), want) < 2e-4
 
 
 def test_control_trajectories_reads_the_sample_tensor_in_place():
