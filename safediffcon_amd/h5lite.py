@@ -28,6 +28,20 @@ def _pad8(n):
     return (n + 7) & ~7
 
 
+def _guard(fn):
+    """a truncated or foreign file shows up as an out-of-range read: report it as H5Error, not as struct.error / IndexError"""
+    def wrapped(self, *a, **k):
+        try:
+            return fn(self, *a, **k)
+        except H5Error:
+            raise
+        except (struct.error, IndexError, OverflowError, UnicodeDecodeError, ValueError) as e:
+            f = getattr(self, "f", self)
+            raise H5Error(f"{getattr(f, 'path', '?')}: malformed or truncated HDF5 structure ({type(e).__name__}: {e})") from e
+    wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+    return wrapped
+
+
 class _Type:
     """a parsed datatype message"""
 
@@ -121,6 +135,7 @@ class Dataset(_Node):
         if self.dtype is None:
             raise H5Error("variable-length datasets are not supported")
 
+    @_guard
     def __getitem__(self, key):
         n = int(np.prod(self.shape)) if self.shape else 1
         if self.data_addr == UNDEF:                          # never written: the fill value, which h5py leaves at zero
@@ -174,7 +189,11 @@ class File(Group):
         with open(path, "rb") as fh:
             self.buf = fh.read()
         self.path = str(path)
-        buf = self.buf
+        self._parse_superblock()
+
+    @_guard
+    def _parse_superblock(self):
+        path, buf = self.path, self.buf
         if buf[:8] != b"\x89HDF\r\n\x1a\n":
             raise H5Error(f"{path}: not an HDF5 file")
         version = buf[8]
@@ -276,6 +295,7 @@ class File(Group):
         walk(btree)
         return links
 
+    @_guard
     def _open(self, addr):
         if addr not in self._cache:
             types = {t for (t, _, _) in self._messages(addr)}
@@ -298,6 +318,7 @@ class File(Group):
             p += 8 + self.L + _pad8(osize)
         raise H5Error(f"global heap object {index} not found in the collection at {coll:#x}")
 
+    @_guard
     def _attribute(self, off):
         buf = self.buf
         version = buf[off]

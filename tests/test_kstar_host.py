@@ -36,6 +36,17 @@ def test_h5lite_reads_the_keras_files_and_the_fixture_is_their_content():
     kstar.load_weights(REF_WEIGHTS, n_models=10)
 
 
+@pytest.mark.skipif(not os.path.isdir(REF_WEIGHTS), reason="the reference's weight files are not on this machine")
+def test_h5lite_reports_a_truncated_file_as_such(tmp_path):
+    blob = open(os.path.join(REF_WEIGHTS, "bpw", "best_model0"), "rb").read()
+    for cut in (100, 3000, 20000):
+        p = tmp_path / f"cut{cut}.h5"
+        p.write_bytes(blob[:cut])
+        with pytest.raises(h5lite.H5Error):
+            f = h5lite.File(p)
+            [d[...] for d in f["model_weights"].visit_datasets().values()]
+
+
 def test_h5lite_rejects_what_it_does_not_read(tmp_path):
     p = tmp_path / "x.h5"
     p.write_bytes(b"not an hdf5 file at all")
