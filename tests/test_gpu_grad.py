@@ -91,7 +91,10 @@ def test_conv_transpose_and_upsample_wgrad():
 
 
 @pytest.mark.parametrize("shape,G,cond,res", [((3, 64, 4, 16, 16), 8, True, True), ((2, 128, 1, 8, 64), 1, True, False),
-                                              ((4, 256, 1, 1, 32), 1, False, True), ((2, 64, 8, 32, 32), 8, False, False)])
+                                              ((4, 256, 1, 1, 32), 1, False, True), ((2, 64, 8, 32, 32), 8, False, False),
+                                              # ragged: row counts that are not multiples of 4, rows that are not multiples of 64 / 256
+                                              ((3, 70, 1, 1, 19), 7, True, True), ((5, 24, 1, 3, 37), 8, True, False),
+                                              ((1, 16, 2, 24, 25), 4, False, False), ((67, 6, 1, 1, 16), 1, True, False)])
 def test_gn_silu_backward(shape, G, cond, res):
     B, Cc = shape[0], shape[1]
     h = det_tensor(shape, 110)
