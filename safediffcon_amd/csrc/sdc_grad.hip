@@ -236,6 +236,210 @@ int launch_wgrad_bkp(const WgradArgs& a, dim3 grid, hipStream_t s) {
     return launch_wgrad<KW, SW, 16>(a, grid, s);
 }
 
+// 3 x 3 (x kD) 'same' convs: one workgroup takes the three kh taps of a (kd, m tile, n tile) together.  Output row oh needs the
+// input rows oh - 1, oh, oh + 1: walking the rows of a (b, od) block in order, every G row and every X row is fetched ONCE and
+// kept in a four-slot LDS ring (slot = row & 3) while it serves three output rows -- a third of the fabric reads of the per-tap
+// kernel above, which at 64 channels (one m and one n tile: nothing else amortises the loads) is what bounds it.
+// Step t of a segment [oh0, oh1) of a block: park X row t and G row t, run the MFMAs of output row t - 1 (t = oh0 - 1 .. oh1).
+template <int BKP>
+__global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
+    constexpr int KW = 3;
+    constexpr int SPAN = BKP - 1 + KW, AP = BKP + 1, BP = SPAN | 1;
+    constexpr int NBL = (64 * SPAN + NT - 1) / NT, GPT = BKP / 4;
+    constexpr int ASZ = 64 * AP, BSZ = 64 * BP;
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    float* const As = wlds;                       // [4][ASZ]
+    float* const Bs = wlds + 4 * ASZ;             // [4][BSZ]
+    const SdcWgradDesc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+    int tb = blockIdx.x;
+    const int kd = tb % d.kD; tb /= d.kD;
+    const int nt = tb % a.Nt;
+    const int mt = tb / a.Nt;
+    const int m0 = mt * 64, n0 = nt * 64;
+    const int split = blockIdx.y;
+    const int R = d.B * d.oD * d.oH;
+    const int r_lo = split * a.rows_per_split;
+    const int r_hi = min(R, r_lo + a.rows_per_split);
+
+    const int gm = tid >> 2, gq = tid & 3;
+    const bool gm_ok = m0 + gm < d.M;
+    const int64_t g_moff = (int64_t)(gm_ok ? m0 + gm : 0) * d.gs[1];
+    const bool gvec = d.gs[4] == 1 && ((d.gs[0] | d.gs[1] | d.gs[2] | d.gs[3]) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.g) & 15) == 0;
+    int xn[NBL], xj[NBL];
+    int64_t x_noff[NBL];
+    bool xn_ok[NBL];
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+        const int e = tid + NT * i;
+        xn[i] = e / SPAN;
+        xj[i] = e - xn[i] * SPAN;
+        xn_ok[i] = e < 64 * SPAN && n0 + xn[i] < d.N;
+        x_noff[i] = (int64_t)(xn_ok[i] ? n0 + xn[i] : 0) * d.xs[1];
+    }
+    const int iWu = d.iW << a.lgW, iDu = d.iD << a.lgD;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float bsum = 0.0f;
+    const bool want_bias = a.bpart != nullptr && nt == 0 && kd == 0;
+
+    // walk: (block blk = (b, od), segment [oh0, oh1) of it inside this split, step t)
+    struct Step { int blk, oh0, oh1, t; };
+    auto open_block = [&](int blk, Step& st) {
+        st.blk = blk;
+        st.oh0 = max(r_lo - blk * d.oH, 0);
+        st.oh1 = min(r_hi - blk * d.oH, d.oH);
+        st.t = st.oh0 - 1;
+    };
+    auto next_step = [&](Step& st) -> bool {            // false when the split is done
+        if (st.t < st.oh1) { ++st.t; return true; }
+        if ((st.blk + 1) * d.oH >= r_hi) return false;
+        open_block(st.blk + 1, st);
+        return true;
+    };
+    auto blk_valid = [&](const Step& st, int& b, int& od, int& idu) {
+        od = st.blk % d.oD; b = st.blk / d.oD;
+        idu = od * d.sD - d.pD + kd;
+        return idu >= 0 && idu < iDu;
+    };
+
+    float greg[GPT], xreg[NBL];
+    auto fetch = [&](const Step& st) {
+        int b, od, idu;
+        const bool bv = blk_valid(st, b, od, idu);
+        const bool gneed = st.t >= st.oh0 && st.t < st.oh1 && (bv || want_bias);
+        const bool xneed = bv && st.t >= 0 && st.t < d.iH;
+        if (gneed) {
+            const int p0 = GPT * gq;
+            const float* gp = a.g + (int64_t)b * d.gs[0] + (int64_t)od * d.gs[2] + (int64_t)st.t * d.gs[3] + g_moff + (int64_t)p0 * d.gs[4];
+            const int left = gm_ok ? d.oW - p0 : 0;
+            if (gvec && left >= GPT) {
+#pragma unroll
+                for (int i = 0; i < GPT / 4; ++i) {
+                    const float4 v = reinterpret_cast<const float4*>(gp)[i];
+                    greg[4 * i] = v.x; greg[4 * i + 1] = v.y; greg[4 * i + 2] = v.z; greg[4 * i + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < GPT; ++i) greg[i] = i < left ? gp[(int64_t)i * d.gs[4]] : 0.0f;
+            }
+        }
+        if (xneed) {
+            const float* xp = a.x + (int64_t)b * d.xs[0] + (int64_t)(idu >> a.lgD) * d.xs[2] + (int64_t)st.t * d.xs[3];
+#pragma unroll
+            for (int i = 0; i < NBL; ++i) {
+                const int iwu = xj[i] - d.pW;
+                const bool ok = xn_ok[i] && iwu >= 0 && iwu < iWu;
+                xreg[i] = ok ? xp[x_noff[i] + (int64_t)(iwu >> a.lgW) * d.xs[4]] : 0.0f;
+            }
+        }
+    };
+    auto park = [&](const Step& st) {
+        int b, od, idu;
+        const bool bv = blk_valid(st, b, od, idu);
+        const bool gneed = st.t >= st.oh0 && st.t < st.oh1 && (bv || want_bias);
+        const bool xneed = bv && st.t >= 0 && st.t < d.iH;
+        const int slot = st.t & 3;
+        if (gneed) {
+            if (want_bias) {
+#pragma unroll
+                for (int i = 0; i < GPT; ++i) bsum += greg[i];
+            }
+            float* Ab = As + slot * ASZ;
+#pragma unroll
+            for (int i = 0; i < GPT; ++i) Ab[gm * AP + GPT * gq + i] = greg[i];
+        }
+        if (xneed) {
+            float* Bb = Bs + slot * BSZ;
+#pragma unroll
+            for (int i = 0; i < NBL; ++i)
+                if (tid + NT * i < 64 * SPAN) Bb[xn[i] * BP + xj[i]] = xreg[i];
+        }
+    };
+    auto compute = [&](const Step& st) {
+        int b, od, idu;
+        const int oh = st.t - 1;
+        if (!(oh >= st.oh0 && oh < st.oh1) || !blk_valid(st, b, od, idu)) return;
+        const float* Ab = As + (oh & 3) * ASZ + (wm * 32 + l31) * AP + lh;
+        const int boff = (wn * 32 + l31) * BP + lh;
+        const bool v0 = oh - 1 >= 0, v2 = oh + 1 < d.iH;
+        const float* B0 = Bs + ((oh - 1) & 3) * BSZ + boff;
+        const float* B1 = Bs + (oh & 3) * BSZ + boff;
+        const float* B2 = Bs + ((oh + 1) & 3) * BSZ + boff;
+#pragma unroll 4
+        for (int kk = 0; kk < BKP / 2; ++kk) {
+            const float av = Ab[2 * kk];
+            if (v0) {
+#pragma unroll
+                for (int t = 0; t < KW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B0[2 * kk + t], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < KW; ++t) acc[3 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B1[2 * kk + t], acc[3 + t], 0, 0, 0);
+            if (v2) {
+#pragma unroll
+                for (int t = 0; t < KW; ++t) acc[6 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B2[2 * kk + t], acc[6 + t], 0, 0, 0);
+            }
+        }
+    };
+
+    if (r_lo < r_hi) {
+        Step cur, nxt;
+        open_block(r_lo / d.oH, cur);
+        fetch(cur);
+        park(cur);
+        __syncthreads();
+        while (true) {
+            nxt = cur;
+            const bool more = next_step(nxt);
+            if (more) fetch(nxt);
+            compute(cur);
+            if (!more) break;
+            if (nxt.blk != cur.blk) __syncthreads();     // a new block's first slot may be one this step still reads
+            park(nxt);
+            __syncthreads();
+            cur = nxt;
+        }
+    }
+
+    const int taps = d.kD * 9;
+    float* P = a.part + (int64_t)split * d.M * d.N * taps;
+    const int n = n0 + wn * 32 + l31;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const int m = m0 + wm * 32 + 8 * (rr >> 2) + 4 * lh + (rr & 3);
+        if (m < d.M && n < d.N) {
+            float* o = P + ((int64_t)m * d.N + n) * taps + kd * 9;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) o[t] = acc[t][rr];
+        }
+    }
+    if (want_bias) {
+        bsum += __shfl_xor(bsum, 1, 64);
+        bsum += __shfl_xor(bsum, 2, 64);
+        if (gq == 0 && gm_ok) a.bpart[(int64_t)split * d.M + m0 + gm] = bsum;
+    }
+}
+
+// the merged-kh form applies to the 3 x 3 (x kD) stride-1 'same' convs whose rows are one chunk
+bool wgrad_mkh_ok(const SdcWgradDesc& d) {
+    return d.kW == 3 && d.sW == 1 && d.kH == 3 && d.sH == 1 && d.pH == 1 && d.uH == 1 && d.iH == d.oH &&
+           (d.oW == 16 || d.oW == 32 || d.oW == 64);
+}
+
+template <int BKP>
+int launch_wgrad_mkh(const WgradArgs& a, dim3 grid, hipStream_t s) {
+    const size_t lds = (size_t)4 * 64 * ((BKP + 1) + ((BKP + 2) | 1)) * sizeof(float);
+    static std::atomic<uint64_t> attr{0};
+    SDC_LDS_OPTIN(attr, (wgrad_mkh_kernel<BKP>), 160 * 1024, "sdc_conv_wgrad");
+    hipLaunchKernelGGL((wgrad_mkh_kernel<BKP>), grid, dim3(NT), lds, s, a);
+    return SDC_OK;
+}
+
 // out[i] = sum_s part[s][i] in a fixed order.  KG = 1: a thread per element, splits in sequence (loads four deep).  KG = 4 (many
 // splits over a small gradient): wave g of the workgroup sums the splits s = g (mod 4) of 64 elements, wave 0 adds the four
 // partial sums in order -- the chain of dependent HBM latencies is what this reduction costs, not its bytes.
@@ -276,7 +480,7 @@ void launch_sum_splits(const float* part, float* out, int64_t n, int nsplit, hip
 
 int wgrad_splits(const SdcWgradDesc& d, int* rows_per_split) {
     const int Mt = (d.M + 63) / 64, Nt = (d.N + 63) / 64;
-    const int64_t tiles = (int64_t)Mt * Nt * d.kD * d.kH;
+    const int64_t tiles = (int64_t)Mt * Nt * d.kD * (wgrad_mkh_ok(d) ? 1 : d.kH);
     const int R = d.B * d.oD * d.oH;
     // splits: ~3 workgroups per CU in flight (a layer with few tiles and long rows is otherwise a handful of workgroups); every
     // split writes, and the reduction re-reads, a full copy of the gradient, at HBM rate: cheap beside idle CUs, bounded at 256 MB
@@ -321,12 +525,14 @@ extern "C" int sdc_conv_wgrad(const SdcWgradDesc* dp, const float* g, const floa
     // one split: the workgroups write the gradient itself (no partial copy, no reduction pass)
     a.part = a.nsplit == 1 ? dw : static_cast<float*>(work);
     a.bpart = dbias ? (a.nsplit == 1 ? dbias : static_cast<float*>(work) + (int64_t)a.nsplit * nw) : nullptr;
-    const int64_t tiles = (int64_t)a.Mt * a.Nt * d.kD * d.kH;
+    const bool mkh = wgrad_mkh_ok(d);
+    const int64_t tiles = (int64_t)a.Mt * a.Nt * d.kD * (mkh ? 1 : d.kH);
     SDC_REQUIRE(tiles < (1ll << 31) && a.nsplit < 65536, SDC_EINVAL, "sdc_conv_wgrad: grid too large");
     dim3 grid((unsigned)tiles, (unsigned)a.nsplit);
     hipStream_t s = sdc::as_stream(stream);
     int lrc;
-    if (d.kW == 1 && d.sW == 1) lrc = launch_wgrad_bkp<1, 1>(a, grid, s);
+    if (mkh) lrc = d.oW == 64 ? launch_wgrad_mkh<64>(a, grid, s) : (d.oW == 32 ? launch_wgrad_mkh<32>(a, grid, s) : launch_wgrad_mkh<16>(a, grid, s));
+    else if (d.kW == 1 && d.sW == 1) lrc = launch_wgrad_bkp<1, 1>(a, grid, s);
     else if (d.kW == 3 && d.sW == 1) lrc = launch_wgrad_bkp<3, 1>(a, grid, s);
     else if (d.kW == 7 && d.sW == 1) lrc = launch_wgrad_bkp<7, 1>(a, grid, s);
     else if (d.kW == 4 && d.sW == 2) lrc = launch_wgrad_bkp<4, 2>(a, grid, s);

@@ -29,6 +29,13 @@ CASES = [
     dict(nd=1, B=3, cin=12, cout=256, sp=(128,), k=7, pad=3),                          # tokamak stem
     dict(nd=2, B=2, cin=64, cout=384, sp=(16, 128), k=1),                              # 1x1 / to_qkv
     dict(nd=3, B=2, cin=64, cout=64, sp=(2, 32, 32), k=(1, 4, 4), stride=(1, 2, 2), pad=(0, 1, 1)),   # smoke Downsample
+    # merged-kh form (3x3 'same', rows of 16 / 32 / 64): splits that start and end inside a (b, od) block, ragged tiles,
+    # single-row and two-row images, 1 x 3 x 3 taps
+    dict(nd=3, B=3, cin=72, cout=100, sp=(3, 10, 64), k=3, pad=1),
+    dict(nd=2, B=5, cin=64, cout=64, sp=(6, 16), k=3, pad=1),
+    dict(nd=2, B=7, cin=32, cout=48, sp=(1, 32), k=3, pad=1),
+    dict(nd=3, B=1, cin=64, cout=64, sp=(5, 2, 64), k=(1, 3, 3), pad=(0, 1, 1)),
+    dict(nd=3, B=2, cin=128, cout=128, sp=(4, 64, 64), k=3, pad=1),
 ]
 
 
