@@ -236,20 +236,25 @@ int launch_wgrad_bkp(const WgradArgs& a, dim3 grid, hipStream_t s) {
     return launch_wgrad<KW, SW, 16>(a, grid, s);
 }
 
-// 3 x 3 (x kD) 'same' convs: one workgroup takes the three kh taps of a (kd, m tile, n tile) together.  Output row oh needs the
-// input rows oh - 1, oh, oh + 1: walking the rows of a (b, od) block in order, every G row and every X row is fetched ONCE and
-// kept in a four-slot LDS ring (slot = row & 3) while it serves three output rows -- a third of the fabric reads of the per-tap
-// kernel above, which at 64 channels (one m and one n tile: nothing else amortises the loads) is what bounds it.
-// Step t of a segment [oh0, oh1) of a block: park X row t and G row t, run the MFMAs of output row t - 1 (t = oh0 - 1 .. oh1).
-template <int BKP>
+// KH x KW (x kD) stride-1 'same' convs (3 x 3, and the 7 x 7 stems in the tap-folded form): one workgroup takes all KH row taps of
+// a (kd, m tile, n tile) together.  Output row oh needs the input rows oh - pH .. oh + pH: walking the rows of a (b, od) block in
+// order, every G row and every X row is fetched ONCE and kept in an LDS ring (slot = row & (size - 1)) while it serves KH output
+// rows -- 1/KH of the fabric reads of the per-tap kernel above, which at 64 channels (one m and one n tile: nothing else
+// amortises the loads) is what bounds it; at the stem (7 input channels) a step now holds 7 x 32 MFMAs per wave instead of 32.
+// Step t of a segment [oh0, oh1) of a block (t = oh0 - pH .. oh1 - 1 + pH): park X row t and G row t - pH, run the MFMAs of
+// output row t - pH.
+template <int KH, int KW, int BKP, bool FOLD>
 __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
-    constexpr int KW = 3;
+    constexpr int PH = KH / 2;
+    constexpr int XS = KH == 3 ? 4 : 8;           // X ring: rows t - 2 PH .. t in use while row t + 1 is parked
+    constexpr int XC = FOLD ? 16 : 64;            // X channels per slot (FOLD: N KW <= 64, so N <= 9)
     constexpr int SPAN = BKP - 1 + KW, AP = BKP + 1, BP = SPAN | 1;
-    constexpr int NBL = (64 * SPAN + NT - 1) / NT, GPT = BKP / 4;
-    constexpr int ASZ = 64 * AP, BSZ = 64 * BP;
+    constexpr int NBL = (XC * SPAN + NT - 1) / NT, GPT = BKP / 4;
+    constexpr int ASZ = 64 * AP, BSZ = XC * BP;
+    constexpr int NACC = FOLD ? KH : KH * KW;
     extern __shared__ __attribute__((aligned(16))) float wlds[];
     float* const As = wlds;                       // [4][ASZ]
-    float* const Bs = wlds + 4 * ASZ;             // [4][BSZ]
+    float* const Bs = wlds + 4 * ASZ;             // [XS][BSZ]
     const SdcWgradDesc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
@@ -275,16 +280,19 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
         const int e = tid + NT * i;
         xn[i] = e / SPAN;
         xj[i] = e - xn[i] * SPAN;
-        xn_ok[i] = e < 64 * SPAN && n0 + xn[i] < d.N;
+        xn_ok[i] = e < XC * SPAN && n0 + xn[i] < d.N;
         x_noff[i] = (int64_t)(xn_ok[i] ? n0 + xn[i] : 0) * d.xs[1];
     }
     const int iWu = d.iW << a.lgW, iDu = d.iD << a.lgD;
 
-    f32x16 acc[9];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    // FOLD: this lane's column n' = wn 32 + l31 -> (channel fci, tap fkw)
+    const int fcol = wn * 32 + l31, fci = fcol / KW, fkw = fcol - fci * KW;
+    const bool fok = fci < d.N;
     float bsum = 0.0f;
     const bool want_bias = a.bpart != nullptr && nt == 0 && kd == 0;
 
@@ -294,10 +302,10 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
         st.blk = blk;
         st.oh0 = max(r_lo - blk * d.oH, 0);
         st.oh1 = min(r_hi - blk * d.oH, d.oH);
-        st.t = st.oh0 - 1;
+        st.t = st.oh0 - PH;
     };
     auto next_step = [&](Step& st) -> bool {            // false when the split is done
-        if (st.t < st.oh1) { ++st.t; return true; }
+        if (st.t < st.oh1 - 1 + PH) { ++st.t; return true; }
         if ((st.blk + 1) * d.oH >= r_hi) return false;
         open_block(st.blk + 1, st);
         return true;
@@ -312,11 +320,12 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
     auto fetch = [&](const Step& st) {
         int b, od, idu;
         const bool bv = blk_valid(st, b, od, idu);
-        const bool gneed = st.t >= st.oh0 && st.t < st.oh1 && (bv || want_bias);
+        const int grow = st.t - PH;
+        const bool gneed = grow >= st.oh0 && grow < st.oh1 && (bv || want_bias);
         const bool xneed = bv && st.t >= 0 && st.t < d.iH;
         if (gneed) {
             const int p0 = GPT * gq;
-            const float* gp = a.g + (int64_t)b * d.gs[0] + (int64_t)od * d.gs[2] + (int64_t)st.t * d.gs[3] + g_moff + (int64_t)p0 * d.gs[4];
+            const float* gp = a.g + (int64_t)b * d.gs[0] + (int64_t)od * d.gs[2] + (int64_t)grow * d.gs[3] + g_moff + (int64_t)p0 * d.gs[4];
             const int left = gm_ok ? d.oW - p0 : 0;
             if (gvec && left >= GPT) {
 #pragma unroll
@@ -342,47 +351,52 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
     auto park = [&](const Step& st) {
         int b, od, idu;
         const bool bv = blk_valid(st, b, od, idu);
-        const bool gneed = st.t >= st.oh0 && st.t < st.oh1 && (bv || want_bias);
+        const int grow = st.t - PH;
+        const bool gneed = grow >= st.oh0 && grow < st.oh1 && (bv || want_bias);
         const bool xneed = bv && st.t >= 0 && st.t < d.iH;
-        const int slot = st.t & 3;
         if (gneed) {
             if (want_bias) {
 #pragma unroll
                 for (int i = 0; i < GPT; ++i) bsum += greg[i];
             }
-            float* Ab = As + slot * ASZ;
+            float* Ab = As + (grow & 3) * ASZ;
 #pragma unroll
             for (int i = 0; i < GPT; ++i) Ab[gm * AP + GPT * gq + i] = greg[i];
         }
         if (xneed) {
-            float* Bb = Bs + slot * BSZ;
+            float* Bb = Bs + (st.t & (XS - 1)) * BSZ;
 #pragma unroll
             for (int i = 0; i < NBL; ++i)
-                if (tid + NT * i < 64 * SPAN) Bb[xn[i] * BP + xj[i]] = xreg[i];
+                if (tid + NT * i < XC * SPAN) Bb[xn[i] * BP + xj[i]] = xreg[i];
         }
     };
     auto compute = [&](const Step& st) {
         int b, od, idu;
-        const int oh = st.t - 1;
+        const int oh = st.t - PH;
         if (!(oh >= st.oh0 && oh < st.oh1) || !blk_valid(st, b, od, idu)) return;
         const float* Ab = As + (oh & 3) * ASZ + (wm * 32 + l31) * AP + lh;
-        const int boff = (wn * 32 + l31) * BP + lh;
-        const bool v0 = oh - 1 >= 0, v2 = oh + 1 < d.iH;
-        const float* B0 = Bs + ((oh - 1) & 3) * BSZ + boff;
-        const float* B1 = Bs + (oh & 3) * BSZ + boff;
-        const float* B2 = Bs + ((oh + 1) & 3) * BSZ + boff;
+        const int boff = FOLD ? (fok ? fci : 0) * BP + fkw + lh : (wn * 32 + l31) * BP + lh;
+        bool v[KH];
+        const float* Bk[KH];
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+            const int ih = oh - PH + kh;
+            v[kh] = ih >= 0 && ih < d.iH;
+            Bk[kh] = Bs + (ih & (XS - 1)) * BSZ + boff;
+        }
 #pragma unroll 4
         for (int kk = 0; kk < BKP / 2; ++kk) {
             const float av = Ab[2 * kk];
-            if (v0) {
 #pragma unroll
-                for (int t = 0; t < KW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B0[2 * kk + t], acc[t], 0, 0, 0);
-            }
+            for (int kh = 0; kh < KH; ++kh) {
+                if (!v[kh]) continue;
+                if constexpr (FOLD) {
+                    acc[kh] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, fok ? Bk[kh][2 * kk] : 0.0f, acc[kh], 0, 0, 0);
+                } else {
 #pragma unroll
-            for (int t = 0; t < KW; ++t) acc[3 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B1[2 * kk + t], acc[3 + t], 0, 0, 0);
-            if (v2) {
-#pragma unroll
-                for (int t = 0; t < KW; ++t) acc[6 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B2[2 * kk + t], acc[6 + t], 0, 0, 0);
+                    for (int t = 0; t < KW; ++t)
+                        acc[kh * KW + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bk[kh][2 * kk + t], acc[kh * KW + t], 0, 0, 0);
+                }
             }
         }
     };
@@ -406,16 +420,22 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
         }
     }
 
-    const int taps = d.kD * 9;
+    const int taps = d.kD * KH * KW;
     float* P = a.part + (int64_t)split * d.M * d.N * taps;
     const int n = n0 + wn * 32 + l31;
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
         const int m = m0 + wm * 32 + 8 * (rr >> 2) + 4 * lh + (rr & 3);
-        if (m < d.M && n < d.N) {
-            float* o = P + ((int64_t)m * d.N + n) * taps + kd * 9;
+        if constexpr (FOLD) {
+            if (m < d.M && fok) {
+                float* o = P + ((int64_t)m * d.N + fci) * taps + kd * KH * KW + fkw;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) o[t] = acc[t][rr];
+                for (int kh = 0; kh < KH; ++kh) o[kh * KW] = acc[kh][rr];
+            }
+        } else if (m < d.M && n < d.N) {
+            float* o = P + ((int64_t)m * d.N + n) * taps + kd * KH * KW;
+#pragma unroll
+            for (int t = 0; t < KH * KW; ++t) o[t] = acc[t][rr];
         }
     }
     if (want_bias) {
@@ -425,19 +445,28 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
     }
 }
 
-// the merged-kh form applies to the 3 x 3 (x kD) stride-1 'same' convs whose rows are one chunk
+// the merged-kh form applies to square stride-1 'same' taps whose rows are one chunk: 3 x 3, and 7 x 7 with N * 7 <= 64 (stems)
 bool wgrad_mkh_ok(const SdcWgradDesc& d) {
-    return d.kW == 3 && d.sW == 1 && d.kH == 3 && d.sH == 1 && d.pH == 1 && d.uH == 1 && d.iH == d.oH &&
-           (d.oW == 16 || d.oW == 32 || d.oW == 64);
+    const bool k3 = d.kW == 3 && d.kH == 3 && d.pH == 1;
+    const bool k7 = d.kW == 7 && d.kH == 7 && d.pH == 3 && d.N * 7 <= 64;
+    return (k3 || k7) && d.sW == 1 && d.sH == 1 && d.uH == 1 && d.iH == d.oH && (d.oW == 16 || d.oW == 32 || d.oW == 64);
 }
 
-template <int BKP>
+template <int KH, int KW, int BKP, bool FOLD>
 int launch_wgrad_mkh(const WgradArgs& a, dim3 grid, hipStream_t s) {
-    const size_t lds = (size_t)4 * 64 * ((BKP + 1) + ((BKP + 2) | 1)) * sizeof(float);
+    constexpr int XS = KH == 3 ? 4 : 8, XC = FOLD ? 16 : 64;
+    const size_t lds = ((size_t)4 * 64 * (BKP + 1) + (size_t)XS * XC * ((BKP - 1 + KW) | 1)) * sizeof(float);
     static std::atomic<uint64_t> attr{0};
-    SDC_LDS_OPTIN(attr, (wgrad_mkh_kernel<BKP>), 160 * 1024, "sdc_conv_wgrad");
-    hipLaunchKernelGGL((wgrad_mkh_kernel<BKP>), grid, dim3(NT), lds, s, a);
+    SDC_LDS_OPTIN(attr, (wgrad_mkh_kernel<KH, KW, BKP, FOLD>), 160 * 1024, "sdc_conv_wgrad");
+    hipLaunchKernelGGL((wgrad_mkh_kernel<KH, KW, BKP, FOLD>), grid, dim3(NT), lds, s, a);
     return SDC_OK;
+}
+
+template <int KH, int KW, bool FOLD>
+int launch_wgrad_mkh_bkp(const WgradArgs& a, dim3 grid, hipStream_t s) {
+    if (a.d.oW == 64) return launch_wgrad_mkh<KH, KW, 64, FOLD>(a, grid, s);
+    if (a.d.oW == 32) return launch_wgrad_mkh<KH, KW, 32, FOLD>(a, grid, s);
+    return launch_wgrad_mkh<KH, KW, 16, FOLD>(a, grid, s);
 }
 
 // out[i] = sum_s part[s][i] in a fixed order.  KG = 1: a thread per element, splits in sequence (loads four deep).  KG = 4 (many
@@ -531,7 +560,7 @@ extern "C" int sdc_conv_wgrad(const SdcWgradDesc* dp, const float* g, const floa
     dim3 grid((unsigned)tiles, (unsigned)a.nsplit);
     hipStream_t s = sdc::as_stream(stream);
     int lrc;
-    if (mkh) lrc = d.oW == 64 ? launch_wgrad_mkh<64>(a, grid, s) : (d.oW == 32 ? launch_wgrad_mkh<32>(a, grid, s) : launch_wgrad_mkh<16>(a, grid, s));
+    if (mkh) lrc = d.kW == 3 ? launch_wgrad_mkh_bkp<3, 3, false>(a, grid, s) : launch_wgrad_mkh_bkp<7, 7, true>(a, grid, s);
     else if (d.kW == 1 && d.sW == 1) lrc = launch_wgrad_bkp<1, 1>(a, grid, s);
     else if (d.kW == 3 && d.sW == 1) lrc = launch_wgrad_bkp<3, 1>(a, grid, s);
     else if (d.kW == 7 && d.sW == 1) lrc = launch_wgrad_bkp<7, 1>(a, grid, s);
