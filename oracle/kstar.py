@@ -207,3 +207,49 @@ def reported_safe_metric(q95, threshold):
     inside = (ratio * safe).sum() / max(safe.sum(), 1)
     outside = (ratio * unsafe).sum() / max(unsafe.sum(), 1)
     return float(inside + outside)
+
+
+# ---- the reference's trained controller in closed loop (what generated its dataset): kstar_data_generator_random_target.py
+LOW_TARGET, HIGH_TARGET = [0.8, 4.0, 0.80], [2.1, 7.0, 1.05]             # :69-70
+TARGET_INIT = [1.45, 5.5, 0.925]                                         # :101
+RAND_TARGET_MINS, RAND_TARGET_MAXS = [1.06, 4.6, 0.85], [1.84, 6.4, 1.00]   # :104-105
+LOOKBACK = 3
+
+
+def rl_policy(policy, observation):
+    """SB2_model.predict (common/model_structure.py:191-204; relu hidden layers, tanh head, bavg = 0): 39 -> 9 actuators"""
+    low = np.array((LOW_ACTION + LOW_TARGET) * LOOKBACK + LOW_TARGET)
+    high = np.array((HIGH_ACTION + HIGH_TARGET) * LOOKBACK + HIGH_TARGET)
+    y = 2 * (observation - low) / (high - low) - 1
+    for i in range(len(policy["layers"])):
+        y = np.maximum(0, y @ policy[f"fc{i}_kernel"] + policy[f"fc{i}_bias"])
+    y = np.tanh(y @ policy["dense_kernel"] + policy["dense_bias"])
+    return 0.5 * (np.array(HIGH_ACTION) - np.array(LOW_ACTION)) * (y + 1) + np.array(LOW_ACTION)
+
+
+def closed_loop(weights, policy, seed=0, n_model_box=1, solver_cls=None):
+    """random_target_simulation (kstar_data_generator_random_target.py:433-520) without the bookkeeping: the controller sees the
+    last three (action, beta_p, q95, l_i) rows and the target, the target changes every 30 steps
+    -> (actions (121, 9), rows (122, 8), targets (121, 3))"""
+    rng = np.random.default_rng(seed)
+
+    def new_target():
+        return [i2f(f2i(rng.uniform(lo, hi))) for lo, hi in zip(RAND_TARGET_MINS, RAND_TARGET_MAXS)]
+
+    s = (solver_cls or KSTARSolver)(weights, n_model_box)
+    s.predict_0d(True)
+    rows = [[s.out[k] for k in OUTPUT_ORDER]]
+    hist = [list(LOW_ACTION) + list(TARGET_INIT)] * LOOKBACK
+    target = new_target()
+    actions, targets = [], []
+    for step in range(1 + 12 * 10):
+        a = rl_policy(policy, np.array(sum(hist, []) + target))
+        s.control(a)
+        s.predict_0d(False)
+        hist = hist[1:] + [list(a) + [s.out["bp"], s.out["q95"], s.out["li"]]]
+        actions.append(a)
+        targets.append(list(target))
+        rows.append([s.out[k] for k in OUTPUT_ORDER])
+        if step % 30 == 29:
+            target = new_target()
+    return np.array(actions), np.array(rows), np.array(targets)

@@ -53,6 +53,24 @@ def test_rollout_equals_the_oracle(nbox):
     assert worst < 2e-4
 
 
+def test_rollout_of_the_controllers_own_action_sequences():
+    """the action traces the reference's trained controller produces in closed loop (what its dataset holds, and what a sampled
+    control sequence looks like): replayed through sdc_kstar_rollout they give the rows the closed loop saw"""
+    w = _weights()
+    policy = dict(np.load(os.path.join(os.path.dirname(GOLD), "kstar_rl_policy.npz")))
+    runs = [okstar.closed_loop(w, policy, seed=s) for s in (0, 1, 2)]
+    acts = torch.from_numpy(np.stack([r[0] for r in runs]).astype(np.float32)).to(DEV)
+    got = kstar.KSTARModel(w, DEV).rollout(acts).cpu().numpy()
+    worst = 0.0
+    for b, (a64, rows, _) in enumerate(runs):
+        # the loop ran on float64 actions; replay the float32 ones the tensor holds through the oracle for the comparison
+        want = okstar.KSTARSolver(w).simulate(acts[b].cpu().numpy())
+        worst = max(worst, _rel(got[b], want))
+        assert _rel(want, rows) < 5e-3                    # float32 actions move a few quantisation cells at most
+    print(f"[measured] KSTAR rollout of closed-loop action traces: {worst:.2e}")
+    assert worst < 2e-4
+
+
 def test_first_row_is_the_steady_state_network_and_constant_inputs_stay_exact():
     """row 0 comes from kstar_nn on the initial inputs alone: identical for every sample; the fp64 side of every row
     (quantised inputs -> H-factor formula) must agree with the Python arithmetic to fp64 rounding"""

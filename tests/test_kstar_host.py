@@ -90,6 +90,48 @@ def test_oracle_rollout_is_physical_and_the_two_surrogates_agree():
     assert okstar.KSTARSolver(_weights()).simulate(np.tile(hi_ip, (121, 1)))[-1, 4] < okstar.KSTARSolver(_weights()).simulate(np.tile(lo_ip, (121, 1)))[-1, 4]
 
 
+def _tracking_error(rows, targets):
+    """mean |controlled - target| / nominal over the last 10 steps of every 30-step target window, per (beta_p, q95, l_i)"""
+    got = rows[1:, [1, 4, 6]]
+    settled = np.arange(121) % 30 >= 20
+    return np.mean(np.abs(got - targets)[settled] / np.array(okstar.TARGET_INIT), axis=0)
+
+
+def test_the_references_trained_controller_tracks_its_targets_on_the_restated_simulator():
+    """Behavioural anchor for a row whose numbers cannot be pinned (no TensorFlow): the reference ships the actor of the RL
+    controller it trained AGAINST ITS OWN simulator (weights/rl/rt_control/3frame_v220505, evaluated in numpy by
+    common/model_structure.py:178-204) and generated its dataset by closing that loop
+    (kstar_data_generator_random_target.py:433-520).  A feed-forward actor without integral action lands on random targets
+    only if the plant in the loop has the steady-state map it was trained on: on the restated simulator it does, to 1-2 %;
+    with the LSTM gates read in another order, or another BatchNormalization epsilon, it misses by 15-80 %."""
+    w = _weights()
+    policy = dict(np.load(os.path.join(os.path.dirname(GOLD), "kstar_rl_policy.npz")))
+    for seed in (0, 1):
+        actions, rows, targets = okstar.closed_loop(w, policy, seed=seed)
+        err = _tracking_error(rows, targets)
+        print(f"[measured] closed loop seed {seed}: mean tracking error (beta_p, q95, l_i) = {np.round(err * 100, 2)} %")
+        assert (err < 0.03).all()
+        assert (actions >= np.array(okstar.LOW_ACTION) - 1e-12).all() and (actions <= np.array(okstar.HIGH_ACTION) + 1e-12).all()
+
+    # negative controls: the same loop around a mis-restated network
+    def swapped_gates(xs, wt, rs):
+        units = wt["recurrent_kernel"].shape[0]
+        perm = np.r_[0:2 * units, 3 * units:4 * units, 2 * units:3 * units]          # i, f, o, c instead of i, f, c, o
+        return real_lstm(xs, {k: (v[..., perm] if k != "x" else v) for k, v in wt.items()}, rs)
+
+    real_lstm, real_bn = okstar.lstm, okstar.batchnorm
+    try:
+        okstar.lstm = swapped_gates
+        bad = _tracking_error(*okstar.closed_loop(w, policy, seed=0)[1:])
+        assert bad.max() > 0.15
+        okstar.lstm = real_lstm
+        okstar.batchnorm = lambda x, bn: real_bn(x, dict(bn, eps=1e-5))
+        bad = _tracking_error(*okstar.closed_loop(w, policy, seed=0)[1:])
+        assert bad.max() > 0.10
+    finally:
+        okstar.lstm, okstar.batchnorm = real_lstm, real_bn
+
+
 def test_oracle_ensemble_is_the_mean_of_its_members():
     w = _weights()
     acts = np.tile(NOMINAL, (121, 1))
