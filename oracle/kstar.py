@@ -3,7 +3,9 @@ cpu_baseline may import it; the product never does).
 
 PARITY UNPINNED.  The reference runs this path through TensorFlow 2.13 / Keras (``tokamak/common/model_structure.py:2``), which
 is not installed here and cannot be (no network); the reference ships no stored outputs of the simulator either (the
-known-answer check of ``tokamak/kstar_solver.py:435-450`` reads data files that are not in the tree).  What this file restates:
+known-answer check of ``tokamak/kstar_solver.py:435-450`` reads data files that are not in the tree).  What anchors it instead:
+the reference's own trained controller, closed around this restatement, reaches its random targets to 1-2 % (``closed_loop``
+below, tests/test_kstar_host.py; mis-restated networks miss by 15-80 %).  What this file restates:
 
   * the Keras layers the surrogate is built from, from Keras' published layer definitions (TF 2.13 ``keras.layers``):
       BatchNormalization at inference   y = x * inv + (beta - mean * inv),  inv = gamma / sqrt(var + eps)  [tf.nn.batch_normalization]
