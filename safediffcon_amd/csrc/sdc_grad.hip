@@ -251,7 +251,14 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
     constexpr int SPAN = BKP - 1 + KW, AP = BKP + 1, BP = SPAN | 1;
     constexpr int NBL = (XC * SPAN + NT - 1) / NT, GPT = BKP / 4;
     constexpr int ASZ = 64 * AP, BSZ = XC * BP;
-    constexpr int NACC = FOLD ? KH : KH * KW;
+    // WINO (the 3 x 3 form): the three kw taps of a row tap as a Winograd F(3,2) correlation over pairs of positions -- the weight
+    // gradient of F(2,3):  dW = G^T [ (A dY) (.) (B^T d) ]  summed over the tiles, dY = (y0, y1) the two gradients of a tile, d its
+    // four inputs;  A dY = (y0, y0 + y1, y0 - y1, -y1),  B^T d = (d0 - d2, d1 + d2, d2 - d1, d1 - d3),
+    // dW = (M0 + (M1 + M2)/2, (M1 - M2)/2, (M1 + M2)/2 + M3).  Four MFMAs per tile pair instead of six (2/3 of the matrix work);
+    // the operands are formed from the raw LDS rows as they are read (one add per MFMA), the 4 -> 3 reduction once at the end.
+    // (rows of 16 positions keep the direct form: four tile pairs per step leave the per-step costs uncovered, measured 11 % slower)
+    constexpr bool WINO = !FOLD && KW == 3 && BKP >= 32;
+    constexpr int NACC = FOLD ? KH : (WINO ? KH * 4 : KH * KW);
     extern __shared__ __attribute__((aligned(16))) float wlds[];
     float* const As = wlds;                       // [4][ASZ]
     float* const Bs = wlds + 4 * ASZ;             // [XS][BSZ]
@@ -384,6 +391,25 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
             v[kh] = ih >= 0 && ih < d.iH;
             Bk[kh] = Bs + (ih & (XS - 1)) * BSZ + boff;
         }
+        if constexpr (WINO) {
+            // lane (l31, lh) feeds tile 2 kk + lh: positions 4 kk + 2 lh, + 1 of the G row; inputs from the same index on (the X
+            // row starts one column left of position 0)
+#pragma unroll 2
+            for (int kk = 0; kk < BKP / 4; ++kk) {
+                const float y0 = Ab[4 * kk + lh], y1 = Ab[4 * kk + lh + 1];      // Ab already holds + lh: index 4 kk + 2 lh
+                const float a1 = y0 + y1, a2 = y0 - y1, a3 = -y1;
+#pragma unroll
+                for (int kh = 0; kh < KH; ++kh) {
+                    if (!v[kh]) continue;
+                    const float* x = Bk[kh] + 4 * kk + lh;                       // Bk holds + lh as well
+                    const float d0 = x[0], d1 = x[1], d2 = x[2], d3 = x[3];
+                    acc[kh * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, d0 - d2, acc[kh * 4 + 0], 0, 0, 0);
+                    acc[kh * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, d1 + d2, acc[kh * 4 + 1], 0, 0, 0);
+                    acc[kh * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, d2 - d1, acc[kh * 4 + 2], 0, 0, 0);
+                    acc[kh * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, d1 - d3, acc[kh * 4 + 3], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll 4
         for (int kk = 0; kk < BKP / 2; ++kk) {
             const float av = Ab[2 * kk];
@@ -398,6 +424,7 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
                         acc[kh * KW + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bk[kh][2 * kk + t], acc[kh * KW + t], 0, 0, 0);
                 }
             }
+        }
         }
     };
 
@@ -434,8 +461,17 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
             }
         } else if (m < d.M && n < d.N) {
             float* o = P + ((int64_t)m * d.N + n) * taps + kd * KH * KW;
+            if constexpr (WINO) {
 #pragma unroll
-            for (int t = 0; t < KH * KW; ++t) o[t] = acc[t][rr];
+                for (int kh = 0; kh < KH; ++kh) {
+                    const float m0v = acc[kh * 4][rr], m1v = acc[kh * 4 + 1][rr], m2v = acc[kh * 4 + 2][rr], m3v = acc[kh * 4 + 3][rr];
+                    const float hs = 0.5f * (m1v + m2v);
+                    o[kh * 3] = m0v + hs; o[kh * 3 + 1] = 0.5f * (m1v - m2v); o[kh * 3 + 2] = hs + m3v;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < KH * KW; ++t) o[t] = acc[t][rr];
+            }
         }
     }
     if (want_bias) {
@@ -447,7 +483,7 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
 
 // the merged-kh form applies to square stride-1 'same' taps whose rows are one chunk: 3 x 3, and 7 x 7 with N * 7 <= 64 (stems)
 bool wgrad_mkh_ok(const SdcWgradDesc& d) {
-    const bool k3 = d.kW == 3 && d.kH == 3 && d.pH == 1;
+    const bool k3 = d.kW == 3 && d.kH == 3 && d.pH == 1 && d.pW == 1;
     const bool k7 = d.kW == 7 && d.kH == 7 && d.pH == 3 && d.N * 7 <= 64;
     return (k3 || k7) && d.sW == 1 && d.sH == 1 && d.uH == 1 && d.iH == d.oH && (d.oW == 16 || d.oW == 32 || d.oW == 64);
 }
