@@ -277,6 +277,7 @@ def kstar_score_check(batch, dev):
     """the tokamak score check that follows a C3 sampling pass (BASELINE config 3; tokamak/utils/metrics.py:60-85): the batch's
     control sequences through the KSTAR surrogate, sdc_kstar_rollout against the CPU restatement timed on two trajectories"""
     import numpy as np
+    import torch
     from oracle import kstar as okstar                 # cpu_baseline leg only
     from safediffcon_amd import kstar
     w = kstar.unflatten_weights(dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "kstar_weights.npz"))))
