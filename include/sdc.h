@@ -295,10 +295,12 @@ int sdc_conv_wgrad(const SdcWgradDesc* d, const float* g, const float* x, float*
 
 /* Backward of sdc_gn_apply (GroupNorm -> (scale+1, shift) -> SiLU; Block, conv3d.py:189-204, 1D/model/unet.py:128-147):
  * h = the conv output the forward normalised (contiguous (B,C,S)), stats from the forward, ss = per-sample rows
- * [scale (C) | shift (C)] at ss + b*ss_b_stride or null.  rows holds (B*C + B*G) * 2 floats.  Writes gh = dL/dh and rows[b][c] = (A1, A2) with
+ * [scale (C) | shift (C)] at ss + b*ss_b_stride or null.  rows: sdc_gn_silu_bwd_floats(B, C, G, S) floats, 8-byte aligned.  Writes
+ * gh = dL/dh and rows[b][c] = (A1, A2) with
  * A1 = sum_S gy silu'(v), A2 = sum_S gy silu'(v) xhat, and -- when dgamma / dbeta (C floats each) are given --
  * dgamma[c] = sum_b (1+scale) A2, dbeta[c] = sum_b (1+scale) A1 and, when dss (contiguous (B, 2C)) is given too,
  * dss[b] = [gamma A2 + beta A1 | A1], the gradient of the ss rows.  (The residual the forward added passes gy through.) */
+size_t sdc_gn_silu_bwd_floats(int B, int C, int G, int64_t S);
 int sdc_gn_silu_bwd(const float* h, const float* gy, const float* stats, const float* gamma, const float* beta,
                     const float* ss, int64_t ss_b_stride, float* rows, float* gh, float* dgamma, float* dbeta, float* dss,
                     int B, int C, int G, int64_t S, void* stream);

@@ -87,6 +87,7 @@ SIGNATURES = {
                                       C.c_float, C.c_float, C.c_float, _stream]),
     "sdc_conv_wgrad_bytes": (C.c_size_t, [C.POINTER(SdcWgradDesc)]),
     "sdc_conv_wgrad": (C.c_int, [C.POINTER(SdcWgradDesc), _f32p, _f32p, _f32p, _f32p, C.c_void_p, C.c_size_t, _stream]),
+    "sdc_gn_silu_bwd_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, _i64]),
     "sdc_gn_silu_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _f32p, _f32p, _f32p, _f32p, _f32p,
                                   C.c_int, C.c_int, C.c_int, _i64, _stream]),
     "sdc_chan_norm_bwd_parts": (C.c_size_t, [C.c_int, _i64]),

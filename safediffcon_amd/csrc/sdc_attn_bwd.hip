@@ -388,12 +388,31 @@ __global__ __launch_bounds__(NT) void tattn_bwd_kernel(const AttnBwdArgs a) {
     }
 }
 
-__global__ __launch_bounds__(NT) void sum_rows_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int nsplit) {
-    const int i = blockIdx.x * NT + threadIdx.x;
-    if (i >= n) return;
+// out[i] = sum_k part[k][i] in a fixed order: 1024 threads = 16 groups x 64 elements, group g adds the slots k = g (mod 16) (loads
+// four deep), group 0 adds the sixteen partial sums in order -- a thread walking a thousand slots alone is a chain of a thousand
+// dependent loads
+constexpr int SR_G = 16;
+__global__ __launch_bounds__(64 * SR_G) void sum_rows_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int nsplit) {
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
     float s = 0.0f;
-    for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * n + i];
-    out[i] = s;
+    if (i < n) {
+        int k = g;
+        for (; k + 3 * SR_G < nsplit; k += 4 * SR_G) {
+            const float v0 = part[(int64_t)k * n + i], v1 = part[(int64_t)(k + SR_G) * n + i];
+            const float v2 = part[(int64_t)(k + 2 * SR_G) * n + i], v3 = part[(int64_t)(k + 3 * SR_G) * n + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < nsplit; k += SR_G) s += part[(int64_t)k * n + i];
+    }
+    __shared__ float sh[SR_G][64];
+    sh[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float t = sh[0][lane];
+        for (int q = 1; q < SR_G; ++q) t += sh[q][lane];
+        out[i] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ linear attention
@@ -665,7 +684,7 @@ extern "C" int sdc_attn_bwd(const float* qkv, const float* dout, const float* ro
         hipLaunchKernelGGL(tattn_bwd_kernel, dim3((unsigned)(a.nslots * heads)), dim3(NT), ldsb, s, a);
         if (a.dbias_part) {
             const int nb = heads * ntok * ntok;
-            hipLaunchKernelGGL(sum_rows_kernel, dim3((nb + NT - 1) / NT), dim3(NT), 0, s, a.dbias_part, dbias, nb, a.nslots);
+            hipLaunchKernelGGL(sum_rows_kernel, dim3((nb + 63) / 64), dim3(64 * SR_G), 0, s, a.dbias_part, dbias, nb, a.nslots);
         }
         return sdc::check_launch("sdc_attn_bwd[mfma]");
     }
@@ -695,7 +714,7 @@ extern "C" int sdc_attn_bwd(const float* qkv, const float* dout, const float* ro
     hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(a.nslots * heads)), dim3(NT), lds_bytes, s, a);
     if (a.dbias_part) {
         const int nb = heads * ntok * ntok;
-        hipLaunchKernelGGL(sum_rows_kernel, dim3((nb + NT - 1) / NT), dim3(NT), 0, s, a.dbias_part, dbias, nb, a.nslots);
+        hipLaunchKernelGGL(sum_rows_kernel, dim3((nb + 63) / 64), dim3(64 * SR_G), 0, s, a.dbias_part, dbias, nb, a.nslots);
     }
     return sdc::check_launch("sdc_attn_bwd");
 }

@@ -674,6 +674,70 @@ __global__ __launch_bounds__(NT) void gn_bwd_rows_kernel(const float* __restrict
     }
 }
 
+// long rows with few of them (3-D levels at a small batch: 256 rows of 131 072 elements): the row is cut into ysplit pieces, one
+// workgroup each, 16-byte loads; the pieces' fp64 sums are added in order by gn_bwd_rows_finish_kernel
+__global__ __launch_bounds__(NT) void gn_bwd_rows_part_kernel(const float* __restrict__ h, const float* __restrict__ gy,
+                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ ss,
+                                                             int64_t ss_b_stride, double* __restrict__ part, int C, int G, int64_t S,
+                                                             int64_t piece) {
+    const int bc = blockIdx.x, y = blockIdx.y;
+    const int b = bc / C, c = bc - b * C;
+    const int g = c / (C / G);
+    const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+    float sc = 1.0f, sh = 0.0f;
+    if (ss) { sc = ss[(int64_t)b * ss_b_stride + c] + 1.0f; sh = ss[(int64_t)b * ss_b_stride + C + c]; }
+    const float ga = gamma[c], be = beta[c];
+    const int64_t lo = (int64_t)y * piece, hi = lo + piece < S ? lo + piece : S;       // piece is a multiple of 4, S too
+    const float4* h4 = reinterpret_cast<const float4*>(h + (int64_t)bc * S);
+    const float4* g4 = reinterpret_cast<const float4*>(gy + (int64_t)bc * S);
+    double a1 = 0.0, a2 = 0.0;
+    for (int64_t i = lo / 4 + threadIdx.x; i < hi / 4; i += NT) {
+        const float4 hv = h4[i], gv4 = g4[i];
+        const float hh[4] = {hv.x, hv.y, hv.z, hv.w}, gg[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xh = (hh[q] - mean) * rstd;
+            const float v = (xh * ga + be) * sc + sh;
+            const float gv = gg[q] * dsilu(v);
+            s1 += gv;
+            s2 += gv * xh;
+        }
+        a1 += (double)s1;
+        a2 += (double)s2;
+    }
+    a1 = sdc::wave_sum(a1);
+    a2 = sdc::wave_sum(a2);
+    __shared__ double shm[2][NT / 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { shm[0][wave] = a1; shm[1][wave] = a2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t1 = 0, t2 = 0;
+        for (int w = 0; w < NT / 64; ++w) { t1 += shm[0][w]; t2 += shm[1][w]; }
+        part[((int64_t)bc * gridDim.y + y) * 2] = t1;
+        part[((int64_t)bc * gridDim.y + y) * 2 + 1] = t2;
+    }
+}
+
+__global__ __launch_bounds__(NT) void gn_bwd_rows_finish_kernel(const double* __restrict__ part, float* __restrict__ rows, int nrows, int ysplit) {
+    const int bc = blockIdx.x * NT + threadIdx.x;
+    if (bc >= nrows) return;
+    double t1 = 0, t2 = 0;
+    for (int y = 0; y < ysplit; ++y) { t1 += part[((int64_t)bc * ysplit + y) * 2]; t2 += part[((int64_t)bc * ysplit + y) * 2 + 1]; }
+    rows[(int64_t)bc * 2] = (float)t1;
+    rows[(int64_t)bc * 2 + 1] = (float)t2;
+}
+
+// pieces per row for the kernel above (1: the row kernels below take the row whole)
+int gn_bwd_ysplit(int nrows, int64_t S) {
+    if (S < 16384 || S % 4 != 0 || nrows >= 1024) return 1;
+    int64_t y = (1024 + nrows - 1) / nrows;
+    if (y > S / 4096) y = S / 4096;
+    return (int)(y < 1 ? 1 : (y > 64 ? 64 : y));
+}
+
 // group means of (k A1, k A2), k = gamma (1 + sc): one workgroup per (b, g) -> gstat[b][g] = (m1, m2)
 __global__ __launch_bounds__(NT) void gn_bwd_group_kernel(const float* __restrict__ rows, const float* __restrict__ gamma,
                                                          const float* __restrict__ ss, int64_t ss_b_stride, float* __restrict__ gstat,
@@ -891,6 +955,12 @@ __global__ __launch_bounds__(NT) void gn_bwd_param_kernel(const float* __restric
     }
 }
 
+extern "C" size_t sdc_gn_silu_bwd_floats(int B, int C, int G, int64_t S) {
+    if (B <= 0 || C <= 0 || G <= 0) return 0;
+    const size_t base = (((size_t)B * C + (size_t)B * G) * 2 + 1) / 2 * 2;
+    return base + (size_t)B * C * gn_bwd_ysplit(B * C, S) * 2 * 2;                // fp64 pieces, counted in floats
+}
+
 extern "C" int sdc_gn_silu_bwd(const float* h, const float* gy, const float* stats, const float* gamma, const float* beta,
                                const float* ss, int64_t ss_b_stride, float* rows, float* gh, float* dgamma, float* dbeta, float* dss,
                                int B, int C, int G, int64_t S, void* stream) {
@@ -901,8 +971,18 @@ extern "C" int sdc_gn_silu_bwd(const float* h, const float* gy, const float* sta
     SDC_REQUIRE((int64_t)B * C < (1ll << 31), SDC_EINVAL, "sdc_gn_silu_bwd: too many rows");
     hipStream_t s = sdc::as_stream(stream);
     const int nrows = B * C;
-    float* gstat = rows + (int64_t)nrows * 2;             // rows = [B][C][2] row sums, then [B][G][2] group means
-    if (S >= 1024)
+    float* gstat = rows + (int64_t)nrows * 2;             // rows = [B][C][2] row sums, then [B][G][2] group means, then the pieces
+    const int ysplit = gn_bwd_ysplit(nrows, S);
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0;
+    if (ysplit > 1 && vec_ok) {
+        const size_t off = (((size_t)(nrows + B * G) * 2 + 1) / 2) * 2;         // doubles start on an 8-byte boundary of the float array
+        double* part = reinterpret_cast<double*>(rows + off);
+        SDC_REQUIRE((reinterpret_cast<uintptr_t>(part) & 7) == 0, SDC_EINVAL, "sdc_gn_silu_bwd: rows must be 8-byte aligned");
+        int64_t piece = ((S + ysplit - 1) / ysplit + 3) / 4 * 4;
+        hipLaunchKernelGGL(gn_bwd_rows_part_kernel, dim3((unsigned)nrows, (unsigned)ysplit), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss,
+                           ss_b_stride, part, C, G, S, piece);
+        hipLaunchKernelGGL(gn_bwd_rows_finish_kernel, dim3((unsigned)((nrows + NT - 1) / NT)), dim3(NT), 0, s, (const double*)part, rows, nrows, ysplit);
+    } else if (S >= 1024)
         hipLaunchKernelGGL(gn_bwd_rows_kernel<1>, dim3((unsigned)nrows), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss, ss_b_stride, rows, nrows, C, G, S);
     else
         hipLaunchKernelGGL(gn_bwd_rows_kernel<4>, dim3((unsigned)((nrows + 3) / 4)), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss, ss_b_stride, rows, nrows, C, G, S);

@@ -81,7 +81,7 @@ def gn_silu_bwd(h, gy, st, gamma, beta, groups, ss=None):
     B, Cc = h.shape[0], h.shape[1]
     S = h.numel() // (B * Cc)
     gy = gy.contiguous()
-    buf = torch.empty((B * Cc + B * groups) * 2, dtype=torch.float32, device=h.device)     # row sums, then the kernel's group means
+    buf = torch.empty(int(lib.sdc_gn_silu_bwd_floats(B, Cc, groups, S)), dtype=torch.float32, device=h.device)   # row sums + kernel scratch
     gh = torch.empty_like(h)
     dgb = torch.empty((2, Cc), dtype=torch.float32, device=h.device)
     dss = None if ss is None else torch.empty((B, 2 * Cc), dtype=torch.float32, device=h.device)

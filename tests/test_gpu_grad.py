@@ -105,7 +105,9 @@ def test_conv_transpose_and_upsample_wgrad():
                                               ((4, 256, 1, 1, 32), 1, False, True), ((2, 64, 8, 32, 32), 8, False, False),
                                               # ragged: row counts that are not multiples of 4, rows that are not multiples of 64 / 256
                                               ((3, 70, 1, 1, 19), 7, True, True), ((5, 24, 1, 3, 37), 8, True, False),
-                                              ((1, 16, 2, 24, 25), 4, False, False), ((67, 6, 1, 1, 16), 1, True, False)])
+                                              ((1, 16, 2, 24, 25), 4, False, False), ((67, 6, 1, 1, 16), 1, True, False),
+                                              # long rows, few of them: the row cut into pieces over several workgroups
+                                              ((2, 16, 16, 32, 32), 4, True, True), ((1, 8, 9, 52, 40), 8, False, False)])
 def test_gn_silu_backward(shape, G, cond, res):
     B, Cc = shape[0], shape[1]
     h = det_tensor(shape, 110)
