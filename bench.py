@@ -33,6 +33,10 @@ import subprocess
 import sys
 import time
 
+# RCCL / CUDA-tensor sharing between the ranks of one node needs dmabuf IPC on this driver (set before anything touches HIP;
+# the GPU boxes export it already, a bare `torchrun bench.py` on another machine may not)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
