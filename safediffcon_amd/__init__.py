@@ -5,6 +5,8 @@ Drop-in classes (same names / signatures as the reference):
   GaussianDiffusionBurgers / Tokamak / Smoke              (safediffcon_amd.diffusion)
   BurgersGuidance / TokamakGuidance / SmokeGuidance       (closed-form guidance specs)
   ConformalCalculator, conformal helpers                  (safediffcon_amd.conformal)
+  control_trajectories (Burgers rollout)                  (safediffcon_amd.solvers)
+  KSTARSolver, control_trajectories, evaluate_samples     (safediffcon_amd.kstar: the tokamak score check)
 
 All compute goes through libsdc_hip.so (include/sdc.h); importing this package
 does not load it, the first kernel call does -- and raises if it is missing.

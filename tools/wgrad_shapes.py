@@ -31,5 +31,8 @@ bench.finetune_step(wl, B, 0, torch.device("cuda:0"), steps=1, eager=False)
 torch.cuda.synchronize()
 rows = [(e0.elapsed_time(e1), *rest) for e0, e1, *rest in calls]
 n = len(rows) // 2                                   # warm-up + 1 timed step: keep the second half
-for ms, gs, gst, xs, xst, k, st, up in sorted(rows[n:], key=lambda r: -r[0])[:12]:
+flt = os.environ.get('WG_K')
+sel = [r for r in rows[n:] if flt is None or 'x'.join(map(str, r[5])) == flt]
+print(f'{len(sel)} calls, {sum(r[0] for r in sel):.2f} ms')
+for ms, gs, gst, xs, xst, k, st, up in sorted(sel, key=lambda r: -r[0])[:int(os.environ.get('WG_TOP', '12'))]:
     print(f"{ms:7.3f} ms  g {gs} {gst}  x {xs} {xst}  k {k} s {st} up {up}", flush=True)
