@@ -145,34 +145,28 @@ __global__ __launch_bounds__(KT) void kstar_rollout_kernel(const SdcKstarModel m
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * NS;
 
-    // (bp, wmhd) net + H factors + the output row (kstar_solver.py:270-350)
-    auto emit_row = [&](int row) {
+    // the (beta_p, W_mhd) net's input [bn, Ip, Bt, (In+Out)/2, (Out-In)/2, Elon, UpTri, LoTri] -> s.va
+    auto bpw_input = [&]() {
         if (tid < NS * 8) {
             const int sm = tid >> 3, j = tid & 7;
             const double* in = s.inp[sm];
-            double v = j == 0 ? s.y[sm][0] : in[j == 1 ? 0 : (j == 2 ? 1 : (j + 7))];      // bn, Ip, Bt, InMid, OutMid, Elon, UpTri, LoTri
+            double v = j == 0 ? s.y[sm][0] : in[j == 1 ? 0 : (j == 2 ? 1 : (j + 7))];
             if (j == 3) v = 0.5 * (in[10] + in[11]);
             if (j == 4) v = 0.5 * (in[11] - in[10]);
             s.va[sm][j] = (float)v;
         }
         __syncthreads();
+    };
+    // (bp, wmhd) net + H factors + the output row (kstar_solver.py:270-350)
+    auto emit_row = [&](int row) {
+        bpw_input();
         if (tid < NS * 2) s.bpw[tid >> 1][tid & 1] = 0.0;
         __syncthreads();
         for (int net = 0; net < m.n_bpw; ++net) {
             const float (*r)[MAXW] = mlp<NS>(m.bpw, net, s);
             if (tid < NS * 2) s.bpw[tid >> 1][tid & 1] += (double)r[tid >> 1][tid & 1] * m.bpw_ystd[tid & 1] + m.bpw_ymean[tid & 1];
             __syncthreads();
-            if (net + 1 < m.n_bpw) {                               // the layers have overwritten the input in s.va
-                if (tid < NS * 8) {
-                    const int sm = tid >> 3, j = tid & 7;
-                    const double* in = s.inp[sm];
-                    double v = j == 0 ? s.y[sm][0] : in[j == 1 ? 0 : (j == 2 ? 1 : (j + 7))];
-                    if (j == 3) v = 0.5 * (in[10] + in[11]);
-                    if (j == 4) v = 0.5 * (in[11] - in[10]);
-                    s.va[sm][j] = (float)v;
-                }
-                __syncthreads();
-            }
+            if (net + 1 < m.n_bpw) bpw_input();                    // the layers have overwritten the input in s.va
         }
         if (tid < NS && b0 + tid < B) {
             const int sm = tid;

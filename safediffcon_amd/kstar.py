@@ -152,10 +152,7 @@ def unflatten_weights(flat):
         fam, i, lname, k = key.split("/")
         v = flat[key]
         v = str(v) if k == "activation" else np.asarray(v)
-        if fam == "lstm":
-            w[fam].setdefault(int(i), {}).setdefault(lname, {})[k] = v
-        else:
-            w[fam].setdefault(int(i), {}).setdefault(lname, {})[k] = v
+        w[fam].setdefault(int(i), {}).setdefault(lname, {})[k] = v
     out = {"lstm": [w["lstm"][i] for i in sorted(w["lstm"])]}
     for fam in ("nn", "bpw"):
         out[fam] = [{"layers": [(ln.split("_", 1)[1], d) for ln, d in sorted(w[fam][i].items())]} for i in sorted(w[fam])]
