@@ -155,3 +155,27 @@ def test_oracle_metrics():
 def test_gpu_only_entry_points_refuse_the_cpu():
     with pytest.raises(RuntimeError):
         kstar.KSTARModel(_weights(), device="cpu")
+
+
+def test_metrics_mirror_on_cpu_tensors():
+    """tokamak/utils/metrics.py:11-151 restated in safediffcon_amd.kstar (plain torch, no kernel): against hand-computed values
+    and the numpy restatement"""
+    import torch
+    rng = np.random.default_rng(3)
+    B, nt = 6, 122
+    diffused = torch.from_numpy(rng.normal(size=(B, 12, 128)).astype(np.float32)) * 0.1 + 5.0
+    controlled = torch.from_numpy(rng.normal(size=(B, 3, nt)).astype(np.float32)) * 0.2 + 5.0
+    target = torch.from_numpy(rng.normal(size=(B, 3, nt)).astype(np.float32)) * 0.2 + 5.0
+    thr = 4.7
+    m = kstar.evaluate_samples(diffused, controlled, target, thr, nt)
+    c, d, t = controlled.numpy().astype(np.float64), diffused.numpy().astype(np.float64), target.numpy().astype(np.float64)
+    dm = ((c - d[:, :3, :nt]) ** 2).mean(axis=(1, 2))
+    assert abs(m["diffusion_mse_mean"] - dm.mean()) < 1e-6 and abs(m["diffusion_mse_std"] - dm.std(ddof=1)) < 1e-6
+    bp, li = ((t[:, 0] - c[:, 0]) ** 2).mean(-1), ((t[:, 2] - c[:, 2]) ** 2).mean(-1)
+    assert abs(m["obj_mse_mean"] - (bp.mean() + li.mean())) < 1e-6 and abs(m["obj_mse_std"] - (bp + li).std(ddof=1)) < 1e-6
+    q = c[:, 1]
+    assert abs(m["time_below_ratio"] - (q < thr).mean()) < 1e-7 and abs(m["sample_below_ratio"] - (q < thr).any(-1).mean()) < 1e-7
+    assert abs(m["safety_score_mean"] - q.min(-1).mean()) < 1e-6
+    assert abs(m["diffused_score_mse"] - ((d[:, 1, :nt].min(-1) - q.min(-1)) ** 2).mean()) < 1e-6
+    assert abs(m["reported_safe_metric"] - okstar.reported_safe_metric(q, thr)) < 1e-5
+    assert np.allclose(kstar.calculate_safety_score(controlled).numpy(), okstar.calculate_safety_score(c), atol=1e-6)
