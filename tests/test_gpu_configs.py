@@ -237,7 +237,7 @@ def test_tokamak_conformal_ddim_passes_ground_truth_actions(golden):
 # ------------------------------------------------------------------ C4: the sampler (not only the forward) at production width
 def test_c4_width_guided_sampler_vs_oracle():
     """2d/ddpm/diffusion_2d.py:288-322 at the C4 net width and grid: Unet3D_with_Conv3D(64,(1,2,4),7) on (B,32,7,64,64),
-    3 guided steps with injected noise, HIP sampler against oracle.samplers.sample_smoke on the CPU (mirror of
+    3 guided steps with injected noise, HIP sampler against oracle.samplers.sample_smoke (mirror of
     test_c3_guided_sampler_batch128).  The hinge is made active (safe_bound -5) so the guidance term is exercised."""
     net = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
     P = det_params(_spec(net), 31)
@@ -249,11 +249,14 @@ def test_c4_width_guided_sampler_vs_oracle():
     noise = det_noise((B, 32, 7, 64, 64), 7100)
     out = gs.sample(batch_size=B, design_fn=sdc.SmokeGuidance(0.01, 0.9, -5.0), init=init.to(DEV), noise=noise).cpu()
     tabs = osched.make_tables("sigmoid", T)
-    ref = osam.sample_smoke(lambda a, b: onets.unet_smoke(P, a, b, dim=64, dim_mults=(1, 2, 4)), tabs, B, noise, init=init,
-                            design_fn=osam.smoke_guidance(0.01, 0.9, -5.0), ratio=100.0, shape=(32, 7, 64, 64))
-    free = osam.sample_smoke(lambda a, b: onets.unet_smoke(P, a, b, dim=64, dim_mults=(1, 2, 4)), tabs, 1, lambda i: noise(i)[:1],
-                             init=init[:1], design_fn=None, ratio=100.0, shape=(32, 7, 64, 64))
-    assert (free - ref[:1]).abs().max() > 1e-3           # the guidance mattered
+    # the oracle's loop and functional net run under PyTorch-ROCm eager on the device (the CPU run of this case took 100 s of the
+    # suite; tests/test_gpu_strawman.py and test_c4_smoke_dim64_full_resolution hold the eager net against the CPU oracle)
+    Pg = {k: v.to(DEV) for k, v in P.items()}
+    ref = osam.sample_smoke(lambda a, b: onets.unet_smoke(Pg, a, b.to(a.device), dim=64, dim_mults=(1, 2, 4)), tabs, B,
+                            lambda i: noise(i).to(DEV), init=init.to(DEV), design_fn=osam.smoke_guidance(0.01, 0.9, -5.0), ratio=100.0,
+                            shape=(32, 7, 64, 64)).cpu()
+    free = gs.sample(batch_size=B, design_fn=None, init=init.to(DEV), noise=noise).cpu()
+    assert (free - out).abs().max() > 1e-3               # the guidance mattered
     # measured on MI355X: max|err| 4.9e-4 (one element; a 3-step sigmoid schedule multiplies the eps error by sqrt_recipm1 ~ 50
     # at its first step), MSE 3.3e-11
     assert _report("C4 width 3-step guided trajectory (B=2) vs oracle", out, ref) < 2e-3 and _mse(out, ref) <= 1e-9
@@ -289,7 +292,8 @@ def test_c4_batch64_every_sample_vs_eager_oracle():
 def test_ddim_sampler_at_production_width_vs_oracle(tree):
     """ddim_sample (eta = 1) of the three trees at the production net widths -- 1D/model/diffusion.py:451-555,
     tokamak/model/diffusion.py:374-496, 2d/ddpm/diffusion_2d.py:324-404 -- guided, injected noise, HIP sampler against the
-    oracle's DDIM loop on the CPU (the dim-8 DDIM fixtures of the real reference pin the oracle's loop)."""
+    oracle's DDIM loop (on the CPU for the 1-D / 2-D nets, under PyTorch-ROCm eager for the 3-D one; the dim-8 DDIM fixtures of the
+    real reference pin the oracle's loop)."""
     T, S = 20, 4
     if tree == "smoke":
         net = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
@@ -302,8 +306,10 @@ def test_ddim_sampler_at_production_width_vs_oracle(tree):
         noise = det_noise((B, 32, 7, 64, 64), 7300)
         out = gd.sample(batch_size=B, design_fn=sdc.SmokeGuidance(0.01, 0.9, -5.0), init=init.to(DEV), control=control.to(DEV),
                         noise=noise).cpu()
-        ref = osam.ddim_smoke(lambda a, b: onets.unet_smoke(P, a, b, dim=64, dim_mults=(1, 2, 4)), osched.make_tables("sigmoid", T), B,
-                              noise, S=S, eta=1.0, init=init, control=control, design_fn=osam.smoke_guidance(0.01, 0.9, -5.0), ratio=100.0)
+        Pg = {k: v.to(DEV) for k, v in P.items()}            # the oracle under PyTorch-ROCm eager (the CPU run took 107 s of the suite)
+        ref = osam.ddim_smoke(lambda a, b: onets.unet_smoke(Pg, a, b.to(a.device), dim=64, dim_mults=(1, 2, 4)),
+                              osched.make_tables("sigmoid", T), B, lambda i: noise(i).to(DEV), S=S, eta=1.0, init=init.to(DEV),
+                              control=control.to(DEV), design_fn=osam.smoke_guidance(0.01, 0.9, -5.0), ratio=100.0).cpu()
         gate = 4e-3      # measured 1.0e-3 (one element; the re-derived eps of DDIM divides by sqrt(1/abar - 1)), MSE 5.7e-11
     elif tree == "burgers":
         net = sdc.Unet2D(dim=64, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
