@@ -117,6 +117,27 @@ def test_c3_guided_sampler_batch128():
                               enable_grad=False)
     assert _report("C3 3-step guided trajectory, samples 0/127 of 128 vs oracle", out[idx], ref) < 5e-4
 
+    # ... and BASELINE configs[2]'s "kstar_solver rollout for score check" on the same batch (tokamak/inference/pipeline.py:347-356):
+    # the sampled actuator channels through the KSTAR surrogate, the two trajectories the oracle sampled through its restatement
+    import os
+    import numpy as np
+    from oracle import kstar as okstar
+    from safediffcon_amd import kstar
+    w = kstar.unflatten_weights(dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "kstar_weights.npz"))))
+    # (the pipeline de-normalises before the rollout; any affine map into the actuator ranges serves here)
+    lo, hi = torch.tensor(kstar.LOW_ACTION)[None, :, None], torch.tensor(kstar.HIGH_ACTION)[None, :, None]
+    phys = out.clone()
+    phys[:, 3:] = lo + (hi - lo) * (0.5 + 0.5 * out[:, 3:].clamp(-1, 1))
+    ctrl = kstar.control_trajectories(phys.to(DEV), 122, seed=0, weights=kstar.KSTARModel(w, DEV))
+    assert ctrl.shape == (B, 3, 122) and torch.isfinite(ctrl).all()
+    want = okstar.control_trajectories(phys[idx].numpy(), 122, w)
+    err = np.max(np.abs(ctrl[idx].cpu().numpy() - want) / np.array([1.8, 5.0, 0.9])[None, :, None])
+    print(f"[measured] C3 score check on the sampled batch: controlled (beta_p, q95, l_i) vs the oracle {err:.2e}")
+    assert err < 2e-4
+    score = kstar.calculate_safety_score(ctrl)
+    assert score.shape == (B,) and torch.isfinite(score).all()
+    assert np.max(np.abs(score[idx].cpu().numpy() - okstar.calculate_safety_score(want))) < 1e-3
+
 
 # ------------------------------------------------------------------ calibration branch at C2 width
 def test_calibration_double_draw_at_c2_width():
