@@ -179,3 +179,40 @@ def test_metrics_mirror_on_cpu_tensors():
     assert abs(m["diffused_score_mse"] - ((d[:, 1, :nt].min(-1) - q.min(-1)) ** 2).mean()) < 1e-6
     assert abs(m["reported_safe_metric"] - okstar.reported_safe_metric(q, thr)) < 1e-5
     assert np.allclose(kstar.calculate_safety_score(controlled).numpy(), okstar.calculate_safety_score(c), atol=1e-6)
+
+
+def test_oracle_layers_against_pytorchs_own_layers():
+    """an independent implementation of the same published layer definitions: torch.nn.LSTM (ATen; gate order i, f, g, o --
+    the same as Keras' i, f, c, o -- sigmoid / tanh), F.batch_norm in eval mode and F.linear, fed the Keras weights of the real
+    surrogate.  Catches a slip in the restatement's arithmetic; which activation Keras itself uses is argued in DESIGN.md section 9."""
+    import torch
+    import torch.nn.functional as F
+    w = _weights()["lstm"][0]
+    x = np.random.default_rng(7).normal(size=(10, 18)).astype(np.float32)
+    # BatchNormalization
+    bn = w["bn0"]
+    want = F.batch_norm(torch.from_numpy(x), torch.from_numpy(bn["mean"]), torch.from_numpy(bn["var"]), torch.from_numpy(bn["gamma"]),
+                        torch.from_numpy(bn["beta"]), training=False, eps=1e-3).numpy()
+    got = okstar.batchnorm(x, bn)
+    assert np.max(np.abs(got - want)) < 2e-5 * max(1.0, np.abs(want).max())
+    # LSTM, both layers chained
+    def torch_lstm(wt, n_in):
+        m = torch.nn.LSTM(n_in, 100, batch_first=True)
+        with torch.no_grad():
+            m.weight_ih_l0.copy_(torch.from_numpy(wt["kernel"].T.copy()))
+            m.weight_hh_l0.copy_(torch.from_numpy(wt["recurrent_kernel"].T.copy()))
+            m.bias_ih_l0.copy_(torch.from_numpy(wt["bias"]))
+            m.bias_hh_l0.zero_()
+        return m
+    v = torch.from_numpy(got)[None]
+    with torch.no_grad():
+        s1, _ = torch_lstm(w["lstm0"], 18)(v)
+        mine1 = okstar.lstm(got, w["lstm0"], True)
+        assert np.max(np.abs(s1[0].numpy() - mine1)) < 1e-5
+        s2, _ = torch_lstm(w["lstm1"], 100)(torch.from_numpy(okstar.batchnorm(mine1, w["bn1"]))[None])
+        mine2 = okstar.lstm(okstar.batchnorm(mine1, w["bn1"]), w["lstm1"], False)
+        assert np.max(np.abs(s2[0, -1].numpy() - mine2)) < 1e-5
+    # Dense(50, sigmoid)
+    d = w["dense0"]
+    z = torch.sigmoid(F.linear(torch.from_numpy(mine2), torch.from_numpy(d["kernel"].T.copy()), torch.from_numpy(d["bias"]))).numpy()
+    assert np.max(np.abs(z - okstar.dense(mine2, d, "sigmoid"))) < 1e-5
