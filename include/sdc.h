@@ -383,6 +383,30 @@ size_t sdc_kstar_lstm_floats(void);
 int sdc_kstar_rollout(const SdcKstarModel* m, const float* actions, int64_t act_b_stride, int64_t act_t_stride,
                       int64_t act_c_stride, double* out, double* work, int B, int nsteps, void* stream);
 
+/* ---- Smoke score check: the fluid rollout behind InferencePipeline.multi_evaluate (2d/inference_2d.py:389-447 ->
+ * 2d/dataset/apps/evaluate_solver.py:209-350 `solver`: per step get_envolve :82-111 = control ring + last interior velocity ->
+ * divergence_free (phi/flow.py:317-326: float64 CG of phi/solver/base.py:63-103 on the matrix of phi/solver/sparse.py:27-77)
+ * -> three semi-Lagrangian advections (phi/math/nd.py:407-428) -> bucket book-keeping :262-336).  Replaces one Python process
+ * per sample with one launch: one 512-thread workgroup per sample, the 127 x 127 pressure problem on chip for the whole rollout.
+ *   c1, c2          controls (B, nt, nx, nx) fp32: element (b, f, y, x) at [b*ctrl_b_stride + f*ctrl_f_stride + y*nx + x]
+ *                   (so the channel slices pred[:, :, 3] / pred[:, :, 4] of a (B, nt, 7, nx, nx) sample are read in place)
+ *   init_density    (B, nx, nx) fp32, batch stride dens_b_stride; init_velocity (128, 128, 2) fp32 staggered, batch stride
+ *                   vel_b_stride (0 = one field for all samples, init_velocity_ evaluate_solver.py:77-79)
+ *   fluid_mask      (127, 127) bytes, 1 = fluid / 0 = obstacle (build_obstacles_pi_128, evaluate_solver.py:29-60)
+ *   bucket_labels, safe_labels   (128, 128) bytes: 0 = none, k = absorbing area k - 1 of get_bucket_mask / get_bucket_mask_safe
+ *                   (evaluate_solver.py:114-178; areas must not overlap); n_buckets in [2, 8], n_safe in [1, 8]
+ *   out             (B, nt, 7, nx, nx) fp64 = multi_evaluate's solver_out: density, velocity x, y, control x, y, smoke_out
+ *                   record, safe record; out_zero (B, nt, nx, nx) fp64 = `zero_densitys`, may be null
+ *   work            sdc_smoke_rollout_workspace_bytes(B) bytes, 16-byte aligned
+ *   nx divides 128, nt divides per_timelength (256); ring_lo/ring_hi = 16/112: the interior the controls do not reach;
+ *   accuracy / max_iterations = 1e-8 / 500 (evaluate_solver.py:108, phi/solver/sparse.py:88). */
+size_t sdc_smoke_rollout_workspace_bytes(int B);
+int sdc_smoke_rollout(const float* c1, const float* c2, int64_t ctrl_b_stride, int64_t ctrl_f_stride,
+                      const float* init_density, int64_t dens_b_stride, const float* init_velocity, int64_t vel_b_stride,
+                      const unsigned char* fluid_mask, const unsigned char* bucket_labels, const unsigned char* safe_labels,
+                      int n_buckets, int n_safe, double* out, double* out_zero, void* work, size_t work_bytes, int B, int nt,
+                      int nx, int per_timelength, int ring_lo, int ring_hi, double accuracy, int max_iterations, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

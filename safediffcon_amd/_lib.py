@@ -105,6 +105,10 @@ SIGNATURES = {
     "sdc_sumpool2": (C.c_int, [_f32p, _f32p, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "sdc_kstar_lstm_floats": (C.c_size_t, []),
     "sdc_kstar_rollout": (C.c_int, [C.POINTER(SdcKstarModel), _f32p, _i64, _i64, _i64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _stream]),
+    "sdc_smoke_rollout_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "sdc_smoke_rollout": (C.c_int, [_f32p, _f32p, _i64, _i64, _f32p, _i64, _f32p, _i64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _stream]),
     "sdc_graph_begin": (C.c_int, [_stream]),
     "sdc_graph_end": (C.c_int, [_stream, C.POINTER(C.c_void_p)]),
     "sdc_graph_launch": (C.c_int, [C.c_void_p, _stream]),

@@ -1,0 +1,146 @@
+"""sdc_smoke_rollout (the smoke task's evaluation rollout, csrc/sdc_smoke.hip, through the C ABI) against
+ * fixtures produced by the REAL reference solver (2d/dataset/apps/evaluate_solver.py + vendored PhiFlow;
+   oracle/make_smoke_solver_fixture.py), 32-step and full 256-step rollouts;
+ * the numpy oracle (oracle/smoke_solver.py, itself bit-identical to those fixtures) on fresh seeded inputs.
+Everything runs in float64 like the reference; what differs from it is the association of the CG's dot products and of the
+bucket sums.  Measured on MI355X: velocity 5e-13 on a scale of 40 after 255 steps x 500 CG iterations, records 1e-16,
+density fields (float32) identical.  Gates: velocity 1e-9 of scale, records 1e-12, density 1e-6 of scale."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+VEL_RTOL, REC_ATOL, DENS_RTOL = 1e-9, 1e-12, 1e-6
+
+
+def _fix(name):
+    return np.load(os.path.join(G, f"smoke_solver_{name}.npz"))
+
+
+def _run(f, dev, B=1):
+    from safediffcon_amd import smoke_solver as ss
+    c1 = torch.from_numpy(f["c1"]).to(dev)[None].repeat(B, 1, 1, 1)
+    c2 = torch.from_numpy(f["c2"]).to(dev)[None].repeat(B, 1, 1, 1)
+    d0 = torch.from_numpy(f["init_density"]).to(dev)[None].repeat(B, 1, 1)
+    return ss.solver(ss.init_sim_128(), ss.init_velocity_(), d0, c1, c2, int(f["per_timelength"]))
+
+
+def _close(a, b, rtol, what):
+    scale = max(float(np.nanmax(np.abs(b))), 1e-30)
+    err = float(np.nanmax(np.abs(a - b))) if a.size else 0.0
+    assert np.array_equal(np.isnan(a), np.isnan(b)), what
+    assert err <= rtol * scale, f"{what}: max|err| {err:.3e} on scale {scale:.3e}"
+    return err
+
+
+@pytest.mark.parametrize("name", ["short_a", "short_nan", "short_128"])
+def test_short_rollouts_vs_reference_fixtures(name):
+    f = _fix(name)
+    dens, zd, vel, oc1, oc2, rec, recs = [o[0].cpu().numpy() for o in _run(f, torch.device("cuda:0"))]
+    assert dens.dtype == np.float64 and vel.shape == f["velocitys"].shape
+    _close(dens, f["densitys"], DENS_RTOL, "densitys")
+    _close(zd, f["zero_densitys"], DENS_RTOL, "zero_densitys")
+    _close(vel, f["velocitys"], VEL_RTOL, "velocitys")
+    assert np.array_equal(oc1, f["out_c1"]) and np.array_equal(oc2, f["out_c2"])
+    for got, want in ((rec, f["smoke_out_record"]), (recs, f["smoke_out_safe_record"])):
+        assert np.array_equal(got, np.broadcast_to(got[:, :1, :1], got.shape), equal_nan=True)       # tiled like the reference's
+        assert np.array_equal(np.isnan(got[:, 0, 0]), np.isnan(want))
+        assert np.nanmax(np.abs(got[:, 0, 0] - want), initial=0.0) <= REC_ATOL
+
+
+@pytest.mark.parametrize("name", ["full_a", "full_b"])
+def test_full_256_step_rollouts_vs_reference_fixtures(name):
+    """the pipeline's shapes: 32 control frames of 64 x 64, 256 steps (255 projections x 500 CG iterations each)"""
+    f = _fix(name)
+    dens, zd, vel, oc1, oc2, rec, recs = [o[0].cpu().numpy() for o in _run(f, torch.device("cuda:0"))]
+    _close(dens, f["densitys"].astype(np.float64), DENS_RTOL, "densitys")
+    _close(zd, f["zero_densitys"].astype(np.float64), DENS_RTOL, "zero_densitys")
+    _close(vel[list(f["f64_frames"])], f["velocitys_f64"], VEL_RTOL, "velocitys (float64 frames)")
+    _close(vel, f["velocitys_f32"].astype(np.float64), 1e-6, "velocitys (all frames, float32 fixture)")
+    assert np.abs(rec[:, 0, 0] - f["smoke_out_record"]).max() <= REC_ATOL
+    assert np.abs(recs[:, 0, 0] - f["smoke_out_safe_record"]).max() <= REC_ATOL
+    assert np.array_equal(oc1, f["out_c1"]) and np.array_equal(oc2, f["out_c2"])
+
+
+def test_vs_oracle_on_fresh_inputs_and_batch_independence():
+    """three different samples in one launch: each equals the oracle's per-sample run, and equals itself launched alone"""
+    from oracle import smoke_solver as osolver
+    from safediffcon_amd import smoke_solver as ss
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    B, nt, nx, T = 3, 3, 64, 24
+    c1 = (rng.standard_normal((B, nt, nx, nx)) * np.array([0.5, 3.0, 12.0])[:, None, None, None]).astype(np.float32)
+    c2 = (rng.standard_normal((B, nt, nx, nx)) * np.array([0.5, 3.0, 12.0])[:, None, None, None]).astype(np.float32)
+    d0 = rng.uniform(0, 1.5, (B, nx, nx)).astype(np.float32)
+    d0[0, 30:, :] = 0
+    sim = ss.init_sim_128()
+    got = ss.solver(sim, ss.init_velocity_(), torch.from_numpy(d0).to(dev), torch.from_numpy(c1).to(dev),
+                    torch.from_numpy(c2).to(dev), T)
+    dom = osolver.domain()
+    for b in range(B):
+        want = osolver.solver(osolver.init_velocity(), d0[b], c1[b], c2[b], T, dom=dom)
+        for k, (g, w) in enumerate(zip(got, want)):
+            g = g[b].cpu().numpy()
+            _close(g, np.asarray(w, dtype=np.float64), REC_ATOL if k >= 5 else (VEL_RTOL if k == 2 else DENS_RTOL), f"sample {b} output {k}")
+        alone = ss.solver(sim, ss.init_velocity_(), torch.from_numpy(d0[b:b + 1]).to(dev), torch.from_numpy(c1[b:b + 1]).to(dev),
+                          torch.from_numpy(c2[b:b + 1]).to(dev), T)
+        for g, a in zip(got, alone):
+            assert torch.equal(torch.nan_to_num(g[b], nan=-7.0), torch.nan_to_num(a[0], nan=-7.0))
+
+
+def test_multi_evaluate_reads_the_sample_tensor_in_place_and_matches_the_oracle():
+    """InferencePipeline.multi_evaluate (2d/inference_2d.py:407-507) on (B, 8, 7, 64, 64) tensors (8 frames x 4 steps)."""
+    from oracle import smoke_solver as osolver
+    from safediffcon_amd import smoke_solver as ss
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    B, nt = 2, 8
+    pred = torch.randn(B, nt, 7, 64, 64, generator=g) * 0.8
+    data = torch.rand(B, nt, 7, 64, 64, generator=g)
+    pred[:, :, 5:] = pred[:, :, 5:].mean((-1, -2), keepdim=True).abs() * 0.1
+    sim = ss.init_sim_128()
+    p_dev = pred.clone().to(dev)
+    out = ss.solver_out(sim, p_dev, data.to(dev), per_timelength=32)
+    assert torch.equal(p_dev[:, 0, 0].cpu(), data[:, 0, 0])                 # pred[:, 0, 0] = data[:, 0, 0], as the reference does
+    assert torch.equal(p_dev[:, 1:, 3:5].cpu(), pred[:, 1:, 3:5])           # caller's control channels are not zeroed in place
+    want = osolver.multi_evaluate_fields(pred.numpy(), data.numpy(), per_timelength=32)
+    got = out.cpu().numpy()
+    for ch, tol in ((0, DENS_RTOL), (1, VEL_RTOL), (2, VEL_RTOL), (3, 0.0), (4, 0.0), (5, 1e-12), (6, 1e-12)):
+        _close(got[:, :, ch], want[:, :, ch], tol, f"solver_out channel {ch}")
+    assert (got[:, :, 3:5, 8:56, 8:56] == 0).all()                          # indirect control
+    # the eight metric arrays, against the reference's formulas (inference_2d.py:460-505) evaluated in numpy on the oracle's fields
+    Q, sb = 0.013, 0.1
+    res = ss.multi_evaluate(pred.clone().to(dev), data.to(dev), Q=Q, safe_bound=sb, sim=sim, per_timelength=32)
+    p = pred.numpy().astype(np.float64).copy()
+    p[:, 0, 0] = data[:, 0, 0].numpy()
+    p[:, 0] = 0
+    d = want.copy()
+    d[:, 0] = 0
+    diff = p - d
+    exp = (-d[:, -1, 5, 0, 0], d[:, -1, 6, 0, 0], np.maximum(d[:, -1, 6, 0, 0] - sb, 0), np.maximum(p[:, -1, 6, 0, 0] + Q - sb, 0),
+           np.maximum(d[:, :, 6, 0, 0] - sb, 0), np.maximum(p[:, :, 6, 0, 0] + Q - sb, 0),
+           np.concatenate((diff[:, :, :3], diff[:, :, -2:]), axis=2).__pow__(2).mean((1, 2, 3, 4)),
+           np.sqrt((diff[:, :, :3] ** 2).sum((1, 2, 3, 4))) / np.sqrt((d[:, :, :3] ** 2).sum((1, 2, 3, 4))))
+    assert len(res) == 8
+    for k, (r, e) in enumerate(zip(res, exp)):
+        assert isinstance(r, np.ndarray) and r.shape == e.shape, k
+        np.testing.assert_allclose(r, e, rtol=1e-6, atol=1e-9, err_msg=f"metric {k}")
+
+
+def test_argument_errors_like_the_reference():
+    from safediffcon_amd import smoke_solver as ss
+    dev = torch.device("cuda:0")
+    sim = ss.init_sim_128()
+    z = lambda *s: torch.zeros(*s, device=dev)
+    with pytest.raises(ValueError):                      # 256 % 5 != 0: the reference's reshape fails the same way
+        ss.solver(sim, ss.init_velocity_(), z(1, 64, 64), z(1, 5, 64, 64), z(1, 5, 64, 64), 256)
+    with pytest.raises(ValueError):                      # nx = 48 does not divide 128
+        ss.solver(sim, ss.init_velocity_(), z(1, 48, 48), z(1, 4, 48, 48), z(1, 4, 48, 48), 32)
+    with pytest.raises(RuntimeError):                    # no CPU fallback
+        ss.solver(sim, ss.init_velocity_(), torch.zeros(1, 64, 64), torch.zeros(1, 4, 64, 64), torch.zeros(1, 4, 64, 64), 32)
+    with pytest.raises(NotImplementedError):
+        sim.set_obstacle(np.ones((3, 3)))
