@@ -13,14 +13,21 @@
 // -- on this domain it always takes the 500 -- so a step is 500 x {5-point mat-vec, three dot products, three vector
 // updates} on 16 129 unknowns: thread t owns column t & 127 of the 32 rows (t >> 7) * 32 ...; x, r and A p sit in its
 // registers (3 x 32 doubles = 192 VGPRs; four vectors would fill the CU's whole 512 KB register file), the search direction p
-// in LDS (129 x 130 doubles with a zero halo = 131 KB of the 160 KB) where the neighbours read it.  CG scalars never leave the
-// device: every thread forms alpha and beta from the same LDS partials, summed in a fixed order (results do not depend on
-// the batch a sample rides in).  Element-wise arithmetic keeps the reference's operation order without FMA contraction
-// (scipy's CSC mat-vec adds a row's terms in ascending column order; numpy multiplies, then adds); only the dot products
-// and the bucket sums associate differently from numpy's pairwise sums.  The CG's first direction update reads the NEW residual
-// on both sides, as the reference's aliased in-place update does.
+// in LDS (129 rows x 128 doubles = 129 KB of the 160 KB; rows -1 and 127 and column 127 stay zero, and column 127 of one
+// row is column -1 of the next, so the open border needs no halo columns) where the neighbours read it.  CG scalars never
+// leave the device: wave partials by DPP lane moves, every thread then forms alpha and beta from the same eight LDS
+// partials in a fixed order (a sample's result does not depend on the batch it rides in).  Element-wise arithmetic keeps
+// the reference's operation order without FMA contraction (scipy's CSC mat-vec adds a row's terms in ascending column
+// order; numpy multiplies, then adds); only the dot products and the bucket sums associate differently from numpy's
+// pairwise sums.  The CG's first direction update reads the NEW residual on both sides, as the reference's aliased
+// in-place update does.
 // Velocity (128 x 128 x 2 doubles) and the three float32 density fields (ping-pong) sit in a per-sample global workspace
 // that stays in L2; they are touched once per step, the CG 500 times.
+// Cost (MI355X, tools/smoke_solver_probe.py): 4.6 us per CG iteration = 0.59 s per 256-step rollout, the same for 1 or 256
+// samples in the batch (one CU each).  Per iteration a thread issues ~820 VALU instructions (two waves per SIMD: ~2.7 us
+// if nothing else stalled) and moves 162 doubles through LDS; the two block-wide reductions cost 0.8 us of it.  A variant
+// that let A p and p share registers (p re-read from LDS under the residual update) needs ~20 VGPRs more than the 256 a
+// thread has at this occupancy and ran slower on its scratch spills (6.5 us).
 #include "sdc_common.h"
 
 #pragma clang fp contract(off)
@@ -31,8 +38,9 @@ constexpr int SN = 127;            // cells per side
 constexpr int SS = 128;            // staggered samples per side
 constexpr int NTHR = 512;
 constexpr int RPT = 32;            // rows per thread
-constexpr int LP = 130;            // LDS pitch of p (doubles): column -1 .. 128
+constexpr int LP = 128;            // LDS pitch of p (doubles): column 127 is always zero and doubles as column -1 of the next row
 constexpr int NWAVE = NTHR / 64;
+constexpr int GR = 4;              // rows per prefetch group of the mat-vec
 constexpr int MAXB = 8;            // buckets per label map
 constexpr size_t VEL_BYTES = (size_t)SS * SS * 2 * sizeof(double);
 constexpr size_t DEN_FLOATS = (size_t)SN * SS;      // pitch 128
@@ -50,11 +58,30 @@ struct SmokeArgs {
     double accuracy;
 };
 
-__device__ __forceinline__ double wsum(double v) { return sdc::wave_sum(v); }
+// wave64 reductions on DPP lane moves (no LDS crossbar round trips): xor 1, xor 2, half-row mirror, row mirror leave
+// the sum of each row of 16 in all its lanes; the four rows are combined through v_readlane in a fixed order.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_get(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wsum(double v) {
+    v += dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);         // row_half_mirror
+    v += dpp_mov<0x140>(v);         // row_mirror
+    return ((lane_get(v, 0) + lane_get(v, 16)) + lane_get(v, 32)) + lane_get(v, 48);
+}
 __device__ __forceinline__ double wmax(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmax(v, dpp_mov<0xB1>(v));
+    v = fmax(v, dpp_mov<0x4E>(v));
+    v = fmax(v, dpp_mov<0x141>(v));
+    v = fmax(v, dpp_mov<0x140>(v));
+    return fmax(fmax(lane_get(v, 0), lane_get(v, 16)), fmax(lane_get(v, 32), lane_get(v, 48)));
 }
 
 // numpy's np.sum over n <= 8 doubles: n < 8 a plain loop, n == 8 the unrolled pairwise block
@@ -67,7 +94,7 @@ __device__ __forceinline__ double np_sum8(const double (&v)[MAXB], int n) {
 }
 
 __global__ __launch_bounds__(NTHR) void smoke_rollout_kernel(SmokeArgs A) {
-    extern __shared__ double P[];                    // (SS + 1) x LP: rows -1 .. 127, columns -1 .. 128
+    extern __shared__ double P[];                    // (SS + 1) x LP: rows -1 .. 127 (rows -1 and 127, column 127 stay zero)
     __shared__ double redA[NWAVE * 2];
     __shared__ double redB[NWAVE * 2];
     __shared__ double redK[NWAVE * 2 * (MAXB + 1)];
@@ -83,14 +110,14 @@ __global__ __launch_bounds__(NTHR) void smoke_rollout_kernel(SmokeArgs A) {
     const int nx = A.nx, si = A.si, ti = A.ti;
     double* outb = A.out + (int64_t)b * A.nt * 7 * nx * nx;
     double* outz = A.out_zero ? A.out_zero + (int64_t)b * A.nt * nx * nx : nullptr;
-    double* Pc = P + (i0 + 1) * LP + (j + 1);        // this thread's first cell
+    double* Pc = P + (i0 + 1) * LP + j;              // this thread's first cell
 
     // ---- domain coefficients of this thread's 32 slots (phi/solver/sparse.py:27-77, phi/flow.py:455-474)
     auto fl = [&](int i, int jj) -> int {            // fluid mask padded with ones (open border: pad_fluid)
         return (i < 0 || i >= SN || jj < 0 || jj >= SN) ? 1 : (int)A.fluid[i * SN + jj];
     };
     unsigned actm = 0, vmxm = 0, vmym = 0;
-    unsigned long long ndm = 0;                      // 2 bits per cell: -diag - 1
+    unsigned nd4[4] = {0, 0, 0, 0};                  // 4 bits per cell: -diag (1 .. 4)
     for (int k = 0; k < RPT; ++k) {
         const int i = i0 + k;
         const int in = (i < SN && j < SN);
@@ -98,7 +125,7 @@ __global__ __launch_bounds__(NTHR) void smoke_rollout_kernel(SmokeArgs A) {
         if (in && f) actm |= 1u << k;
         int nd = fl(i + 1, j) + fl(i - 1, j) + fl(i, j + 1) + fl(i, j - 1);
         if (nd < 1) nd = 1;                          // minimum(centre, -1)
-        ndm |= (unsigned long long)(nd - 1) << (2 * k);
+        nd4[k >> 3] |= (unsigned)nd << (4 * (k & 7));
         if (min(f, fl(i, j - 1))) vmxm |= 1u << k;
         if (min(f, fl(i - 1, j))) vmym |= 1u << k;
     }
@@ -263,25 +290,46 @@ __global__ __launch_bounds__(NTHR) void smoke_rollout_kernel(SmokeArgs A) {
         // ---- conjugate_gradient (phi/solver/base.py:63-103)
         for (int it = 0; rmax >= A.accuracy && it < A.max_iter; ++it) {
             __syncthreads();                         // p (and the previous partials' readers) settled
-            asm volatile("" : "+v"(ndm), "+v"(actm)); // keep the 32 per-cell coefficients packed: no hoisted copies in VGPRs
+            asm volatile("" : "+v"(nd4[0]), "+v"(nd4[1]), "+v"(nd4[2]), "+v"(nd4[3]), "+v"(actm));   // keep the per-cell
+                                                     // coefficients packed: no hoisted float64 copies in VGPRs
             double s1 = 0.0, s2 = 0.0;
             {
+                // mat-vec in groups of four rows, the next group's neighbours in flight while this one is computed
+                const double* Pl = Pc - 1;
+                const double* Pr = Pc + 1;
+                double L[2][GR], R[2][GR], Dn[2][GR];
+#pragma unroll
+                for (int q = 0; q < GR; ++q) { L[0][q] = Pl[q * LP]; R[0][q] = Pr[q * LP]; Dn[0][q] = Pc[(q + 1) * LP]; }
                 double up = Pc[-LP], c = Pc[0];
 #pragma unroll
-                for (int k = 0; k < RPT; ++k) {
-                    const double dn = Pc[(k + 1) * LP];
-                    const double l = Pc[k * LP - 1], rr = Pc[k * LP + 1];
-                    const double dk = (double)(int)(((ndm >> (2 * k)) & 3) + 1);
-                    double y = up + l;               // rows ascend in column index: (i-1,j), (i,j-1), (i,j), (i,j+1), (i+1,j)
-                    y = y - c * dk;
-                    y = y + rr;
-                    y = y + dn;
-                    y = ((actm >> k) & 1) ? y : 0.0;
-                    Ap[k] = y;
-                    s1 = __builtin_fma(c, y, s1);
-                    s2 = __builtin_fma(c, r[k], s2);
-                    up = c;
-                    c = dn;
+                for (int g = 0; g < RPT / GR; ++g) {
+                    if (g + 1 < RPT / GR) {
+#pragma unroll
+                        for (int q = 0; q < GR; ++q) {
+                            const int k = (g + 1) * GR + q;
+                            L[(g + 1) & 1][q] = Pl[k * LP];
+                            R[(g + 1) & 1][q] = Pr[k * LP];
+                            Dn[(g + 1) & 1][q] = Pc[(k + 1) * LP];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < GR; ++q) {
+                        const int k = g * GR + q;
+                        const double dn = Dn[g & 1][q];
+                        const double dk = (double)((nd4[k >> 3] >> (4 * (k & 7))) & 15u);
+                        double y = up + L[g & 1][q];   // a row's terms in ascending column index: (i-1,j), (i,j-1), (i,j), (i,j+1), (i+1,j)
+                        y = y - c * dk;
+                        y = y + R[g & 1][q];
+                        y = y + dn;
+                        const int m = ((int)(actm << (31 - k))) >> 31;
+                        y = __hiloint2double(__double2hiint(y) & m, __double2loint(y) & m);
+                        Ap[k] = y;
+                        s1 = __builtin_fma(c, y, s1);
+                        s2 = __builtin_fma(c, r[k], s2);
+                        up = c;
+                        c = dn;
+                    }
                 }
             }
             s1 = wsum(s1);
@@ -309,13 +357,19 @@ __global__ __launch_bounds__(NTHR) void smoke_rollout_kernel(SmokeArgs A) {
 #pragma unroll
             for (int w = 0; w < NWAVE; ++w) { rAp += redB[w * 2]; rmax = fmax(rmax, redB[w * 2 + 1]); }
             const double bb = -rAp / tmp;
-            const bool first = (it == 0);
+            if (it == 0) {                           // the reference's first update reads the new residual as momentum
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const double po = Pc[k * LP];
-                x[k] = x[k] + a * po;
-                const double pb = first ? r[k] : po;  // the reference's first update reads the new residual as momentum
-                Pc[k * LP] = r[k] + bb * pb;
+                for (int k = 0; k < RPT; ++k) {
+                    x[k] = x[k] + a * Pc[k * LP];
+                    Pc[k * LP] = r[k] + bb * r[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    const double po = Pc[k * LP];
+                    x[k] = x[k] + a * po;
+                    Pc[k * LP] = r[k] + bb * po;
+                }
             }
         }
         // ---- velocity -= mask * gradient(pressure), masked again (phi/flow.py:317-326, evaluate_solver.py:109)
@@ -329,9 +383,9 @@ __global__ __launch_bounds__(NTHR) void smoke_rollout_kernel(SmokeArgs A) {
             for (int k = 0; k < RPT; ++k) {
                 const int i = i0 + k;
                 const int ci = min(i, SN - 1), cim = min(max(i - 1, 0), SN - 1);
-                const double pc = P[(ci + 1) * LP + cj + 1];
-                const double gx = pc - P[(ci + 1) * LP + cjm + 1];
-                const double gy = pc - P[(cim + 1) * LP + cj + 1];
+                const double pc = P[(ci + 1) * LP + cj];
+                const double gx = pc - P[(ci + 1) * LP + cjm];
+                const double gy = pc - P[(cim + 1) * LP + cj];
                 double2 v = reinterpret_cast<double2*>(V)[i * SS + j];
                 v.x = ((vmxm >> k) & 1) ? v.x - gx : 0.0;
                 v.y = ((vmym >> k) & 1) ? v.y - gy : 0.0;
