@@ -306,6 +306,47 @@ def kstar_score_check(batch, dev):
             "parity": "unpinned: the reference's simulator needs TensorFlow (DESIGN.md section 9)"}
 
 
+def smoke_score_check(batch, dev, cpu_steps=8):
+    """the smoke score check that follows a C4 sampling pass (2d/inference_2d.py:407-456 multi_evaluate ->
+    2d/dataset/apps/evaluate_solver.py:209-350): every sampled control sequence through the 255-step fluid rollout,
+    sdc_smoke_rollout (one launch for the batch) beside the CPU restatement timed on a few steps of one sample"""
+    import numpy as np
+    import torch
+    from oracle import smoke_solver as osolver         # cpu_baseline leg only
+    from safediffcon_amd import smoke_solver as ss
+    g = torch.Generator().manual_seed(3)
+    pred = torch.randn(batch, 32, 7, 64, 64, generator=g) * 0.8
+    data = torch.rand(batch, 32, 7, 64, 64, generator=g)
+    data[:, 0, 0, 40:, :] = 0
+    sim = ss.init_sim_128()
+    pd, dd = pred.to(dev), data.to(dev)
+    out = ss.solver_out(sim, pd.clone(), dd)             # warm-up (LDS opt-in, label upload)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = ss.solver_out(sim, pd.clone(), dd)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    # CPU restatement (bit-identical to the reference solver, tests/test_smoke_solver_oracle.py): `cpu_steps` projections
+    # of sample 0, extrapolated to the 255 of a rollout; and the error of the HIP fields against it at the first recorded frame
+    T = 8 * (cpu_steps // 8 + 1)
+    p0, d0 = pred[0].numpy().copy(), data[0].numpy()
+    p0[:, 3:5, 8:56, 8:56] = 0
+    t0 = time.perf_counter()
+    want = osolver.solver(osolver.init_velocity(), d0[0, 0], p0[:T // 8, 3], p0[:T // 8, 4], T)
+    cpu_s_per_step = (time.perf_counter() - t0) / (T - 1)
+    got = out[0].cpu().numpy()
+    err_v = float(np.abs(got[1, 1] - want[2][1][..., 0]).max() / max(np.abs(want[2][1]).max(), 1e-30))
+    err_d = float(np.abs(got[1, 0] - want[0][1]).max())
+    return {"what": "multi_evaluate's solver: 255 steps x (500-iteration float64 CG pressure projection + 3 semi-Lagrangian "
+                    "advections + bucket book-keeping) for every sampled control sequence, one launch, one workgroup per sample",
+            "batch": batch, "hip_ms_per_batch": round(ms, 1), "trajectories_per_s": round(batch / ms * 1e3, 1),
+            "us_per_cg_iteration": round(ms * 1e3 / 255 / 500, 2),
+            "cpu_restatement_s_per_trajectory": round(cpu_s_per_step * 255, 1), "cpu_sample": f"{T - 1} steps of one trajectory, 1 thread, x 255 / {T - 1}",
+            "reference_runs": "one Python process per trajectory (2d/inference_2d.py:422-447)",
+            "max_rel_err_velocity_frame1_vs_cpu_restatement": float(f"{err_v:.2e}"), "max_abs_err_density_frame1": float(f"{err_d:.2e}"),
+            "parity": "pinned: oracle bit-identical to fixtures from the reference solver (tests/golden/smoke_solver_*.npz)"}
+
+
 def finetune_step(name, batch, dim, dev, steps=3, eager=True):
     """One fine-tuning step (loss = mean(w_b p_losses_b); loss.backward(), 2d/inference_2d.py:267-279) through the
     drop-in net's differentiable HIP path, beside the same step of the oracle's functional net under PyTorch-ROCm autograd."""
@@ -656,6 +697,8 @@ def worker(a):
                 extra["finetune_step"] = finetune_step(wl, a.finetune_batch or {"c2": 64, "c3": 64, "c4": 4}[wl], a.dim, dev)
         if world == 1 and not a.no_extra and wl == "c3":
             extra["kstar_score_check"] = kstar_score_check(B, dev)
+        if world == 1 and not a.no_extra and wl == "c4":
+            extra["smoke_score_check"] = smoke_score_check(B, dev)
         if a.full_sample and rank == 0:
             S3 = W["prep"]()
             torch.cuda.synchronize()
