@@ -57,10 +57,16 @@ def _free_port():
 
 def launch_workers(n, argv):
     """Parent of `bench.py --gpus N`: no GPU call here (a process that has initialised HIP must not spawn the ranks)."""
-    import torch
     if "SDC_FORCE_DEVICE" not in os.environ and "--selftest-launcher" not in argv:
-        ndev = torch.cuda.device_count()                   # (counts devices without initialising HIP)
-        if ndev < n:
+        # the count comes from a throwaway child: torch.cuda.device_count() falls back to hipGetDeviceCount (which initialises
+        # the HIP runtime in THIS process) whenever amdsmi discovery is unavailable.  No count -> let each rank report it.
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                               text=True, timeout=300)
+            ndev = int(r.stdout.strip().splitlines()[-1])
+        except (ValueError, IndexError, subprocess.SubprocessError):
+            ndev = None
+        if ndev is not None and ndev < n:
             raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible on this node")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -81,7 +87,7 @@ def shard_config(name, B, world):
                 alpha={"c2": 0.98, "c3": 0.9, "c4": 0.04}[name])
 
 
-def workload(name, dim, B, dev, rank, world, precision=4):
+def workload(name, dim, B, dev, rank, world, precision=4, cal_steps=5):
     """-> dict(desc, gd, prep() -> _Loop, conformal=dict(Q, n_cal, alpha, ms), calib(...) -> calibration-mode _Loop)"""
     import torch
     import safediffcon_amd as sdc
@@ -107,6 +113,20 @@ def workload(name, dim, B, dev, rank, world, precision=4):
         return dict(Q=Q, n_cal_per_rank=n_cal, n_cal=n_cal * world, alpha=alpha, score_kernel_ms=round((t1 - t0) * 1e3, 3),
                     allgather_quantile_ms=round((t2 - t1) * 1e3, 3))
 
+    def sampled_pred(calib, cal_B):
+        """this rank's calibration shard drawn by the calibration-mode sampler itself (a bounded sample: `cal_steps` reverse
+        steps per batch, like extra.calibration) -- the tensors the score kernel then reads are sampler output, not synthetic"""
+        Bc = min(cal_B, n_cal)
+        out = []
+        for _ in range((n_cal + Bc - 1) // Bc):
+            Sc = calib(Bc)
+            Sc.init()
+            for _ in range(cal_steps):
+                Sc.step()
+            out.append(Sc.x.clone())
+            Sc.close()
+        return torch.cat(out)[:n_cal]
+
     if name == "c2":
         dim = dim or 64
         net = sdc.Unet2D(dim=dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1).to(dev)
@@ -115,10 +135,8 @@ def workload(name, dim, B, dev, rank, world, precision=4):
                                           train_on_padded_locations=False).to(dev)
         u0 = (0.1 * torch.randn(B, 128, generator=g1)).clamp(-0.1, 0.3).to(dev)
         uT = (0.1 * torch.randn(B, 128, generator=g1)).clamp(-0.1, 0.3).to(dev)
-        pred = (0.1 * torch.randn(n_cal, 3, 16, 128, generator=g1)).to(dev)
         truth = (0.1 * torch.randn(n_cal, 3, 16, 128, generator=g1)).to(dev)
-        cf = quantile("burgers", pred, truth, [500.0, 0.8 ** 2, 0.0, 10.0], 0.98)
-        guid = sdc.BurgersGuidance(cf["Q"], 500.0, 0.8, use_max_safety=True)     # 1D/configs/inference_config.py:122
+        guid = sdc.BurgersGuidance(0.0, 500.0, 0.8, use_max_safety=True)         # 1D/configs/inference_config.py:122; Q set below
         prep = lambda: gd.sample(batch_size=B, clip_denoised=True, u_init=u0, u_final=uT, guidance_u0=True,   # noqa: E731
                                  nablaJ=guid, J_scheduler=None, enable_grad=False, _prepare=True)
 
@@ -127,6 +145,9 @@ def workload(name, dim, B, dev, rank, world, precision=4):
             return gd.sample(batch_size=Bc, clip_denoised=True, guidance_u0=False, u_init=u0[:Bc], u_final=uT[:Bc],
                              w_groundtruth=wgt, nablaJ=None, enable_grad=False, _prepare=True)
         cal_B, cal_batches = 250, 4
+        net.precision = precision
+        cf = quantile("burgers", sampled_pred(calib, cal_B), truth, [500.0, 0.8 ** 2, 0.0, 10.0], 0.98)
+        guid.Q = cf["Q"]
         desc = f"C2: 1D Burgers Unet2D dim={dim} (1,2,4,8) state (B,3,16,128), guided 1000-step DDPM, conformal quantile on"
     elif name == "c3":
         dim = dim or 256
@@ -136,10 +157,8 @@ def workload(name, dim, B, dev, rank, world, precision=4):
         uT = (0.6 + 0.02 * torch.randn(B, 2, 122, generator=g1).cumsum(-1)).clamp(0.3, 0.9).to(dev)
         target = (uT.new_zeros(B, 3, 122))
         target[:, 0], target[:, 2] = uT[:, 0] * 2, uT[:, 1] * 2
-        pred = (0.5 + 0.3 * torch.randn(n_cal, 12, 128, generator=g1)).to(dev)
         truth = (0.5 + 0.3 * torch.randn(n_cal, 12, 128, generator=g1)).to(dev)
         tgt_cal = (1.0 + 0.3 * torch.randn(n_cal, 3, 122, generator=g1)).to(dev)
-        cf = quantile("tokamak", pred, truth, [0.0, 1.0, 0.01, 4.98, 0.0], 0.9, target=tgt_cal)
         # tokamak/scripts/finetune.sh:13, configs/inference_config.py:25,107-111 (the pipeline always uses Q = 0.0)
         guid = sdc.TokamakGuidance(target, 122, w_obj=0.0, w_safe=1.0, guidance_scaler=0.01, Q=0.0, safety_threshold=4.98)
         prep = lambda: gd.sample(batch_size=B, clip_denoised=True, u_init=u0, u_final=uT, guidance_u0=True,   # noqa: E731
@@ -149,6 +168,8 @@ def workload(name, dim, B, dev, rank, world, precision=4):
             return gd.sample(batch_size=Bc, clip_denoised=True, guidance_u0=False, u_init=u0[:Bc], u_final=uT[:Bc],
                              nablaJ=None, enable_grad=False, _prepare=True)
         cal_B, cal_batches = 125, 8
+        net.precision = precision
+        cf = quantile("tokamak", sampled_pred(calib, cal_B), truth, [0.0, 1.0, 0.01, 4.98, 0.0], 0.9, target=tgt_cal)
         desc = f"C3: tokamak Unet1D dim={dim} (1,2,4,8) state (B,12,128), guided 1000-step DDPM"
     elif name == "c4":
         dim = dim or 64
@@ -156,23 +177,87 @@ def workload(name, dim, B, dev, rank, world, precision=4):
         gd = sdc.GaussianDiffusionSmoke(net, image_size=64, frames=32, timesteps=T_DDPM, loss_type="l2",
                                         standard_fixed_ratio=100.0).to(dev)
         init = (0.5 * torch.rand(B, 64, 64, generator=g1)).to(dev)
-        pred = (0.3 * torch.randn(n_cal, 32, 7, 64, 64, generator=g1)).to(dev)
-        truth = (0.3 * torch.randn(n_cal, 32, 7, 64, 64, generator=g1)).to(dev)
-        cf = quantile("smoke", pred, truth, [0.9, 0.1, 0.0, 100.0], 0.04, smoke=True)
-        del pred, truth
-        guid = sdc.SmokeGuidance(cf["Q"], w_safe=0.9, safe_bound=0.1)            # 2d/scripts/posttrain.sh:20-21
+        guid = sdc.SmokeGuidance(0.0, w_safe=0.9, safe_bound=0.1)                # 2d/scripts/posttrain.sh:20-21; Q set below
         prep = lambda: gd.sample(batch_size=B, design_fn=guid, enable_grad=False, init=init, _prepare=True)  # noqa: E731
 
         def calib(Bc):      # 2d/inference_2d.py:129-134: unguided, frame-0 density and the two control channels imposed
             control = (0.3 * torch.randn(Bc, 32, 2, 64, 64, generator=g1)).to(dev)
             return gd.sample(batch_size=Bc, design_fn=None, enable_grad=False, init=init[:Bc], control=control, _prepare=True)
         cal_B, cal_batches = 25, 8
+        net.precision = precision
+        truth = (0.3 * torch.randn(n_cal, 32, 7, 64, 64, generator=g1)).to(dev)
+        cf = quantile("smoke", sampled_pred(calib, cal_B), truth, [0.9, 0.1, 0.0, 100.0], 0.04, smoke=True)
+        del truth
+        guid.Q = cf["Q"]
         desc = (f"{cfgN['tag']}: 2D smoke Unet3D_with_Conv3D dim={dim} (1,2,4) state (B,32,7,64,64), B={B} per GPU, guided 1000-step DDPM, "
                 f"conformal quantile on")
     else:
         raise SystemExit(f"unknown workload {name}")
-    net.precision = precision
+    cf["source"] = (f"this rank's {n_cal} calibration trajectories drawn by the calibration-mode sampler ({cal_steps} reverse steps each: "
+                    f"a bounded sample), scored against synthetic ground truth (no dataset ships with the reference)")
     return dict(desc=desc, gd=gd, prep=prep, conformal=cf, calib=calib, cal_B=cal_B, cal_batches=cal_batches)
+
+
+class GpuSensors:
+    """Shader clock and socket power of the GPU under test, sampled from the amdgpu hwmon files every 50 ms by a thread while
+    the timed region runs (no child process, no HIP call: plain sysfs reads).  VERDICT r3: a sustained-clock figure is evidence
+    only with the clock log beside it."""
+
+    def __init__(self, dev_index=0):
+        import glob
+        import torch
+        self.dir = None
+        try:
+            p = torch.cuda.get_device_properties(dev_index)
+            slot = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            hw = glob.glob(f"/sys/bus/pci/devices/{slot}/hwmon/hwmon*")
+            if hw and os.path.exists(os.path.join(hw[0], "freq1_input")):
+                self.dir, self.slot = hw[0], slot
+        except Exception:                                  # noqa: BLE001  (sensors are optional)
+            pass
+        self.samples, self._stop, self._th = [], False, None
+
+    def read(self):
+        if self.dir is None:
+            return None
+        try:
+            with open(os.path.join(self.dir, "freq1_input")) as f:
+                mhz = int(f.read()) / 1e6
+            with open(os.path.join(self.dir, "power1_input")) as f:
+                w = int(f.read()) / 1e6
+            return mhz, w
+        except (OSError, ValueError):
+            return None
+
+    def start(self):
+        import threading
+        if self.dir is None:
+            return
+        self.samples, self._stop = [], False
+
+        def loop():
+            while not self._stop:
+                r = self.read()
+                if r:
+                    self.samples.append(r)
+                time.sleep(0.05)
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        if self._th is None:
+            return None
+        self._stop = True
+        self._th.join()
+        self._th = None
+        if not self.samples:
+            return None
+        clk = sorted(s[0] for s in self.samples)
+        pw = [s[1] for s in self.samples]
+        return {"source": f"hwmon freq1_input / power1_input of {self.slot}, sampled every 50 ms over warm-up + timed region",
+                "samples": len(clk), "sclk_mhz_min": round(clk[0]), "sclk_mhz_median": round(clk[len(clk) // 2]),
+                "sclk_mhz_max": round(clk[-1]), "sclk_mhz_mean": round(sum(clk) / len(clk)),
+                "power_w_mean": round(sum(pw) / len(pw)), "power_w_max": round(max(pw))}
 
 
 def cpu_model():
@@ -552,7 +637,9 @@ def selftest_worker(a):
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     if rank == 0:
+        sc = shard_config("c4", DEFAULT_B["c4"], world)
         print(json.dumps({"metric": "selftest (launcher + conformal all-gather, no GPU)", "n_gpus": world, "backend": backend,
+                          "config": sc["tag"], "global_batch": sc["global_batch"], "calibration_per_rank": per,
                           "dist_world_size": dist.get_world_size() if world > 1 else 1, "conformal_Q": round(float(Q), 6),
                           "allgather_quantile_ms": round(el.item() * 1e3, 3)}), flush=True)
     if world > 1:
@@ -620,11 +707,18 @@ def worker(a):
 
     extra = {}
     with torch.cuda.stream(side), torch.no_grad():
-        W = workload(wl, a.dim, B, dev, rank, world, prec)
+        W = workload(wl, a.dim, B, dev, rank, world, prec, cal_steps=a.cal_steps)
         torch.manual_seed(2 + rank)                            # noise: seed 2 (+rank)
         S = W["prep"]()
         S.init()
+        sensors = GpuSensors(local) if rank == 0 else None
+        idle = sensors.read() if sensors else None
+        if sensors:
+            sensors.start()
         dt = timed(S, a.warmup, a.steps)
+        clocks = sensors.stop() if sensors else None
+        if clocks and idle:
+            clocks["sclk_mhz_before"], clocks["power_w_before"] = round(idle[0]), round(idle[1])
         finite = bool(torch.isfinite(S.x).all().item())
         step_ms = dt / a.steps * 1e3
         roof = build_roofline(S, lib, side.cuda_stream, step_ms, wl) if rank == 0 else None
@@ -766,6 +860,8 @@ def worker(a):
                               ranks_counted_by_all_reduce=ranks_seen, dist_world_size=world),
             "roofline": roof,
         }
+        if clocks:
+            out["gpu_sensors"] = clocks
         if extra:
             out["extra"] = extra
         if not a.no_cpu_baseline and world == 1:          # reported on rank 0 at N=1 only

@@ -458,52 +458,6 @@ def forward_train_smoke(net, x, t):
     spatial = T.spatial_linear
 
     h = T.conv("init_conv", x5)
-    r = h
-    hs = []
-    for i in range(nres):
-        p = f"downs.{i}"
-        h = T.resnet(f"{p}.0", h, cond)
-        hs.append(h)
-        h = T.resnet(f"{p}.1", h, cond)
-        h = T.linattn_lucid(f"{p}.2", h, mode)
-        hs.append(h)
-        last = i == nres - 1
-        if last:
-            h = T.conv(f"{p}.3", h)
-        elif nd == 2:
-            h = T.conv(f"{p}.3.1", h, kind="unshuffle")
-        else:
-            h = T.conv(f"{p}.3", h, stride=(1, 1, 2), pad=(0, 0, 1))
-    h = T.resnet("mid_block1", h, cond)
-    h = T.fullattn_lucid("mid_attn", h, mode)
-    h = T.resnet("mid_block2", h, cond)
-    for i in range(nres):
-        p = f"ups.{i}"
-        h = T.resnet(f"{p}.0", h, cond, x1=hs.pop())
-        h = T.resnet(f"{p}.1", h, cond, x1=hs.pop())
-        h = T.linattn_lucid(f"{p}.2", h, mode)
-        last = i == nres - 1
-        if last:
-            h = T.conv(f"{p}.3", h)
-        else:
-            h = T.conv(f"{p}.3.1", h, up=(1, 2, 2) if nd == 2 else (1, 1, 2))
-    h = T.resnet("final_res_block", h, cond, x1=r)
-    out = T.conv("final_conv", h)
-    return out.reshape(x.shape[0], -1, *x.shape[2:])
-
-
-def forward_train_smoke(net, x, t):
-    """Unet3D_with_Conv3D: conv3d.py:487-574; x (B, F, C, H, W) frame-major"""
-    T = net._trainer()
-    nres = len(net.dim_mults)
-    x5 = x.permute(0, 2, 1, 3, 4)
-    cond = T.time_cond(t)
-
-    tables = T._temporal_tables(x5.shape[2], x.device)
-    temporal = lambda pre, h: T.temporal(pre, h, tables)        # noqa: E731
-    spatial = T.spatial_linear
-
-    h = T.conv("init_conv", x5)
     h = temporal("init_temporal_attn", h)
     r = h
     hs = []

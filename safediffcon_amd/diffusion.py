@@ -640,8 +640,13 @@ class GaussianDiffusionBurgers(_SamplerBase):
             guide = None
         return self._dispatch(kwargs.get("_prepare", False), batch_size, (C_, H, W, 1), noise=noise, guide=guide,
                               J_scheduler=J_sched, k_const=1.0, cond=(kwargs["u_init"], kwargs["u_final"], w_groundtruth),
-                              flags=flags, impose_last=False, final_update=self.guidance_u0 or not enable_grad, ddim=ddim,
-                              grad_tail=bool(enable_grad and ddim and self.guidance_u0))
+                              flags=flags, impose_last=False,
+                              # DDPM quirk (:431-447): with enable_grad and guidance_u0=False the t = 0 step's result is dropped;
+                              # ddim_sample always takes x_start of its last step (:493-496)
+                              final_update=ddim or self.guidance_u0 or not enable_grad, ddim=ddim,
+                              # ddim_sample runs its last step under torch.enable_grad() whenever enable_grad is set, with or
+                              # without guidance on x0 (:524-531): the returned sample carries a graph over the model
+                              grad_tail=bool(enable_grad and ddim))
 
 
 class GaussianDiffusionTokamak(_SamplerBase):
@@ -720,8 +725,8 @@ class GaussianDiffusionTokamak(_SamplerBase):
         return self._dispatch(kwargs.get("_prepare", False), batch_size, (self.channels, self.seq_length, 1, 1), noise=noise,
                               guide=guide, J_scheduler=J_sched, k_const=1.0,
                               cond=(kwargs["u_init"], kwargs["u_final"], w_groundtruth), flags=flags, impose_last=False,
-                              target=target, final_update=self.guidance_u0 or not enable_grad, ddim=ddim,
-                              grad_tail=bool(enable_grad and ddim and self.guidance_u0))
+                              target=target, final_update=ddim or self.guidance_u0 or not enable_grad, ddim=ddim,
+                              grad_tail=bool(enable_grad and ddim))    # as in the 1-D class (tokamak/model/diffusion.py:455-470)
 
 
 class GaussianDiffusionSmoke(_SamplerBase):

@@ -34,14 +34,18 @@ def shard(t, dim=0):
 
 
 def init_from_env(backend=None):
-    """one process per GPU, launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    """one process per GPU, launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  The rank binds
+    its device FIRST and hands it to init_process_group (`device_id`): the RCCL communicator is then created eagerly on
+    that device instead of lazily on whatever device the first collective happens to see."""
     import torch.distributed as dist
     ws = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    if use_gpu:
+        torch.cuda.set_device(local)
     if ws > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")     # "nccl" IS RCCL on ROCm
-        dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=ws)
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if torch.cuda.is_available():
-        torch.cuda.set_device(local)
+        backend = backend or ("nccl" if use_gpu else "gloo")     # "nccl" IS RCCL on ROCm
+        kw = dict(device_id=torch.device("cuda", local)) if (backend == "nccl" and use_gpu) else {}
+        dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=ws, **kw)
     return int(os.environ.get("RANK", "0")), ws, local

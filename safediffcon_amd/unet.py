@@ -329,12 +329,29 @@ class _HipUNet(nn.Module):
         self.refresh()
         return r
 
+    def _weights_stamp(self):
+        """changes whenever a parameter is written in place (optimizer.step, load_state_dict, p.data.copy_: the autograd
+        version counters only grow) or re-seated (p.data = ...)"""
+        v, h = 0, 0
+        for p in self.parameters():
+            v += p._version
+            h ^= p.data_ptr()
+        return (v, h)
+
+    def _refresh_entry(self, e, stamp):
+        e["plan"].refresh_weights()
+        e["cond"].refresh_weights()
+        e["lut_valid"] = False
+        e["wstamp"] = stamp
+
     def refresh(self):
-        """Re-pack weights of every cached plan (call after an optimiser step)."""
+        """Re-pack weights of every cached plan now.  Optional: `entry()` -- hence `forward`, `sample` and the fine-tuning
+        path -- re-packs a plan by itself when the parameters have changed since it was packed (the reference's loops
+        call optimizer.step() and sample again without any such call: 1D/inference/inference_ft.py:183-187,
+        tokamak/inference/pipeline.py:238-263, 2d/inference_2d.py:267-279)."""
+        stamp = self._weights_stamp()
         for e in self._plans.values():
-            e["plan"].refresh_weights()
-            e["cond"].refresh_weights()
-            e["lut_valid"] = False
+            self._refresh_entry(e, stamp)
 
     # ------------------------------------------------------------------ plans
     def device(self):
@@ -344,6 +361,10 @@ class _HipUNet(nn.Module):
         """Plan for an input of `shape` whose conditioning table has `rows` rows: one row per sample
         (lut=False, forward(x, time)) or one row per timestep read through a device-side t (lut=True, samplers)."""
         key = (tuple(shape), rows, bool(lut), int(self.precision), bool(self.fuse_linattn), bool(self.subpixel_upsample))
+        stamp = self._weights_stamp()
+        ent = self._plans.get(key)
+        if ent is not None and ent["wstamp"] != stamp:        # parameters changed since this plan packed them
+            self._refresh_entry(ent, stamp)
         if key not in self._plans:
             dev = self.device()
             if dev.type != "cuda":
@@ -370,7 +391,7 @@ class _HipUNet(nn.Module):
             ss = cond.conv(temb, wcat, bcat, self.cond_width, (1, 1, 1))
             assert temb.shape[1] == td
             self._plans[key] = dict(plan=plan, cond=cond, x=x, eps=eps, emb=emb, ss=ss, rows=rows, lut_valid=False,
-                                    t_dev=None)
+                                    t_dev=None, wstamp=stamp)
         return self._plans[key]
 
     def bind_cond(self, ent, t_dev):

@@ -85,7 +85,9 @@ def test_finetune_loss_and_gradients_vs_reference(golden, tree):
 
 
 def test_finetune_step_updates_the_sampler():
-    """loss.backward(); optimizer.step(); net.refresh() -> the graph-replayed sampler sees the new weights"""
+    """loss.backward(); optimizer.step() -> the graph-replayed sampler sees the new weights WITHOUT a refresh() call: the
+    reference's loops (1D/inference/inference_ft.py:183-187, tokamak/inference/pipeline.py:238-263, 2d/inference_2d.py:267-279)
+    never make one; a plan re-packs itself when the parameters' version counters have moved"""
     torch.manual_seed(0)
     net = sdc.Unet2D(dim=16, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1).to(DEV)
     gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=1000, temporal=True, use_conv2d=True,
@@ -101,7 +103,6 @@ def test_finetune_step_updates_the_sampler():
         opt.zero_grad()
         loss.backward()
         opt.step()
-        net.refresh()
         losses.append(loss.item())
     e1 = net(x, t)
     assert losses[-1] < losses[0] and not torch.equal(e0, e1) and torch.isfinite(e1).all()
@@ -109,6 +110,25 @@ def test_finetune_step_updates_the_sampler():
     with torch.no_grad():
         e2 = net.forward_train(x, t)
     assert (e1 - e2).abs().max().item() < 1e-4 * e1.abs().max().item()
+    # a fresh net loaded with the updated weights is the same function
+    net2 = sdc.Unet2D(dim=16, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1).to(DEV)
+    net2.load_state_dict(net.state_dict())
+    assert torch.equal(net2(x, t), e1)
+    # ... and so is a sample() after the step: same injected noise, stale-plan net vs fresh net
+    gd2 = sdc.GaussianDiffusionBurgers(net2, seq_length=(16, 128), timesteps=1000, sampling_timesteps=4, ddim_sampling_eta=1.0,
+                                       temporal=True, use_conv2d=True, is_condition_u0=True, is_condition_uT=True).to(DEV)
+    gd1 = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=1000, sampling_timesteps=4, ddim_sampling_eta=1.0,
+                                       temporal=True, use_conv2d=True, is_condition_u0=True, is_condition_uT=True).to(DEV)
+    u0, uT = det_tensor((2, 128), 3, 0.1).to(DEV), det_tensor((2, 128), 4, 0.1).to(DEV)
+    noise = lambda i: det_tensor((2, 3, 16, 128), 100 + i)
+    s_before = gd1.sample(batch_size=2, u_init=u0, u_final=uT, guidance_u0=False, enable_grad=False, noise=noise)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.mul_(1.01)
+    net2.load_state_dict(net.state_dict())
+    s1 = gd1.sample(batch_size=2, u_init=u0, u_final=uT, guidance_u0=False, enable_grad=False, noise=noise)
+    s2 = gd2.sample(batch_size=2, u_init=u0, u_final=uT, guidance_u0=False, enable_grad=False, noise=noise)
+    assert torch.equal(s1, s2) and not torch.equal(s1, s_before)
 
 
 @pytest.mark.parametrize("tree", ["smoke", "burgers", "tokamak"])

@@ -747,7 +747,8 @@ def test_conv_direct_big_grids(plan_cls, case):
 
 @pytest.mark.parametrize("B,Cc,G,sp,cond,res", [(128, 256, 1, (64,), True, False), (96, 256, 1, (4, 32), True, True),
                                                  (64, 2048, 1, (16,), False, True), (80, 64, 8, (2, 8, 8), False, False),
-                                                 (70, 96, 1, (3, 7), True, True)])
+                                                 (70, 96, 1, (3, 7), True, True),
+                                                 (2, 256, 1, (64,), True, True)])       # the choice does not depend on the batch
 def test_gn_fused_small_groups_equal_the_three_launch_path(B, Cc, G, sp, cond, res):
     """sdc_gn_fused (statistics + apply in one launch for small groups: the deep levels of Unet2D / Unet1D) against
     sdc_gn_stats + sdc_gn_apply and against torch in fp64"""

@@ -96,8 +96,7 @@ def test_forward_graph_replay_equals_call_list(golden):
     assert torch.equal(outs[True][0], outs[True][2]) and not torch.equal(outs[True][0], outs[True][1])
     net.forward_graph = True
     with torch.no_grad():
-        net.final_conv.bias.add_(1.0)
-    net.refresh()
+        net.final_conv.bias.add_(1.0)                # (no refresh(): the plan notices the parameter's version counter)
     x = det_tensor((2, 3, 16, 128), 1).to(DEV)
     torch.testing.assert_close(net(x, torch.tensor([3, 500], device=DEV)), outs[True][0] + 1.0, rtol=0, atol=1e-6)
 

@@ -91,3 +91,28 @@ def test_removed_precision_1_is_refused():
     buf = C.create_string_buffer(128)
     assert _lib.get_lib().sdc_conv_describe(C.byref(d), buf, 128, None) != 0
     assert "precision" in _lib.last_error()
+
+
+def test_bench_launches_itself_world8_gloo_prints_the_c5_line():
+    """`python bench.py --gpus 8` (BASELINE configs[4]): eight ranks through torch.distributed.run (gloo, no GPU touched), 25
+    calibration scores per rank, rank 0 relays one line tagged C5 with global batch 512 and the un-sharded Q"""
+    import json
+    import subprocess
+    import sys
+    import torch
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SDC_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--selftest-launcher"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["dist_world_size"] == 8 and out["config"] == "C5"
+    assert out["global_batch"] == 512 and out["calibration_per_rank"] == 25
+    from oracle import samplers as osam
+    g = torch.Generator().manual_seed(7)
+    scores, weights = torch.rand(200, generator=g), torch.rand(200, generator=g) * 3
+    want = osam.quantile_smoke(osam.normalize_weights(weights, smoke=True) * scores, 0.04)
+    assert abs(out["conformal_Q"] - float(want)) < 1e-6

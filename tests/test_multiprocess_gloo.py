@@ -57,6 +57,47 @@ def test_conformal_allgather_world2(smoke, alpha, n):
     assert res[0][2] == res[1][2] == nw.tolist()
 
 
+def _worker_c5(rank, world, port, q):
+    """BASELINE configs[4] arithmetic on the CPU: 8 ranks x 25 calibration scores of the smoke task (2d/inference_2d.py:113-165:
+    n = 8 x 25, alpha = 0.04, the smoke rank rule), dist.init_from_env as a torch.distributed.run rank would call it"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from safediffcon_amd import conformal
+    from safediffcon_amd.dist import init_from_env, shard, shard_range
+    r, w, local = init_from_env("gloo")
+    assert (r, w, local) == (rank, world, rank) and dist.get_world_size() == world
+    g = torch.Generator().manual_seed(11)
+    scores = torch.rand(200, generator=g) * 0.3
+    weights = torch.exp(-3.0 * torch.rand(200, generator=g))
+    assert shard_range(200) == (rank * 25, rank * 25 + 25) and shard_range(512) == (rank * 64, rank * 64 + 64)
+    Q, nw = conformal.weighted_quantile(shard(scores), shard(weights), 0.04, smoke=True)
+    q.put((rank, float(Q), float(nw.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c5_arithmetic_world8():
+    """8 ranks x 25 scores -> all-gather -> Q identical on all eight ranks = the oracle on the un-sharded 200"""
+    from oracle import samplers as osam
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c5, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(11)
+    scores = torch.rand(200, generator=g) * 0.3
+    weights = torch.exp(-3.0 * torch.rand(200, generator=g))
+    nw = osam.normalize_weights(weights, smoke=True)
+    want = float(osam.quantile_smoke(nw * scores, 0.04))
+    assert [r[0] for r in res] == list(range(8))
+    assert all(r[1] == want for r in res) and all(abs(r[2] - 200.0) < 1e-3 for r in res)
+
+
 def test_shard_range_rejects_ragged():
     from safediffcon_amd.dist import shard_range
     assert shard_range(512, 3, 8) == (192, 256)
