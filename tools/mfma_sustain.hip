@@ -1,0 +1,54 @@
+// How fast does a bare v_mfma_f32_32x32x2_f32 loop run when it runs for SECONDS (the sampler's C4 step keeps the matrix
+// cores busy for minutes), and what do the clock and the socket power do meanwhile?  Prints one line per ~0.25 s window:
+// TFLOP/s of the window.  tools/mfma_sustain.py runs this as a child and samples the amdgpu hwmon files beside it.
+// usage: mfma_sustain <seconds> <0 constant | 1 random operands>
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void mfma_loop(float* out, const float* in, int iters) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a[8], b[8];
+    for (int i = 0; i < 8; ++i) { a[i] = in[(threadIdx.x * 16 + i) & 4095]; b[i] = in[(threadIdx.x * 16 + 8 + i) & 4095]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[(k + i) & 7], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+int main(int argc, char** argv) {
+    const double seconds = argc > 1 ? atof(argv[1]) : 4.0;
+    const int mode = argc > 2 ? atoi(argv[2]) : 1;
+    const int blocks = 1024, iters = 4000;             // ~17 ms per launch at 125 TFLOP/s
+    float *out, *in;
+    (void)hipMalloc(&out, blocks * 256 * 4);
+    (void)hipMalloc(&in, 4096 * 4);
+    static float h[4096];
+    for (int i = 0; i < 4096; ++i) h[i] = mode ? (float)rand() / RAND_MAX * 2.f - 1.f : 0.5f;
+    (void)hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const double flops_per_launch = (double)blocks * 4.0 * iters * 8 * 4 * 4096.0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    printf("mode %s operands\n", mode ? "random" : "constant");
+    for (;;) {
+        (void)hipEventRecord(e0, 0);
+        for (int r = 0; r < 15; ++r) hipLaunchKernelGGL(mfma_loop, dim3(blocks), dim3(256), 0, 0, out, in, iters);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        printf("t=%.2f s  window %.1f ms  %.1f TFLOP/s\n", t, ms, 15 * flops_per_launch / (ms * 1e-3) / 1e12);
+        fflush(stdout);
+        if (t > seconds) break;
+    }
+    return 0;
+}
