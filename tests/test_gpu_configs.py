@@ -280,7 +280,7 @@ def test_c4_width_guided_sampler_vs_oracle():
     assert (free - out).abs().max() > 1e-3               # the guidance mattered
     # measured on MI355X: max|err| 4.9e-4 (one element; a 3-step sigmoid schedule multiplies the eps error by sqrt_recipm1 ~ 50
     # at its first step), MSE 3.3e-11
-    assert _report("C4 width 3-step guided trajectory (B=2) vs oracle", out, ref) < 2e-3 and _mse(out, ref) <= 1e-9
+    assert _report("C4 width 3-step guided trajectory (B=2) vs oracle", out, ref) < 1e-3 and _mse(out, ref) <= 1e-10   # 2x / 3x measured
 
 
 def test_c4_batch64_every_sample_vs_eager_oracle():
@@ -331,7 +331,7 @@ def test_ddim_sampler_at_production_width_vs_oracle(tree):
         ref = osam.ddim_smoke(lambda a, b: onets.unet_smoke(Pg, a, b.to(a.device), dim=64, dim_mults=(1, 2, 4)),
                               osched.make_tables("sigmoid", T), B, lambda i: noise(i).to(DEV), S=S, eta=1.0, init=init.to(DEV),
                               control=control.to(DEV), design_fn=osam.smoke_guidance(0.01, 0.9, -5.0), ratio=100.0).cpu()
-        gate = 4e-3      # measured 1.0e-3 (one element; the re-derived eps of DDIM divides by sqrt(1/abar - 1)), MSE 5.7e-11
+        gate = 2e-3      # (2x measured) measured 1.0e-3 (one element; the re-derived eps of DDIM divides by sqrt(1/abar - 1)), MSE 5.7e-11
     elif tree == "burgers":
         net = sdc.Unet2D(dim=64, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
         P = det_params(_spec(net), 11)

@@ -1,0 +1,106 @@
+"""-m gpu: parity widened where it is cheap.
+ * FULL-schedule (T = 1000) guided DDPM trajectories at PRODUCTION width for C2 (Unet2D dim 64) and C3 (Unet1D dim 256),
+   injected noise, HIP sampler against the oracle's loop + functional net executed by PyTorch-ROCm eager on the same device
+   (that eager run is itself held to the CPU oracle in tests/test_gpu_strawman.py; the dim-8 T = 1000 fixtures of the real
+   reference pin the oracle's loop).  Reference: 1D/model/diffusion.py:368-449, tokamak/model/diffusion.py:310-372.
+ * the C4 guided SAMPLER (not only the forward) at the full batch of 64: two steps, every one of the 64 trajectories
+   against the eager-GPU oracle.  Reference: 2d/ddpm/diffusion_2d.py:288-322.
+Gates: element-wise <= ~2x the error measured on MI355X (printed, `pytest -s`), and the MSE gate of the north star."""
+import pytest
+import torch
+
+import safediffcon_amd as sdc
+from oracle import nets as onets
+from oracle import samplers as osam
+from oracle import schedules as osched
+from oracle.detweights import det_noise, det_params, det_tensor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _spec(net):
+    return [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+
+
+def _report(tag, got, want):
+    err = (got - want).abs().max().item()
+    mse = ((got - want) ** 2).mean().item()
+    print(f"[measured] {tag}: max|err| {err:.3e}  MSE {mse:.3e}  (|ref|max {want.abs().max().item():.3f})")
+    return err, mse
+
+
+def test_t1000_guided_trajectory_at_production_width_burgers():
+    net = sdc.Unet2D(dim=64, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+    P = det_params(_spec(net), 11)
+    net.load_state_dict(P)
+    net.to(DEV)
+    T, B = 1000, 4
+    gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=T, temporal=True, use_conv2d=True,
+                                      is_condition_u0=True, is_condition_uT=True, condition_idx=10,
+                                      train_on_padded_locations=False).to(DEV)
+    u0, uT = det_tensor((B, 128), 61, 0.1), det_tensor((B, 128), 62, 0.1)
+    noise = det_noise((B, 3, 16, 128), 91000)
+    Q, w, ub = 0.01, 500.0, 0.3                       # u_bound 0.3: the hinge is active along the way
+    out = gd.sample(batch_size=B, clip_denoised=True, u_init=u0, u_final=uT, guidance_u0=True,
+                    nablaJ=sdc.BurgersGuidance(Q, w, ub, use_max_safety=True), J_scheduler=None, enable_grad=False, noise=noise).cpu()
+    Pg = {k: v.to(DEV) for k, v in P.items()}
+    ref = osam.sample_burgers(lambda a, b: onets.unet_burgers(Pg, a, b.to(a.device), dim=64), osched.make_tables("cosine", T), B,
+                              lambda i: noise(i).to(DEV), u_init=u0.to(DEV), u_final=uT.to(DEV),
+                              nablaJ=osam.burgers_guidance(Q, w, ub, True), enable_grad=False,
+                              train_on_padded_locations=False).cpu()
+    free = gd.sample(batch_size=B, clip_denoised=True, u_init=u0, u_final=uT, guidance_u0=True, nablaJ=None, enable_grad=False,
+                     noise=noise).cpu()
+    assert (free - out).abs().max() > 1e-3            # the guidance mattered
+    err, mse = _report("C2 width, T = 1000 guided DDPM (B = 4) vs the eager-GPU oracle", out, ref)
+    assert err < 1.2e-5 and mse <= 2e-13              # measured on MI355X: 5.9e-6, 6.5e-14
+
+
+def test_t1000_guided_trajectory_at_production_width_tokamak():
+    net = sdc.Unet1D(dim=256, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+    P = det_params(_spec(net), 21)
+    net.load_state_dict(P)
+    net.to(DEV)
+    T, B = 1000, 4
+    gd = sdc.GaussianDiffusionTokamak(net, seq_length=128, nt=122, timesteps=T).to(DEV)
+    u0 = det_tensor((B, 3), 51, 0.1) + 0.6
+    uT = det_tensor((B, 2, 122), 52, 0.1) + 0.6
+    target = det_tensor((B, 3, 122), 53, 0.3) + 1.0
+    noise = det_noise((B, 12, 128), 92000)
+    args = dict(w_obj=0.3, w_safe=1.0, guidance_scaler=0.5, Q=0.05, safety_threshold=4.98)
+    out = gd.sample(batch_size=B, u_init=u0, u_final=uT, nablaJ=sdc.TokamakGuidance(target, 122, **args), enable_grad=False,
+                    noise=noise).cpu()
+    Pg = {k: v.to(DEV) for k, v in P.items()}
+    ref = osam.sample_tokamak(lambda a, b: onets.unet_tokamak(Pg, a, b.to(a.device), dim=256), osched.make_tables("cosine", T), B,
+                              lambda i: noise(i).to(DEV), u_init=u0.to(DEV), u_final=uT.to(DEV),
+                              nablaJ=osam.tokamak_guidance(target.to(DEV), 122, 0.05, 4.98, 0.3, 1.0, 0.5), enable_grad=False).cpu()
+    err, mse = _report("C3 width, T = 1000 guided DDPM (B = 4) vs the eager-GPU oracle", out, ref)
+    assert err < 1.1e-5 and mse <= 5e-13              # measured on MI355X: 5.1e-6, 2.4e-13
+
+
+def test_c4_guided_sampler_batch64_every_trajectory_vs_eager_oracle():
+    net = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+    P = det_params(_spec(net), 31)
+    net.load_state_dict(P)
+    net.to(DEV)
+    T, B = 2, 64
+    gs = sdc.GaussianDiffusionSmoke(net, image_size=64, frames=32, timesteps=T, standard_fixed_ratio=100.0).to(DEV)
+    init = det_tensor((B, 64, 64), 43, 0.2).abs()
+    noise = det_noise((B, 32, 7, 64, 64), 7000)
+    out = gs.sample(batch_size=B, design_fn=sdc.SmokeGuidance(0.01, 0.9, -5.0), init=init.to(DEV), noise=noise)
+    assert torch.isfinite(out).all() and torch.equal(out[:, 0, 0].cpu(), init)
+    Pg = {k: v.to(DEV) for k, v in P.items()}
+    tabs = osched.make_tables("sigmoid", T)
+    worst, worst_mse = 0.0, 0.0
+    for i in range(0, B, 4):                            # the eager net keeps every activation: 4 trajectories at a time
+        ref = osam.sample_smoke(lambda a, b: onets.unet_smoke(Pg, a, b.to(a.device), dim=64, dim_mults=(1, 2, 4)), tabs, 4,
+                                lambda s, i=i: noise(s)[i:i + 4].to(DEV), init=init[i:i + 4].to(DEV),
+                                design_fn=osam.smoke_guidance(0.01, 0.9, -5.0), ratio=100.0, shape=(32, 7, 64, 64))
+        d = out[i:i + 4] - ref
+        worst = max(worst, d.abs().max().item())
+        worst_mse = max(worst_mse, (d ** 2).flatten(1).mean(1).max().item())
+        del ref, d
+    print(f"[measured] C4 B = 64, 2-step guided sampler, all 64 trajectories vs the eager-GPU oracle: max|err| {worst:.3e}, "
+          f"worst per-trajectory MSE {worst_mse:.3e}")
+    # a 2-step sigmoid schedule multiplies the eps error by sqrt(1/abar - 1) ~ 50 at its first step (cf. test_gpu_configs.py)
+    assert worst < 1.1e-3 and worst_mse <= 2e-10          # measured on MI355X: 5.4e-4, 8.1e-11
