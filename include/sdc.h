@@ -89,6 +89,12 @@ typedef struct SdcConvDesc {
                                         = sum_{kd,kh,kw} G[jd][kd] G[j][kh] G[xi][kw] w[co][ci][kd][kh][kw]; other tap shapes:
                                         layout of 3.  y is used as scratch for partial plane sums while the kernel runs (it
                                         must not alias an input).  Shapes it does not take fall back to 3's kernels.
+                                    5 = as 4, plus Winograd F(4,3) along W for the 1-D convs (kD == kH == 1, rows of whole quads,
+                                        Cout >= 128; half of the matrix work): such a conv's buffer is Wp | Wg | Wg43 with
+                                        Wg43[xi][Cin][Cout], xi < 6, = G43 g (rows (1/4,0,0), (-1/6,-1/6,-1/6), (-1/6,1/6,-1/6),
+                                        (1/24,1/12,1/6), (1/24,-1/12,1/6), (0,0,1)).  Opt-in, not the nets' default: on MI355X it is
+                                        no faster than 2's kernel (the transform is not hidden behind the MFMAs it saves) and
+                                        rounds three times coarser (~3e-6 of the output scale).
                                     (1 was a split-bf16 mode in rounds 1-2; removed: every mode is fp32 arithmetic) */
     int64_t x0s[5], x1s[5], ys[5], rs[5];   /* element strides (b,c,d,h,w) */
 } SdcConvDesc;
@@ -167,6 +173,17 @@ size_t sdc_linattn_block_bytes(int outer, int inner, int C, int64_t n);
 int sdc_linattn_block(const float* x, const float* g_pre, const float* wqkv, const float* wo, const float* bo,
                       const float* g_post, float* work, float* y, int outer, int inner, int C, int64_t n,
                       int64_t so, int64_t sc, int64_t si, int pre_mode, int post_mode, float eps, void* stream);
+/* The same block reading the RAW output of the producing conv: the ResnetBlock's second GroupNorm + SiLU (+ the residual
+ * branch) -- conv3d.py:189-230 block2 / res_conv, consumed only by the attention block that follows (conv3d.py:537-545:
+ * block2 -> spatial_attn -> temporal_attn -> skip) -- is applied while pass 1 loads its tiles, instead of in a separate
+ * sdc_gn_apply pass:  h = SiLU(x_raw * rstd gamma + (beta - mean rstd gamma)) + residual; pass 1 leaves h in y, where pass 2
+ * reads it tile by tile before overwriting it (y must not alias x_raw or the residual).
+ * gn_stats = (mean, rstd) per (outer index, group) as sdc_gn_finalize / sdc_gn_stats write them; gn_residual has x_raw's
+ * strides or is null.  Same arithmetic as sdc_gn_apply followed by sdc_linattn_block. */
+int sdc_linattn_block_gn(const float* x_raw, const float* gn_stats, const float* gn_gamma, const float* gn_beta, int gn_G,
+                         const float* gn_residual, const float* g_pre, const float* wqkv, const float* wo, const float* bo,
+                         const float* g_post, float* work, float* y, int outer, int inner, int C, int64_t n,
+                         int64_t so, int64_t sc, int64_t si, int pre_mode, int post_mode, float eps, void* stream);
 
 /* Fused temporal-attention block of the smoke U-Net, dim 64, 32 frames, heads 4 x 32:
  *   y = x + Wo . softmax( rot(s Wq xn) rot(Wk xn)^T + relpos ) (Wv xn),  xn = channel LayerNorm(x) * gamma
@@ -313,7 +330,7 @@ size_t sdc_chan_norm_bwd_bytes(int B, int C, int64_t S);
 int sdc_chan_norm_bwd(const float* x, const float* gy, const float* g, float* gx, float* gpart, int B, int C, int64_t S,
                       int mode, float eps, void* stream);
 
-/* Kernel layout of an nn.Conv weight w (Cout, Cin, kD, kH, kW) for SdcConvDesc.precision (0, 2, 3, 4) in one launch: Wp followed
+/* Kernel layout of an nn.Conv weight w (Cout, Cin, kD, kH, kW) for SdcConvDesc.precision (0, 2, 3, 4, 5) in one launch: Wp followed
  * by the Winograd taps the precision / tap shape call for (layouts: SdcConvDesc.precision above), transformed taps summed in fp64
  * and rounded once.  flip != 0 packs the DATA-GRADIENT weight of the same conv instead (channels transposed, taps flipped; then the
  * arguments Cout / Cin are those of the packed weight, i.e. swapped).  out holds sdc_pack_conv_weight_floats(...) floats. */

@@ -70,6 +70,8 @@ SIGNATURES = {
     "sdc_linattn_block_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, _i64]),
     "sdc_linattn_block": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64,
                                     _i64, _i64, _i64, C.c_int, C.c_int, C.c_float, _stream]),
+    "sdc_linattn_block_gn": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
+                                       C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, _i64, C.c_int, C.c_int, C.c_float, _stream]),
     "sdc_tattn_block": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                   _i64, _i64, _i64, C.c_float, _stream]),
     "sdc_attn": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, _i64,

@@ -57,6 +57,8 @@ def conv_raw(x, wp, bias, cout, k, *, x1=None, stride=(1, 1, 1), pad=(0, 0, 0), 
     prec = 0
     if k[2] == 3 and n != nw:
         prec = 2 if n == nw + nw // 3 * 4 else (3 if n == nw + nw // 3 * 4 + nw // 9 * 16 else 4)
+        if tuple(k) == (1, 1, 3) and n == nw + nw // 3 * 4 + nw // 3 * 6:
+            prec = 5                                                     # 1-D conv packed with its F(4,3) taps
         assert prec != 4 or n == nw + nw // 3 * 4 + nw // 9 * 16 + nw // 27 * 64, (n, nw)
     else:
         assert n == nw, (n, nw, k, c0, c1, cout)

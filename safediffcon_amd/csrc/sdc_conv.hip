@@ -714,9 +714,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BKT == 8 ? 4
 // of in a second pass over y: per lane for every 8-row block (i, rr >> 2) of its rows, reduced over the wave, then over
 // the waves of the workgroup through `scratch` (the dead staging LDS) in a fixed order -> one fp64 (sum, sum of
 // squares) pair per (sample, group, part), summed by sdc_gn_finalize.  Deterministic: no atomics.
-template <int TM, int TP, int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[4][TM][TP], int mw, int pw, int lane,
-                                            float* scratch, int wave, int m0, int n0) {
+// NX = 6: the F(4,3) form (1-D convs, see conv_wg_kernel): four outputs per tile from six products,
+//     y0 = m0+m1+m2+m3+m4,  y1 = (m1-m2) + 2(m3-m4),  y2 = (m1+m2) + 4(m3+m4),  y3 = (m1-m2) + 8(m3-m4) + m5.
+template <int TM, int TP, int BM, int BN, int WM, int WN, int NX = 4>
+__device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[NX][TM][TP], int mw, int pw, int lane,
+                                            float* scratch, int wave, int m0, int n0, bool active = true) {
+    constexpr int NO = NX == 6 ? 4 : 2;
     const SdcConvDesc& d = a.d;
     const int l31 = lane & 31, lh = lane >> 5;
     const bool v2 = a.vec2;
@@ -739,13 +742,53 @@ __device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[4][
         }
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
-            const int pp = 2 * (pw + j * 32 + l31);          // even position; pp + 1 is in the same row (oW even)
-            const bool pok = pp < a.Ntot;
+            const int pp = NO * (pw + j * 32 + l31);         // first position of the tile; the tile lies in one row (oW % NO == 0)
+            const bool pok = pp < a.Ntot && active;          // (the second k-half of a split workgroup only joins the barriers)
             int r = pok ? pp : 0;
             const int qw = r % d.oW; r /= d.oW;
             const int qh = r % d.oH; r /= d.oH;
             const int qd = r % d.oD; const int qb = r / d.oD;
             const int64_t yoff = qb * d.ys[0] + qd * d.ys[2] + qh * d.ys[3] + qw * d.ys[4];
+            if constexpr (NX == 6) {
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const int co = cob + (rr & 3) + 8 * (rr >> 2);
+                    float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (a.res) {
+                        const int64_t roff = qb * d.rs[0] + qd * d.rs[2] + qh * d.rs[3] + qw * d.rs[4];
+                        const float* rp = a.res + roff + (co < d.Cout ? co : d.Cout - 1) * d.rs[1];
+                        if (v2) {
+                            const float2 t0 = *reinterpret_cast<const float2*>(rp), t1 = *reinterpret_cast<const float2*>(rp + 2);
+                            rv[0] = t0.x; rv[1] = t0.y; rv[2] = t1.x; rv[3] = t1.y;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) rv[q] = rp[q * d.rs[4]];
+                        }
+                    }
+                    const float m0 = acc[0][i][j][rr], m1 = acc[1][i][j][rr], m2 = acc[2][i][j][rr], m3 = acc[3][i][j][rr],
+                                m4 = acc[4][i][j][rr], m5 = acc[5][i][j][rr];
+                    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                    float yv[4];
+                    yv[0] = ((m0 + s12) + s34) + bv[rr] + rv[0];
+                    yv[1] = (d12 + 2.0f * d34) + bv[rr] + rv[1];
+                    yv[2] = (s12 + 4.0f * s34) + bv[rr] + rv[2];
+                    yv[3] = ((d12 + 8.0f * d34) + m5) + bv[rr] + rv[3];
+                    if (pok && co < d.Cout) {
+                        float* yp = a.y + yoff + co * d.ys[1];
+                        if (v2) {
+                            *reinterpret_cast<float2*>(yp) = make_float2(yv[0], yv[1]);
+                            *reinterpret_cast<float2*>(yp + 2) = make_float2(yv[2], yv[3]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) yp[q * d.ys[4]] = yv[q];
+                        }
+                        if (gn) {
+                            gs[i][rr >> 2] += ((double)yv[0] + (double)yv[1]) + ((double)yv[2] + (double)yv[3]);
+                            gq[i][rr >> 2] += ((double)yv[0] * yv[0] + (double)yv[1] * yv[1]) + ((double)yv[2] * yv[2] + (double)yv[3] * yv[3]);
+                        }
+                    }
+                }
+            } else {
             float r0[16], r1[16];
             if (a.res) {
                 const int64_t roff = qb * d.rs[0] + qd * d.rs[2] + qh * d.rs[3] + qw * d.rs[4];
@@ -772,6 +815,7 @@ __device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[4][
                     else { yp[0] = y0; yp[d.ys[4]] = y1; }
                     if (gn) { gs[i][rr >> 2] += (double)y0 + (double)y1; gq[i][rr >> 2] += (double)y0 * y0 + (double)y1 * y1; }
                 }
+            }
             }
         }
     }
@@ -812,27 +856,43 @@ __device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[4][
 // UPS: the input is read through a virtual nearest-neighbour x2 upsampling along H and/or W (Upsample + conv,
 // 1D/model/unet.py:24-37): the staged row is the upsampled one (column >> 1), and the source row of tap kh,
 // (oh - pH + kh) >> 1, differs per output row, so its offset is kept per lane for the (<= 3) kh taps; kD = 1, one input.
-template <int BM, int BN, int WM, int WN, int SK, int NTH, bool UPS>
+// NX = 6: F(4,3) along W for the 1-D convs (kD = kH = 1: the tokamak Unet1D, 85 % of its FLOPs): an output quad and the six
+// inputs d0..d5 under it,
+//     V = B^T d:  4 d0 - 5 d2 + d4 | (d4 - 4 d2) +- (d3 - 4 d1) | (d4 - d2) +- 2 (d3 - d1) | 4 d1 - 5 d3 + d5,
+// six GEMMs with N = positions / 4 instead of three with N = positions: HALF the fp32 MFMA work of the direct form (F(2,3): 2/3).
+// The six taps G g (G rows (1/4,0,0), (-1/6,-1/6,-1/6), (-1/6,1/6,-1/6), (1/24,1/12,1/6), (1/24,-1/12,1/6), (0,0,1)), formed in
+// fp64 and rounded once, follow the F(2,3) taps in the packed weight.  Twelve VALU operations per k-step and tile feed six
+// MFMAs.  The larger transform constants cost accuracy: ~5e-6 of the output scale against fp64 (F(2,3): ~1e-6).
+// KS = 2: the C3 layers are ~1024 wave tiles each -- one per SIMD -- and a lone wave cannot hide its transform / staging VALU
+// behind its own MFMAs (measured: 65 TFLOP/s issued); the k-steps of every stage are therefore split over TWO waves per SIMD
+// that own the same output tile, and the second half's accumulators are added through the (dead) staging LDS before the epilogue.
+template <int BM, int BN, int WM, int WN, int SK, int NTH, bool UPS, int NX = 4, int KS = 1>
 __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
+    static_assert(NX == 4 || (NX == 6 && !UPS), "F(4,3) serves the plain 1-D convs");
+    static_assert(KS == 1 || (KS == 2 && SK % 8 == 0), "k-split");
+    constexpr int NO = NX == 6 ? 4 : 2;                         // outputs per tile
+    constexpr int NF2 = NX / 2;                                 // float2 reads per tile: d0..d3 / d0..d5
     constexpr int TM = BM / WM / 32;
-    constexpr int TP = BN / 2 / WN / 32;                        // 32-pair column tiles per wave
+    constexpr int TP = BN / NO / WN / 32;                       // 32-tile column tiles per wave
     constexpr int KSMAX = BN + (BN / 16) * 2;                   // LDS floats per k row, worst case (16-wide rows)
     constexpr int NCOL = (KSMAX + 63) / 64;
     constexpr int KROWS = SK / (NTH / 64);
-    constexpr int NA4 = 4 * SK * BM / 4 / NTH;                  // float4 weight loads per thread per stage
-    static_assert(TM >= 1 && TP >= 1 && KROWS >= 1 && NA4 >= 1 && WM * WN * 64 == NTH, "bad tile");
+    constexpr int NA4 = NX * SK * BM / 4 / NTH;                 // float4 weight loads per thread per stage
+    static_assert(TM >= 1 && TP >= 1 && KROWS >= 1 && NA4 >= 1 && WM * WN * KS * 64 == NTH, "bad tile");
     extern __shared__ __attribute__((aligned(16))) float ldsw[];
     constexpr int PITCH = NCOL * 64 + 8;                        // LDS floats per staged k row: every (lane, sweep) slot exists, so the
                                                                 // staging stores need no per-lane predicate (+8: bank spread of the two half-waves)
-    constexpr int ASZ = 4 * SK * BM, BSZ = SK * PITCH;          // floats per buffer
-    float* const As = ldsw;                                     // [2][4][SK][BM]
+    constexpr int ASZ = NX * SK * BM, BSZ = SK * PITCH;         // floats per buffer
+    float* const As = ldsw;                                     // [2][NX][SK][BM]
     float* const Bs = ldsw + 2 * ASZ;                           // [2][SK * ks_stride]
 
     const SdcConvDesc& d = a.d;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = SDC_UNIFORM(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    const int kh = KS == 1 ? 0 : wave / (WM * WN);              // k-half this wave multiplies
+    const int wv = KS == 1 ? wave : wave % (WM * WN);
+    const int wm = wv / WN, wn = wv % WN;
     const int n0 = xcd_tile(blockIdx.x, gridDim.x) * BN;
     const int m0 = blockIdx.y * BM;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -911,7 +971,7 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
     int boff[TP];
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
-        const int pos = 2 * (wn * (TP * 32) + j * 32 + l31);
+        const int pos = NO * (wn * (TP * 32) + j * 32 + l31);
         const int sg = pos / seg;
         boff[j] = sg * rowlen + (pos - sg * seg);
     }
@@ -927,7 +987,8 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
         a_ok[i] = (m0 + c4) < d.Cout;
         a_voff[i] = (uint32_t)(((int64_t)(xi * a.Cin + kr) * d.Cout + (a_ok[i] ? (m0 + c4) : 0)) * 4);
     }
-    const float* wg = a.wp + (int64_t)a.Ktot * d.Cout;          // transformed taps, 4 per (kd, kh)
+    // transformed taps, NX per (kd, kh): the F(2,3) section follows Wp, the F(4,3) section (1-D convs only) follows that
+    const float* wg = a.wp + (int64_t)a.Ktot * d.Cout + (NX == 6 ? (int64_t)(a.Ktot / 3 * 4) * d.Cout : 0);
 
     float breg[KROWS][NCOL];
     float4 areg[NA4];
@@ -969,7 +1030,7 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
         typedef const __attribute__((address_space(1))) char* gchar_p;
         typedef float nfloat4 __attribute__((ext_vector_type(4)));
         typedef const __attribute__((address_space(1))) nfloat4* gfloat4_p;
-        const gfloat_p wbase = uniform_ptr(wg + ((int64_t)(l_tap * 4) * a.Cin + l_ci) * d.Cout);
+        const gfloat_p wbase = uniform_ptr(wg + ((int64_t)(l_tap * NX) * a.Cin + l_ci) * d.Cout);
 #pragma unroll
         for (int i = 0; i < NA4; ++i) {
             if (i % NSL != p) continue;
@@ -1005,9 +1066,9 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
     };
     auto store_piece = [&](int buf, int p) { store_piece_from(buf, p, breg, areg, mbits); };
 
-    f32x16 acc[4][TM][TP];
+    f32x16 acc[NX][TM][TP];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < NX; ++x)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1037,63 +1098,84 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
 
     for (int st = 0; st < nstages; ++st) {
         const int buf = st & 1;
-        const float* Ab = As + buf * ASZ;
-        const float* Bb = Bs + buf * BSZ;
-        float fa[2][4][TM];
-        float2 fb[2][TP][2];
+        constexpr int KST = SK / 2 / KS;                        // k-steps of a stage this wave multiplies
+        const float* Ab = As + buf * ASZ + (2 * KST * kh) * BM;
+        const float* Bb = Bs + buf * BSZ + (2 * KST * kh) * PITCH;
+        const uint32_t mb_prev = mbits;
+        float fa[2][NX][TM];
+        float2 fb[2][TP][NF2];
         auto read_frag = [&](int ks, int set) {
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
+            for (int x = 0; x < NX; ++x)
 #pragma unroll
                 for (int i = 0; i < TM; ++i) fa[set][x][i] = Ab[(x * SK + 2 * ks + lh) * BM + am + i * 32];
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
                 const float2* bp = reinterpret_cast<const float2*>(Bb + (2 * ks + lh) * PITCH + boff[j]);
-                fb[set][j][0] = bp[0];
-                fb[set][j][1] = bp[1];
+#pragma unroll
+                for (int q = 0; q < NF2; ++q) fb[set][j][q] = bp[q];
             }
         };
         // Input transform of a k-step's B fragments is done one step ahead, and the LDS reads, the staging piece and
         // that transform are spread over the shadows of the step's MFMAs (sched_group_barrier): a wave that issues its
         // MFMAs back to back and only then its other instructions leaves the matrix pipe idle while it catches up --
         // the two waves of a SIMD drift into running one after the other, so nobody else fills those gaps.
-        float bt[2][TP][4];
+        float bt[2][TP][NX];
         auto transform = [&](int set) {
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                const float2 p0 = fb[set][j][0], p1 = fb[set][j][1];
-                bt[set][j][0] = p0.x - p1.x;
-                bt[set][j][1] = p0.y + p1.x;
-                bt[set][j][2] = p1.x - p0.y;
-                bt[set][j][3] = p0.y - p1.y;
+                if constexpr (NX == 6) {
+                    const float d0 = fb[set][j][0].x, d1 = fb[set][j][0].y, d2 = fb[set][j][1].x, d3 = fb[set][j][1].y,
+                                d4 = fb[set][j][2].x, d5 = fb[set][j][2].y;
+                    const float e42 = fmaf(-4.0f, d2, d4), e31 = fmaf(-4.0f, d1, d3);
+                    const float c42 = d4 - d2, c31 = d3 - d1;
+                    bt[set][j][0] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
+                    bt[set][j][1] = e42 + e31;
+                    bt[set][j][2] = e42 - e31;
+                    bt[set][j][3] = fmaf(2.0f, c31, c42);
+                    bt[set][j][4] = fmaf(-2.0f, c31, c42);
+                    bt[set][j][5] = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
+                } else {
+                    const float2 p0 = fb[set][j][0], p1 = fb[set][j][1];
+                    bt[set][j][0] = p0.x - p1.x;
+                    bt[set][j][1] = p0.y + p1.x;
+                    bt[set][j][2] = p1.x - p0.y;
+                    bt[set][j][3] = p0.y - p1.y;
+                }
             }
         };
         read_frag(0, 0);
         transform(0);
 #pragma unroll
-        for (int ks = 0; ks < SK / 2; ++ks) {
+        for (int ks = 0; ks < KST; ++ks) {
             const int set = ks & 1;
-            if (ks + 1 < SK / 2) read_frag(ks + 1, set ^ 1);
-            if (ks < NSL) {
+            if (ks + 1 < KST) read_frag(ks + 1, set ^ 1);
+            if constexpr (KS == 2) {
+                // half as many k-steps per wave: every step parks one piece of stage st+1 and fetches the same piece of stage st+2
+                static_assert(KS == 1 || KST == NSL, "one staging piece per k-step");
+                store_piece_from(buf ^ 1, ks, breg, areg, mb_prev);
+                if (ks == 0) load_begin();
+                load_piece(ks);
+            } else if (ks < NSL) {
                 store_piece(buf ^ 1, ks);
             } else {
                 if (ks == NSL) load_begin();
                 load_piece(ks - NSL);
             }
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
+            for (int x = 0; x < NX; ++x)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TP; ++j)
                         acc[x][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][x][i], bt[set][j][x], acc[x][i][j], 0, 0, 0);
-            if (ks + 1 < SK / 2) transform(set ^ 1);
+            if (ks + 1 < KST) transform(set ^ 1);
             // interleave: the next fragments' LDS reads behind the first MFMA, then per MFMA a few VALU and one staging
             // access (LDS write / global load)
 #pragma unroll
-            for (int m = 0; m < 4 * TM * TP; ++m) {
+            for (int m = 0; m < NX * TM * TP; ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (m < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM + 2 * TP, 0);
+                if (m < 2) __builtin_amdgcn_sched_group_barrier(0x100, (NX / 2) * TM + NF2 * TP, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x220, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
@@ -1102,19 +1184,48 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
         }
         __syncthreads();
     }
-    wg_epilogue<TM, TP, BM, BN, WM, WN>(a, acc, m0 + wm * (TM * 32), n0 / 2 + wn * (TP * 32), lane, ldsw, wave, m0, n0);
+    if constexpr (KS == 2) {
+        // the two k-halves of a tile meet in the staging LDS (dead after the last stage's barrier): [tile wave][register][lane]
+        float* red = ldsw + (size_t)wv * (NX * TM * TP * 16) * 64 + lane;
+        if (kh == 1) {
+#pragma unroll
+            for (int x = 0; x < NX; ++x)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) red[(((x * TM + i) * TP + j) * 16 + r) * 64] = acc[x][i][j][r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int x = 0; x < NX; ++x)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[x][i][j][r] += red[(((x * TM + i) * TP + j) * 16 + r) * 64];
+        }
+        __syncthreads();
+    }
+    wg_epilogue<TM, TP, BM, BN, WM, WN, NX>(a, acc, m0 + wm * (TM * 32), n0 / NO + wn * (TP * 32), lane, ldsw, wv, m0, n0, kh == 0);
 }
 
 
-template <int BM, int BN, int WM, int WN, int SK, int NTH = 256, bool UPS = false>
+template <int BM, int BN, int WM, int WN, int SK, int NTH = 256, bool UPS = false, int NX = 4, int KS = 1>
 int launch_wg(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
     constexpr int KSMAX = BN + (BN / 16) * 2;
     constexpr int NCOLH = (KSMAX + 63) / 64;
-    const size_t lds = (2u * 4u * SK * BM + 2u * SK * (NCOLH * 64 + 8)) * sizeof(float);
+    const size_t lds = (2u * NX * SK * BM + 2u * SK * (NCOLH * 64 + 8)) * sizeof(float);
+    static_assert((2u * NX * SK * BM + 2u * SK * (NCOLH * 64 + 8)) * sizeof(float) <= 160u * 1024u, "stage buffers exceed the LDS");
+    static_assert(KS == 1 || (size_t)WM * WN * NX * (BM / WM / 32) * (BN / (NX == 6 ? 4 : 2) / WN / 32) * 16 * 64 * sizeof(float) <=
+                                 (2u * NX * SK * BM + 2u * SK * (NCOLH * 64 + 8)) * sizeof(float), "k-split partials exceed the staging LDS");
     static std::atomic<uint64_t> attr{0};
-    SDC_LDS_OPTIN(attr, (conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS>), 160 * 1024, "sdc_conv[winograd]");
-    hipLaunchKernelGGL((conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS>), grid, dim3(NTH), lds, s, a);
+    SDC_LDS_OPTIN(attr, (conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS, NX, KS>), 160 * 1024, "sdc_conv[winograd]");
+    hipLaunchKernelGGL((conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS, NX, KS>), grid, dim3(NTH), lds, s, a);
     return SDC_OK;
 }
 
@@ -1198,9 +1309,16 @@ WgPick wg_pick(const SdcConvDesc& d, int64_t ntot, bool small, bool rowhalo) {
         if (pick == 10 && !fits(512)) pick = 3;
         if (pick != 6 && pick != 7 && pick != 9 && pick != 10) pick = 3;
     }
+    // precision 5 (opt-in): 1-D convs (kD = kH = 1, one row per sample and channel) whose rows are whole quads take F(4,3), half of
+    // the direct form's MFMAs instead of two thirds; 128 x 128 outputs per workgroup (the C3 layers are ~256 such tiles each).
+    // NOT the default: measured at C3 the six-product kernel issues 74 TFLOP/s where the F(2,3) one
+    // issues 97 -- twelve transform operations per six MFMAs are not hidden behind them -- 6.09 ms against 5.99 ms for the 33
+    // layers, at three times the rounding error
+    static const int no_f43 = exp_env("SDC_NO_F43");
+    if (!no_f43 && d.precision == 5 && !w.ups && d.kD == 1 && d.kH == 1 && d.oD == 1 && d.oH == 1 && d.oW % 4 == 0 && d.Cout >= 128) pick = 13;
     w.pick = pick;
-    w.bm = (pick == 6 || pick == 9) ? 128 : 64;
-    w.bn = pick == 3 ? 128 : (pick == 6 ? 128 : (pick == 10 ? 512 : 256));
+    w.bm = (pick == 6 || pick == 9 || pick == 13) ? 128 : 64;
+    w.bn = (pick == 3 || pick == 6 || pick == 13) ? 128 : (pick == 10 ? 512 : 256);
     return w;
 }
 
@@ -1271,7 +1389,7 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
     SDC_REQUIRE(d.Cin1 == 0 || x1, SDC_ENULL, "sdc_conv: Cin1 > 0 but x1 is null");
     SDC_REQUIRE(d.kD > 0 && d.kH > 0 && d.kW > 0 && d.sD > 0 && d.sH > 0 && d.sW > 0, SDC_EINVAL,
                 "sdc_conv: bad kernel/stride");
-    SDC_REQUIRE(d.precision == 0 || (d.precision >= 2 && d.precision <= 4), SDC_EINVAL, "sdc_conv: precision must be 0 (fp32 MFMA, direct form), 2 (fp32 Winograd along W), 3 (fp32 Winograd over H and W) or 4 (fp32 Winograd over D, H and W)");
+    SDC_REQUIRE(d.precision == 0 || (d.precision >= 2 && d.precision <= 5), SDC_EINVAL, "sdc_conv: precision must be 0 (fp32 MFMA, direct form), 2 (fp32 Winograd along W), 3 (fp32 Winograd over H and W), 4 (fp32 Winograd over D, H and W) or 5 (as 4, F(4,3) for the 1-D convs)");
     SDC_REQUIRE(!gn_part || d.precision >= 2, SDC_EINVAL, "sdc_conv_gn: fused GroupNorm statistics need precision 2, 3 or 4 (sdc_conv_gnparts returned 0)");
     // the caller sized `parts` with sdc_conv_gnparts(d, G), which sees the descriptor only: a kernel picked here on other
     // grounds (pointer alignment, a residual) with a different part count would write a table the finalize pass misreads
@@ -1368,7 +1486,8 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
             else { SDC_PICK("conv_wg_kernel<64,128,2,2,16,256,ups>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 128, 2, 2, 16, 256, true>(a, s); if (rc_) return rc_; } }
             return sdc::check_launch("sdc_conv[winograd,upsample]");
         }
-        if (wgp.pick == 6) { SDC_PICK("conv_wg_kernel<128,128,4,2,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<128, 128, 4, 2, 16, 512>(a, s); if (rc_) return rc_; } }
+        if (wgp.pick == 13) { SDC_PICK("conv_wg_kernel<128,128,4,1,16,512,F43>", 0.5); { const int rc_ = launch_wg<128, 128, 4, 1, 16, 512, false, 6, 2>(a, s); if (rc_) return rc_; } }
+        else if (wgp.pick == 6) { SDC_PICK("conv_wg_kernel<128,128,4,2,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<128, 128, 4, 2, 16, 512>(a, s); if (rc_) return rc_; } }
         else if (wgp.pick == 7) { SDC_PICK("conv_wg_kernel<64,256,2,4,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 256, 2, 4, 16, 512>(a, s); if (rc_) return rc_; } }
         else if (wgp.pick == 9) { SDC_PICK("conv_wg_kernel<128,256,4,2,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<128, 256, 4, 2, 16, 512>(a, s); if (rc_) return rc_; } }       // (2 x 4 waves measured the same)
         else if (wgp.pick == 10) { SDC_PICK("conv_wg_kernel<64,512,1,8,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 512, 1, 8, 16, 512>(a, s); if (rc_) return rc_; } }     // (each wave: both 32-row tiles x 32 pairs; measured 3 % ahead of 1 x 2)

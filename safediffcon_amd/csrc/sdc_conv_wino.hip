@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
 // blocks, the row pairs of a workgroup inside one plane, 8-byte aligned rows of y (and of the residual)
 bool wg3_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
     auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
-    if (!(d.precision == 4 && d.kD == 3 && d.oD % 2 == 0 && (d.oW == 16 || d.oW == 32 || d.oW == 64) && d.Cout % W2_BM == 0)) return false;
+    if (!(d.precision >= 4 && d.kD == 3 && d.oD % 2 == 0 && (d.oW == 16 || d.oW == 32 || d.oW == 64) && d.Cout % W2_BM == 0)) return false;
     SdcConvDesc e = d;
     e.precision = 3;
     if (!wg2_ok(e, small, rowhalo)) return false;

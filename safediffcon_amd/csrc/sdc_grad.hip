@@ -1073,7 +1073,7 @@ __device__ __forceinline__ double wino_g(int row, int tap) {
 struct PackArgs {
     const float* w; float* out;
     int Cout, Cin, kD, kH, kW, flip;       // logical (packed) channel counts
-    int64_t n0, n1, n2, n3;                // floats of the four sections
+    int64_t n0, n1, n2, n3, n4;            // floats of the five sections (n4: F(4,3) taps of a 1-D conv, after the others)
 };
 
 // One workgroup stages a (co_t co) x (ci_t ci) x taps block of the weight through LDS -- read along the source's contiguous axis
@@ -1126,6 +1126,23 @@ __global__ __launch_bounds__(NT) void pack_weight_kernel(const PackArgs a, const
                         o[((int64_t)((kd * a.kH + kh) * 4 + xi) * a.Cin + ci0 + ci) * a.Cout + co0 + co] = (float)v;
                     }
     }
+    if (a.n4) {                                           // Wg43[xi][ci][co], xi < 6: F(4,3) taps of a 1-D conv (kD = kH = 1)
+        float* o = a.out + a.n0 + a.n1 + a.n2 + a.n3;
+        for (int xi = 0; xi < 6; ++xi)
+            for (int e = threadIdx.x; e < cell; e += NT) {
+                const int co = e & (co_t - 1), ci = e >> co_sh;
+                if (co >= nco || ci >= nci) continue;
+                const double g0 = wv(co, ci, 0, 0, 0), g1 = wv(co, ci, 0, 0, 1), g2 = wv(co, ci, 0, 0, 2);
+                double v;
+                if (xi == 0) v = g0 / 4.0;
+                else if (xi == 1) v = -((g0 + g2) + g1) / 6.0;
+                else if (xi == 2) v = -((g0 + g2) - g1) / 6.0;
+                else if (xi == 3) v = (g0 / 4.0 + g2) / 6.0 + g1 / 12.0;
+                else if (xi == 4) v = (g0 / 4.0 + g2) / 6.0 - g1 / 12.0;
+                else v = g2;
+                o[((int64_t)xi * a.Cin + ci0 + ci) * a.Cout + co0 + co] = (float)v;
+            }
+    }
     // the 2-D / 3-D Winograd taps: a thread forms the (kd, kh)-weighted sums of the three kw taps once (rows 0 and 3 of G pick one
     // tap, rows 1 and 2 weigh all three by +-1/2) and writes the four xi taps of its (jd, j) as one 16-byte store
     auto g_lo = [](int r) { return r == 3 ? 2 : 0; };
@@ -1169,33 +1186,34 @@ __global__ __launch_bounds__(NT) void pack_weight_kernel(const PackArgs a, const
 
 void pack_sections(int Cout, int Cin, int kD, int kH, int kW, int precision, int64_t* n) {
     const int64_t nw = (int64_t)Cout * Cin * kD * kH * kW;
-    n[0] = nw; n[1] = n[2] = n[3] = 0;
+    n[0] = nw; n[1] = n[2] = n[3] = n[4] = 0;
     if (precision >= 2 && kW == 3) {
         n[1] = nw / 3 * 4;
+        if (precision == 5 && kD == 1 && kH == 1) n[4] = nw / 3 * 6;
         if (precision >= 3 && kH == 3) {
             n[2] = nw / 9 * 16;
-            if (precision == 4 && kD == 3) n[3] = nw / 27 * 64;
+            if (precision >= 4 && kD == 3) n[3] = nw / 27 * 64;
         }
     }
 }
 }  // namespace
 
 extern "C" size_t sdc_pack_conv_weight_floats(int Cout, int Cin, int kD, int kH, int kW, int precision) {
-    int64_t n[4];
+    int64_t n[5];
     pack_sections(Cout, Cin, kD, kH, kW, precision, n);
-    return (size_t)(n[0] + n[1] + n[2] + n[3]);
+    return (size_t)(n[0] + n[1] + n[2] + n[3] + n[4]);
 }
 
 extern "C" int sdc_pack_conv_weight(const float* w, float* out, int Cout, int Cin, int kD, int kH, int kW, int precision, int flip,
                                     void* stream) {
     SDC_REQUIRE(w && out, SDC_ENULL, "sdc_pack_conv_weight: null pointer");
-    SDC_REQUIRE(Cout > 0 && Cin > 0 && kD > 0 && kH > 0 && kW > 0 && (precision == 0 || (precision >= 2 && precision <= 4)), SDC_EINVAL,
+    SDC_REQUIRE(Cout > 0 && Cin > 0 && kD > 0 && kH > 0 && kW > 0 && (precision == 0 || (precision >= 2 && precision <= 5)), SDC_EINVAL,
                 "sdc_pack_conv_weight: bad arguments");
     PackArgs a;
     a.w = w; a.out = out; a.Cout = Cout; a.Cin = Cin; a.kD = kD; a.kH = kH; a.kW = kW; a.flip = flip;
-    int64_t n[4];
+    int64_t n[5];
     pack_sections(Cout, Cin, kD, kH, kW, precision, n);
-    a.n0 = n[0]; a.n1 = n[1]; a.n2 = n[2]; a.n3 = n[3];
+    a.n0 = n[0]; a.n1 = n[1]; a.n2 = n[2]; a.n3 = n[3]; a.n4 = n[4];
     const int taps = kD * kH * kW;
     int ci_sh = 4, co_sh = 6;
     while (ci_sh > 0 && (taps << ci_sh) > 128) --ci_sh;

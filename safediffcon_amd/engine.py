@@ -69,7 +69,7 @@ def pack_conv_weight(t, kind="conv", precision=0):
         t5 = as5(t)                                       # (Cout, Cin, kD, kH, kW)
         return t5.permute(2, 3, 4, 1, 0).reshape(-1, t5.shape[0]).contiguous()
     wp = base().to(torch.float32)
-    if precision not in (2, 3, 4) or kind != "conv" or t.shape[-1] != 3:
+    if precision not in (2, 3, 4, 5) or kind != "conv" or t.shape[-1] != 3:
         return wp
     # fp32 Wp followed by the Winograd F(2,3) taps along W, [(kd*kH + kh)*4 + xi][Cin][Cout]:
     # G g with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], formed in fp64 and rounded once;
@@ -78,10 +78,16 @@ def pack_conv_weight(t, kind="conv", precision=0):
     G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64, device=t5.device)
     u = torch.einsum("xk,oidhk->dhxio", G, t5)    # (kD, kH, 4, Cin, Cout)
     parts = [wp.reshape(-1), u.reshape(-1).to(torch.float32)]
+    if precision == 5 and t5.shape[2] == 1 and t5.shape[3] == 1:
+        # precision 5, 1-D convs: the F(4,3) taps G43 g, [xi][Cin][Cout] with xi < 6, after everything else (csrc/sdc_conv.hip conv_wg_kernel NX = 6)
+        G43 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                            [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64, device=t5.device)
+        u43 = torch.einsum("xk,oik->xio", G43, t5[:, :, 0, 0])
+        return torch.cat(parts + [u43.reshape(-1).to(torch.float32)])
     if precision >= 3 and t5.shape[3] == 3:
         u2 = torch.einsum("jh,xk,oidhk->diojx", G, G, t5)   # (kD, Cin, Cout, 4, 4): 16 components contiguous
         parts.append(u2.reshape(-1).to(torch.float32))
-        if precision == 4 and t5.shape[2] == 3:
+        if precision >= 4 and t5.shape[2] == 3:
             # F(2x2x2,3x3x3) taps, G along the depth as well: [jd][Cin][Cout][j*4 + xi]
             u3 = torch.einsum("zd,jh,xk,oidhk->ziojx", G, G, G, t5)
             parts.append(u3.reshape(-1).to(torch.float32))
@@ -120,7 +126,7 @@ class Plan:
         # conv algorithm (include/sdc.h): 0 direct fp32 MFMA | 2 fp32 Winograd F(2,3) along W | 3 F(2x2,3x3) over (H, W) where
         # covered, else as 2 | 4 (default of the nets) F(2x2x2,3x3x3) over (D, H, W) where covered, else as 3
         self.precision = int(precision)
-        if self.precision not in (0, 2, 3, 4):
+        if self.precision not in (0, 2, 3, 4, 5):
             raise ValueError(f"precision must be 0, 2, 3 or 4 (got {precision})")
         self.calls = []          # (fn, args, keepalive)
         self.pool = Pool(self.device)
@@ -201,9 +207,10 @@ class Plan:
             o = tuple(out.shape[2:])
         nw = k[0] * k[1] * k[2] * (c0 + c1) * cout
         wino = wp.dim() == 1 and k[2] == 3 and wp.numel() == nw + nw // 3 * 4
+        wino43 = wp.dim() == 1 and tuple(k) == (1, 1, 3) and wp.numel() == nw + nw // 3 * 4 + nw // 3 * 6   # precision 5: + F(4,3) taps
         wino2 = wp.dim() == 1 and k[1] == 3 and k[2] == 3 and wp.numel() == nw + nw // 3 * 4 + nw // 9 * 16
         wino3 = wp.dim() == 1 and tuple(k) == (3, 3, 3) and wp.numel() == nw + nw // 3 * 4 + nw // 9 * 16 + nw // 27 * 64
-        assert wino or wino2 or wino3 or wp.numel() == nw, (wp.shape, k, c0, c1, cout)
+        assert wino or wino2 or wino3 or wino43 or wp.numel() == nw, (wp.shape, k, c0, c1, cout)
         d = SdcConvDesc()
         d.B, d.Cin0, d.Cin1, d.Cout = B, c0, c1, cout
         d.iD, d.iH, d.iW = iD, iH, iW
@@ -212,7 +219,7 @@ class Plan:
         d.sD, d.sH, d.sW = stride
         d.pD, d.pH, d.pW = pad
         d.uD, d.uH, d.uW = up
-        d.up_mode, d.precision = up_mode, (4 if wino3 else 3 if wino2 else 2 if wino else 0)
+        d.up_mode, d.precision = up_mode, (5 if wino43 else 4 if wino3 else 3 if wino2 else 2 if wino else 0)
         d.x0s[:] = _s5(x)
         d.x1s[:] = _s5(x1) if x1 is not None else (0,) * 5
         d.ys[:] = _s5(out)
@@ -300,12 +307,37 @@ class Plan:
         self._emit(self.lib.sdc_linattn, _ptr(qkv), _ptr(ctx), _ptr(out), outer, inner, heads, n, *q_strides, *o_strides)
         return out
 
-    def linattn_block(self, x, g_pre, wqkv, wo, bo, g_post, outer, inner, n, strides, pre_mode, post_mode, eps=1e-5):
-        """Residual(PreNorm(LinearAttention)) in one call (dim 64 / 128, n % 64 == 0); returns y shaped like x."""
+    def gn_stats_deferred(self, x, groups, eps=1e-5):
+        """GroupNorm statistics of x -- (mean, rstd) per (sample, group) -- WITHOUT the apply pass: the consumer
+        (linattn_block(..., gn=...)) normalises, activates and adds the residual while it loads its tiles."""
+        assert x.is_contiguous()
+        B, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (B * Cc)
+        st = torch.empty(B * groups * 2, dtype=torch.float32, device=self.device)     # its own buffer: read two launches later
+        self.keep += [x, st]
+        fused = self._gn_parts.pop(x.data_ptr(), None)
+        if fused is not None and fused[2] == groups:
+            self._emit(self.lib.sdc_gn_finalize, _ptr(fused[0]), _ptr(st), B, groups, fused[1], (Cc // groups) * S, eps)
+        else:
+            self._emit(self.lib.sdc_gn_stats, _ptr(x), _ptr(st), B, Cc, groups, S, eps)
+        return st
+
+    def linattn_block(self, x, g_pre, wqkv, wo, bo, g_post, outer, inner, n, strides, pre_mode, post_mode, eps=1e-5, gn=None):
+        """Residual(PreNorm(LinearAttention)) in one call (dim 64 / 128, n % 64 == 0); returns y shaped like x.
+        gn = (stats, gamma, beta, groups, residual): x is the RAW conv output of the producing ResnetBlock, whose GroupNorm +
+        SiLU + residual add is applied on load (sdc_linattn_block_gn); `outer` must then be the batch axis."""
         Cc = x.shape[1]
         y = self.pool.get(tuple(x.shape))
         work = torch.empty(int(self.lib.sdc_linattn_block_bytes(outer, inner, Cc, n)) // 4, dtype=torch.float32, device=self.device)
         self.keep += [x, g_pre, wqkv, wo, bo, g_post, work, y]
+        if gn is not None:
+            st, gamma, beta, groups, res = gn
+            assert outer == x.shape[0] and (res is None or (tuple(res.shape) == tuple(x.shape) and res.stride() == x.stride()))
+            self.keep += [st, gamma, beta, res]
+            self._emit(self.lib.sdc_linattn_block_gn, _ptr(x), _ptr(st), _ptr(gamma), _ptr(beta), groups, _ptr(res), _ptr(g_pre),
+                       _ptr(wqkv), _ptr(wo), _ptr(bo), _ptr(g_post), _ptr(work), _ptr(y), outer, inner, Cc, n, *strides, pre_mode,
+                       post_mode, eps)
+            return y
         self._emit(self.lib.sdc_linattn_block, _ptr(x), _ptr(g_pre), _ptr(wqkv), _ptr(wo), _ptr(bo), _ptr(g_post), _ptr(work),
                    _ptr(y), outer, inner, Cc, n, *strides, pre_mode, post_mode, eps)
         return y

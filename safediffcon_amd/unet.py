@@ -226,19 +226,26 @@ class _Builder:
         if cond_off is not None:
             self.cond_sites.append((len(self.plan.calls) - 1, cond_off))
 
-    def resnet(self, prefix, x, groups, *, x1=None):
+    def resnet(self, prefix, x, groups, *, x1=None, defer_gn=False):
+        """defer_gn: leave block2's GroupNorm + SiLU + residual add to the consumer: returns (raw conv output, gn tuple for
+        Plan.linattn_block, residual buffer to recycle afterwards or None)"""
         net, pool = self.net, self.plan.pool
         h = self.conv(x, f"{prefix}.block1.proj", x1=x1, gn_groups=groups)
         self.gn(h, f"{prefix}.block1.norm", groups, cond_off=net.cond_offsets.get(prefix))
         g = self.conv(h, f"{prefix}.block2.proj", gn_groups=groups)
         pool.put(h)
-        if net.has(f"{prefix}.res_conv.weight"):
+        own = net.has(f"{prefix}.res_conv.weight")
+        if own:
             r = self.conv(x, f"{prefix}.res_conv", x1=x1)
-            self.gn(g, f"{prefix}.block2.norm", groups, residual=r)
-            pool.put(r)
         else:
             assert x1 is None
-            self.gn(g, f"{prefix}.block2.norm", groups, residual=x)
+            r = x
+        if defer_gn:
+            st = self.plan.gn_stats_deferred(g, groups)
+            return g, (st, self.V(f"{prefix}.block2.norm.weight"), self.V(f"{prefix}.block2.norm.bias"), groups, r), (r if own else None)
+        self.gn(g, f"{prefix}.block2.norm", groups, residual=r)
+        if own:
+            pool.put(r)
         return g
 
 
@@ -261,6 +268,9 @@ class _HipUNet(nn.Module):
         # LinearAttention blocks of width 64 / 128 as the fused 3-launch form (csrc/sdc_lablock.hip); False = the
         # unfused chain norm -> 1x1 -> attention core -> 1x1 -> norm (kept for wider layers and for A/B checks)
         self.fuse_linattn = True
+        # smoke net: the ResnetBlock in front of a fused LinearAttention block hands it its raw conv output; GroupNorm + SiLU +
+        # residual add happen on the attention kernels' tile loads (False = a separate sdc_gn_apply pass, for A/B checks)
+        self.fuse_gn_into_linattn = True
         # nearest-x2 upsample + 3x3 conv as four sub-pixel 2x2 convs with merged taps (4/9 of the multiply-adds; the merged
         # weights change the summation order by ~1e-7 relative); False = one conv with the upsampling folded into its gather
         self.subpixel_upsample = True
@@ -360,7 +370,8 @@ class _HipUNet(nn.Module):
     def entry(self, shape, rows, lut=False):
         """Plan for an input of `shape` whose conditioning table has `rows` rows: one row per sample
         (lut=False, forward(x, time)) or one row per timestep read through a device-side t (lut=True, samplers)."""
-        key = (tuple(shape), rows, bool(lut), int(self.precision), bool(self.fuse_linattn), bool(self.subpixel_upsample))
+        key = (tuple(shape), rows, bool(lut), int(self.precision), bool(self.fuse_linattn), bool(self.subpixel_upsample),
+               bool(self.fuse_gn_into_linattn))
         stamp = self._weights_stamp()
         ent = self._plans.get(key)
         if ent is not None and ent["wstamp"] != stamp:        # parameters changed since this plan packed them
@@ -659,14 +670,34 @@ class Unet3D_with_Conv3D(_HipUNet):
         pool.put(o)
         return y
 
-    def _spatial_linear(self, b, prefix, x):
+    def _la_fusable(self, shape):
+        B, C, F, H, W = shape
+        return self.fuse_linattn and C in (64, 128) and (H * W) % 64 == 0 and B * F < 65536
+
+    def _resnet_then_spatial_linear(self, b, res_prefix, la_prefix, x, G):
+        """ResnetBlock -> SpatialLinearAttention (conv3d.py:537-545, :552-557).  The ResnetBlock's output feeds nothing but the
+        attention block, so where the fused attention kernels run its last GroupNorm + SiLU + residual add rides on their tile
+        loads (sdc_linattn_block_gn) instead of a pass of its own over HBM."""
+        pool = b.plan.pool
+        cout = self.P(f"{res_prefix}.block2.proj.weight").shape[0]
+        if self.fuse_gn_into_linattn and self._la_fusable((x.shape[0], cout, *x.shape[2:])):
+            g, gn, r = b.resnet(res_prefix, x, G, defer_gn=True)
+            y = self._spatial_linear(b, la_prefix, g, gn=gn)
+            if r is not None:
+                pool.put(r)
+            return y, g
+        a = b.resnet(res_prefix, x, G)
+        return self._spatial_linear(b, la_prefix, a), a
+
+    def _spatial_linear(self, b, prefix, x, gn=None):
         plan, pool = b.plan, b.plan.pool
         B, C, F, H, W = x.shape
         hw = H * W
-        if self.fuse_linattn and C in (64, 128) and hw % 64 == 0 and B * F < 65536:
+        if self._la_fusable(x.shape):
             return plan.linattn_block(x, b.V(f"{prefix}.fn.norm.gamma"), b.W(f"{prefix}.fn.fn.to_qkv.weight"),
                                       b.W(f"{prefix}.fn.fn.to_out.weight"), b.V(f"{prefix}.fn.fn.to_out.bias"), None,
-                                      B, F, hw, (C * F * hw, F * hw, hw), 0, -1)
+                                      B, F, hw, (C * F * hw, F * hw, hw), 0, -1, gn=gn)
+        assert gn is None
         xn = plan.chan_norm(x, b.V(f"{prefix}.fn.norm.gamma"), 0)
         qkv = b.conv(xn, f"{prefix}.fn.fn.to_qkv", bias=False)
         pool.put(xn)
@@ -706,9 +737,8 @@ class Unet3D_with_Conv3D(_HipUNet):
             a1 = b.resnet(f"{p}.0", h, G)
             if h is not r:
                 pool.put(h)
-            a2 = b.resnet(f"{p}.1", a1, G)
+            a3, a2 = self._resnet_then_spatial_linear(b, f"{p}.1", f"{p}.2", a1, G)
             pool.put(a1)
-            a3 = self._spatial_linear(b, f"{p}.2", a2)
             pool.put(a2)
             a4 = self._temporal(b, f"{p}.3", a3)
             pool.put(a3)
@@ -728,9 +758,8 @@ class Unet3D_with_Conv3D(_HipUNet):
             s = hs.pop()
             u1 = b.resnet(f"{p}.0", h, G, x1=s)
             pool.put(h), pool.put(s)
-            u2 = b.resnet(f"{p}.1", u1, G)
+            u3, u2 = self._resnet_then_spatial_linear(b, f"{p}.1", f"{p}.2", u1, G)
             pool.put(u1)
-            u3 = self._spatial_linear(b, f"{p}.2", u2)
             pool.put(u2)
             u4 = self._temporal(b, f"{p}.3", u3)
             pool.put(u3)

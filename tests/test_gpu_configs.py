@@ -57,7 +57,7 @@ def test_wide_fixtures_from_the_reference(golden):
     eps = net(x.to(DEV), g["t"].to(DEV)).cpu()
     assert _report("smoke dim 64, 32 frames 32x32 vs reference", eps, g["eps"]) < 5e-5 and _mse(eps, g["eps"]) <= 1e-9
     used = {fn.__name__ for fn, _ in net.entry(tuple(x.shape), 1)["plan"].calls}
-    assert {"sdc_tattn_block", "sdc_linattn_block", "sdc_conv_gn"} <= used      # the production kernels ran
+    assert {"sdc_tattn_block", "sdc_linattn_block_gn", "sdc_conv_gn"} <= used   # the production kernels ran
 
 
 # ------------------------------------------------------------------ C4 at the full batch

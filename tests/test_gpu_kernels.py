@@ -774,3 +774,48 @@ def test_gn_fused_small_groups_equal_the_three_launch_path(B, Cc, G, sp, cond, r
         u = u * (ss.double().cpu()[:, :Cc].reshape(bs) + 1) + ss.double().cpu()[:, Cc:].reshape(bs)
     want = F.silu(u) + (r.double().cpu() if res else 0)
     assert (outs[0].cpu().double().reshape(want.shape) - want).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=8, cin=256, cout=256, W=128, G=1),                              # tokamak level 0: GroupNorm(1) sums in the epilogue
+    dict(B=8, cin=512, cin1=512, cout=512, W=32, residual=True),           # up path: skip concat, residual
+    dict(B=16, cin=1024, cout=2048, W=16, G=1),                            # deepest level: 16-wide rows, 8 samples per tile (no fused sums)
+    dict(B=3, cin=48, cout=160, W=64, G=1),                                # ragged Cout (128 + 32), Cin = 3 stages
+    dict(B=5, cin=64, cout=128, W=20),                                     # W = 20: rows shorter than a tile and not a divisor -> not covered
+    dict(B=2, cin=32, cout=128, W=256, residual=True),                     # rows longer than a tile
+])
+def test_conv1d_f43_mode(plan_cls, case):
+    """Conv1d k3 (the tokamak Unet1D's hot op, tokamak/model/unet.py Block) on the F(4,3) Winograd kernel: six products per output
+    quad = half of the direct form's MFMA work.  fp32 end to end; the larger transform constants cost accuracy against fp64:
+    gate 1e-5 of the output scale, measured 2-6e-6 (F(2,3): ~1e-6).  GroupNorm statistics from its epilogue normalise
+    like torch."""
+    from safediffcon_amd.engine import as5
+    B, cin, cin1, cout, W, G = case["B"], case["cin"], case.get("cin1", 0), case["cout"], case["W"], case.get("G", 0)
+    x, x1 = det_tensor((B, cin, W), 401), (det_tensor((B, cin1, W), 402) if cin1 else None)
+    w, b = det_tensor((cout, cin + cin1, 3), 403, 0.2 / (cin + cin1) ** 0.5 * 8), det_tensor((cout,), 404, 0.1)
+    xin = x if x1 is None else torch.cat((x, x1), 1)
+    ref = F.conv1d(xin.double(), w.double(), b.double(), padding=1)
+    res = det_tensor(tuple(ref.shape), 405) if case.get("residual") else None
+    if res is not None:
+        ref = ref + res.double()
+    plan = plan_cls(DEV, precision=5)          # opt-in mode: as 4, plus F(4,3) on the 1-D convs
+    out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, (1, 1, 3),
+                    x1=None if x1 is None else as5(x1.to(DEV)), pad=(0, 0, 1), residual=None if res is None else as5(res.to(DEV)),
+                    gn_groups=G)
+    buf, share = C.create_string_buffer(128), C.c_double(0)
+    assert plan.lib.sdc_conv_describe(C.byref(plan.calls[0][1][0]._obj), buf, 128, C.byref(share)) == 0
+    covered = W % 4 == 0 and (W % 128 == 0 or 128 % W == 0)
+    assert buf.value.decode().endswith("F43>") == covered, buf.value
+    assert (share.value == 0.5) == covered
+    if G:
+        gam, bet = 1 + 0.3 * det_tensor((cout,), 406), 0.2 * det_tensor((cout,), 407)
+        y = plan.pool.get(tuple(out.shape))
+        plan.gn_silu(out, gam.to(DEV), bet.to(DEV), G, out=y)
+        assert any(fn.__name__ == "sdc_conv_gn" for fn, _ in plan.calls) == (covered and W % 128 == 0)   # a tile must lie inside one sample
+    _run(plan)
+    e = (out.cpu().reshape(ref.shape).double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"[measured] conv1d {buf.value.decode()} {case}: rel err vs fp64 {e:.2e}")
+    assert e < 1e-5, e
+    if G:
+        want = F.silu(F.group_norm(ref, G, gam.double(), bet.double(), eps=1e-5))
+        assert (y.cpu().reshape(want.shape).double() - want).abs().max().item() < 6e-5     # (the conv error over the group's std)

@@ -351,7 +351,7 @@ def test_mid_width_nets_odd_batches_vs_oracle(B):
     torch.testing.assert_close(net3(x3.to(DEV), t.to(DEV)).cpu(),
                                onets.unet_smoke(P3, x3, t, dim=64, dim_mults=(1, 2, 4)), rtol=2e-3, atol=2e-4)
     used = {fn.__name__ for fn, _ in net3.entry(tuple(x3.shape), B)["plan"].calls}
-    assert {"sdc_tattn_block", "sdc_linattn_block", "sdc_conv_gn"} <= used
+    assert {"sdc_tattn_block", "sdc_linattn_block_gn", "sdc_conv_gn"} <= used
 
 
 # ------------------------------------------------------------------ full schedule: T = 1000 against the REAL reference

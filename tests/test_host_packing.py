@@ -100,9 +100,24 @@ def test_winograd_2d_taps():
                 gk = w[co, ci, kd].double()
                 want = torch.stack([torch.stack([(d[a:a + 3, b:b + 3] * gk).sum() for b in range(2)]) for a in range(2)])
                 torch.testing.assert_close(Y, want, rtol=1e-5, atol=1e-6)
-    # taps that are not 3x3 over (H, W) keep the precision-2 layout (Conv1d k3: along W only)
+    # taps that are not 3x3 over (H, W) keep the precision-2 layout; a Conv1d k3 (kD = kH = 1) appends its six F(4,3) taps:
+    # [Wp | Wg (F(2,3)) | Wg43], and the four outputs of a quad from the six products equal the direct correlation
     w1 = torch.randn(4, 3, 1, 1, 3, generator=g)
     assert p3.conv_weight(w1).numel() == 36 + 48
+    buf1 = Plan("cpu", precision=5).conv_weight(w1)                      # precision 5 (opt-in): as 4 + the F(4,3) taps of 1-D convs
+    assert buf1.numel() == 36 + 48 + 72
+    u43 = buf1[36 + 48:].double().reshape(6, 3, 4)                       # (xi, ci, co)
+    Bt43 = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0],
+                         [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=torch.float64)
+    At43 = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64)
+    d6 = torch.randn(6, generator=g, dtype=torch.float64)
+    for ci in range(3):
+        for co in range(4):
+            y = At43 @ (u43[:, ci, co] * (Bt43 @ d6))
+            want = torch.stack([(d6[i:i + 3] * w1[co, ci, 0, 0].double()).sum() for i in range(4)])
+            torch.testing.assert_close(y, want, rtol=1e-5, atol=1e-6)
+    w2 = torch.randn(4, 3, 1, 2, 3, generator=g)                         # kH = 2: no F(4,3) section
+    assert Plan("cpu", precision=5).conv_weight(w2).numel() == 72 + 96
 
 
 def test_winograd_3d_taps():

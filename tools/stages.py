@@ -60,9 +60,16 @@ def classify(lib, fn, a):
         fl = seqs * nn * (2 * 2 * 32 * 32 + 10 * 32)
         return dict(stage="linear attention core", kernel="la_ctx/la_out", flops=fl, issued=seqs * nn * 4.0 * 32 * 32,
                     bytes=4.0 * seqs * nn * 32 * 4)
-    if fn is lib.sdc_linattn_block:
-        outer, inner, Cc, nn = a[8], a[9], a[10], a[11]
+    if fn is lib.sdc_linattn_block or fn is lib.sdc_linattn_block_gn:
+        gnf = fn is lib.sdc_linattn_block_gn
+        outer, inner, Cc, nn = (a[13], a[14], a[15], a[16]) if gnf else (a[8], a[9], a[10], a[11])
         toks = outer * inner * nn
+        if gnf:
+            # + the producing ResnetBlock's GroupNorm apply + SiLU + residual add, done on pass 1's tile loads: x_raw and the
+            # residual read, y written (h parks in y between the passes: not algorithmic traffic)
+            mm = toks * (2.0 * Cc * 384 + 4 * 2 * 2 * 32 * 32 + 2.0 * 128 * Cc)
+            return dict(stage="fused LinearAttention block + the ResnetBlock's GroupNorm apply / SiLU / residual on load",
+                        kernel="la_blk_* (gn)", flops=mm + toks * 24.0 * Cc, issued=mm, bytes=12.0 * toks * Cc)
         # reference-equivalent work: qkv 1x1 (C -> 384), attention core (4 heads x two 32x32 products), out 1x1 (128 -> C),
         # two channel norms; bytes: x read once, y written once (what the fused block is priced against)
         mm = toks * (2.0 * Cc * 384 + 4 * 2 * 2 * 32 * 32 + 2.0 * 128 * Cc)
