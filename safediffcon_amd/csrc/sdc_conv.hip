@@ -827,7 +827,8 @@ __device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[NX]
 #pragma unroll
             for (int b4 = 0; b4 < 4; ++b4) {
                 const double s1 = sdc::wave_sum(gs[i][b4]), q1 = sdc::wave_sum(gq[i][b4]);
-                if (lane == 0) { scr[(wave * TM * 4 + i * 4 + b4) * 2] = s1; scr[(wave * TM * 4 + i * 4 + b4) * 2 + 1] = q1; }
+                // (the idle k-half of a split workgroup shares its partner's slot: it must not write)
+                if (lane == 0 && active) { scr[(wave * TM * 4 + i * 4 + b4) * 2] = s1; scr[(wave * TM * 4 + i * 4 + b4) * 2 + 1] = q1; }
             }
         __syncthreads();
         const int ngl = a.gn_cpg >= BM ? 1 : BM / a.gn_cpg;       // groups inside this workgroup's rows
@@ -1214,15 +1215,256 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// F(4,3) along W for the 1-D convs (kD = kH = 1, stride 1, pad 1: the tokamak Unet1D's Conv1d k3, 85 % of its FLOPs) with
+// the input transform done ONCE per workgroup.  conv_wg_kernel<.., NX = 6> forms V = B^T d per wave at fragment-read time:
+// the four waves that share a position tile each repeat the twelve operations per k-step, in front of their own six MFMAs,
+// where they are not hidden (measured: 74 TFLOP/s issued, no faster than F(2,3) at 97).  Here the pipeline is one stage
+// deeper on the B side:   stage s+3 -> registers | raw rows of s+2 -> LDS | V(s+1) = B^T d (one (k row, quad) per thread,
+// 12 operations per STAGE) -> LDS | MFMAs of stage s read V(s) and the six taps as they lie.
+// 128 x 128 outputs per workgroup, 512 threads: waves (wm, kh) -- four 32-row tiles x the two halves of a stage's k-steps
+// (two waves per SIMD on the same accumulators' tile; the halves meet in LDS before the epilogue).  One barrier per stage.
+//   V = (4 d0 - 5 d2 + d4 | (d4 - 4 d2) +- (d3 - 4 d1) | (d4 - d2) +- 2 (d3 - d1) | 4 d1 - 5 d3 + d5),  six GEMMs over K = Cin.
+template <int BM, int BN, int WM, int SK>
+__global__ __launch_bounds__(512) void conv_f43_kernel(const ConvArgs a) {
+    constexpr int NX = 6, NTH = 512, KSP = 2;
+    constexpr int TM = BM / WM / 32, NQ = BN / 4;
+    constexpr int KSMAX = BN + (BN / 16) * 2, NCOL = (KSMAX + 63) / 64, PITCH = NCOL * 64 + 8;
+    constexpr int KROWS = SK / (NTH / 64), NA4 = NX * SK * BM / 4 / NTH, NSL = 4, KST = SK / 2 / KSP;
+    constexpr int VP = NX * NQ + 32;                            // V row of one k: [xi][quad], +32: the two half-waves on disjoint banks
+    constexpr int ASZ = NX * SK * BM, BSZ = SK * PITCH, VSZ = SK * VP;
+    static_assert(TM == 1 && NQ == 32 && WM * KSP * 64 == NTH && KST == NSL && KROWS >= 1 && NA4 >= 1 && SK * NQ == NTH, "tile");
+    extern __shared__ __attribute__((aligned(16))) float ldsw[];
+    float* const As = ldsw;                                     // [2][NX][SK][BM]
+    float* const Bs = ldsw + 2 * ASZ;                           // [2][SK][PITCH]   raw rows with their halo columns
+    float* const Vs = Bs + 2 * BSZ;                             // [2][SK][VP]      transformed
+
+    const SdcConvDesc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = SDC_UNIFORM(tid >> 6);
+    const int kh = wave / WM, wm = wave % WM;
+    const int n0 = xcd_tile(blockIdx.x, gridDim.x) * BN;
+    const int m0 = blockIdx.y * BM;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int seg = d.oW < BN ? d.oW : BN, nseg = BN / seg, rowlen = seg + 2, ks_stride = nseg * rowlen;
+    const bool two = d.Cin1 > 0;
+
+    // gather state of this lane's columns of a staged k row (1-D: a segment is a row of a sample, or a piece of one)
+    int v0[NCOL], v1[NCOL];
+    uint32_t okm = 0;
+    {
+        const int ow_b = n0 % d.oW, row_b = n0 / d.oW;
+#pragma unroll
+        for (int t = 0; t < NCOL; ++t) {
+            const int cidx = lane + 64 * t;
+            v0[t] = 0; v1[t] = 0;
+            if (cidx < ks_stride) {
+                const int sg = cidx / rowlen, cc = cidx - sg * rowlen;
+                if (n0 + sg * seg < a.Ntot) {
+                    const int ob = row_b + (nseg > 1 ? sg : 0);
+                    const int col = ow_b + cc - d.pW;
+                    if (col >= 0 && col < d.iW) okm |= 1u << t;
+                    v0[t] = (int)(ob * d.x0s[0] + col * d.x0s[4]);
+                    if (two) v1[t] = (int)(ob * d.x1s[0] + col * d.x1s[4]);
+                }
+            }
+        }
+    }
+    uint32_t a_voff[NA4];
+    bool a_ok[NA4];
+#pragma unroll
+    for (int i = 0; i < NA4; ++i) {
+        const int f = tid + i * NTH;
+        const int c4 = (f % (BM / 4)) * 4, row = f / (BM / 4);
+        const int xi = row / SK, kr = row % SK;
+        a_ok[i] = (m0 + c4) < d.Cout;
+        a_voff[i] = (uint32_t)(((int64_t)(xi * a.Cin + kr) * d.Cout + (a_ok[i] ? (m0 + c4) : 0)) * 4);
+    }
+    const float* wg = a.wp + (int64_t)a.Ktot * d.Cout + (int64_t)(a.Ktot / 3 * 4) * d.Cout;     // Wp | F(2,3) taps | F(4,3) taps
+    // transform item of this thread: (k row, quad) -> raw offset of d0 (even: 8-byte aligned), V offset of component 0
+    const int tk = tid >> 5, tq = tid & 31;
+    int t_src, t_dst;
+    {
+        const int pos = 4 * tq, sg = pos / seg;
+        t_src = tk * PITCH + sg * rowlen + (pos - sg * seg);
+        t_dst = tk * VP + tq;
+    }
+
+    typedef const __attribute__((address_space(1))) char* gchar_p;
+    typedef float nfloat4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) nfloat4* gfloat4_p;
+    float breg[KROWS][NCOL];
+    float4 areg[NA4];
+    int ca = 0, cb = 0;                                         // channel walks of the weight and of the input fetches
+    auto fetch_a = [&](int p, float4 (&ar)[NA4], int ci) {
+        const gfloat_p wbase = uniform_ptr(wg + (int64_t)ci * d.Cout);
+#pragma unroll
+        for (int i = 0; i < NA4; ++i) {
+            if (i % NSL != p) continue;
+            const nfloat4 wv = *(gfloat4_p)((gchar_p)wbase + a_voff[i]);
+            ar[i] = make_float4(wv.x, wv.y, wv.z, wv.w);
+        }
+    };
+    auto fetch_b = [&](int p, float (&br)[KROWS][NCOL], int ci) {
+        const bool first = ci < d.Cin0;
+        const int64_t sc = first ? d.x0s[1] : d.x1s[1];
+        const float* base = (first ? a.x0 + (int64_t)ci * sc : a.x1 + (int64_t)(ci - d.Cin0) * sc) + (int64_t)(wave * KROWS) * sc;
+#pragma unroll
+        for (int r = 0; r < KROWS; ++r) {
+            const gfloat_p rb = uniform_ptr(base + r * sc);
+#pragma unroll
+            for (int t = 0; t < NCOL; ++t)
+                if ((r * NCOL + t) % NSL == p) br[r][t] = ld_sv(rb, ((okm >> t) & 1u) ? (uint32_t)(first ? v0[t] : v1[t]) * 4u : 0u);
+        }
+    };
+    auto park_a = [&](int buf, int p, const float4 (&ar)[NA4]) {
+#pragma unroll
+        for (int i = 0; i < NA4; ++i) {
+            if (i % NSL != p) continue;
+            const int f = tid + i * NTH;
+            const int row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
+            float4 v = ar[i];
+            if (!a_ok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(As + buf * ASZ + row * BM + c4) = v;
+        }
+    };
+    auto park_b = [&](int buf, int p, const float (&br)[KROWS][NCOL]) {
+#pragma unroll
+        for (int r = 0; r < KROWS; ++r)
+#pragma unroll
+            for (int t = 0; t < NCOL; ++t)
+                if ((r * NCOL + t) % NSL == p)
+                    Bs[buf * BSZ + (wave * KROWS + r) * PITCH + lane + 64 * t] = ((okm >> t) & 1u) ? br[r][t] : 0.0f;
+    };
+    auto next_ci = [&](int& c) { c += SK; if (c >= a.Cin) c = 0; };      // (past the last stage the walk wraps: in bounds, never consumed)
+    auto transform = [&](int buf) {
+        const float2* sp = reinterpret_cast<const float2*>(Bs + buf * BSZ + t_src);
+        const float2 p0 = sp[0], p1 = sp[1], p2 = sp[2];
+        const float d0 = p0.x, d1 = p0.y, d2 = p1.x, d3 = p1.y, d4 = p2.x, d5 = p2.y;
+        const float e42 = fmaf(-4.0f, d2, d4), e31 = fmaf(-4.0f, d1, d3);
+        const float c42 = d4 - d2, c31 = d3 - d1;
+        float* dp = Vs + buf * VSZ + t_dst;
+        dp[0 * NQ] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
+        dp[1 * NQ] = e42 + e31;
+        dp[2 * NQ] = e42 - e31;
+        dp[3 * NQ] = fmaf(2.0f, c31, c42);
+        dp[4 * NQ] = fmaf(-2.0f, c31, c42);
+        dp[5 * NQ] = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
+    };
+
+    f32x16 acc[NX];
+#pragma unroll
+    for (int x = 0; x < NX; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
+
+    const int nstages = a.Cin / SK;
+    {   // prologue: A(0) -> LDS, A(1) -> registers;  B(0) -> raw -> V(0), B(1) -> raw, B(2) -> registers
+        float breg0[KROWS][NCOL], breg1[KROWS][NCOL];
+        float4 areg0[NA4];
+#pragma unroll
+        for (int p = 0; p < NSL; ++p) { fetch_a(p, areg0, ca); fetch_b(p, breg0, cb); }
+        next_ci(ca); next_ci(cb);
+#pragma unroll
+        for (int p = 0; p < NSL; ++p) { fetch_a(p, areg, ca); fetch_b(p, breg1, cb); }
+        next_ci(ca); next_ci(cb);
+#pragma unroll
+        for (int p = 0; p < NSL; ++p) fetch_b(p, breg, cb);
+        next_ci(cb);
+#pragma unroll
+        for (int p = 0; p < NSL; ++p) { park_a(0, p, areg0); park_b(0, p, breg0); park_b(1, p, breg1); }
+        __syncthreads();
+        transform(0);
+    }
+    __syncthreads();
+    const int am = wm * 32 + l31;
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+
+    for (int st = 0; st < nstages; ++st) {
+        const int buf = st & 1;
+        const float* Ab = As + buf * ASZ + (2 * KST * kh + lh) * BM + am;
+        const float* Vb = Vs + buf * VSZ + (2 * KST * kh + lh) * VP + l31;
+        float fa[2][NX], fv[2][NX];
+        auto read_frag = [&](int ks, int set) {
+#pragma unroll
+            for (int x = 0; x < NX; ++x) {
+                fa[set][x] = Ab[(x * SK + 2 * ks) * BM];
+                fv[set][x] = Vb[(2 * ks) * VP + x * NQ];
+            }
+        };
+        read_frag(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) {
+            const int set = ks & 1;
+            if (ks + 1 < KST) read_frag(ks + 1, set ^ 1);
+            // staging piece ks: weights of stage st+1 and raw rows of stage st+2 to LDS, their registers re-used for the fetches
+            // of st+2 / st+3; k-step 0 also turns this thread's item of raw(st+1) into V(st+1)
+            park_a(buf ^ 1, ks, areg);
+            park_b(buf, ks, breg);
+            fetch_a(ks, areg, ca);
+            fetch_b(ks, breg, cb);
+            if (ks == 0) transform(buf ^ 1);
+#pragma unroll
+            for (int x = 0; x < NX; ++x) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][x], fv[set][x], acc[x], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < NX; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (m < 2) __builtin_amdgcn_sched_group_barrier(0x100, NX, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x220, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        next_ci(ca); next_ci(cb);
+        __syncthreads();
+    }
+    // the two k-halves of a tile meet in the staging LDS (dead after the last stage's barrier): [tile wave][register][lane]
+    {
+        float* red = ldsw + (size_t)wm * (NX * 16) * 64 + lane;
+        if (kh == 1) {
+#pragma unroll
+            for (int x = 0; x < NX; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(x * 16 + r) * 64] = acc[x][r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int x = 0; x < NX; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][r] += red[(x * 16 + r) * 64];
+        }
+        __syncthreads();
+    }
+    f32x16 acc3[NX][1][1];
+#pragma unroll
+    for (int x = 0; x < NX; ++x) acc3[x][0][0] = acc[x];
+    wg_epilogue<1, 1, BM, BN, WM, 1, NX>(a, acc3, m0 + wm * 32, n0 / 4, lane, ldsw, wm, m0, n0, kh == 0);
+}
+
+template <int BM, int BN, int WM, int SK>
+int launch_f43(const ConvArgs& a, hipStream_t s) {
+    dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
+    constexpr int KSMAX = BN + (BN / 16) * 2, NCOL = (KSMAX + 63) / 64, PITCH = NCOL * 64 + 8, VP = 6 * (BN / 4) + 32;
+    constexpr size_t lds = (2u * 6 * SK * BM + 2u * SK * PITCH + 2u * SK * VP) * sizeof(float);
+    static_assert(lds <= 160u * 1024u && (size_t)WM * 6 * 16 * 64 * sizeof(float) <= lds, "LDS");
+    static std::atomic<uint64_t> attr{0};
+    SDC_LDS_OPTIN(attr, (conv_f43_kernel<BM, BN, WM, SK>), 160 * 1024, "sdc_conv[winograd F(4,3)]");
+    hipLaunchKernelGGL((conv_f43_kernel<BM, BN, WM, SK>), grid, dim3(512), lds, s, a);
+    return SDC_OK;
+}
+
 template <int BM, int BN, int WM, int WN, int SK, int NTH = 256, bool UPS = false, int NX = 4, int KS = 1>
 int launch_wg(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
     constexpr int KSMAX = BN + (BN / 16) * 2;
     constexpr int NCOLH = (KSMAX + 63) / 64;
-    const size_t lds = (2u * NX * SK * BM + 2u * SK * (NCOLH * 64 + 8)) * sizeof(float);
-    static_assert((2u * NX * SK * BM + 2u * SK * (NCOLH * 64 + 8)) * sizeof(float) <= 160u * 1024u, "stage buffers exceed the LDS");
-    static_assert(KS == 1 || (size_t)WM * WN * NX * (BM / WM / 32) * (BN / (NX == 6 ? 4 : 2) / WN / 32) * 16 * 64 * sizeof(float) <=
-                                 (2u * NX * SK * BM + 2u * SK * (NCOLH * 64 + 8)) * sizeof(float), "k-split partials exceed the staging LDS");
+    constexpr size_t STAGE = (2u * NX * SK * BM + 2u * SK * (NCOLH * 64 + 8)) * sizeof(float);
+    // k-split: the second half's accumulators pass through the same LDS after the last stage
+    constexpr size_t PART = KS == 1 ? 0 : (size_t)WM * WN * NX * (BM / WM / 32) * (BN / (NX == 6 ? 4 : 2) / WN / 32) * 16 * 64 * sizeof(float);
+    constexpr size_t lds = STAGE > PART ? STAGE : PART;
+    static_assert(lds <= 160u * 1024u, "stage buffers / k-split partials exceed the LDS");
     static std::atomic<uint64_t> attr{0};
     SDC_LDS_OPTIN(attr, (conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS, NX, KS>), 160 * 1024, "sdc_conv[winograd]");
     hipLaunchKernelGGL((conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS, NX, KS>), grid, dim3(NTH), lds, s, a);
@@ -1486,12 +1728,17 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
             else { SDC_PICK("conv_wg_kernel<64,128,2,2,16,256,ups>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 128, 2, 2, 16, 256, true>(a, s); if (rc_) return rc_; } }
             return sdc::check_launch("sdc_conv[winograd,upsample]");
         }
-        if (wgp.pick == 13) { SDC_PICK("conv_wg_kernel<128,128,4,1,16,512,F43>", 0.5); { const int rc_ = launch_wg<128, 128, 4, 1, 16, 512, false, 6, 2>(a, s); if (rc_) return rc_; } }
+        if (wgp.pick == 13) { SDC_PICK("conv_f43_kernel<128,128,4,16,F43>", 0.5); { const int rc_ = launch_f43<128, 128, 4, 16>(a, s); if (rc_) return rc_; } }
         else if (wgp.pick == 6) { SDC_PICK("conv_wg_kernel<128,128,4,2,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<128, 128, 4, 2, 16, 512>(a, s); if (rc_) return rc_; } }
         else if (wgp.pick == 7) { SDC_PICK("conv_wg_kernel<64,256,2,4,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 256, 2, 4, 16, 512>(a, s); if (rc_) return rc_; } }
         else if (wgp.pick == 9) { SDC_PICK("conv_wg_kernel<128,256,4,2,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<128, 256, 4, 2, 16, 512>(a, s); if (rc_) return rc_; } }       // (2 x 4 waves measured the same)
         else if (wgp.pick == 10) { SDC_PICK("conv_wg_kernel<64,512,1,8,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 512, 1, 8, 16, 512>(a, s); if (rc_) return rc_; } }     // (each wave: both 32-row tiles x 32 pairs; measured 3 % ahead of 1 x 2)
-        else { SDC_PICK("conv_wg_kernel<64,128,2,2,16,256>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 128, 2, 2, 16>(a, s); if (rc_) return rc_; } }
+        else {
+            // small grids (fewer than 256 of the 128 x 128 tiles): 64 x 128 tiles, each stage's k-steps split over two waves per SIMD
+            // (a lone wave per SIMD left the transform / staging VALU exposed: 68 TFLOP/s issued)
+            SDC_PICK("conv_wg_kernel<64,128,2,2,16,512,ks2>", 2.0 / 3.0);
+            { const int rc_ = launch_wg<64, 128, 2, 2, 16, 512, false, 4, 2>(a, s); if (rc_) return rc_; }
+        }
         return sdc::check_launch("sdc_conv[winograd]");
     }
     SDC_REQUIRE(!gn_part, SDC_EINVAL, "sdc_conv_gn: shape not covered by the fused statistics (sdc_conv_gnparts returned 0)");

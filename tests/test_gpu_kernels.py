@@ -805,7 +805,7 @@ def test_conv1d_f43_mode(plan_cls, case):
     buf, share = C.create_string_buffer(128), C.c_double(0)
     assert plan.lib.sdc_conv_describe(C.byref(plan.calls[0][1][0]._obj), buf, 128, C.byref(share)) == 0
     covered = W % 4 == 0 and (W % 128 == 0 or 128 % W == 0)
-    assert buf.value.decode().endswith("F43>") == covered, buf.value
+    assert buf.value.decode().endswith("F43>") == covered, buf.value      # conv_f43_kernel<128,128,4,16,F43>
     assert (share.value == 0.5) == covered
     if G:
         gam, bet = 1 + 0.3 * det_tensor((cout,), 406), 0.2 * det_tensor((cout,), 407)
