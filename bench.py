@@ -43,7 +43,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 T_DDPM = 1000
 DEFAULT_B = {"c2": 256, "c3": 128, "c4": 64}
-PMC_FILES = ("r3_pmc_traffic.json",)      # stamped with the kernel-source hash they were collected on (tools/pmc_to_json.py)
+PMC_FILES = ("r4_pmc_traffic.json",)      # stamped with the kernel-source hash they were collected on (tools/pmc_to_json.py)
 
 
 # --------------------------------------------------------------------------- launcher (N > 1 without a torchrun parent)
@@ -562,7 +562,8 @@ def build_roofline(S, lib, stream, step_ms, wl):
                       "[F(2x2,3x3)] or 8/27 [F(2x2x2,3x3x3)] of the direct-form multiply-adds); effective_tflops = direct-form "
                       "(algorithmic) FLOPs per second",
                 traffic=traffic, traffic_source=src, algorithmic_bytes_per_launch=alg_bytes,
-                sustained_peak_measured=123.0,   # bare v_mfma_f32_32x32x2 loop on an MI355X of this pool (tools/mfma_peak.hip)
+                sustained_peak_measured=123.5,   # bare v_mfma_f32_32x32x2 loop held for seconds on an MI355X of this pool, at
+                                                 # 2.38 GHz (tools/mfma_sustain.py, profiles/r4_mfma_sustain_clock_power.log)
                 launches_per_step=g["launches"], avg_launch_ms=round(g["ms"] / g["launches"], 4),
                 share_of_step=round(g["ms"] / step_ms, 3))
 
@@ -758,10 +759,15 @@ def worker(a):
                 S2.init()
                 dt2 = timed(S2, 3, a.extra_steps)
                 ok2 = bool(torch.isfinite(S2.x).all().item())
+                # the dominant kernel of this workload against its roofline, like the headline's (PMC traffic: profiles/r4_pmc_traffic.json)
+                r2 = build_roofline(S2, lib, side.cuda_stream, dt2 / a.extra_steps * 1e3, other)
                 S2.close()
                 extra[other] = {"workload": W2["desc"], "batch": DEFAULT_B[other], "steps": a.extra_steps,
                                 "ms_per_step": round(dt2 / a.extra_steps * 1e3, 4),
-                                "value": round(DEFAULT_B[other] / (T_DDPM * dt2 / a.extra_steps), 4), "unit": "trajectories/s", "finite": ok2}
+                                "value": round(DEFAULT_B[other] / (T_DDPM * dt2 / a.extra_steps), 4), "unit": "trajectories/s", "finite": ok2,
+                                "roofline": {k: r2[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "effective_tflops",
+                                                                "traffic", "traffic_source", "algorithmic_bytes_per_launch",
+                                                                "launches_per_step", "avg_launch_ms", "share_of_step")}}
                 del W2, S2
             if a.other_precisions:
                 def other_prec(mode):

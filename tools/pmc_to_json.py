@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""FETCH_SIZE / WRITE_SIZE / SQ passes of tools/pmc_traffic.py -> profiles/r3_pmc_traffic.json + r3_pmc_mfma_busy.json, stamped
+"""FETCH_SIZE / WRITE_SIZE / SQ passes of tools/pmc_traffic.py -> profiles/r4_pmc_traffic.json + r4_pmc_mfma_busy.json, stamped
 with the hash of the kernel sources they were collected on (safediffcon_amd.build.source_hash; bench.py refuses a stale record).
 usage: python tools/pmc_to_json.py <fetch_dir> <write_dir> <sq_dir> <cases.json> <out_traffic.json> <out_busy.json>"""
 import csv
@@ -46,7 +46,7 @@ cal = dict(kernel="act_kernel over 64Mi floats (dword per lane)", known_read_byt
            fetch_factor=round(n / (fa.get("FETCH_SIZE", 1) * 1024.0), 4), write_factor=round(n / (wa.get("WRITE_SIZE", 1) * 1024.0), 4),
            correction="bytes = FETCH_SIZE*1024*fetch_factor (gfx950 tallies 128-B requests at 64 B: factor 2, calibrated here on a known-size "
                       "stream in the same run), WRITE_SIZE*1024*write_factor")
-out = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/pmc_traffic.py {B}, MI355X, round 3",
+out = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/pmc_traffic.py {B}, MI355X, round 4",
        "kernel_source_hash": source_hash(), "calibration": cal}
 for sub, c in cases.items():
     if sub == "act_kernel":
@@ -57,8 +57,12 @@ for sub, c in cases.items():
         continue
     rd = fc["FETCH_SIZE"] * 1024.0 * cal["fetch_factor"]
     wr = wc["WRITE_SIZE"] * 1024.0 * cal["write_factor"]
-    key = sub + ">" if sub.endswith(("<64", "<32", "<16")) else (sub.split("<")[0] if "<" in sub else sub)   # bench.py's name of the instance
-    out[key] = dict(kernel_symbol=kname, shape=c["shape"], workload="c4", FETCH_SIZE_KB=fc["FETCH_SIZE"], WRITE_SIZE_KB=wc["WRITE_SIZE"],
+    # bench.py's name of the instance (tools/stages.py): conv_wg*_kernel<W>, conv_wg_kernel<tile...>, conv_f43_kernel<...> by prefix
+    key = sub + ">" if sub.endswith(("<64", "<32", "<16", "<128", "512")) else (sub.split("<")[0] if "<" in sub else sub)
+    key = key.replace(", ", ",")
+    if sub.startswith("conv_f43_kernel"):
+        key = "conv_f43_kernel<128,128,4,16,F43>"
+    out[key] = dict(kernel_symbol=kname, shape=c["shape"], workload=c.get("workload", "c4"), FETCH_SIZE_KB=fc["FETCH_SIZE"], WRITE_SIZE_KB=wc["WRITE_SIZE"],
                     hbm_read_bytes=int(rd), hbm_write_bytes=int(wr), traffic_bytes=int(rd + wr), algorithmic_bytes=c["algorithmic"],
                     traffic_over_algorithmic=round((rd + wr) / c["algorithmic"], 3))
 json.dump(out, open(out_t, "w"), indent=1)

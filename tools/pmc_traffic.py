@@ -56,9 +56,27 @@ x1 = torch.randn(B, 128, 32, 32, 32, device=dev)
 w1 = torch.randn(384, 128, 1, 1, 1, device=dev) * 0.1
 o1 = plan.conv(as5(x1), plan.conv_weight(w1), None, 384, (1, 1, 1))
 cases["conv_pw_kernel<128"] = dict(algorithmic=4 * (x1.numel() + o1.numel() + w1.numel()), shape=f"1x1x1 conv 128->384 at ({B},128,32,32,32)")
+# the dominant kernels of the other two single-GPU workloads, at their own batch sizes
+x2 = torch.randn(256, 64, 16, 128, device=dev)
+w2 = torch.randn(64, 64, 3, 3, device=dev) * 0.05
+o2 = plan.conv(as5(x2), plan.conv_weight(w2), torch.randn(64, device=dev), 64, (1, 3, 3), pad=(0, 1, 1), gn_groups=1)
+cases["conv_wg2_kernel<128"] = dict(algorithmic=4 * (x2.numel() + o2.numel() + w2.numel()), workload="c2",
+                                    shape="C2: 64->64 3x3 at (256,64,16,128) + GN statistics (Burgers level 0)")
+x3 = torch.randn(128, 256, 128, device=dev)
+w3 = torch.randn(256, 256, 3, device=dev) * 0.03
+o3 = plan.conv(as5(x3), plan.conv_weight(w3), torch.randn(256, device=dev), 256, (1, 1, 3), pad=(0, 0, 1))
+cases["conv_wg_kernel<128, 128, 4, 2, 16, 512"] = dict(algorithmic=4 * (x3.numel() + o3.numel() + w3.numel()), workload="c3",
+                                                      shape="C3: 256->256 Conv1d k3 at (128,256,128) (tokamak level 0), F(2,3)")
+x4 = torch.randn(128, 2048, 16, device=dev)
+w4 = torch.randn(2048, 2048, 3, device=dev) * 0.01
+plan5 = Plan(dev, precision=5)
+o4 = plan5.conv(as5(x4), plan5.conv_weight(w4), torch.randn(2048, device=dev), 2048, (1, 1, 3), pad=(0, 0, 1))
+cases["conv_f43_kernel"] = dict(algorithmic=4 * (x4.numel() + o4.numel() + w4.numel()), workload="c3",
+                                shape="C3 (precision 5): 2048->2048 Conv1d k3 at (128,2048,16) (tokamak mid level), F(4,3)")
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
     plan.run(s)
+    plan5.run(s)
 torch.cuda.synchronize()
 os.makedirs(os.path.dirname(cases_path) or ".", exist_ok=True)
 json.dump(dict(batch=B, cases=cases), open(cases_path, "w"), indent=1)

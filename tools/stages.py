@@ -31,6 +31,8 @@ def classify(lib, fn, a):
             kind += " [Winograd F(2x2x2,3x3x3) over (D,H,W)]"
         elif "conv_wg2" in kern:
             kind += " [Winograd F(2x2,3x3) over (H,W)]"
+        elif "conv_f43" in kern:
+            kind += " [Winograd F(4,3) along W]"
         elif "conv_wg" in kern:
             kind += " [Winograd F(2,3) along W]"
         if fn is lib.sdc_conv_gn:
