@@ -313,7 +313,8 @@ class Plan:
         assert x.is_contiguous()
         B, Cc = x.shape[0], x.shape[1]
         S = x.numel() // (B * Cc)
-        st = torch.empty(B * groups * 2, dtype=torch.float32, device=self.device)     # its own buffer: read two launches later
+        # its own buffer (read two launches later), sized like _stats_buf: sdc_gn_stats keeps its fp64 partials behind the (mean, rstd) pairs
+        st = torch.empty((int(self.lib.sdc_gn_stats_bytes(B, groups)) + 3) // 4, dtype=torch.float32, device=self.device)
         self.keep += [x, st]
         fused = self._gn_parts.pop(x.data_ptr(), None)
         if fused is not None and fused[2] == groups:

@@ -819,3 +819,36 @@ def test_conv1d_f43_mode(plan_cls, case):
     if G:
         want = F.silu(F.group_norm(ref, G, gam.double(), bet.double(), eps=1e-5))
         assert (y.cpu().reshape(want.shape).double() - want).abs().max().item() < 6e-5     # (the conv error over the group's std)
+
+
+@pytest.mark.parametrize("Cc,F_,hw,res", [(64, 3, (16, 16), True), (128, 2, (8, 16), True), (64, 1, (8, 8), False)])
+def test_linattn_block_with_groupnorm_on_load(plan_cls, Cc, F_, hw, res):
+    """sdc_linattn_block_gn (the producing ResnetBlock's GroupNorm(8) + SiLU + residual applied while pass 1 loads its tiles,
+    conv3d.py:189-230 -> :232-258) == sdc_gn_stats + sdc_gn_apply followed by sdc_linattn_block, bit for bit: same expressions,
+    same statistics kernel.  (The statistics buffer carries sdc_gn_stats' fp64 partials behind the (mean, rstd) pairs.)"""
+    from safediffcon_amd.engine import Plan
+    B, G = 2, 8
+    H, W = hw
+    x = det_tensor((B, Cc, F_, H, W), 501).to(DEV)
+    r = det_tensor((B, Cc, F_, H, W), 502).to(DEV) if res else None
+    gam, bet = (1 + 0.2 * det_tensor((Cc,), 503)).to(DEV), (0.1 * det_tensor((Cc,), 504)).to(DEV)
+    g_pre = (1 + 0.1 * det_tensor((Cc,), 505)).to(DEV)
+    outs = []
+    for fused in (True, False):
+        plan = Plan(DEV)
+        wqkv = plan.conv_weight(det_tensor((384, Cc, 1, 1), 506, 0.1).to(DEV))
+        wo = plan.conv_weight(det_tensor((Cc, 128, 1, 1), 507, 0.1).to(DEV))
+        bo = (0.1 * det_tensor((Cc,), 508)).to(DEV)
+        xx = x.clone()
+        n = H * W
+        strides = (Cc * F_ * n, F_ * n, n)
+        if fused:
+            st = plan.gn_stats_deferred(xx, G)
+            y = plan.linattn_block(xx, g_pre, wqkv, wo, bo, None, B, F_, n, strides, 0, -1, gn=(st, gam, bet, G, r))
+        else:
+            h = plan.gn_silu(xx, gam, bet, G, residual=r)
+            y = plan.linattn_block(h, g_pre, wqkv, wo, bo, None, B, F_, n, strides, 0, -1)
+        _run(plan)
+        outs.append(y.clone())
+        assert torch.isfinite(y).all()
+    assert torch.equal(outs[0], outs[1])
