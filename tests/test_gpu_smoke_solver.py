@@ -144,3 +144,34 @@ def test_argument_errors_like_the_reference():
         ss.solver(sim, ss.init_velocity_(), torch.zeros(1, 64, 64), torch.zeros(1, 4, 64, 64), torch.zeros(1, 4, 64, 64), 32)
     with pytest.raises(NotImplementedError):
         sim.set_obstacle(np.ones((3, 3)))
+
+
+def test_c4_sample_then_score_check_end_to_end():
+    """BASELINE configs[3] with its caller-side step: a (short-schedule) guided C4 sample -> un-rescale -> channel means like
+    InferencePipeline.run_model (2d/inference_2d.py:197-237) -> multi_evaluate on the sampled controls, all on device tensors."""
+    import safediffcon_amd as sdc
+    from oracle.detweights import det_noise, det_params, det_tensor
+    from safediffcon_amd import smoke_solver as ss
+    dev = torch.device("cuda:0")
+    net = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+    net.load_state_dict(det_params([(k, tuple(v.shape)) for k, v in net.state_dict().items()], 31))
+    net.to(dev)
+    B = 4
+    gs = sdc.GaussianDiffusionSmoke(net, image_size=64, frames=32, timesteps=2, standard_fixed_ratio=100.0).to(dev)
+    state = torch.rand(B, 32, 7, 64, 64, generator=torch.Generator().manual_seed(3))
+    state[:, 0, 0, 32:] = 0
+    R = torch.tensor(sdc.diffusion.SMOKE_RESCALER, dtype=torch.float32).reshape(1, 1, 7, 1, 1)
+    out = gs.sample(batch_size=B, design_fn=sdc.SmokeGuidance(0.01, 0.9, 0.1), init=(state[:, 0, 0] / R[0, 0, 0, 0, 0]).to(dev),
+                    noise=det_noise((B, 32, 7, 64, 64), 8000)) * R.to(dev)
+    pred = torch.zeros_like(out)
+    pred[:, :, :-2] = out[:, :, :-2]
+    pred[:, :, -2] = out[:, :, -2].mean((-2, -1), keepdim=True).expand(-1, -1, 64, 64)
+    pred[:, :, -1] = out[:, :, -1].mean((-2, -1), keepdim=True).expand(-1, -1, 64, 64)
+    res = ss.multi_evaluate(pred, state.to(dev), Q=0.01, safe_bound=0.1)
+    J_target, safe_target, J_safe, J_safe_pred, J_time, J_pred_time, mse, n_l2 = res
+    assert J_target.shape == safe_target.shape == J_safe.shape == mse.shape == n_l2.shape == (B,)
+    assert J_time.shape == J_pred_time.shape == (B, 32)
+    assert np.isfinite(mse).all() and np.isfinite(n_l2).all() and (safe_target[np.isfinite(safe_target)] >= 0).all()
+    # each trajectory's score is its own: the same call on the first two samples alone
+    res2 = ss.multi_evaluate(pred[:2].clone(), state[:2].to(dev), Q=0.01, safe_bound=0.1)
+    assert np.array_equal(res2[0], J_target[:2], equal_nan=True) and np.array_equal(res2[6], mse[:2])
