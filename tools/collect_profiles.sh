@@ -13,7 +13,7 @@ find $O -name "*kernel_trace.csv" -delete
 echo "pmc done"
 timeout -k 10 700 python bench.py > $O/r4_bench_c4.json.log 2> $O/bench_c4.err || exit 1
 echo "bench c4 done"; tail -c 200 $O/r4_bench_c4.json.log
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-extra --no-cpu-baseline > $O/stats.log 2>&1 || exit 2
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-extra --no-cpu-baseline --cal-steps 0 > $O/stats.log 2>&1 || exit 2   # (--cal-steps 0: no calibration-batch launches of the same kernels at B = 25 in the averages)
 find $O/stats -name "*kernel_trace.csv" -delete
 echo "kernel stats done"
 timeout -k 10 200 python tools/stage_report.py smoke 64 > $O/r4_stage_roofline_c4.md 2>$O/stage_c4.err || exit 7
