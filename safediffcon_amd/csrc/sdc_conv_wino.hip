@@ -40,7 +40,8 @@ typedef float w2f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ w2f2 pk_add2(w2f2 a, w2f2 b) { w2f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ w2f2 pk_sub2(w2f2 a, w2f2 b) { w2f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ w2f2 pk_mul2(w2f2 a, w2f2 b) { w2f2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// a * b - c ;  c - a * b
+// a * b + c ;  a * b - c ;  c - a * b
+__device__ __forceinline__ w2f2 pk_fma2(w2f2 a, w2f2 b, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ w2f2 pk_fms2(w2f2 a, w2f2 b, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ w2f2 pk_fnma2(w2f2 a, w2f2 b, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 // (c1, c2) -> (c1 + c2, c2 - c1)
@@ -134,7 +135,19 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     };
 
     // ---- park geometry of this thread: k row inside the stage, row pair r, first column c0 (CPL columns c0 .. c0+CPL-1)
-    const bool parker = CPL != 8 || wave < 2;                      // W = 128: 128 items per stage, waves 0 and 1 park
+    // W = 128: 128 items per stage and two wave pairs on them.  Waves 0/1 produce the transformed rows j = 0, 1 (input rows 0,
+    // 1, 2 of the item), waves 2/3 the rows j = 2, 3 (input rows 1, 2, 3): three row loads, three packed H ops per column
+    // pair and two W transforms per wave instead of 4 / 6 / 4 on half of the waves.  Both pairs run the same instructions;
+    // which rows they load and the signs of the 0 / 1 factors are wave-uniform:
+    //   t = S1 * (s k12);  "inner" row = S2 * k12 + t;  "outer" row = S0 * (s k_o) - t
+    //   pair 0: s = +1, (S0, S1, S2) = rows (0, 2, 1): outer = d0 - d2 (j = 0), inner = d1 + d2 (j = 1)
+    //   pair 1: s = -1, (S0, S1, S2) = rows (3, 1, 2): outer = d1 - d3 (j = 3), inner = d2 - d1 (j = 2)
+    // (the products are exact, so the results are those of the four-row form bit for bit)
+    const bool parker = true;
+    const int pw = CPL == 8 ? (wave & 1) : wave;                   // which k rows of the stage this wave parks
+    const int jhalf = CPL == 8 ? (wave >> 1) : 0;
+    constexpr int NJ = CPL == 8 ? 2 : 4;                           // transformed rows per wave
+    constexpr int NR = CPL == 8 ? 3 : 4;                           // input rows per wave
     const int ksub = CPL == 4 ? (lane >> 5) : (CPL == 8 ? (lane >> 4) : 0);        // k row inside the wave's group (CPL = 2: the item)
     const int lik = lane & (LPK - 1);
     int pr, pc0;
@@ -157,9 +170,13 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
             vp0 = (uint32_t)(ksub * d.x0s[1] + ob * d.x0s[0] + od * d.x0s[2] + (2 * hp) * OW + pc0) * 4u;
             if (two) vp1 = (uint32_t)(ksub * d.x1s[1] + ob * d.x1s[0] + od * d.x1s[2] + (2 * hp) * OW + pc0) * 4u;
         }
+        if (CPL == 8 && jhalf) { m0f = -m3f; rsel0 = 0u - rsel3; }      // the pair's outer row is row 3, its factor negated
     }
-    // park position: V[k][j][tile][4]; k = wave * KPW + ksub (+ item for CPL = 2), tile = pr * TW + c0 / 2 (+ t)
-    const int vpark = ((wave * KPW + ksub) * 4 * W2_TILES + pr * TW + (pc0 >> 1)) * 4;          // floats; + j * 256, + item * 1024
+    const float sgn = (CPL == 8 && jhalf) ? -1.0f : 1.0f;
+    const int row_t = (CPL == 8 && !jhalf) ? OW * 4 : 0, row_i = (CPL == 8 && jhalf) ? OW * 4 : 0;    // bytes: rows S1, S2 (CPL = 8)
+    // park position: V[k][j][tile][4]; k = pw * KPW + ksub (+ item for CPL = 2), tile = pr * TW + c0 / 2 (+ t)
+    const int vpark = ((pw * KPW + ksub) * 4 * W2_TILES + pr * TW + (pc0 >> 1)) * 4;          // floats; + j * 256, + item * 1024
+    const int vpark_o = vpark + 3 * jhalf * (W2_TILES * 4), vpark_i = vpark + (1 + jhalf) * (W2_TILES * 4);      // CPL = 8: outer / inner row
     // B fragments: tile n = wn * 32 + l31 of k row 2ks + lh: four 16-byte reads (j = 0..3)
     const int boff = (lh * 4 * W2_TILES + wn * 32 + l31) * 4;
     // A fragments: row (k = 2ks + lh, m): four 16-byte chunks, chunk q at slot q ^ ((m >> 2) & 3)
@@ -194,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         const bool first = s_ci < cin0;
         f_sc = first ? xs1_0 : xs1_1;
         const float* bsel = first ? x0p : x1p;
-        const int cbase = (first ? s_ci : s_ci - cin0) + wave * KPW;
+        const int cbase = (first ? s_ci : s_ci - cin0) + pw * KPW;
         const uint32_t dsb = (uint32_t)((s_kd - pDn) * (first ? xs2_0 : xs2_1) * 4);   // bytes, two's complement
         f_x = uniform_ptr(bsel + (int64_t)cbase * f_sc);
         f_w = uniform_ptr(wg2p + ((int64_t)(s_kd * cin + s_ci) * coutn) * 16);
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         const float md = dv ? 1.0f : 0.0f, a0 = dv ? m0f : 0.0f, a3 = dv ? m3f : 0.0f;
         mk12 = w2f2{md, md};
         mk0 = w2f2{a0, a0};
-        mk3 = w2f2{a3, a3};
+        mk3 = CPL == 8 ? w2f2{sgn * md, sgn * md} : w2f2{a3, a3};
         s_ci += SK;
         // (past the last stage the walk wraps to the first one: the extra fetches of the pipeline tail stay in bounds and are
         // never consumed)
@@ -218,7 +235,8 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     // A lane whose row is outside the image reads the first elements of the channel instead and is zeroed when parked.
     auto fetch_b_row = [&](int it, int j, w2f2 (&br)[NIT][4][TPL]) {
         const gchar_p rb = (gchar_p)f_x + (CPL == 2 ? (int64_t)it * f_sc * 4 : 0);
-        const gchar_p p = j == 0 ? rb + voff0 : (j == 3 ? rb + voff3 : (j == 1 ? rb + voff : rb + voff + OW * 4));
+        const gchar_p p = CPL == 8 ? (j == 0 ? rb + voff0 : (j == 1 ? rb + row_t + voff : rb + row_i + voff))
+                                   : (j == 0 ? rb + voff0 : (j == 3 ? rb + voff3 : (j == 1 ? rb + voff : rb + voff + OW * 4)));
         if (CPL == 2) { const nfloat2 v = *(gfloat2_p)p; br[it][j][0] = w2f2{v.x, v.y}; }
         else {
 #pragma unroll
@@ -231,7 +249,7 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     };
     auto fetch_b = [&](int it, w2f2 (&br)[NIT][4][TPL]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fetch_b_row(it, j, br);
+        for (int j = 0; j < NR; ++j) fetch_b_row(it, j, br);
     };
     auto park_a = [&](int buf, int i, const nfloat4 (&ar)[8]) {
         *reinterpret_cast<nfloat4*>(As + buf * W2_ASZ + i * (BM * 16) + apark) = ar[i];
@@ -241,6 +259,15 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     // edge tiles through DPP -- and one 16-byte store per tile, slot order (V1, V2, V0, V3)
     w2f2 hrow[4][TPL];
     auto park_b_h = [&](int it, const w2f2 (&br)[NIT][4][TPL], w2f2 k0, w2f2 k12, w2f2 k3) {
+        if (CPL == 8) {       // k0 = s k_o, k3 = s k12 (see the top of the kernel)
+#pragma unroll
+            for (int t = 0; t < TPL; ++t) {
+                const w2f2 ts = pk_mul2(br[it][1][t], k3);
+                hrow[1][t] = pk_fma2(br[it][2][t], k12, ts);
+                hrow[0][t] = pk_fms2(br[it][0][t], k0, ts);
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < TPL; ++t) {
             const w2f2 t1 = pk_mul2(br[it][1][t], k12), t2 = pk_mul2(br[it][2][t], k12);
@@ -251,7 +278,8 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         }
     };
     auto park_b_w = [&](int buf, int it, int j) {
-        float* dst = Vs + buf * W2_BSZ + vpark + (CPL == 2 ? it * (4 * W2_TILES * 4) : 0) + j * (W2_TILES * 4);
+        float* dst = CPL == 8 ? Vs + buf * W2_BSZ + (j == 0 ? vpark_o : vpark_i)
+                              : Vs + buf * W2_BSZ + vpark + (CPL == 2 ? it * (4 * W2_TILES * 4) : 0) + j * (W2_TILES * 4);
 #pragma unroll
         for (int t = 0; t < TPL; ++t) {
             const w2f2 cc = hrow[j][t];
@@ -266,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     auto park_b = [&](int buf, int it, const w2f2 (&br)[NIT][4][TPL], w2f2 k0, w2f2 k12, w2f2 k3) {
         park_b_h(it, br, k0, k12, k3);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) park_b_w(buf, it, j);
+        for (int j = 0; j < NJ; ++j) park_b_w(buf, it, j);
     };
 
     f32x16 acc[16];
@@ -354,10 +382,10 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
                     const bool bwork = parker && p < NIT;
                     if (c < 4) { if (!(DBG & 32)) park_a(wbuf, 2 * c + p, areg); }
                     else if (c == 4) { if (bwork && !(DBG & 8)) park_b_h(p, braw, pk0, pk12, pk3); }
-                    else if (c < 9) { if (bwork && !(DBG & 8)) park_b_w(wbuf, p, c - 5); }
+                    else if (c < 9) { if (bwork && !(DBG & 8) && c - 5 < NJ) park_b_w(wbuf, p, c - 5); }
                     else if (c == 9) { if (p == 0) { fetch_begin(); nk0 = mk0; nk12 = mk12; nk3 = mk3; } }
                     else if (c < 14) {
-                        if (bwork && !(DBG & 16)) fetch_b_row(p, c - 10, braw);
+                        if (bwork && !(DBG & 16) && c - 10 < NR) fetch_b_row(p, c - 10, braw);
                         if (c >= 12 && !(DBG & 64)) fetch_a(2 * (c - 12) + p, areg);
                     }
                     else { if (!(DBG & 64)) fetch_a(2 * (c - 12) + p, areg); if (c == 15 && p == 1) { pk0 = nk0; pk12 = nk12; pk3 = nk3; } }
@@ -597,7 +625,6 @@ __device__ __forceinline__ uint64_t lo64(float k) { return (uint64_t)__builtin_b
 // a * k, a * k + c with a wave-uniform factor k (both halves)
 __device__ __forceinline__ w2f2 pks_mul(w2f2 a, float k) { w2f2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "s"(lo64(k))); return r; }
 __device__ __forceinline__ w2f2 pks_fma(w2f2 a, float k, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "s"(lo64(k)), "v"(c)); return r; }
-__device__ __forceinline__ w2f2 pk_fma2(w2f2 a, w2f2 b, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 template <int OW, int DBG>
 __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
