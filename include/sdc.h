@@ -337,6 +337,23 @@ int sdc_chan_norm_bwd(const float* x, const float* gy, const float* g, float* gx
 size_t sdc_pack_conv_weight_floats(int Cout, int Cin, int kD, int kH, int kW, int precision);
 int sdc_pack_conv_weight(const float* w, float* out, int Cout, int Cin, int kD, int kH, int kW, int precision, int flip, void* stream);
 
+/* The same packing for MANY weights in one launch (a fine-tuning step re-packs every conv of the net, twice: forward and
+ * data-gradient form -- reference callers 1D/inference/inference_ft.py:183-226, 2d/inference_2d.py:267-279 step the optimiser
+ * between forwards).  The caller fills w, out, Cout, Cin, kD, kH, kW, precision, flip of every item (meaning as in
+ * sdc_pack_conv_weight; out holds sdc_pack_conv_weight_floats(...) floats); sdc_pack_batch_plan (host only, no GPU call)
+ * fills the remaining fields and returns the launch size; the caller copies the table to device memory once and calls
+ * sdc_pack_batch_run(table_dev, ...) whenever the weights changed.  Results are those of sdc_pack_conv_weight bit for bit. */
+typedef struct SdcPackItem {
+    const float* w;
+    float* out;
+    int Cout, Cin, kD, kH, kW, precision, flip;
+    int co_sh, ci_sh, grid_x, grid_y, block0;     /* filled by sdc_pack_batch_plan */
+    unsigned tap_magic;
+    int64_t n[5];
+} SdcPackItem;
+int sdc_pack_batch_plan(SdcPackItem* items, int n, int* total_blocks, int* lds_bytes);
+int sdc_pack_batch_run(const SdcPackItem* items_dev, int n, int total_blocks, int lds_bytes, void* stream);
+
 /* Backward of the attention cores (same tensor conventions as sdc_attn / sdc_linattn: q, k, v = channel ranges of qkv, the
  * gradients dqkv in the same layout; dout = dL/dout in the layout of `out`).
  * sdc_attn_bwd: dbias (heads, ntok, ntok) = sum over sequences of dS, or null (built for ntok <= 32: the temporal attention's

@@ -36,6 +36,12 @@ class SdcWgradDesc(C.Structure):
         "uD", "uH", "uW", "_pad")] + [("gs", C.c_int64 * 5), ("xs", C.c_int64 * 5)]
 
 
+class SdcPackItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p)] + [(n, C.c_int32) for n in (
+        "Cout", "Cin", "kD", "kH", "kW", "precision", "flip", "co_sh", "ci_sh", "grid_x", "grid_y", "block0")] + [
+        ("tap_magic", C.c_uint32), ("_pad", C.c_int32), ("n", C.c_int64 * 5)]
+
+
 class SdcKstarMlp(C.Structure):
     _fields_ = [("nlayers", C.c_int32), ("width", C.c_int32 * 7), ("act", C.c_int32 * 6), ("params", C.c_void_p), ("stride", C.c_int64)]
 
@@ -97,6 +103,8 @@ SIGNATURES = {
     "sdc_chan_norm_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, _i64, C.c_int, C.c_float, _stream]),
     "sdc_pack_conv_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sdc_pack_conv_weight": (C.c_int, [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "sdc_pack_batch_plan": (C.c_int, [C.POINTER(SdcPackItem), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sdc_pack_batch_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _stream]),
     "sdc_attn_bwd_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sdc_attn_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _stream]),

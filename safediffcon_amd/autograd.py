@@ -20,7 +20,9 @@ relative-position bias from its 32 x 4 embedding, O(B C) parameter-gradient sums
 element-wise loss.
 PyTorch is otherwise plumbing (device memory, the current stream, the autograd tape).  There is no CPU path.
 """
+import contextlib
 import ctypes as C
+import functools
 import math
 
 import torch
@@ -97,6 +99,9 @@ def _transposed_422(x, w, bias, cout):
     return out
 
 
+_ARENA = [None]          # the PackArena of the net whose training forward is being recorded (Trainer.step)
+
+
 class ConvFn(Function):
     """y = conv(x [| x1], w) + b for every conv form of the three U-Nets.  cfg = (kind, stride, pad, up, precision):
        kind 'conv'      nn.Conv1d/2d/3d / nn.Linear (1x1) with stride / pad; up = nearest upsampling of x folded into the read
@@ -112,8 +117,9 @@ class ConvFn(Function):
         ctx.has_bias = b is not None
         bb = None if b is None else b.detach().contiguous()
         wd = w.detach()
+        ctx.arena = arena = _ARENA[0] if (_ARENA[0] is not None and grad_ops.PackArena.cacheable(w)) else None
         if kind == "conv":
-            return conv_raw(x, grad_ops.pack_conv_weight(wd, prec), bb, w.shape[0], _k5(w), x1=x1, stride=stride, pad=pad, up=up)
+            return conv_raw(x, grad_ops.pack_conv_weight(wd, prec, arena=arena), bb, w.shape[0], _k5(w), x1=x1, stride=stride, pad=pad, up=up)
         if kind == "convT422":
             return _transposed_422(x, wd, bb, w.shape[1])
         if kind == "unshuffle":
@@ -140,7 +146,7 @@ class ConvFn(Function):
                 w5 = as5(wd)
                 if stride == (1, 1, 1):
                     # correlation with the flipped, transposed taps; pad k - 1 - p restores the input size
-                    ga = conv_raw(gy, grad_ops.pack_conv_weight(w5, prec, flip=True), None, w5.shape[1], k,
+                    ga = conv_raw(gy, grad_ops.pack_conv_weight(w5, prec, flip=True, arena=ctx.arena), None, w5.shape[1], k,
                                   pad=tuple(kk - 1 - p for kk, p in zip(k, pad)))
                     if up != (1, 1, 1):
                         ga = grad_ops.sumpool2(ga, up[1], up[2])       # VJP of the folded nearest upsampling
@@ -276,8 +282,10 @@ class LinAttnCoreFn(Function):
 
 
 # --------------------------------------------------------------------------------------------------- helpers
+@functools.lru_cache(maxsize=8)
 def _relpos_buckets(n, device, num_buckets=32, max_distance=32):
-    """RelativePositionBias bucket indices, conv3d.py:74-112 (integer arithmetic, no gradient)"""
+    """RelativePositionBias bucket indices, conv3d.py:74-112 (integer arithmetic, no gradient; cached per (n, device): the
+    host-to-device copy of the table would otherwise drain the stream once per training forward)"""
     q = torch.arange(n)
     m = -(q[None, :] - q[:, None])
     nb = num_buckets // 2
@@ -296,6 +304,17 @@ class Trainer:
     def __init__(self, net):
         self.net = net
         self.prec = net.precision
+        self.arena = grad_ops.PackArena()
+
+    @contextlib.contextmanager
+    def step(self, device):
+        """one training forward: every packed conv weight refreshed by one launch, conv nodes bound to this net's arena"""
+        self.arena.begin(device)
+        prev, _ARENA[0] = _ARENA[0], self.arena
+        try:
+            yield
+        finally:
+            _ARENA[0] = prev
 
     def P(self, key):
         return self.net.P(key)

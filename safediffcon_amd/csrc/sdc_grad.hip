@@ -1079,12 +1079,13 @@ struct PackArgs {
 // One workgroup stages a (co_t co) x (ci_t ci) x taps block of the weight through LDS -- read along the source's contiguous axis
 // ([co][ci, taps] rows, or [ci][co, taps] rows when flipped), written along co, the packed layouts' contiguous axis -- and emits
 // that block of every section.
-__global__ __launch_bounds__(NT) void pack_weight_kernel(const PackArgs a, const int co_sh, const int ci_sh, const unsigned tap_magic) {
-    extern __shared__ float tile[];                       // [co_t][ci_t * taps + 1], element (co, ci, logical tap)
+__device__ __forceinline__ void pack_weight_tile(const PackArgs& a, const int co_sh, const int ci_sh, const unsigned tap_magic,
+                                                 const int bx, const int by, float* tile) {
+    // tile: [co_t][ci_t * taps + 1], element (co, ci, logical tap)
     const int co_t = 1 << co_sh, ci_t = 1 << ci_sh;
     const int taps = a.kD * a.kH * a.kW;
     const int pitch = ci_t * taps + 1;
-    const int co0 = blockIdx.x << co_sh, ci0 = blockIdx.y << ci_sh;
+    const int co0 = bx << co_sh, ci0 = by << ci_sh;
     const int nco = a.Cout - co0 < co_t ? a.Cout - co0 : co_t;
     const int nci = a.Cin - ci0 < ci_t ? a.Cin - ci0 : ci_t;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1184,6 +1185,40 @@ __global__ __launch_bounds__(NT) void pack_weight_kernel(const PackArgs a, const
     }
 }
 
+__global__ __launch_bounds__(NT) void pack_weight_kernel(const PackArgs a, const int co_sh, const int ci_sh, const unsigned tap_magic) {
+    extern __shared__ float tile[];
+    pack_weight_tile(a, co_sh, ci_sh, tap_magic, blockIdx.x, blockIdx.y, tile);
+}
+
+// Every conv weight of a net in ONE launch (a fine-tuning step packs each conv twice, forward and data-gradient form: 187
+// launches of ~13 us on the tokamak net).  Workgroup b belongs to the item with block0 <= b < block0 + grid_x * grid_y
+// (binary search over the table, which lives in device memory and is built once per net: sdc_pack_batch_plan).
+__global__ __launch_bounds__(NT) void pack_weight_batch_kernel(const SdcPackItem* __restrict__ items, const int n) {
+    extern __shared__ float tile[];
+    const int b = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].block0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const SdcPackItem& it = items[lo];
+    PackArgs a;
+    a.w = it.w; a.out = it.out; a.Cout = it.Cout; a.Cin = it.Cin; a.kD = it.kD; a.kH = it.kH; a.kW = it.kW; a.flip = it.flip;
+    a.n0 = it.n[0]; a.n1 = it.n[1]; a.n2 = it.n[2]; a.n3 = it.n[3]; a.n4 = it.n[4];
+    const int r = b - it.block0;
+    pack_weight_tile(a, it.co_sh, it.ci_sh, it.tap_magic, r % it.grid_x, r / it.grid_x, tile);
+}
+
+// source block (co_t x ci_t channels, all taps) of one workgroup: <= 128 (ci, tap) columns, <= 48 KB, and at least ~4
+// workgroups per CU where the weight is large enough (a tile's emit loops are a few thousand fp64 sums per thread)
+void pack_tile_shape(int Cout, int Cin, int taps, int& co_sh, int& ci_sh, size_t& lds) {
+    ci_sh = 4; co_sh = 6;
+    while (ci_sh > 0 && (taps << ci_sh) > 128) --ci_sh;
+    while (co_sh > 0 && ((size_t)((taps << ci_sh) + 1) << co_sh) * sizeof(float) > 48u * 1024u) --co_sh;
+    while (ci_sh > 1 && (int64_t)((Cout + (1 << co_sh) - 1) >> co_sh) * ((Cin + (1 << ci_sh) - 1) >> ci_sh) < 1024) --ci_sh;
+    lds = ((size_t)((taps << ci_sh) + 1) << co_sh) * sizeof(float);
+}
+
 void pack_sections(int Cout, int Cin, int kD, int kH, int kW, int precision, int64_t* n) {
     const int64_t nw = (int64_t)Cout * Cin * kD * kH * kW;
     n[0] = nw; n[1] = n[2] = n[3] = n[4] = 0;
@@ -1214,17 +1249,49 @@ extern "C" int sdc_pack_conv_weight(const float* w, float* out, int Cout, int Ci
     int64_t n[5];
     pack_sections(Cout, Cin, kD, kH, kW, precision, n);
     a.n0 = n[0]; a.n1 = n[1]; a.n2 = n[2]; a.n3 = n[3]; a.n4 = n[4];
+    int co_sh, ci_sh;
+    size_t lds;
+    pack_tile_shape(Cout, Cin, kD * kH * kW, co_sh, ci_sh, lds);
     const int taps = kD * kH * kW;
-    int ci_sh = 4, co_sh = 6;
-    while (ci_sh > 0 && (taps << ci_sh) > 128) --ci_sh;
-    while (co_sh > 0 && ((size_t)((taps << ci_sh) + 1) << co_sh) * sizeof(float) > 48u * 1024u) --co_sh;
-    // at least ~4 workgroups per CU: a tile's emit loops are a few thousand fp64 sums per thread
-    while (ci_sh > 1 && (int64_t)((Cout + (1 << co_sh) - 1) >> co_sh) * ((Cin + (1 << ci_sh) - 1) >> ci_sh) < 1024) --ci_sh;
-    const size_t lds = ((size_t)((taps << ci_sh) + 1) << co_sh) * sizeof(float);
     SDC_REQUIRE(lds <= 64u * 1024u && ((int64_t)taps * taps << co_sh) < (1 << 24), SDC_EINVAL, "sdc_pack_conv_weight: too many taps");
     const dim3 grid((unsigned)((Cout + (1 << co_sh) - 1) >> co_sh), (unsigned)((Cin + (1 << ci_sh) - 1) >> ci_sh));
     SDC_REQUIRE(grid.y < 65536u, SDC_EINVAL, "sdc_pack_conv_weight: too many input channels");
     const unsigned tap_magic = (unsigned)(((1u << 24) + taps - 1) / taps);
     hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(NT), lds, sdc::as_stream(stream), a, co_sh, ci_sh, tap_magic);
     return sdc::check_launch("sdc_pack_conv_weight");
+}
+
+extern "C" int sdc_pack_batch_plan(SdcPackItem* items, int n, int* total_blocks, int* lds_bytes) {
+    SDC_REQUIRE(items && total_blocks && lds_bytes, SDC_ENULL, "sdc_pack_batch_plan: null pointer");
+    SDC_REQUIRE(n > 0, SDC_EINVAL, "sdc_pack_batch_plan: no items");
+    int64_t blocks = 0;
+    size_t lds_max = 0;
+    for (int i = 0; i < n; ++i) {
+        SdcPackItem& it = items[i];
+        SDC_REQUIRE(it.w && it.out, SDC_ENULL, "sdc_pack_batch_plan: item %d: null pointer", i);
+        SDC_REQUIRE(it.Cout > 0 && it.Cin > 0 && it.kD > 0 && it.kH > 0 && it.kW > 0 &&
+                    (it.precision == 0 || (it.precision >= 2 && it.precision <= 5)), SDC_EINVAL, "sdc_pack_batch_plan: item %d: bad arguments", i);
+        const int taps = it.kD * it.kH * it.kW;
+        size_t lds;
+        pack_tile_shape(it.Cout, it.Cin, taps, it.co_sh, it.ci_sh, lds);
+        SDC_REQUIRE(lds <= 64u * 1024u && ((int64_t)taps * taps << it.co_sh) < (1 << 24), SDC_EINVAL, "sdc_pack_batch_plan: item %d: too many taps", i);
+        pack_sections(it.Cout, it.Cin, it.kD, it.kH, it.kW, it.precision, it.n);
+        it.tap_magic = (unsigned)(((1u << 24) + taps - 1) / taps);
+        it.grid_x = (it.Cout + (1 << it.co_sh) - 1) >> it.co_sh;
+        it.grid_y = (it.Cin + (1 << it.ci_sh) - 1) >> it.ci_sh;
+        it.block0 = (int)blocks;
+        blocks += (int64_t)it.grid_x * it.grid_y;
+        SDC_REQUIRE(blocks < (1ll << 30), SDC_EINVAL, "sdc_pack_batch_plan: too many workgroups");
+        if (lds > lds_max) lds_max = lds;
+    }
+    *total_blocks = (int)blocks;
+    *lds_bytes = (int)lds_max;
+    return SDC_OK;
+}
+
+extern "C" int sdc_pack_batch_run(const SdcPackItem* items_dev, int n, int total_blocks, int lds_bytes, void* stream) {
+    SDC_REQUIRE(items_dev, SDC_ENULL, "sdc_pack_batch_run: null pointer");
+    SDC_REQUIRE(n > 0 && total_blocks > 0 && lds_bytes > 0 && lds_bytes <= 64 * 1024, SDC_EINVAL, "sdc_pack_batch_run: bad arguments");
+    hipLaunchKernelGGL(pack_weight_batch_kernel, dim3((unsigned)total_blocks), dim3(NT), (size_t)lds_bytes, sdc::as_stream(stream), items_dev, n);
+    return sdc::check_launch("sdc_pack_batch_run");
 }

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import SdcWgradDesc, check
+from ._lib import SdcPackItem, SdcWgradDesc, check
 from .engine import as5
 
 
@@ -176,11 +176,102 @@ def linattn_core_bwd(qkv, dout, heads, outer, inner, n, qs, os_):
     return dqkv
 
 
-def pack_conv_weight(w, precision, flip=False):
+class PackArena:
+    """The packed conv weights of ONE net, refreshed by one launch per training forward (sdc_pack_batch_run).
+
+    A fine-tuning step needs every conv weight in kernel layout twice (forward form, data-gradient form) and the optimiser
+    changes them between steps, so they are re-packed every step: 187 launches of ~13 us on the tokamak net.  The arena
+    records which (parameter, precision, flip) layouts a step asked for; from the next step on ``begin()`` packs all of
+    them in one launch into one buffer and ``get()`` hands out slices.  Only ``nn.Parameter`` storage is cached (a weight
+    computed inside the graph has no stable address); the arena holds a reference to every source tensor, so a table entry
+    never points at freed memory, and entries nobody asked for in two consecutive steps are dropped."""
+
+    def __init__(self):
+        self.index = {}        # key -> (offset, numel) in self.buf
+        self.meta = {}         # key -> (source tensor, precision, flip)
+        self.idle = {}         # key -> steps since the entry was last asked for
+        self.pending = {}      # asked for, not in the table yet
+        self.used = set()
+        self.buf = self.table = None
+        self.launch = None     # (n, total_blocks, lds_bytes)
+        self.fresh = False     # the buffer holds this step's weights
+
+    @staticmethod
+    def cacheable(w):
+        b = w._base if w._base is not None else w
+        return isinstance(b, torch.nn.Parameter) and w.is_contiguous() and w.is_cuda
+
+    @staticmethod
+    def _key(w5, precision, flip):
+        return (w5.data_ptr(), tuple(w5.shape), int(precision), bool(flip))
+
+    def _rebuild(self, device):
+        lib = _lib.get_lib()
+        for k in [k for k, n in self.idle.items() if n >= 2]:
+            del self.meta[k], self.idle[k]
+        for k, m in self.pending.items():
+            self.meta[k] = m
+            self.idle[k] = 0
+        self.pending = {}
+        self.index, off = {}, 0
+        items = (SdcPackItem * max(len(self.meta), 1))()
+        for it, (k, (w5, prec, flip)) in zip(items, self.meta.items()):
+            co, ci, kD, kH, kW = w5.shape
+            if flip:
+                co, ci = ci, co
+            n = int(lib.sdc_pack_conv_weight_floats(co, ci, kD, kH, kW, prec))
+            self.index[k] = (off, n)
+            it.w = w5.data_ptr()
+            it.Cout, it.Cin, it.kD, it.kH, it.kW, it.precision, it.flip = co, ci, kD, kH, kW, prec, 1 if flip else 0
+            it.out = off                                   # offset in floats for now
+            off += (n + 3) & ~3                            # 16-byte aligned sections
+        if not self.meta:
+            self.buf = self.table = self.launch = None
+            return
+        self.buf = torch.empty(off, dtype=torch.float32, device=device)
+        base = self.buf.data_ptr()
+        for it in items:
+            it.out = base + 4 * (it.out or 0)
+        nb, lds = C.c_int(0), C.c_int(0)
+        check(lib.sdc_pack_batch_plan(items, len(self.meta), C.byref(nb), C.byref(lds)), "sdc_pack_batch_plan")
+        self.table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(device)
+        self.launch = (len(self.meta), nb.value, lds.value)
+
+    def begin(self, device):
+        """start of a training forward: fold the last step's requests into the table, then pack everything once"""
+        for k in self.idle:
+            self.idle[k] = 0 if k in self.used else self.idle[k] + 1
+        self.used = set()
+        if self.pending or any(n >= 2 for n in self.idle.values()):
+            self._rebuild(device)
+        self.fresh = False
+        if self.table is not None:
+            n, nb, lds = self.launch
+            check(_lib.get_lib().sdc_pack_batch_run(self.table.data_ptr(), n, nb, lds, torch.cuda.current_stream(device).cuda_stream),
+                  "sdc_pack_batch_run")
+            self.fresh = True
+
+    def get(self, w5, precision, flip):
+        """this step's packed layout, or None (then the caller packs it alone and the next step's table holds it)"""
+        k = self._key(w5, precision, flip)
+        ent = self.index.get(k)
+        if ent is not None and self.fresh and self.buf.device == w5.device:
+            self.used.add(k)
+            return self.buf[ent[0]:ent[0] + ent[1]]
+        if k not in self.meta:
+            self.pending[k] = (w5, int(precision), bool(flip))
+        return None
+
+
+def pack_conv_weight(w, precision, flip=False, arena=None):
     """kernel layout of a contiguous nn.Conv weight (Cout, Cin, *k) on the device in one launch (sdc_pack_conv_weight);
-    flip: the data-gradient weight (transposed channels, flipped taps)"""
+    flip: the data-gradient weight (transposed channels, flipped taps).  arena: the net's PackArena when w is parameter storage."""
     _need_cuda(w)
     lib = _lib.get_lib()
+    if arena is not None:
+        hit = arena.get(as5(w.detach()), precision, flip)
+        if hit is not None:
+            return hit
     w5 = as5(w.detach()).contiguous()
     co, ci, kD, kH, kW = w5.shape
     if flip:

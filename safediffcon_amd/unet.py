@@ -314,7 +314,8 @@ class _HipUNet(nn.Module):
                                "there is no CPU fallback")
         from . import autograd
         fn = autograd.forward_train_smoke if isinstance(self, Unet3D_with_Conv3D) else autograd.forward_train_lucid
-        return fn(self, x.to(torch.float32), time)
+        with self._trainer().step(x.device):
+            return fn(self, x.to(torch.float32), time)
 
     def _drop_plans(self):
         """device moves / dtype casts invalidate bound pointers: destroy the captured graphs, forget the plans"""

@@ -239,3 +239,70 @@ def test_differentiable_ddim_tail(golden):
     print(f"[measured] differentiable DDIM tail: sample vs gradient-free sampler {err:.2e}; loss {loss.item():.3e} vs {lref.item():.3e}; "
           f"worst relative gradient error vs PyTorch-ROCm autograd of the oracle {worst:.2e}")
     assert abs(loss.item() - lref.item()) < 1e-4 * abs(lref.item()) + 1e-9 and worst < 5e-4
+
+
+def test_batched_weight_packing_equals_the_single_launch_form():
+    """sdc_pack_batch_run packs many conv weights in one launch; bit for bit what sdc_pack_conv_weight writes for each"""
+    from safediffcon_amd import grad_ops
+    from safediffcon_amd.grad_ops import PackArena
+    torch.manual_seed(3)
+    shapes = [((64, 7, 1, 1, 3), 2), ((64, 7, 1, 1, 3), 5), ((24, 40, 1, 3, 3), 3), ((16, 24, 3, 3, 3), 4), ((130, 66, 1, 1, 1), 0),
+              ((8, 12, 1, 7, 7), 0), ((256, 512, 1, 1, 3), 2), ((33, 17, 1, 3, 3), 4)]
+    ws = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s, _ in shapes]
+    arena = PackArena()
+    arena.begin(torch.device(DEV))
+    for w, (_, prec) in zip(ws, shapes):                       # first step: nothing cached, every request recorded
+        assert PackArena.cacheable(w)
+        for flip in (False, True):
+            assert arena.get(w, prec, flip) is None
+    arena.begin(torch.device(DEV))                             # second step: one launch
+    assert arena.launch is not None and arena.launch[0] == 2 * len(ws)
+    for w, (_, prec) in zip(ws, shapes):
+        for flip in (False, True):
+            got = arena.get(w, prec, flip)
+            ref = grad_ops.pack_conv_weight(w, prec, flip=flip)
+            assert got is not None and got.shape == ref.shape and torch.equal(got, ref), (tuple(w.shape), prec, flip)
+    with torch.no_grad():                                      # the optimiser moves the weights in place: the next step re-packs
+        for w in ws:
+            w.mul_(1.5)
+    arena.begin(torch.device(DEV))
+    for w, (_, prec) in zip(ws, shapes):
+        assert torch.equal(arena.get(w, prec, True), grad_ops.pack_conv_weight(w, prec, flip=True))
+    # a weight computed inside the graph has no stable address: never cached
+    assert not PackArena.cacheable(ws[0] * 2.0)
+    # entries nobody asks for are dropped after two steps
+    arena.begin(torch.device(DEV)); arena.begin(torch.device(DEV)); arena.begin(torch.device(DEV))
+    assert arena.launch is None and not arena.meta
+
+
+@pytest.mark.parametrize("tree", ["burgers", "tokamak", "smoke"])
+def test_finetune_steps_through_the_pack_arena(golden, tree):
+    """step 1 packs conv by conv and records; step 2 onwards reads every parameter conv weight from the arena's one launch:
+    same loss, same gradients to the bit; after an in-place parameter update the arena follows (a fresh net agrees)"""
+    spec = golden(tree + "_unet").spec()
+    net, gd, x0, noise = _build(tree, spec)
+    x0, noise = x0.to(DEV), noise.to(DEV)
+    t = torch.tensor([5, 400, 900], device=DEV)
+
+    def step(n, g):
+        n.zero_grad(set_to_none=True)
+        loss = g.p_losses(x0, t, noise=noise, mean=False).mean()
+        loss.backward()
+        return loss.item(), {k: p.grad.clone() for k, p in n.named_parameters() if p.grad is not None}
+
+    l1, g1 = step(net, gd)
+    arena = net._trainer().arena
+    assert arena.launch is None and arena.pending
+    l2, g2 = step(net, gd)
+    assert arena.launch is not None and arena.used and not arena.pending
+    assert l1 == l2 and all(torch.equal(g1[k], g2[k]) for k in g1)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.mul_(1.02)
+    l3, g3 = step(net, gd)
+    assert l3 != l2
+    net2, gd2, _, _ = _build(tree, spec)
+    net2.load_state_dict(net.state_dict())
+    l4, g4 = step(net2, gd2)                                  # a fresh net: packs conv by conv
+    assert net2._trainer().arena.launch is None
+    assert l3 == l4 and all(torch.equal(g3[k], g4[k]) for k in g3)

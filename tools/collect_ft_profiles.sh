@@ -6,7 +6,7 @@ export FT_NO_EAGER=1
 for wl in c4 c2 c3; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/$wl --output-format csv -- python3 tools/ft_time.py $wl > $O/$wl.log 2>&1 || exit 2
   find $O/$wl -name "*kernel_trace.csv" -delete
-  cp $(find $O/$wl -name "*kernel_stats.csv" | head -1) $O/r3_finetune_${wl}_kernel_stats.csv
+  cp $(find $O/$wl -name "*kernel_stats.csv" | head -1) $O/r4_finetune_${wl}_kernel_stats.csv
   tail -1 $O/$wl.log | cut -c1-160
 done
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/kstar --output-format csv -- python3 tools/kstar_time.py 128 512 > $O/kstar.log 2>&1 || exit 3
