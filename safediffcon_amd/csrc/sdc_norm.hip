@@ -68,7 +68,10 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, float* __res
 
 // ---------------------------------------------------------------- GroupNorm apply
 // grid.x = b*C + c (one channel row), grid.y walks 4-element vectors of that row.
-template <bool VEC>
+// STREAM (tensors far beyond the 256 MB Infinity Cache, i.e. the smoke net's upper levels): one vector per thread, no
+// grid-stride loop, nontemporal loads and stores -- tools/stream_probe.hip: 6.5-6.7 TB/s on 1 GiB tensors against 4.6-5.4 for
+// the looping / cached forms.  Tensors that fit the cache keep the cached form: their consumer finds them there.
+template <bool VEC, bool STREAM = false>
 __global__ __launch_bounds__(NT) void gn_apply_kernel(const float* x, const float* __restrict__ stats,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ ss, const int32_t* __restrict__ t_dev,
@@ -76,6 +79,15 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const float* x, const floa
                                                       const float* res, float* y, int C,
                                                       int G, int64_t S) {
     const int bc = blockIdx.x;
+    typedef float nf4 __attribute__((ext_vector_type(4)));
+    nf4 sv = {0.f, 0.f, 0.f, 0.f}, sr = {0.f, 0.f, 0.f, 0.f};
+    const int64_t si = (int64_t)blockIdx.y * NT + threadIdx.x;            // STREAM: gridDim.y * NT >= S / 4
+    if constexpr (VEC && STREAM) {                                        // the stream loads travel while the row constants are fetched
+        if (si < (S >> 2)) {
+            sv = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(x + (int64_t)bc * S) + si);
+            if (res) sr = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(res + (int64_t)bc * S) + si);
+        }
+    }
     const int b = bc / C, c = bc - b * C;
     const int g = c / (C / G);
     const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
@@ -93,6 +105,18 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const float* x, const floa
         const float4* x4 = reinterpret_cast<const float4*>(x + base);
         const float4* r4 = res ? reinterpret_cast<const float4*>(res + base) : nullptr;
         float4* y4 = reinterpret_cast<float4*>(y + base);
+        if constexpr (STREAM) {
+            if (si < nv) {
+                nf4 v;
+                v.x = sdc::silu_f(sv.x * mul + add);
+                v.y = sdc::silu_f(sv.y * mul + add);
+                v.z = sdc::silu_f(sv.z * mul + add);
+                v.w = sdc::silu_f(sv.w * mul + add);
+                if (r4) v += sr;
+                __builtin_nontemporal_store(v, reinterpret_cast<nf4*>(y4) + si);
+            }
+            return;
+        }
         for (int64_t i = (int64_t)blockIdx.y * NT + threadIdx.x; i < nv; i += (int64_t)gridDim.y * NT) {
             float4 v = x4[i];
             v.x = sdc::silu_f(v.x * mul + add);
@@ -424,6 +448,10 @@ extern "C" int sdc_gn_apply(const float* x, const float* stats, const float* gam
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(gn_apply_flat_kernel, dim3((unsigned)blocks), dim3(NT), 0, s, x, stats, gamma, beta, ss, t_dev,
                            ss_t_stride, ss_b_stride, ss_off, residual, y, C, G, (int)(S / 4), nvt);
+    } else if (vec && (int64_t)B * C * S * 4 >= (512ll << 20) && (work + NT - 1) / NT < 65536) {
+        grid.y = (unsigned)((work + NT - 1) / NT);
+        hipLaunchKernelGGL((gn_apply_kernel<true, true>), grid, dim3(NT), 0, s, x, stats, gamma, beta, ss, t_dev, ss_t_stride,
+                           ss_b_stride, ss_off, residual, y, C, G, S);
     } else if (vec)
         hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(NT), 0, s, x, stats, gamma, beta, ss, t_dev, ss_t_stride,
                            ss_b_stride, ss_off, residual, y, C, G, S);

@@ -5,6 +5,8 @@
    reference pin the oracle's loop).  Reference: 1D/model/diffusion.py:368-449, tokamak/model/diffusion.py:310-372.
  * the C4 guided SAMPLER (not only the forward) at the full batch of 64: two steps, every one of the 64 trajectories
    against the eager-GPU oracle.  Reference: 2d/ddpm/diffusion_2d.py:288-322.
+ * one FULL-schedule (T = 1000) guided trajectory at C4 width (dim 64, 32 frames of 64 x 64) against the eager-GPU oracle
+   (B = 2 of the same run: tools/c4_t1000_parity.py, profiles/r4_c4_t1000_parity.log).
 Gates: element-wise <= ~2x the error measured on MI355X (printed, `pytest -s`), and the MSE gate of the north star."""
 import pytest
 import torch
@@ -104,3 +106,23 @@ def test_c4_guided_sampler_batch64_every_trajectory_vs_eager_oracle():
           f"worst per-trajectory MSE {worst_mse:.3e}")
     # a 2-step sigmoid schedule multiplies the eps error by sqrt(1/abar - 1) ~ 50 at its first step (cf. test_gpu_configs.py)
     assert worst < 1.1e-3 and worst_mse <= 2e-10          # measured on MI355X: 5.4e-4, 8.1e-11
+
+
+def test_t1000_guided_trajectory_at_production_width_smoke():
+    net = sdc.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7)
+    P = det_params(_spec(net), 31)
+    net.load_state_dict(P)
+    net.to(DEV)
+    T, B = 1000, 1
+    gs = sdc.GaussianDiffusionSmoke(net, image_size=64, frames=32, timesteps=T, standard_fixed_ratio=100.0).to(DEV)
+    init = det_tensor((B, 64, 64), 43, 0.2).abs()
+    noise = det_noise((B, 32, 7, 64, 64), 7000)
+    out = gs.sample(batch_size=B, design_fn=sdc.SmokeGuidance(0.01, 0.9, -5.0), init=init.to(DEV), noise=noise).cpu()
+    free = gs.sample(batch_size=B, design_fn=None, init=init.to(DEV), noise=noise).cpu()
+    assert (free - out).abs().max() > 1e-3            # the guidance mattered
+    Pg = {k: v.to(DEV) for k, v in P.items()}
+    ref = osam.sample_smoke(lambda a, b: onets.unet_smoke(Pg, a, b.to(a.device), dim=64, dim_mults=(1, 2, 4)),
+                            osched.make_tables("sigmoid", T), B, lambda s: noise(s).to(DEV), init=init.to(DEV),
+                            design_fn=osam.smoke_guidance(0.01, 0.9, -5.0), ratio=100.0, shape=(32, 7, 64, 64)).cpu()
+    err, mse = _report("C4 width, T = 1000 guided DDPM (B = 1) vs the eager-GPU oracle", out, ref)
+    assert err < 4e-5 and mse <= 1e-12                # measured on MI355X at B = 2: 2.0e-5, 2.0e-13
