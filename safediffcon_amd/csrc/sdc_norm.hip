@@ -359,6 +359,82 @@ __global__ __launch_bounds__(NT) void chan_norm_kernel(const float* x, const flo
     }
 }
 
+// Long rows whose length is a multiple of 4 (the smoke net's temporal / spatial attention pre-norms, 1 GB tensors): PLV position
+// lanes of FOUR adjacent positions each, NT / PLV channel slices, the thread's <= 32 channels x 4 positions cached in registers:
+// x is read from HBM once with 16-byte nontemporal loads in runs of 16 PLV bytes per channel row, y written the same way
+// (the scalar form above moved 3.3 TB/s at C = 128 / 256).  Same arithmetic per position as chan_norm_kernel<., true>; with
+// PLV = 64 (C <= 128) also the same summation order.
+template <int PLV>
+__global__ __launch_bounds__(NT) void chan_norm_vec_kernel(const float* x, const float* __restrict__ g, const float* res, float* y, int C,
+                                                           int64_t S, int mode, float eps) {
+    constexpr int NSL = NT / PLV;
+    constexpr int CPT = 32;
+    typedef float nf4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x % PLV, slice = threadIdx.x / PLV;
+    const int b = blockIdx.y;
+    const int64_t S4 = S >> 2;
+    const int64_t pos = (int64_t)blockIdx.x * PLV + lane;
+    const bool ok = pos < S4;
+    const int64_t base = (int64_t)b * C * S4 + pos;
+    const nf4* x4 = reinterpret_cast<const nf4*>(x);
+    const nf4 zero = {0.f, 0.f, 0.f, 0.f};
+    nf4 vc[CPT];
+    nf4 s = zero, q = zero;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = slice + i * NSL;
+        vc[i] = (ok && c < C) ? __builtin_nontemporal_load(x4 + base + (int64_t)c * S4) : zero;
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        s += vc[i];
+        q += vc[i] * vc[i];
+    }
+    __shared__ nf4 sh[2][NSL][PLV];
+    sh[0][slice][lane] = s;
+    sh[1][slice][lane] = q;
+    __syncthreads();
+    s = zero; q = zero;
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) { s += sh[0][i][lane]; q += sh[1][i][lane]; }
+    nf4 mean, mul;
+    if (mode == 0) {
+        mean = s / (float)C;
+        nf4 q2 = zero;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const nf4 dv = (slice + i * NSL < C) ? vc[i] - mean : zero;
+            q2 += dv * dv;
+        }
+        __syncthreads();
+        sh[1][slice][lane] = q2;
+        __syncthreads();
+        nf4 var = zero;
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) var += sh[1][i][lane];
+        var = var / (float)C + eps;
+        mul.x = 1.0f / sqrtf(var.x); mul.y = 1.0f / sqrtf(var.y); mul.z = 1.0f / sqrtf(var.z); mul.w = 1.0f / sqrtf(var.w);
+    } else {
+        mean = zero;
+        const float rc = sqrtf((float)C);
+        mul.x = rc / fmaxf(sqrtf(q.x), 1e-12f); mul.y = rc / fmaxf(sqrtf(q.y), 1e-12f);
+        mul.z = rc / fmaxf(sqrtf(q.z), 1e-12f); mul.w = rc / fmaxf(sqrtf(q.w), 1e-12f);
+    }
+    if (!ok) return;
+    const nf4* r4 = reinterpret_cast<const nf4*>(res);
+    nf4* y4 = reinterpret_cast<nf4*>(y);
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = slice + i * NSL;
+        if (c < C) {
+            const int64_t o = base + (int64_t)c * S4;
+            nf4 v = (vc[i] - mean) * mul * g[c];
+            if (res) v += __builtin_nontemporal_load(r4 + o);
+            __builtin_nontemporal_store(v, y4 + o);
+        }
+    }
+}
+
 __global__ __launch_bounds__(NT) void act_kernel(const float* x, float* y, int64_t n,
                                                  int kind) {
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
@@ -524,7 +600,17 @@ extern "C" int sdc_chan_norm(const float* x, const float* g, const float* residu
     // 64-position tiles for long rows only; shorter rows take the 16-lane form (more, smaller workgroups: those launches
     // are latency-bound, not bandwidth-bound).  The choice depends on the row length alone, never on the batch, so a
     // trajectory's rounding does not depend on how many others share the launch.
-    if (S >= 1024) {
+    const bool al16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
+    if (S >= 1024 && S % 4 == 0 && al16 && C <= 512) {
+        // (row length and width alone decide, never the batch)
+        const int64_t S4 = S / 4;
+        if (C <= 128)
+            hipLaunchKernelGGL((chan_norm_vec_kernel<64>), dim3((unsigned)((S4 + 63) / 64), B), dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
+        else if (C <= 256)
+            hipLaunchKernelGGL((chan_norm_vec_kernel<32>), dim3((unsigned)((S4 + 31) / 32), B), dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
+        else
+            hipLaunchKernelGGL((chan_norm_vec_kernel<16>), dim3((unsigned)((S4 + 15) / 16), B), dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
+    } else if (S >= 1024) {
         dim3 grid((unsigned)((S + 63) / 64), B);
         if (C <= 128)
             hipLaunchKernelGGL((chan_norm_kernel<64, true>), grid, dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);
