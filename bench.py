@@ -113,10 +113,12 @@ def workload(name, dim, B, dev, rank, world, precision=4, cal_steps=5):
         return dict(Q=Q, n_cal_per_rank=n_cal, n_cal=n_cal * world, alpha=alpha, score_kernel_ms=round((t1 - t0) * 1e3, 3),
                     allgather_quantile_ms=round((t2 - t1) * 1e3, 3))
 
-    def sampled_pred(calib, cal_B):
+    def sampled_pred(calib, cal_B, like):
         """this rank's calibration shard drawn by the calibration-mode sampler itself (a bounded sample: `cal_steps` reverse
         steps per batch, like extra.calibration) -- the tensors the score kernel then reads are sampler output, not synthetic"""
         Bc = min(cal_B, n_cal)
+        if cal_steps <= 0:      # profiling runs (--cal-steps 0): no calibration-batch launches at all, Q from plain noise
+            return torch.randn(tuple(like.shape), generator=torch.Generator().manual_seed(5)).to(dev)
         out = []
         for _ in range((n_cal + Bc - 1) // Bc):
             Sc = calib(Bc)
@@ -146,7 +148,7 @@ def workload(name, dim, B, dev, rank, world, precision=4, cal_steps=5):
                              w_groundtruth=wgt, nablaJ=None, enable_grad=False, _prepare=True)
         cal_B, cal_batches = 250, 4
         net.precision = precision
-        cf = quantile("burgers", sampled_pred(calib, cal_B), truth, [500.0, 0.8 ** 2, 0.0, 10.0], 0.98)
+        cf = quantile("burgers", sampled_pred(calib, cal_B, truth), truth, [500.0, 0.8 ** 2, 0.0, 10.0], 0.98)
         guid.Q = cf["Q"]
         desc = f"C2: 1D Burgers Unet2D dim={dim} (1,2,4,8) state (B,3,16,128), guided 1000-step DDPM, conformal quantile on"
     elif name == "c3":
@@ -169,7 +171,7 @@ def workload(name, dim, B, dev, rank, world, precision=4, cal_steps=5):
                              nablaJ=None, enable_grad=False, _prepare=True)
         cal_B, cal_batches = 125, 8
         net.precision = precision
-        cf = quantile("tokamak", sampled_pred(calib, cal_B), truth, [0.0, 1.0, 0.01, 4.98, 0.0], 0.9, target=tgt_cal)
+        cf = quantile("tokamak", sampled_pred(calib, cal_B, truth), truth, [0.0, 1.0, 0.01, 4.98, 0.0], 0.9, target=tgt_cal)
         desc = f"C3: tokamak Unet1D dim={dim} (1,2,4,8) state (B,12,128), guided 1000-step DDPM"
     elif name == "c4":
         dim = dim or 64
@@ -186,7 +188,7 @@ def workload(name, dim, B, dev, rank, world, precision=4, cal_steps=5):
         cal_B, cal_batches = 25, 8
         net.precision = precision
         truth = (0.3 * torch.randn(n_cal, 32, 7, 64, 64, generator=g1)).to(dev)
-        cf = quantile("smoke", sampled_pred(calib, cal_B), truth, [0.9, 0.1, 0.0, 100.0], 0.04, smoke=True)
+        cf = quantile("smoke", sampled_pred(calib, cal_B, truth), truth, [0.9, 0.1, 0.0, 100.0], 0.04, smoke=True)
         del truth
         guid.Q = cf["Q"]
         desc = (f"{cfgN['tag']}: 2D smoke Unet3D_with_Conv3D dim={dim} (1,2,4) state (B,32,7,64,64), B={B} per GPU, guided 1000-step DDPM, "
