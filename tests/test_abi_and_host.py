@@ -82,3 +82,33 @@ def test_guidance_specs_match_reference_functions(golden):
     g = golden("smoke_guidance")
     s = SmokeGuidance(g.scalar("Q"), g.scalar("w_safe"), g.scalar("safe_bound"))
     torch.testing.assert_close(s(g["x"]), g["grad"], rtol=1e-6, atol=1e-9)
+
+
+def test_pack_batch_plan_is_host_only_and_consistent():
+    """sdc_pack_batch_plan (no GPU call): sections as sdc_pack_conv_weight_floats reports them, a block prefix without gaps, the
+    largest LDS tile, and the argument errors of the single-weight entry point"""
+    import ctypes as C
+    from safediffcon_amd._lib import SdcPackItem
+    lib = _lib.get_lib()
+    shapes = [(64, 7, 1, 1, 3, 2, 0), (64, 7, 1, 1, 3, 5, 1), (24, 40, 1, 3, 3, 3, 0), (16, 24, 3, 3, 3, 4, 1), (130, 66, 1, 1, 1, 0, 0),
+              (8, 12, 1, 7, 7, 0, 0), (2048, 2048, 1, 1, 3, 2, 1)]
+    items = (SdcPackItem * len(shapes))()
+    for it, (co, ci, kd, kh, kw, prec, flip) in zip(items, shapes):
+        it.w, it.out = 0x1000, 0x2000                      # never dereferenced by the plan
+        it.Cout, it.Cin, it.kD, it.kH, it.kW, it.precision, it.flip = co, ci, kd, kh, kw, prec, flip
+    nb, lds = C.c_int(0), C.c_int(0)
+    assert lib.sdc_pack_batch_plan(items, len(shapes), C.byref(nb), C.byref(lds)) == 0
+    blocks = 0
+    for it, (co, ci, kd, kh, kw, prec, _) in zip(items, shapes):
+        assert sum(it.n) == lib.sdc_pack_conv_weight_floats(co, ci, kd, kh, kw, prec)
+        assert it.n[0] == co * ci * kd * kh * kw
+        assert it.block0 == blocks and it.grid_x == -(-co // (1 << it.co_sh)) and it.grid_y == -(-ci // (1 << it.ci_sh))
+        taps = kd * kh * kw
+        assert ((taps << it.ci_sh) + 1 << it.co_sh) * 4 <= lds.value <= 64 * 1024
+        assert all((c * it.tap_magic) >> 24 == c // taps for c in range(0, taps << it.co_sh, 7))
+        blocks += it.grid_x * it.grid_y
+    assert nb.value == blocks
+    items[2].precision = 1
+    assert lib.sdc_pack_batch_plan(items, len(shapes), C.byref(nb), C.byref(lds)) != 0 and "item 2" in _lib.last_error()
+    assert lib.sdc_pack_batch_plan(items, 0, C.byref(nb), C.byref(lds)) != 0
+    assert lib.sdc_pack_batch_run(None, 1, 1, 1024, None) != 0
