@@ -24,9 +24,29 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, const float* in, in
         for (int r = 0; r < 16; ++r) s += acc[i][r];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// the same FLOPs through v_mfma_f32_16x16x4_f32 (8 passes, 2048 FLOP per instruction): is the sustained rate a property of the shape?
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mfma_loop16(float* out, const float* in, int iters) {
+    f32x4 acc[16];
+    for (int i = 0; i < 16; ++i)
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    float a[8], b[8];
+    for (int i = 0; i < 8; ++i) { a[i] = in[(threadIdx.x * 16 + i) & 4095]; b[i] = in[(threadIdx.x * 16 + 8 + i) & 4095]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[(k + i) & 7], b[(k + 2 * i) & 7], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i)
+        for (int r = 0; r < 4; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
 int main(int argc, char** argv) {
     const double seconds = argc > 1 ? atof(argv[1]) : 4.0;
     const int mode = argc > 2 ? atoi(argv[2]) : 1;
+    const int shape = argc > 3 ? atoi(argv[3]) : 0;          // 0: 32x32x2, 1: 16x16x4 (same FLOPs per launch)
     const int blocks = 1024, iters = 4000;             // ~17 ms per launch at 125 TFLOP/s
     float *out, *in;
     (void)hipMalloc(&out, blocks * 256 * 4);
@@ -38,10 +58,13 @@ int main(int argc, char** argv) {
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const double flops_per_launch = (double)blocks * 4.0 * iters * 8 * 4 * 4096.0;
     const auto t_begin = std::chrono::steady_clock::now();
-    printf("mode %s operands\n", mode ? "random" : "constant");
+    printf("mode %s operands, %s\n", mode ? "random" : "constant", shape ? "v_mfma_f32_16x16x4_f32" : "v_mfma_f32_32x32x2_f32");
     for (;;) {
         (void)hipEventRecord(e0, 0);
-        for (int r = 0; r < 15; ++r) hipLaunchKernelGGL(mfma_loop, dim3(blocks), dim3(256), 0, 0, out, in, iters);
+        for (int r = 0; r < 15; ++r) {
+            if (shape == 0) hipLaunchKernelGGL(mfma_loop, dim3(blocks), dim3(256), 0, 0, out, in, iters);
+            else hipLaunchKernelGGL(mfma_loop16, dim3(blocks), dim3(256), 0, 0, out, in, iters);       // 64 x 2048 = 32 x 4096 FLOP per iteration
+        }
         (void)hipEventRecord(e1, 0);
         (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
