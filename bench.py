@@ -811,10 +811,28 @@ def worker(a):
             S3.final()
             torch.cuda.synchronize()
             full_s = time.perf_counter() - t0
+            sampled = S3.x.clone()
             S3.close()
             extra["full_sample"] = {"seconds_for_one_1000_step_sample": round(full_s, 3),
                                     "trajectories_per_s": round(B / full_s, 4),
                                     "note": "includes x_T draw, conditioning, graph capture and the final eager step"}
+            if wl == "c4":
+                # the pipeline's next call on exactly these trajectories (2d/inference_2d.py:389-456): the score check
+                import numpy as np
+                from safediffcon_amd import smoke_solver as ss
+                data = torch.zeros_like(sampled)
+                data[:, 0, 0] = sampled[:, 0, 0]              # the simulator starts from the imposed frame-0 density
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = ss.multi_evaluate(sampled, data, float(W["conformal"]["Q"]), 0.1)
+                torch.cuda.synchronize()
+                ev_s = time.perf_counter() - t0
+                J, safe = res[0], res[1]
+                extra["full_sample"]["score_check_of_the_sampled_batch"] = {
+                    "seconds": round(ev_s, 3), "finite_objective": int(np.isfinite(J).sum()), "batch": int(B),
+                    "mean_J_target": float(np.nanmean(J)), "mean_safe_target": float(np.nanmean(safe)),
+                    "sample_plus_score_check_trajectories_per_s": round(B / (full_s + ev_s), 4),
+                    "note": "random-init weights: the sampled controls are noise-like, the numbers only show the chain runs end to end"}
         if a.full_calibration and rank == 0:
             # one complete calibration pass end to end: cal_batches x (1000-step calibration-mode sample) -> scores -> quantile
             from safediffcon_amd import conformal
