@@ -452,6 +452,10 @@ __global__ __launch_bounds__(NT) void attn256_kernel(const AttnArgs a) {
     float* ob = a.out + o * a.oso + i * a.osi + (int64_t)(head * DH) * a.osc;
     for (int u = 0; u < 2; ++u) {
         const int q0 = (wave + 4 * u) * 32;
+        // (the K / V fragment reads below do not depend on u: left to itself the compiler hoists all 256 of them out of this
+        // loop and keeps them in scratch -- 80 spilled registers; an offset it cannot see through keeps them where they are used)
+        int koff = lh * 256 + l31, voff = l31 * A2_VP + 4 * lh;
+        asm volatile("" : "+v"(koff), "+v"(voff));
         // B fragments of Q^T: B[d = 2s + lh][query = l31]
         float qf[16];
 #pragma unroll
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(NT) void attn256_kernel(const AttnArgs a) {
             for (int r = 0; r < 16; ++r) sc[kbk][r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 16; ++s)           // A[key = l31][d = 2s + lh]
-                sc[kbk] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(2 * s + lh) * 256 + kbk * 32 + l31], qf[s], sc[kbk], 0, 0, 0);
+                sc[kbk] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[koff + (2 * s) * 256 + kbk * 32], qf[s], sc[kbk], 0, 0, 0);
         }
         // lane (query = l31, half lh) holds keys kbk*32 + (r&3) + 8*(r>>2) + 4*lh
         float mx = -INFINITY;
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(NT) void attn256_kernel(const AttnArgs a) {
         for (int kbk = 0; kbk < 8; ++kbk)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[l31 * A2_VP + kbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh], sc[kbk][r], oacc, 0, 0, 0);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[voff + kbk * 32 + (r & 3) + 8 * (r >> 2)], sc[kbk][r], oacc, 0, 0, 0);
         // lane (query = l31, half lh) holds d = (r&3) + 8*(r>>2) + 4*lh: 128-byte runs along the tokens
 #pragma unroll
         for (int r = 0; r < 16; ++r) ob[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.osc + q0 + l31] = oacc[r] * inv;
