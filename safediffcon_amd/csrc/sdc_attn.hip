@@ -278,140 +278,173 @@ constexpr int TA_NS = 8;                 // sequences (adjacent pixels) per work
 constexpr int TA_SQ = 32 * 32 + 8;       // LDS floats per pixel, [d][f] image (+8: bank spread of the transposing store)
 constexpr int TA_SV = 32 * 33 + 8;       // LDS floats per pixel, [f][d] image with a 33-float frame pitch
 
-__global__ __launch_bounds__(NT) void tattn_kernel(const AttnArgs a) {
+// wave-uniform base (SGPR pair) + one 32-bit per-lane byte offset for all 32 channel rows of a thread's element
+typedef __attribute__((address_space(1))) float* ta_gptr;
+typedef __attribute__((address_space(1))) char* ta_gcptr;
+__device__ __forceinline__ ta_gptr ta_uni(const float* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return (ta_gptr)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float ta_ld(ta_gptr base, uint32_t byte_off) { return *(ta_gptr)((ta_gcptr)base + byte_off); }
+__device__ __forceinline__ void ta_st(ta_gptr base, uint32_t byte_off, float v) { *(ta_gptr)((ta_gcptr)base + byte_off) = v; }
+
+__global__ __launch_bounds__(NT, 2) void tattn_kernel(const AttnArgs a, const int tiles_per_wg) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     __shared__ float Ks[TA_NS * TA_SQ];
     __shared__ float QVs[TA_NS * TA_SV];         // Q ([d][f], TA_SQ pitch) first, then V / O ([f][d], TA_SV pitch)
     __shared__ float biasT[32][33];              // [key][query] of this head
-    __shared__ float rotc[32][16], rots[32][16];
+    __shared__ float rotc[16][33], rots[16][33];   // [m][frame]: a wave reads one m, 32 frames
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    // XCD-aware numbering: consecutive logical ids stay on one XCD
-    const int nblk = gridDim.x;
-    int bid = blockIdx.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-    const int head = bid % a.heads;
-    const int grp = bid / a.heads;
-    const int seq0 = grp * TA_NS;
-    const int o = seq0 / a.inner, i0 = seq0 - o * a.inner;
-    const float* qb = a.qkv + o * a.so + i0 + (int64_t)(head * DH) * a.sc;
-    const float* kb = qb + (int64_t)(a.heads * DH) * a.sc;
-    const float* vb = kb + (int64_t)(a.heads * DH) * a.sc;
+    // A workgroup walks tiles_per_wg tiles, gridDim.x apart (the host picks gridDim.x as a multiple of 8 heads, so all of them
+    // belong to one head: bias / rotary tables are staged once) and requests tile t+1's Q and K while tile t is on the matrix
+    // cores -- two workgroups per CU (LDS) did not cover each other's load phases: 2.9 TB/s.
+    // XCD-aware numbering of the virtual tile id: consecutive logical ids stay on one XCD.
+    const int nblk = gridDim.x * tiles_per_wg;
+    // (a workgroup's tiles are gridDim.x apart on purpose: the four pixel groups that share a 128-byte line must be in flight on
+    // one XCD at the same time -- walking them one after the other in one workgroup fetched every line four times: 2.6 -> 4.3 ms)
+    auto tile_of = [&](int t) { const int v = blockIdx.x + t * gridDim.x; return ((nblk & 7) == 0) ? (v & 7) * (nblk >> 3) + (v >> 3) : v; };
+    const int head = tile_of(0) % a.heads;
     const float scale = 0.17677669529663687f;
-
-    // ---- stage Q (scaled) and K: element e = tid + 256*it -> (d = e>>8, f = (e>>3)&31, hw = e&7)
-    float vreg[32];
+    // element e = tid + 256*it of a tile -> (d = e>>8 = it, f = (e>>3)&31, hw = e&7): channel row it from a scalar base, the
+    // thread's (frame, pixel) as ONE byte offset (host check: a frame stride x 32 frames stays below 2^32 bytes)
+    float kreg[32], qreg[32], vreg[32];
+    const uint32_t toff = (uint32_t)(((int64_t)((tid >> 3) & 31) * a.st + (tid & 7)) * 4);
+    const uint32_t toffo = (uint32_t)(((int64_t)((tid >> 3) & 31) * a.ost + (tid & 7)) * 4);
+    auto tile_base = [&](int bid, const float*& qb, float*& ob) {
+        const int seq0 = (bid / a.heads) * TA_NS;
+        const int o = seq0 / a.inner, i0 = seq0 - o * a.inner;
+        qb = a.qkv + o * a.so + i0 + (int64_t)(head * DH) * a.sc;
+        ob = a.out + o * a.oso + i0 + (int64_t)(head * DH) * a.osc;
+    };
+    auto load_qk = [&](const float* qb) {
+        const float* kb = qb + (int64_t)(a.heads * DH) * a.sc;
 #pragma unroll
-    for (int it = 0; it < 32; ++it) {
-        const int e = tid + it * NT;
-        const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
-        const int64_t g = (int64_t)d * a.sc + (int64_t)f * a.st + hw;
-        Ks[hw * TA_SQ + d * 32 + f] = kb[g];
-        QVs[hw * TA_SQ + d * 32 + f] = qb[g] * scale;
-    }
-    // V is only needed after the softmax: issue its loads now, park them in registers
-#pragma unroll
-    for (int it = 0; it < 32; ++it) {
-        const int e = tid + it * NT;
-        const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
-        vreg[it] = vb[(int64_t)d * a.sc + (int64_t)f * a.st + hw];
-    }
+        for (int it = 0; it < 32; ++it) {
+            kreg[it] = ta_ld(ta_uni(kb + (int64_t)it * a.sc), toff);
+            qreg[it] = ta_ld(ta_uni(qb + (int64_t)it * a.sc), toff);
+        }
+    };
     for (int e = tid; e < 32 * 32; e += NT) {
         const int q = e >> 5, kk = e & 31;
         biasT[kk][q] = a.bias ? a.bias[((int64_t)head * 32 + q) * 32 + kk] : 0.0f;
     }
     if (a.rot)
         for (int e = tid; e < 32 * 16; e += NT) {
-            rotc[e >> 4][e & 15] = a.rot[e * 2];
-            rots[e >> 4][e & 15] = a.rot[e * 2 + 1];
+            rotc[e & 15][e >> 4] = a.rot[e * 2];
+            rots[e & 15][e >> 4] = a.rot[e * 2 + 1];
         }
-    __syncthreads();
-    if (a.rot) {
-        // rotate (d = 2m, 2m+1) pairs of Q and K in place; angle = frame * freq[m]
-        for (int e = tid; e < TA_NS * 16 * 32; e += NT) {
-            const int f = e & 31, m = (e >> 5) & 15, hw = e >> 9;
-            const float c = rotc[f][m], sn = rots[f][m];
-            const int l0 = hw * TA_SQ + (2 * m) * 32 + f, l1 = l0 + 32;
-            float x0 = Ks[l0], x1 = Ks[l1];
-            Ks[l0] = x0 * c - x1 * sn; Ks[l1] = x1 * c + x0 * sn;
-            x0 = QVs[l0]; x1 = QVs[l1];
-            QVs[l0] = x0 * c - x1 * sn; QVs[l1] = x1 * c + x0 * sn;
+    const float* qb; float* ob;
+    tile_base(tile_of(0), qb, ob);
+    load_qk(qb);
+    for (int t = 0; t < tiles_per_wg; ++t) {
+        // ---- stage Q (scaled) and K of this tile from the registers; V is only needed after the softmax: issue its loads now
+#pragma unroll
+        for (int it = 0; it < 32; ++it) {
+            const int e = tid + it * NT;
+            const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
+            Ks[hw * TA_SQ + d * 32 + f] = kreg[it];
+            QVs[hw * TA_SQ + d * 32 + f] = qreg[it] * scale;
+        }
+        {
+            const float* vb = qb + (int64_t)(2 * a.heads * DH) * a.sc;
+#pragma unroll
+            for (int it = 0; it < 32; ++it) vreg[it] = ta_ld(ta_uni(vb + (int64_t)it * a.sc), toff);
+        }
+        float* const ob_cur = ob;
+        if (t + 1 < tiles_per_wg) {                      // the next tile's Q and K travel under this tile's products
+            tile_base(tile_of(t + 1), qb, ob);
+            load_qk(qb);
         }
         __syncthreads();
-    }
+        if (a.rot) {
+            // rotate (d = 2m, 2m+1) pairs of Q and K in place; angle = frame * freq[m]
+            for (int e = tid; e < TA_NS * 16 * 32; e += NT) {
+                const int f = e & 31, m = (e >> 5) & 15, hw = e >> 9;
+                const float c = rotc[m][f], sn = rots[m][f];
+                const int l0 = hw * TA_SQ + (2 * m) * 32 + f, l1 = l0 + 32;
+                float x0 = Ks[l0], x1 = Ks[l1];
+                Ks[l0] = x0 * c - x1 * sn; Ks[l1] = x1 * c + x0 * sn;
+                x0 = QVs[l0]; x1 = QVs[l1];
+                QVs[l0] = x0 * c - x1 * sn; QVs[l1] = x1 * c + x0 * sn;
+            }
+            __syncthreads();
+        }
 
-    // ---- S^T = K . Q^T, softmax over keys; wave w owns pixels 2w and 2w+1
-    f32x16 p[2];
+        // ---- S^T = K . Q^T, softmax over keys; wave w owns pixels 2w and 2w+1
+        f32x16 p[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int hw = wave * 2 + u;
-        f32x16 acc;
+        for (int u = 0; u < 2; ++u) {
+            const int hw = wave * 2 + u;
+            f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float af = Ks[hw * TA_SQ + (2 * s + lh) * 32 + l31];      // A[key][d]
-            const float bf = QVs[hw * TA_SQ + (2 * s + lh) * 32 + l31];     // B[d][query]
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+            for (int s = 0; s < 16; ++s) {
+                const float af = Ks[hw * TA_SQ + (2 * s + lh) * 32 + l31];      // A[key][d]
+                const float bf = QVs[hw * TA_SQ + (2 * s + lh) * 32 + l31];     // B[d][query]
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+            }
+            // lane (query = l31, half lh) holds keys (r&3) + 8*(r>>2) + 4*lh
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[r] += biasT[(r & 3) + 8 * (r >> 2) + 4 * lh][l31];
+                mx = fmaxf(mx, acc[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[r] = expf(acc[r] - mx); sum += acc[r]; }
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= inv;
+            p[u] = acc;
         }
-        // lane (query = l31, half lh) holds keys (r&3) + 8*(r>>2) + 4*lh
-        float mx = -INFINITY;
+        __syncthreads();                              // every wave is done with the Q tile
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            acc[r] += biasT[(r & 3) + 8 * (r >> 2) + 4 * lh][l31];
-            mx = fmaxf(mx, acc[r]);
+        for (int it = 0; it < 32; ++it) {
+            const int e = tid + it * NT;
+            const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
+            QVs[hw * TA_SV + f * 33 + d] = vreg[it];
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[r] = expf(acc[r] - mx); sum += acc[r]; }
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] *= inv;
-        p[u] = acc;
-    }
-    __syncthreads();                              // every wave is done with the Q tile
-#pragma unroll
-    for (int it = 0; it < 32; ++it) {
-        const int e = tid + it * NT;
-        const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
-        QVs[hw * TA_SV + f * 33 + d] = vreg[it];
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- O = P^T . V : k-step r pairs key (r&3)+8*(r>>2) [half 0] with that key + 4 [half 1] -- exactly register r
-    f32x16 oacc[2];
+        // ---- O = P^T . V : k-step r pairs key (r&3)+8*(r>>2) [half 0] with that key + 4 [half 1] -- exactly register r
+        f32x16 oacc[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int hw = wave * 2 + u;
-        f32x16 acc;
+        for (int u = 0; u < 2; ++u) {
+            const int hw = wave * 2 + u;
+            f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float bf = QVs[hw * TA_SV + key * 33 + l31];              // B[key][d]
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p[u][r], bf, acc, 0, 0, 0);   // A[query][key] = P^T
+            for (int r = 0; r < 16; ++r) {
+                const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float bf = QVs[hw * TA_SV + key * 33 + l31];              // B[key][d]
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p[u][r], bf, acc, 0, 0, 0);   // A[query][key] = P^T
+            }
+            oacc[u] = acc;
         }
-        oacc[u] = acc;
-    }
-    __syncthreads();                              // V no longer needed: reuse its tile for the output image
+        __syncthreads();                              // V no longer needed: reuse its tile for the output image
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int hw = wave * 2 + u;
-        // lane (d = l31, half lh) holds queries (r&3) + 8*(r>>2) + 4*lh
+        for (int u = 0; u < 2; ++u) {
+            const int hw = wave * 2 + u;
+            // lane (d = l31, half lh) holds queries (r&3) + 8*(r>>2) + 4*lh
 #pragma unroll
-        for (int r = 0; r < 16; ++r) QVs[hw * TA_SV + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + l31] = oacc[u][r];
-    }
-    __syncthreads();
-    float* ob = a.out + o * a.oso + i0 + (int64_t)(head * DH) * a.osc;
+            for (int r = 0; r < 16; ++r) QVs[hw * TA_SV + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + l31] = oacc[u][r];
+        }
+        __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 32; ++it) {
-        const int e = tid + it * NT;
-        const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
-        ob[(int64_t)d * a.osc + (int64_t)f * a.ost + hw] = QVs[hw * TA_SV + f * 33 + d];
+        for (int it = 0; it < 32; ++it) {
+            const int e = tid + it * NT;
+            const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
+            ta_st(ta_uni(ob_cur + (int64_t)d * a.osc), toffo, QVs[hw * TA_SV + f * 33 + d]);
+        }
+        __syncthreads();                              // the next tile's staging writes Ks / QVs
     }
 }
 
@@ -527,9 +560,14 @@ extern "C" int sdc_attn(const float* qkv, float* out, const float* rot, const fl
     a.so = q_so; a.sc = q_sc; a.si = q_si; a.st = q_st;
     a.oso = o_so; a.osc = o_sc; a.osi = o_si; a.ost = o_st;
     a.tok_contig = (q_st == 1);
-    if (!a.tok_contig && ntok == 32 && inner % TA_NS == 0 && q_si == 1 && o_si == 1) {
+    if (!a.tok_contig && ntok == 32 && inner % TA_NS == 0 && q_si == 1 && o_si == 1 && q_st > 0 && o_st > 0 && q_st < (1ll << 24) && o_st < (1ll << 24)) {     // (frame stride x 32 frames x 4 bytes < 2^32: 32-bit lane offsets)
         const int nblk = (outer * inner / TA_NS) * heads;
-        hipLaunchKernelGGL(tattn_kernel, dim3((unsigned)nblk), dim3(NT), 0, sdc::as_stream(stream), a);
+        // tiles per workgroup: the largest of 4 / 2 / 1 that leaves a grid of a multiple of 8 heads (one head per workgroup under
+        // the XCD numbering) and still >= 4 workgroups per CU
+        int tpw = 1;
+        for (int t = 4; t > 1; t >>= 1)
+            if (nblk % (t * 8 * heads) == 0 && nblk / t >= 1024) { tpw = t; break; }
+        hipLaunchKernelGGL(tattn_kernel, dim3((unsigned)(nblk / tpw)), dim3(NT), 0, sdc::as_stream(stream), a, tpw);
         return sdc::check_launch("sdc_attn[mfma]");
     }
     if (a.tok_contig && ntok == 256 && !rot && !bias && o_st == 1 && q_sc % 4 == 0 && q_so % 4 == 0 && q_si % 4 == 0 &&
