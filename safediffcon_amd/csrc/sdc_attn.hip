@@ -274,9 +274,7 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs a) {
 // Q.K^T runs, written over the Q tile afterwards); rotary + rel-pos bias + softmax run on the accumulators; the
 // output goes back through LDS so that global stores are 32-byte runs again.  Workgroups are numbered so that the
 // 4 pixel groups sharing a 128-byte line land on the same XCD (speed only).
-constexpr int TA_NS = 8;                 // sequences (adjacent pixels) per workgroup
-constexpr int TA_SQ = 32 * 32 + 8;       // LDS floats per pixel, [d][f] image (+8: bank spread of the transposing store)
-constexpr int TA_SV = 32 * 33 + 8;       // LDS floats per pixel, [f][d] image with a 33-float frame pitch
+constexpr int TA_NS = 8;                 // sequences (adjacent pixels) per workgroup, at least (16 where the image allows)
 
 // wave-uniform base (SGPR pair) + one 32-bit per-lane byte offset for all 32 channel rows of a thread's element
 typedef __attribute__((address_space(1))) float* ta_gptr;
@@ -289,12 +287,20 @@ __device__ __forceinline__ ta_gptr ta_uni(const float* p) {
 __device__ __forceinline__ float ta_ld(ta_gptr base, uint32_t byte_off) { return *(ta_gptr)((ta_gcptr)base + byte_off); }
 __device__ __forceinline__ void ta_st(ta_gptr base, uint32_t byte_off, float v) { *(ta_gptr)((ta_gcptr)base + byte_off) = v; }
 
-__global__ __launch_bounds__(NT, 2) void tattn_kernel(const AttnArgs a, const int tiles_per_wg) {
+// NS = 8 pixels per workgroup (4 waves, 32-byte runs, two workgroups per CU) or 16 (8 waves, 64-byte runs = one whole HBM
+// burst per row, one workgroup per CU): the same LDS bytes and waves per CU, half the partly used bursts.
+template <int NS>
+__global__ __launch_bounds__(NS * 32, NS == 8 ? 2 : 1) void tattn_kernel(const AttnArgs a, const int tiles_per_wg) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
-    __shared__ float Ks[TA_NS * TA_SQ];
-    __shared__ float QVs[TA_NS * TA_SV];         // Q ([d][f], TA_SQ pitch) first, then V / O ([f][d], TA_SV pitch)
-    __shared__ float biasT[32][33];              // [key][query] of this head
-    __shared__ float rotc[16][33], rots[16][33];   // [m][frame]: a wave reads one m, 32 frames
+    constexpr int NT = NS * 32;                                       // (shadows the file's 256)
+    constexpr int TA_SQ = NS == 8 ? 32 * 32 + 8 : 32 * 32 + 2;        // pixel pitch of the [d][f] image: 8 hw + f (NS = 8) / 2 hw + f (16) spreads a store over the banks
+    constexpr int TA_SV = NS == 8 ? 32 * 33 + 8 : 32 * 33 + 2;        // pixel pitch of the [f][d] image (33-float frame pitch)
+    extern __shared__ float ta_lds[];
+    float* const Ks = ta_lds;                                         // [NS][TA_SQ]
+    float* const QVs = Ks + NS * TA_SQ;                               // Q ([d][f], TA_SQ pitch) first, then V / O ([f][d], TA_SV pitch)
+    float (*const biasT)[33] = reinterpret_cast<float (*)[33]>(QVs + NS * TA_SV);       // [key][query] of this head
+    float (*const rotc)[33] = biasT + 32;                             // [m][frame]: a wave reads one m, 32 frames
+    float (*const rots)[33] = rotc + 16;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -308,23 +314,28 @@ __global__ __launch_bounds__(NT, 2) void tattn_kernel(const AttnArgs a, const in
     auto tile_of = [&](int t) { const int v = blockIdx.x + t * gridDim.x; return ((nblk & 7) == 0) ? (v & 7) * (nblk >> 3) + (v >> 3) : v; };
     const int head = tile_of(0) % a.heads;
     const float scale = 0.17677669529663687f;
-    // element e = tid + 256*it of a tile -> (d = e>>8 = it, f = (e>>3)&31, hw = e&7): channel row it from a scalar base, the
+    // element e = tid + NT*it of a tile -> (d = it, f = (e / NS) & 31, hw = e % NS): channel row it from a scalar base, the
     // thread's (frame, pixel) as ONE byte offset (host check: a frame stride x 32 frames stays below 2^32 bytes)
     float kreg[32], qreg[32], vreg[32];
-    const uint32_t toff = (uint32_t)(((int64_t)((tid >> 3) & 31) * a.st + (tid & 7)) * 4);
-    const uint32_t toffo = (uint32_t)(((int64_t)((tid >> 3) & 31) * a.ost + (tid & 7)) * 4);
+    const uint32_t toff = (uint32_t)(((int64_t)((tid / NS) & 31) * a.st + (tid % NS)) * 4);
+    const uint32_t toffo = (uint32_t)(((int64_t)((tid / NS) & 31) * a.ost + (tid % NS)) * 4);
     auto tile_base = [&](int bid, const float*& qb, float*& ob) {
-        const int seq0 = (bid / a.heads) * TA_NS;
+        const int seq0 = (bid / a.heads) * NS;
         const int o = seq0 / a.inner, i0 = seq0 - o * a.inner;
         qb = a.qkv + o * a.so + i0 + (int64_t)(head * DH) * a.sc;
         ob = a.out + o * a.oso + i0 + (int64_t)(head * DH) * a.osc;
     };
     auto load_qk = [&](const float* qb) {
         const float* kb = qb + (int64_t)(a.heads * DH) * a.sc;
+        // (running scalar bases: 64 base pairs computed up front do not fit the SGPR file and were spilled into VGPR lanes)
+        ta_gptr kp = ta_uni(kb), qp = ta_uni(qb);
+        const int64_t step = a.sc;
 #pragma unroll
         for (int it = 0; it < 32; ++it) {
-            kreg[it] = ta_ld(ta_uni(kb + (int64_t)it * a.sc), toff);
-            qreg[it] = ta_ld(ta_uni(qb + (int64_t)it * a.sc), toff);
+            kreg[it] = ta_ld(kp, toff);
+            qreg[it] = ta_ld(qp, toff);
+            kp += step; qp += step;
+            asm volatile("" : "+s"(kp), "+s"(qp));
         }
     };
     for (int e = tid; e < 32 * 32; e += NT) {
@@ -344,14 +355,20 @@ __global__ __launch_bounds__(NT, 2) void tattn_kernel(const AttnArgs a, const in
 #pragma unroll
         for (int it = 0; it < 32; ++it) {
             const int e = tid + it * NT;
-            const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
+            const int hw = e % NS, f = (e / NS) & 31, d = e / (NS * 32);
             Ks[hw * TA_SQ + d * 32 + f] = kreg[it];
             QVs[hw * TA_SQ + d * 32 + f] = qreg[it] * scale;
         }
         {
             const float* vb = qb + (int64_t)(2 * a.heads * DH) * a.sc;
+            ta_gptr vp = ta_uni(vb);
+            const int64_t step = a.sc;
 #pragma unroll
-            for (int it = 0; it < 32; ++it) vreg[it] = ta_ld(ta_uni(vb + (int64_t)it * a.sc), toff);
+            for (int it = 0; it < 32; ++it) {
+                vreg[it] = ta_ld(vp, toff);
+                vp += step;
+                asm volatile("" : "+s"(vp));
+            }
         }
         float* const ob_cur = ob;
         if (t + 1 < tiles_per_wg) {                      // the next tile's Q and K travel under this tile's products
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(NT, 2) void tattn_kernel(const AttnArgs a, const in
         __syncthreads();
         if (a.rot) {
             // rotate (d = 2m, 2m+1) pairs of Q and K in place; angle = frame * freq[m]
-            for (int e = tid; e < TA_NS * 16 * 32; e += NT) {
+            for (int e = tid; e < NS * 16 * 32; e += NT) {
                 const int f = e & 31, m = (e >> 5) & 15, hw = e >> 9;
                 const float c = rotc[m][f], sn = rots[m][f];
                 const int l0 = hw * TA_SQ + (2 * m) * 32 + f, l1 = l0 + 32;
@@ -408,7 +425,7 @@ __global__ __launch_bounds__(NT, 2) void tattn_kernel(const AttnArgs a, const in
 #pragma unroll
         for (int it = 0; it < 32; ++it) {
             const int e = tid + it * NT;
-            const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
+            const int hw = e % NS, f = (e / NS) & 31, d = e / (NS * 32);
             QVs[hw * TA_SV + f * 33 + d] = vreg[it];
         }
         __syncthreads();
@@ -438,11 +455,14 @@ __global__ __launch_bounds__(NT, 2) void tattn_kernel(const AttnArgs a, const in
             for (int r = 0; r < 16; ++r) QVs[hw * TA_SV + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + l31] = oacc[u][r];
         }
         __syncthreads();
+        ta_gptr op = ta_uni(ob_cur);
 #pragma unroll
         for (int it = 0; it < 32; ++it) {
             const int e = tid + it * NT;
-            const int hw = e & 7, f = (e >> 3) & 31, d = e >> 8;
-            ta_st(ta_uni(ob_cur + (int64_t)d * a.osc), toffo, QVs[hw * TA_SV + f * 33 + d]);
+            const int hw = e % NS, f = (e / NS) & 31, d = e / (NS * 32);
+            ta_st(op, toffo, QVs[hw * TA_SV + f * 33 + d]);
+            op += a.osc;
+            asm volatile("" : "+s"(op));
         }
         __syncthreads();                              // the next tile's staging writes Ks / QVs
     }
@@ -561,13 +581,23 @@ extern "C" int sdc_attn(const float* qkv, float* out, const float* rot, const fl
     a.oso = o_so; a.osc = o_sc; a.osi = o_si; a.ost = o_st;
     a.tok_contig = (q_st == 1);
     if (!a.tok_contig && ntok == 32 && inner % TA_NS == 0 && q_si == 1 && o_si == 1 && q_st > 0 && o_st > 0 && q_st < (1ll << 24) && o_st < (1ll << 24)) {     // (frame stride x 32 frames x 4 bytes < 2^32: 32-bit lane offsets)
-        const int nblk = (outer * inner / TA_NS) * heads;
+        const int ns = inner % 16 == 0 ? 16 : 8;
+        const int nblk = (outer * inner / ns) * heads;
         // tiles per workgroup: the largest of 4 / 2 / 1 that leaves a grid of a multiple of 8 heads (one head per workgroup under
         // the XCD numbering) and still >= 4 workgroups per CU
         int tpw = 1;
         for (int t = 4; t > 1; t >>= 1)
             if (nblk % (t * 8 * heads) == 0 && nblk / t >= 1024) { tpw = t; break; }
-        hipLaunchKernelGGL(tattn_kernel, dim3((unsigned)(nblk / tpw)), dim3(NT), 0, sdc::as_stream(stream), a, tpw);
+        const size_t ldsb = sizeof(float) * (size_t)(ns * ((ns == 8 ? 1032 : 1026) + (ns == 8 ? 1064 : 1058)) + 64 * 33);
+        if (ns == 16) {
+            static std::atomic<uint64_t> attr_t{0};
+            SDC_LDS_OPTIN(attr_t, tattn_kernel<16>, 160 * 1024, "sdc_attn[mfma]");
+            hipLaunchKernelGGL(tattn_kernel<16>, dim3((unsigned)(nblk / tpw)), dim3(512), ldsb, sdc::as_stream(stream), a, tpw);
+        } else {
+            static std::atomic<uint64_t> attr_t8{0};
+            SDC_LDS_OPTIN(attr_t8, tattn_kernel<8>, 160 * 1024, "sdc_attn[mfma]");
+            hipLaunchKernelGGL(tattn_kernel<8>, dim3((unsigned)(nblk / tpw)), dim3(256), ldsb, sdc::as_stream(stream), a, tpw);
+        }
         return sdc::check_launch("sdc_attn[mfma]");
     }
     if (a.tok_contig && ntok == 256 && !rot && !bias && o_st == 1 && q_sc % 4 == 0 && q_so % 4 == 0 && q_si % 4 == 0 &&

@@ -204,7 +204,9 @@ def test_linear_attention_core(plan_cls, B, inner, n):
 
 @pytest.mark.parametrize("contig,B,inner,ntok,rot_bias", [
     (True, 3, 1, 32, False), (True, 2, 1, 16, False), (True, 2, 4, 256, False), (True, 5, 3, 20, False),
-    (False, 2, 64, 32, True), (False, 1, 12, 8, True), (False, 2, 7, 32, True)])
+    (False, 2, 64, 32, True), (False, 1, 12, 8, True), (False, 2, 7, 32, True),
+    (False, 3, 24, 32, True),          # 8 pixels per workgroup (inner % 16 != 0)
+    (False, 2, 4096, 32, True)])       # 16 pixels per workgroup, two pipelined tiles per workgroup
 def test_softmax_attention_core(plan_cls, contig, B, inner, ntok, rot_bias):
     heads = 4
     if contig:     # (B, 384, inner, ntok): tokens contiguous
