@@ -587,7 +587,9 @@ def build_roofline(S, lib, stream, step_ms, wl):
         elif k.startswith("fused temporal-attention block"):
             st["ta_block_w" + k.split("width ")[1].split(" ")[0]] = mfma_stage(v)
         elif k == "temporal attention core":
-            st["tattn_core"] = mfma_stage(v)
+            # an MFMA kernel whose time is its q / k / v / o traffic (16 FLOP per byte): both fractions, the larger one is the bound
+            m, h = mfma_stage(v), hbm_stage(v)
+            st["tattn_core"] = dict(h if h["frac"] >= m["frac"] else m, mfma_frac=m["frac"], hbm_frac=h["frac"])
         elif k.startswith("fused LinearAttention"):
             st["la_block"] = mfma_stage(v)
     # every temporal-attention launch together (fused blocks + unfused cores): the north star's "MFMA utilisation on temporal attention"
