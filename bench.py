@@ -564,8 +564,9 @@ def build_roofline(S, lib, stream, step_ms, wl):
                       "[F(2x2,3x3)] or 8/27 [F(2x2x2,3x3x3)] of the direct-form multiply-adds); effective_tflops = direct-form "
                       "(algorithmic) FLOPs per second",
                 traffic=traffic, traffic_source=src, algorithmic_bytes_per_launch=alg_bytes,
-                sustained_peak_measured=123.5,   # bare v_mfma_f32_32x32x2 loop held for seconds on an MI355X of this pool, at
-                                                 # 2.38 GHz (tools/mfma_sustain.py, profiles/r4_mfma_sustain_clock_power.log)
+                # bare v_mfma_f32_32x32x2 loop held for seconds on an MI355X of this pool (tools/mfma_sustain.py,
+                # profiles/r4_mfma_sustain_clock_power.log): the pipe holds the datasheet rate with <= 2 waves per SIMD issuing
+                mfma_loop_measured={"one_or_two_waves_per_simd": 154.5, "three_or_more_waves_per_simd": 123.5},
                 launches_per_step=g["launches"], avg_launch_ms=round(g["ms"] / g["launches"], 4),
                 share_of_step=round(g["ms"] / step_ms, 3))
 

@@ -8,6 +8,8 @@
 #include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void mfma_loop(float* out, const float* in, int iters) {
+    extern __shared__ float occupancy_lds[];      // dynamic LDS only limits how many workgroups share a CU (argument 4)
+    if (iters < 0) occupancy_lds[threadIdx.x] = 0.f;
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i)
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
@@ -47,6 +49,8 @@ int main(int argc, char** argv) {
     const double seconds = argc > 1 ? atof(argv[1]) : 4.0;
     const int mode = argc > 2 ? atoi(argv[2]) : 1;
     const int shape = argc > 3 ? atoi(argv[3]) : 0;          // 0: 32x32x2, 1: 16x16x4 (same FLOPs per launch)
+    const int wg_per_cu = argc > 4 ? atoi(argv[4]) : 4;      // workgroups (= waves per SIMD) sharing a CU: 4 (default), 3, 2 or 1, enforced through LDS
+    const size_t lds = wg_per_cu >= 4 ? 0 : (wg_per_cu == 3 ? 50 * 1024 : (wg_per_cu == 2 ? 72 * 1024 : 96 * 1024));
     const int blocks = 1024, iters = 4000;             // ~17 ms per launch at 125 TFLOP/s
     float *out, *in;
     (void)hipMalloc(&out, blocks * 256 * 4);
@@ -58,11 +62,12 @@ int main(int argc, char** argv) {
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const double flops_per_launch = (double)blocks * 4.0 * iters * 8 * 4 * 4096.0;
     const auto t_begin = std::chrono::steady_clock::now();
-    printf("mode %s operands, %s\n", mode ? "random" : "constant", shape ? "v_mfma_f32_16x16x4_f32" : "v_mfma_f32_32x32x2_f32");
+    if (lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_loop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    printf("mode %s operands, %s, %d workgroup(s) of 4 waves per CU\n", mode ? "random" : "constant", shape ? "v_mfma_f32_16x16x4_f32" : "v_mfma_f32_32x32x2_f32", wg_per_cu);
     for (;;) {
         (void)hipEventRecord(e0, 0);
         for (int r = 0; r < 15; ++r) {
-            if (shape == 0) hipLaunchKernelGGL(mfma_loop, dim3(blocks), dim3(256), 0, 0, out, in, iters);
+            if (shape == 0) hipLaunchKernelGGL(mfma_loop, dim3(blocks), dim3(256), lds, 0, out, in, iters);
             else hipLaunchKernelGGL(mfma_loop16, dim3(blocks), dim3(256), 0, 0, out, in, iters);       // 64 x 2048 = 32 x 4096 FLOP per iteration
         }
         (void)hipEventRecord(e1, 0);

@@ -72,7 +72,13 @@ int main(int argc, char** argv) {
     f4 *x, *y;
     float *out, *in;
     CK(hipMalloc(&x, nv * 16)); CK(hipMalloc(&y, nv * 16)); CK(hipMalloc(&out, 4096 * 256 * 4)); CK(hipMalloc(&in, 4096 * 4));
-    CK(hipMemset(x, 0, nv * 16)); CK(hipMemset(in, 0, 4096 * 4));
+    CK(hipMemset(x, 0, nv * 16));
+    {   // random operands: an MFMA loop on zeros draws far less power and is not throttled (155.9 TFLOP/s for seconds)
+        static float h[4096];
+        srand(5);
+        for (int i = 0; i < 4096; ++i) h[i] = (float)rand() / (float)RAND_MAX * 2.f - 1.f;
+        CK(hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice));
+    }
     const int mblocks = 2048, miters = 1000;                // MFMA kernel: 2048 workgroups, ~4 ms on the whole chip
     const size_t mlds = 96 * 1024;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_loop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
@@ -92,9 +98,9 @@ int main(int argc, char** argv) {
         return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
     };
     printf("%d CUs; MFMA share %d CUs, stream share %d CUs\n", ncu, nA, nB);
-    const double tm_all = wall([&] { run_m(sAll); }, 10);
+    const double tm_all = wall([&] { run_m(sAll); }, 200);
     printf("MFMA kernel alone, all CUs            %7.3f ms  %6.1f TFLOP/s\n", tm_all, mflops / tm_all / 1e9);
-    const double tm_a = wall([&] { run_m(sA); }, 10);
+    const double tm_a = wall([&] { run_m(sA); }, 200);
     printf("MFMA kernel alone, its share          %7.3f ms  %6.1f TFLOP/s\n", tm_a, mflops / tm_a / 1e9);
     for (int blocks : {ncu * 8, nB * 8, nB * 16}) {
         const double ts_all = wall([&] { run_s(sAll, blocks); }, 10);
@@ -105,9 +111,9 @@ int main(int argc, char** argv) {
     // one MFMA kernel and K stream kernels: back to back on one stream, on two unmasked streams, on the two CU shares
     for (int K : {4, 8}) {
         const int sb = nB * 16;
-        const double serial = wall([&] { run_m(sAll); for (int k = 0; k < K; ++k) run_s(sAll, ncu * 8); }, 5);
-        const double plain2 = wall([&] { run_m(sAll); for (int k = 0; k < K; ++k) run_s(sAll2, ncu * 8); }, 5);
-        const double masked = wall([&] { run_m(sA); for (int k = 0; k < K; ++k) run_s(sB, sb); }, 5);
+        const double serial = wall([&] { run_m(sAll); for (int k = 0; k < K; ++k) run_s(sAll, ncu * 8); }, 150);      // (~1.5 s each: the sustained regime)
+        const double plain2 = wall([&] { run_m(sAll); for (int k = 0; k < K; ++k) run_s(sAll2, ncu * 8); }, 150);
+        const double masked = wall([&] { run_m(sA); for (int k = 0; k < K; ++k) run_s(sB, sb); }, 150);
         printf("1 MFMA kernel + %d stream kernels: one stream %7.3f ms | two plain streams %7.3f ms | CU-masked shares %7.3f ms\n", K, serial, plain2, masked);
     }
     return 0;
