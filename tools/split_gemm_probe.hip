@@ -261,6 +261,8 @@ int main(int argc, char** argv) {
     };
     printf("C = A B, M %d N %d K %d, tile 128 x 128 x 16, 4 waves\n", M, N, K);
     timeit("fp32 pipe  (v_mfma_f32_32x32x2_f32)", [&] { hipLaunchKernelGGL(gemm_f32, grid, dim3(NT), 0, 0, A, B, C, M, N, K); });
+    // the same kernel with its occupancy cut to two workgroups per CU by an unused dynamic-LDS request (two waves per SIMD: DESIGN 3.5)
+    timeit("fp32 pipe, two workgroups per CU", [&] { hipLaunchKernelGGL(gemm_f32, grid, dim3(NT), 30 * 1024, 0, A, B, C, M, N, K); });
     timeit("bf16 pipe, 6 products per fp32 product", [&] { hipLaunchKernelGGL(gemm_split<6>, grid, dim3(NT), 0, 0, A3, B, C, M, N, K); });
     {   // B^T planes for the pre-split bound
         std::vector<float> hBT((size_t)N * K);
