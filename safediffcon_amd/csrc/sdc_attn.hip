@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs a) {
 #pragma unroll
         for (int d = 0; d < DH; ++d) s += q[d] * Kq[d * a.ld + j * a.lj];
         if (brow) s += brow[j];
-        const float p = expf(s - mx);
+        const float p = sdc::softmax_exp(s - mx);
         l += p;
 #pragma unroll
         for (int d = 0; d < DH; ++d) o[d] += p * Vq[d * a.ld + j * a.lj];
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(NS * 32, NS == 8 ? 2 : 1) void tattn_kernel(const A
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[r] = expf(acc[r] - mx); sum += acc[r]; }
+            for (int r = 0; r < 16; ++r) { acc[r] = sdc::softmax_exp(acc[r] - mx); sum += acc[r]; }
             sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.0f / sum;
 #pragma unroll
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(NT) void attn256_kernel(const AttnArgs a) {
 #pragma unroll
         for (int kbk = 0; kbk < 8; ++kbk)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sc[kbk][r] = expf(sc[kbk][r] - mx); sum += sc[kbk][r]; }
+            for (int r = 0; r < 16; ++r) { sc[kbk][r] = sdc::softmax_exp(sc[kbk][r] - mx); sum += sc[kbk][r]; }
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
         // O^T[d][query] = sum_key V[d][key] P[key][query]: A[d = l31][key], B = P registers (k-step r of block kbk)

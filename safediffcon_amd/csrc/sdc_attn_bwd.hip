@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnBwdArgs a) {
 #pragma unroll
                 for (int d = 0; d < DH; ++d) { kk[d] = Kq[d * a.ld + j * a.lj]; s += q[d] * kk[d]; dp += g[d] * Vq[d * a.ld + j * a.lj]; }
                 if (brow) s += brow[j];
-                const float e = expf(s - mx);
+                const float e = sdc::softmax_exp(s - mx);
                 l += e;
                 dn += e * dp;
                 const float edp = e * dp;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnBwdArgs a) {
                 for (int d = 0; d < DH; ++d) { qq[d] = Qq[d * a.ld + i * a.lj]; gg[d] = Gq[d * a.ld + i * a.lj]; s += qq[d] * k[d]; dp += gg[d] * v[d]; }
                 if (a.bias) s += a.bias[((int64_t)head * ntok + i) * ntok + ti];
                 const int r = sbase + i * sstep;
-                const float p = expf(s - Mx[r]) * Li[r];
+                const float p = sdc::softmax_exp(s - Mx[r]) * Li[r];
                 const float ds = p * (dp - Dd[r]);
 #pragma unroll
                 for (int d = 0; d < DH; ++d) { dk[d] += ds * qq[d]; dv[d] += p * gg[d]; }
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(NT) void tattn_bwd_kernel(const AttnBwdArgs a) {
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sT[r] = expf(sT[r] - mx); sum += sT[r]; }
+            for (int r = 0; r < 16; ++r) { sT[r] = sdc::softmax_exp(sT[r] - mx); sum += sT[r]; }
             sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.0f / sum;
             float D = 0.f;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(NT) void tattn_bwd_kernel(const AttnBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = row_of(r);
-                const float p = expf(sN[r] + biasN[q * TB_P + l31] - st_m[q]) * st_l[q];
+                const float p = sdc::softmax_exp(sN[r] + biasN[q * TB_P + l31] - st_m[q]) * st_l[q];
                 sN[r] = p;                                        // P[q][key]
                 dpN[r] = p * (dpN[r] - st_d[q]);                  // dS[q][key]
             }

@@ -56,6 +56,13 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 
+// exp of a softmax exponent (x <= 0 after the row maximum is subtracted): v_mul + v_exp.  libm's expf is 13 instructions per
+// element here (argument split, ldexp, two range guards) -- 208 of the ~440 VALU instructions of a temporal-attention head in
+// ta_block_kernel, in a kernel where every VALU instruction costs matrix-pipe time.  The rounding of x * log2(e) leaves a
+// relative error of |x| * 6e-8 in the term: terms that matter in a softmax have small |x|, and the row sum weighs the rest down
+// (measured against fp64 in tests/test_gpu_kernels.py: no change in the fifth digit of the gates).
+__device__ __forceinline__ float softmax_exp(float x) { return __expf(x); }
+
 // wave64 reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

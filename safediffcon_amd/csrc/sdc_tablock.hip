@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[r] = expf(acc[r] - mx); sum += acc[r]; }
+            for (int r = 0; r < 16; ++r) { acc[r] = sdc::softmax_exp(acc[r] - mx); sum += acc[r]; }
             sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.0f / sum;
 #pragma unroll
