@@ -626,7 +626,9 @@ __device__ __forceinline__ uint64_t lo64(float k) { return (uint64_t)__builtin_b
 __device__ __forceinline__ w2f2 pks_mul(w2f2 a, float k) { w2f2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "s"(lo64(k))); return r; }
 __device__ __forceinline__ w2f2 pks_fma(w2f2 a, float k, w2f2 c) { w2f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "s"(lo64(k)), "v"(c)); return r; }
 
-template <int OW, int DBG>
+// ODD: the number of 8-channel stages per pass is odd (a compile-time property: a run-time choice between the two pass shapes
+// below cost 60-110 spilled registers)
+template <int OW, int DBG, bool ODD = false>
 __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
     constexpr int SK = W2_SK, BM = W2_BM;
     constexpr int TW = OW / 2;
@@ -707,7 +709,9 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
     const float* const x0p = a.x0 + (int64_t)ob * d.x0s[0] + (int64_t)od * d.x0s[2];
     const float* const x1p = two ? a.x1 + (int64_t)ob * d.x1s[0] + (int64_t)od * d.x1s[2] : x0p;
     const int64_t xs2_0 = d.x0s[2], xs2_1 = two ? d.x1s[2] : d.x0s[2];
-    const uint32_t lo_u = od > 0, hi_u = od + 2 < d.iD;          // planes od - 1 / od + 2 exist
+    // planes od - 1 / od + 2 exist -- as sign bits of scalar integers: a uniform `bool` widened to an integer came back as
+    // v_cndmask + v_readfirstlane, and everything derived from it (the factors below, per stage) as VALU
+    const uint32_t lo_u = (uint32_t)(-od) >> 31, hi_u = (uint32_t)(od + 2 - d.iD) >> 31;
     gfloat_p f_w = uniform_ptr(wg3p), f_w4 = f_w, f_xa = uniform_ptr(x0p), f_xb = f_xa;
     int64_t f_sc = 0;
     uint32_t voff = 0, voff0 = 0, voff3 = 0;
@@ -722,10 +726,11 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
         // (integer arithmetic on the float bits: nested selects became branches, and a branch in this loop costs
         // conservative memory waits at its join)
         // pass s_jd (0..3) works on depth component 1, 2, 0, 3 (see the fold)
-        const uint32_t j0 = s_jd == 2, j2 = s_jd == 1, j3 = s_jd == 3;
-        const int jdc = s_jd + 1 - 3 * (int)j0 - (int)j3;
+        const int jd_u = SDC_UNIFORM(s_jd);          // (told to be scalar: the sign / zero factors below were formed with ~15 VALU instructions per stage)
+        const uint32_t j0 = (uint32_t)((jd_u ^ 2) - 1) >> 31, j2 = (uint32_t)((jd_u ^ 1) - 1) >> 31, j3 = (uint32_t)((jd_u ^ 3) - 1) >> 31;   // jd == 2 | 1 | 3
+        const int jdc = jd_u + 1 - 3 * (int)j0 - (int)j3;
         const int da = -(int)(j0 & lo_u);                                    // -1 | 0 | 0 | 0
-        const int db = 1 + (int)j3 * (hi_u ? 1 : -1);                        //  1 | 1 | 1 | 2 (0 past the volume)
+        const int db = 1 + (int)j3 * (2 * (int)hi_u - 1);                    //  1 | 1 | 1 | 2 (0 past the volume)
         mka = __builtin_bit_cast(float, (0x3F800000u & ((j0 & (lo_u ^ 1u)) - 1u)) | (j2 << 31));       // lo_ok | 1 | -1 | 1
         mkb = __builtin_bit_cast(float, (0x3F800000u & ((j3 & (hi_u ^ 1u)) - 1u)) | ((j0 | (j3 & hi_u)) << 31));   // -1 | 1 | 1 | -hi_ok
         f_xa = uniform_ptr(bsel + da * xs2);
@@ -742,7 +747,8 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
     };
     // (the offset passes through an empty asm so that its zero-extension is not hoisted out of the loop as a 64-bit
     // register pair: the load then takes the scalar base + 32-bit lane offset form)
-    auto fetch_a = [&](int i, nfloat4 (&ar)[8]) { uint32_t o = a_voff[i & 3]; asm volatile("" : "+v"(o)); ar[i] = *(gfloat4_p)((gchar_p)(i < 4 ? f_w : f_w4) + o); };
+    // (... applied to the offset register itself: through a copy it cost one v_mov per load, 8 per stage)
+    auto fetch_a = [&](int i, nfloat4 (&ar)[8]) { asm volatile("" : "+v"(a_voff[i & 3])); ar[i] = *(gfloat4_p)((gchar_p)(i < 4 ? f_w : f_w4) + a_voff[i & 3]); };
     auto fetch_b_row = [&](int it, int sl, int j, w2f2 (&br)[NIT][2][4][TPL]) __attribute__((always_inline)) {
         const gchar_p rb = (gchar_p)(sl ? f_xb : f_xa) + (CPL == 2 ? (int64_t)it * f_sc * 4 : 0);
         const gchar_p p = j == 0 ? rb + voff0 : (j == 3 ? rb + voff3 : (j == 1 ? rb + voff : rb + voff + OW * 4));
@@ -931,13 +937,16 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
     // Main loop, per depth component: stage st computes from buffer st & 1 and parks stage st+1 in the other one during its
     // k-steps 0-1, re-using each register piece for the fetch of stage st+2 as soon as it is parked; one barrier at the end of
     // k-step 2; k-step 3 reads the first fragments of stage st+1 (slots as in the kernel above, 8 row loads instead of 4).
-    int rbuf = 0;
     // The first stage of a pass is a copy of the stage body whose first k-step starts the accumulators from zero (from the
     // bias for component (1, 1) of the first pass = depth component 1) in the MFMA itself: 256 register writes per pass less in the fold.
-    auto stage = [&](auto FIRST, const int jd) __attribute__((always_inline)) {
+    // The LDS buffer a stage reads is a compile-time constant (the body is instantiated per buffer; a pass of an even number of
+    // stages always starts on buffer 0, with an odd number pass jd starts on buffer jd & 1): every LDS address of a stage is lane offset + immediate; with a
+    // run-time buffer index each stage formed them with 13 VALU additions, in a loop where a VALU instruction costs MFMA time.
+    auto stage = [&](auto FIRST, auto RB, const int jd) __attribute__((always_inline)) {
         constexpr bool first = decltype(FIRST)::value && !(DBG & 4);     // (the no-fold experiment lets the passes accumulate on)
+        constexpr int rbuf = decltype(RB)::value;
         {
-            const int wbuf = rbuf ^ 1;
+            constexpr int wbuf = rbuf ^ 1;
             const float* Ab = As + rbuf * W2_ASZ;
             const float* Vb = Vs + rbuf * W2_BSZ;
             const float* An = As + wbuf * W2_ASZ;
@@ -971,20 +980,28 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
                 }
                 if (ks == 2) __syncthreads();
             }
-            rbuf = wbuf;
         }
     };
     auto run_pass = [&](auto JD) __attribute__((always_inline)) {
         constexpr int jd = decltype(JD)::value;
-        stage(std::true_type{}, jd);
-        for (int st = 1; st < S1; ++st) stage(std::false_type{}, jd);
+        constexpr int sb = ODD ? (jd & 1) : 0;                        // odd stage counts: pass jd starts on buffer jd & 1 and ends on the other
+        constexpr std::integral_constant<int, sb> BS{};
+        constexpr std::integral_constant<int, sb ^ 1> BT{};
+        stage(std::true_type{}, BS, jd);
+        if constexpr (ODD) {
+            for (int st = 1; st < S1; st += 2) { stage(std::false_type{}, BT, jd); stage(std::false_type{}, BS, jd); }
+        } else {
+            for (int st = 1; st + 1 < S1; st += 2) { stage(std::false_type{}, BT, jd); stage(std::false_type{}, BS, jd); }
+            stage(std::false_type{}, BT, jd);
+        }
         if (!(DBG & 4)) {
             fold(jd);
             // (the first fragments of the next stage, read again: carried across the fold they cost 32 registers there)
+            constexpr int nb = ODD ? sb ^ 1 : 0;                      // the buffer the next pass starts on
 #pragma unroll
-            for (int q = 0; q < 4; ++q) read_a(As + rbuf * W2_ASZ, 0, q);
+            for (int q = 0; q < 4; ++q) read_a(As + nb * W2_ASZ, 0, q);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) read_v(Vs + rbuf * W2_BSZ, 0, j);
+            for (int j = 0; j < 4; ++j) read_v(Vs + nb * W2_BSZ, 0, j);
         }
     };
     run_pass(std::integral_constant<int, 0>{});
@@ -1051,11 +1068,18 @@ int launch_wg3(const ConvArgs& a, hipStream_t s) {
     const int64_t tiles = (int64_t)d.B * (d.oD / 2) * (d.oH / 2) * (d.oW / 2);
     dim3 grid((unsigned)((tiles / W2_TILES) * (d.Cout / W2_BM)));
     const size_t lds = (size_t)W2_NBUF * (W2_ASZ + W2_BSZ) * sizeof(float) + 4 * 8 * sizeof(double) + 256 * 8 * sizeof(float);
+    const bool odd_stages = ((a.Cin / W2_SK) & 1) != 0;
 #define W3_LAUNCH(OWV, D)                                                                                                        \
     do {                                                                                                                         \
         static std::atomic<uint64_t> attr{0};                                                                                    \
-        SDC_LDS_OPTIN(attr, (conv_wg3_kernel<OWV, D>), 160 * 1024, "sdc_conv[winograd 2x2x2]");                                  \
-        hipLaunchKernelGGL((conv_wg3_kernel<OWV, D>), grid, dim3(256), lds, s, a);                                               \
+        static std::atomic<uint64_t> attr_odd{0};                                                                                \
+        if (odd_stages) {                                                                                                        \
+            SDC_LDS_OPTIN(attr_odd, (conv_wg3_kernel<OWV, D, true>), 160 * 1024, "sdc_conv[winograd 2x2x2]");                    \
+            hipLaunchKernelGGL((conv_wg3_kernel<OWV, D, true>), grid, dim3(256), lds, s, a);                                     \
+        } else {                                                                                                                 \
+            SDC_LDS_OPTIN(attr, (conv_wg3_kernel<OWV, D>), 160 * 1024, "sdc_conv[winograd 2x2x2]");                              \
+            hipLaunchKernelGGL((conv_wg3_kernel<OWV, D>), grid, dim3(256), lds, s, a);                                           \
+        }                                                                                                                        \
     } while (0)
 #ifdef SDC_KERNEL_EXPERIMENTS
     // kernel experiments (2, 4: WRONG RESULTS): 2 no read-back, 4 no folds, 8 all read-backs of a fold up front
