@@ -91,7 +91,8 @@ __device__ __forceinline__ float sub_next(float a, float x) {
     return r;
 }
 
-template <int OW, int DBG>
+// ODD: an odd number of stages (compile-time, like the LDS buffer a stage works on: see the main loop)
+template <int OW, int DBG, bool ODD = false>
 __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     constexpr int SK = W2_SK, BM = W2_BM;
     constexpr int TW = OW / 2, RP = W2_TILES / TW;
@@ -230,7 +231,8 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     };
     // (the offset passes through an empty asm so that its zero-extension is not hoisted out of the loop as a 64-bit
     // register pair: the load then takes the scalar base + 32-bit lane offset form)
-    auto fetch_a = [&](int i, nfloat4 (&ar)[8]) { uint32_t o = a_voff[i]; asm volatile("" : "+v"(o)); ar[i] = *(gfloat4_p)((gchar_p)f_w + o); };
+    // (applied to the offset register itself: through a copy it cost one v_mov per load, 8 per stage)
+    auto fetch_a = [&](int i, nfloat4 (&ar)[8]) { asm volatile("" : "+v"(a_voff[i])); ar[i] = *(gfloat4_p)((gchar_p)f_w + a_voff[i]); };
     // the 4 input rows under the row pair, CPL adjacent columns each: one vector load per row, row tap (j - 1) as an immediate.
     // A lane whose row is outside the image reads the first elements of the channel instead and is zeroed when parked.
     auto fetch_b_row = [&](int it, int j, w2f2 (&br)[NIT][4][TPL]) {
@@ -355,9 +357,11 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     // one barrier sits at the end of k-step 2; k-step 3 reads the first fragments of stage st+1, so the MFMA stream runs
     // through the stage boundary.  The non-MFMA work of a k-step sits in 16 slots, one behind each MFMA, in source order;
     // no branch inside the loop (a per-slot fast / masked choice cost conservative vmcnt waits at every join).
-    int rbuf = 0;
-    for (int st = 0; st < nstages; ++st) {
-        const int wbuf = rbuf ^ 1;
+    // The LDS buffer of a stage is a compile-time constant (body instantiated per buffer): every LDS address of a stage is lane
+    // offset + immediate; with a run-time buffer index each stage formed them with a dozen VALU additions.
+    auto stage = [&](auto RB) __attribute__((always_inline)) {
+        constexpr int rbuf = decltype(RB)::value;
+        constexpr int wbuf = rbuf ^ 1;
         const float* Ab = As + rbuf * W2_ASZ;
         const float* Vb = Vs + rbuf * W2_BSZ;
         const float* An = As + wbuf * W2_ASZ;
@@ -394,7 +398,20 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
             }
             if (ks == 2 && !(DBG & 4)) __syncthreads();
         }
-        rbuf = wbuf;
+    };
+    {
+        constexpr std::integral_constant<int, 0> B0{};
+        constexpr std::integral_constant<int, 1> B1{};
+        if constexpr (ODD) {
+            for (int st = 0; st + 1 < nstages; st += 2) { stage(B0); stage(B1); }
+            stage(B0);
+        } else {
+            // (the last pair outside the loop, like the odd form's last stage: with the plain pair loop the W = 16 / 32 / 64 instances
+            // spilled 8-28 registers, with this shape none)
+            for (int st = 0; st + 2 < nstages; st += 2) { stage(B0); stage(B1); }
+            stage(B0);
+            stage(B1);
+        }
     }
 
     if (DBG & 128) {      // experiment: no epilogue (keeps the accumulators alive through one store)
@@ -575,11 +592,18 @@ int launch_wg2(const ConvArgs& a, hipStream_t s) {
     const int MT = (d.Cout + W2_BM - 1) / W2_BM;
     dim3 grid((unsigned)(((tiles + W2_TILES - 1) / W2_TILES) * MT));
     const size_t lds = (size_t)W2_NBUF * (W2_ASZ + W2_BSZ) * sizeof(float) + 4 * 8 * sizeof(double);     // stage buffers + GroupNorm scratch
+    const bool odd_stages = ((d.kD * (a.Cin / W2_SK)) & 1) != 0;
 #define W2_LAUNCH(OWV, D)                                                                                                        \
     do {                                                                                                                         \
         static std::atomic<uint64_t> attr{0};                                                                                    \
-        SDC_LDS_OPTIN(attr, (conv_wg2_kernel<OWV, D>), 160 * 1024, "sdc_conv[winograd 2x2]");                                    \
-        hipLaunchKernelGGL((conv_wg2_kernel<OWV, D>), grid, dim3(256), lds, s, a);                                               \
+        static std::atomic<uint64_t> attr_odd{0};                                                                                \
+        if (odd_stages) {                                                                                                        \
+            SDC_LDS_OPTIN(attr_odd, (conv_wg2_kernel<OWV, D, true>), 160 * 1024, "sdc_conv[winograd 2x2]");                      \
+            hipLaunchKernelGGL((conv_wg2_kernel<OWV, D, true>), grid, dim3(256), lds, s, a);                                     \
+        } else {                                                                                                                 \
+            SDC_LDS_OPTIN(attr, (conv_wg2_kernel<OWV, D>), 160 * 1024, "sdc_conv[winograd 2x2]");                                \
+            hipLaunchKernelGGL((conv_wg2_kernel<OWV, D>), grid, dim3(256), lds, s, a);                                           \
+        }                                                                                                                        \
     } while (0)
 #ifdef SDC_KERNEL_EXPERIMENTS
     // parts of the loop switched off (WRONG RESULTS): never compiled into the shipping library
