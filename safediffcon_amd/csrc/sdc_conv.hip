@@ -869,7 +869,9 @@ __device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[NX]
 // KS = 2: the C3 layers are ~1024 wave tiles each -- one per SIMD -- and a lone wave cannot hide its transform / staging VALU
 // behind its own MFMAs (measured: 65 TFLOP/s issued); the k-steps of every stage are therefore split over TWO waves per SIMD
 // that own the same output tile, and the second half's accumulators are added through the (dead) staging LDS before the epilogue.
-template <int BM, int BN, int WM, int WN, int SK, int NTH, bool UPS, int NX = 4, int KS = 1>
+// P1: kD * kH == 1 (the 1-D nets' Conv1d): one tap row, so a lane's gather offsets and padding mask are the same for every stage --
+// formed once before the loop instead of ~40 VALU instructions per stage (64-bit mask shifts, selects, address sums)
+template <int BM, int BN, int WM, int WN, int SK, int NTH, bool UPS, int NX = 4, int KS = 1, bool P1 = false>
 __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
     static_assert(NX == 4 || (NX == 6 && !UPS), "F(4,3) serves the plain 1-D convs");
     static_assert(KS == 1 || (KS == 2 && SK % 8 == 0), "k-split");
@@ -1007,7 +1009,30 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
     const float* l_base = a.x0;
     int64_t l_sc = 0;
     uint32_t l_off[NCOL];                         // byte offsets (every operand spans < 2^30 elements: host check `small`)
+    uint32_t p1_off0[P1 ? NCOL : 1], p1_off1[P1 ? NCOL : 1], p1_bits = 0;     // P1: the stage-invariant offsets of the two inputs, the mask
+    if constexpr (P1) {
+#pragma unroll
+        for (int t = 0; t < NCOL; ++t) {
+            const bool ok = smask[t] & 1u;
+            p1_off0[t] = ok ? (uint32_t)v0[t] * 4u : 0u;
+            p1_off1[t] = ok ? (uint32_t)(two ? v1[t] : v0[t]) * 4u : 0u;
+            p1_bits |= (ok ? 1u : 0u) << t;
+        }
+    }
     auto load_begin = [&]() {
+        if constexpr (P1) {
+            l_tap = 0;
+            l_ci = s_ci;
+            const bool first = s_ci < d.Cin0;
+            l_sc = first ? d.x0s[1] : d.x1s[1];
+            l_base = (first ? a.x0 + (int64_t)s_ci * l_sc : a.x1 + (int64_t)(s_ci - d.Cin0) * l_sc) + (int64_t)(wave * KROWS) * l_sc;
+#pragma unroll
+            for (int t = 0; t < NCOL; ++t) l_off[t] = first ? p1_off0[t] : p1_off1[t];
+            mbits = p1_bits;
+            s_ci += SK;
+            if (s_ci >= a.Cin) s_ci = 0;
+            return;
+        }
         l_tap = s_kd * d.kH + s_kh;
         l_ci = s_ci;
         const bool first = s_ci < d.Cin0;
@@ -1055,9 +1080,9 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
             if (i % NSL != p) continue;
             const int f = tid + i * NTH;
             const int row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
-            float4 v = areg[i];
-            if (!a_ok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(As + buf * ASZ + row * BM + c4) = v;
+            // (rows beyond Cout were fetched from a valid row (a_voff) and are never stored or summed by the epilogue: no zeroing --
+            // it was 16 selects per stage)
+            *reinterpret_cast<float4*>(As + buf * ASZ + row * BM + c4) = areg[i];
         }
 #pragma unroll
         for (int r = 0; r < KROWS; ++r)
@@ -1459,6 +1484,7 @@ int launch_f43(const ConvArgs& a, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int SK, int NTH = 256, bool UPS = false, int NX = 4, int KS = 1>
 int launch_wg(const ConvArgs& a, hipStream_t s) {
+    const bool p1 = !UPS && a.d.kD * a.d.kH == 1;
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
     constexpr int KSMAX = BN + (BN / 16) * 2;
     constexpr int NCOLH = (KSMAX + 63) / 64;
@@ -1467,7 +1493,15 @@ int launch_wg(const ConvArgs& a, hipStream_t s) {
     constexpr size_t PART = KS == 1 ? 0 : (size_t)WM * WN * NX * (BM / WM / 32) * (BN / (NX == 6 ? 4 : 2) / WN / 32) * 16 * 64 * sizeof(float);
     constexpr size_t lds = STAGE > PART ? STAGE : PART;
     static_assert(lds <= 160u * 1024u, "stage buffers / k-split partials exceed the LDS");
-    static std::atomic<uint64_t> attr{0};
+    static std::atomic<uint64_t> attr{0}, attr1{0};
+    if constexpr (!UPS) {
+        if (p1) {
+            SDC_LDS_OPTIN(attr1, (conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS, NX, KS, true>), 160 * 1024, "sdc_conv[winograd]");
+            hipLaunchKernelGGL((conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS, NX, KS, true>), grid, dim3(NTH), lds, s, a);
+            return SDC_OK;
+        }
+    }
+    (void)p1;
     SDC_LDS_OPTIN(attr, (conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS, NX, KS>), 160 * 1024, "sdc_conv[winograd]");
     hipLaunchKernelGGL((conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS, NX, KS>), grid, dim3(NTH), lds, s, a);
     return SDC_OK;
