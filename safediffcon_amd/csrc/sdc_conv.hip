@@ -1062,6 +1062,7 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < NA4; ++i) {
             if (i % NSL != p) continue;
+            asm volatile("" : "+v"(a_voff[i]));      // (keeps the load in scalar base + 32-bit lane offset form: otherwise a 64-bit add per load)
             const nfloat4 wv = *(gfloat4_p)((gchar_p)wbase + a_voff[i]);
             areg[i] = make_float4(wv.x, wv.y, wv.z, wv.w);
         }
@@ -1124,8 +1125,10 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
     // the later-dispatched half of an 8-wave workgroup loses every arbitration against its SIMD partner: static priority
     if (NTH == 512 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
-    for (int st = 0; st < nstages; ++st) {
-        const int buf = st & 1;
+    // P1 (an even number of stages: launch_wg): the LDS buffer of a stage is a compile-time constant, the body instantiated per
+    // buffer -- LDS addresses become lane offset + immediate instead of ~15 VALU additions per 32 MFMAs
+    auto stage = [&](auto bufc) __attribute__((always_inline)) {
+        const int buf = bufc;
         constexpr int KST = SK / 2 / KS;                        // k-steps of a stage this wave multiplies
         const float* Ab = As + buf * ASZ + (2 * KST * kh) * BM;
         const float* Bb = Bs + buf * BSZ + (2 * KST * kh) * PITCH;
@@ -1211,6 +1214,15 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+    };
+    if constexpr (P1) {
+        constexpr std::integral_constant<int, 0> B0{};
+        constexpr std::integral_constant<int, 1> B1{};
+        for (int st = 0; st + 2 < nstages; st += 2) { stage(B0); stage(B1); }
+        stage(B0);
+        stage(B1);
+    } else {
+        for (int st = 0; st < nstages; ++st) stage(st & 1);
     }
     if constexpr (KS == 2) {
         // the two k-halves of a tile meet in the staging LDS (dead after the last stage's barrier): [tile wave][register][lane]
@@ -1484,7 +1496,7 @@ int launch_f43(const ConvArgs& a, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int SK, int NTH = 256, bool UPS = false, int NX = 4, int KS = 1>
 int launch_wg(const ConvArgs& a, hipStream_t s) {
-    const bool p1 = !UPS && a.d.kD * a.d.kH == 1;
+    const bool p1 = !UPS && a.d.kD * a.d.kH == 1 && ((a.Cin / SK) & 1) == 0;       // (single tap row, an even number of stages)
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
     constexpr int KSMAX = BN + (BN / 16) * 2;
     constexpr int NCOLH = (KSMAX + 63) / 64;
