@@ -52,6 +52,15 @@ inline int lds_optin(std::atomic<uint64_t>& mask, const void* kernel, int bytes,
         if (rc_ != SDC_OK) return rc_;                                                                       \
     } while (0)
 
+// Keeps the backend from pairing LDS accesses into ds_read2 / ds_write2 forms (function attribute, device pass only).  Their two
+// offsets are 8-bit, so every pair further than 1 KB from its base register costs a VALU addition to form a new base -- 66 per
+// 128 MFMAs in la_blk_out -- in kernels where a VALU instruction costs matrix-pipe time and an LDS instruction does not.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SDC_NO_DS_MERGE __attribute__((target("no-load-store-opt")))
+#else
+#define SDC_NO_DS_MERGE
+#endif
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }

@@ -50,12 +50,30 @@ struct LaArgs {
 // mode 0: (x - mean) * rsqrt(var + eps) * g (two-pass variance); mode 1: x / max(||x||, 1e-12) * g * sqrt(C).
 // fetch_tile only issues the loads (the next tile's are issued while the current one is on the matrix cores);
 // norm_tile consumes them; `xr`, when given, keeps the raw tile for the residual add.
+// wave-uniform base (SGPR pair) + one 32-bit per-lane byte offset: the channel row of an access is wave-uniform (a wave owns whole
+// rows: grp = tid >> 6), only the token is per lane -- left to the compiler every access formed a 64-bit address per lane
+// (17 v_lshl_add_u64 + 20-66 v_add_u32 per tile in these kernels, where a VALU instruction costs matrix-pipe time)
+typedef __attribute__((address_space(1))) float* la_gptr;
+typedef __attribute__((address_space(1))) char* la_gcptr;
+__device__ __forceinline__ la_gptr la_uni(const float* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return (la_gptr)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float la_ld(la_gptr base, uint32_t byte_off) { return *(la_gptr)((la_gcptr)base + byte_off); }
+__device__ __forceinline__ void la_st(la_gptr base, uint32_t byte_off, float v) { *(la_gptr)((la_gcptr)base + byte_off) = v; }
+
 template <int C>
 __device__ __forceinline__ void fetch_tile(const float* __restrict__ xb, int64_t sc, int tid, float (&v)[C / 4]) {
     constexpr int CG = C / 4;
-    const int tok = tid & 63, grp = tid >> 6;
+    const int tok = tid & 63, grp = __builtin_amdgcn_readfirstlane(tid >> 6);
+    la_gptr rp = la_uni(xb + (int64_t)(grp * CG) * sc);
 #pragma unroll
-    for (int k = 0; k < CG; ++k) v[k] = xb[(int64_t)(grp * CG + k) * sc + tok];
+    for (int k = 0; k < CG; ++k) {
+        v[k] = la_ld(rp, (uint32_t)tok * 4u);
+        rp += sc;
+        asm volatile("" : "+s"(rp));
+    }
 }
 
 // GroupNorm-on-load form (template GN; the producing ResnetBlock's second GroupNorm + SiLU + residual add, conv3d.py:189-230,
@@ -67,8 +85,18 @@ __device__ __forceinline__ void gn_apply_tile(float (&v)[C / 4], const float* __
     constexpr int CG = C / 4;
     const int tok = tid & 63, grp = tid >> 6;
     float rv[CG];                                   // the residual tile is requested first: it travels under the SiLUs
+    if (rb) {
+        la_gptr rp = la_uni(rb + (int64_t)(__builtin_amdgcn_readfirstlane(grp) * CG) * sc);
 #pragma unroll
-    for (int k = 0; k < CG; ++k) rv[k] = rb ? rb[(int64_t)(grp * CG + k) * sc + tok] : 0.f;
+        for (int k = 0; k < CG; ++k) {
+            rv[k] = la_ld(rp, (uint32_t)tok * 4u);
+            rp += sc;
+            asm volatile("" : "+s"(rp));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < CG; ++k) rv[k] = 0.f;
+    }
 #pragma unroll
     for (int k = 0; k < CG; ++k) {
         const float mul = gcoef[grp * CG + k], add = gcoef[C + grp * CG + k];
@@ -146,7 +174,7 @@ __device__ __forceinline__ void project(const float (&wreg)[C / 2], const float*
 //   M^T[c][d] += sum_tok xn[c][tok] p[tok][d]:  A = xn from LDS, B = the P registers as they stand (the contraction
 //   index tok is walked in accumulator-row order); the online rescale factor is per d = per lane, one multiply per register.
 template <int C, bool GN>
-__global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) void la_blk_ctx(const LaArgs a) {
+__global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) SDC_NO_DS_MERGE void la_blk_ctx(const LaArgs a) {
     constexpr int NCT = C / 32;                     // row tiles of M^T (channels)
     extern __shared__ float lds[];                  // C = 128 needs 67 KB: dynamic
     float* const xs = lds;                          // [C][XP]
@@ -183,8 +211,13 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) void la_blk_ctx(const LaArgs
             gn_apply_tile<C>(xv, rseq ? rseq + (int64_t)tile * TT : nullptr, a.sc, gcoef, tid);
             float* hb = a.gn_hout + o * a.so + i * a.si + (int64_t)tile * TT;
             constexpr int CG = C / 4;
+            la_gptr hp = la_uni(hb + (int64_t)(__builtin_amdgcn_readfirstlane(tid >> 6) * CG) * a.sc);
 #pragma unroll
-            for (int k = 0; k < CG; ++k) hb[(int64_t)((tid >> 6) * CG + k) * a.sc + (tid & 63)] = xv[k];
+            for (int k = 0; k < CG; ++k) {
+                la_st(hp, (uint32_t)(tid & 63) * 4u, xv[k]);
+                hp += a.sc;
+                asm volatile("" : "+s"(hp));
+            }
         }
         norm_tile<C>(xv, a.g_pre, a.pre_mode, a.eps, xs, nullptr, red, tid);
         if (tile + 1 < t1) fetch_tile<C>(xseq + (int64_t)(tile + 1) * TT, a.sc, tid, xv);
@@ -291,7 +324,7 @@ __global__ __launch_bounds__(NT) void la_blk_mid(const LaArgs a) {
 
 // ------------------------------------------------------------------ pass 2: per (tile group, sequence)
 template <int C>
-__global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) void la_blk_out(const LaArgs a) {
+__global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) SDC_NO_DS_MERGE void la_blk_out(const LaArgs a) {
     constexpr int NRT = C / 32;                     // row tiles of y (channels)
     constexpr int TPW = NRT / 2;                    // y tiles per wave (one row tile, TPW column tiles)
     extern __shared__ float lds[];
@@ -406,14 +439,18 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) void la_blk_out(const LaArgs
             }
         }
         // + x, store (tokens on lanes: coalesced rows)
+        // (rows co = rt*32 + (r & 3) + 8 (r >> 2) from a scalar base, the half-wave's 4 rows and the column as one lane offset:
+        // host check `4 sc` elements < 2^30)
 #pragma unroll
-        for (int u = 0; u < TPW; ++u)
+        for (int u = 0; u < TPW; ++u) {
+            const int col = (ct0 + u) * 32 + l31;
+            const uint32_t loff = (uint32_t)((int64_t)(4 * lh) * a.sc + col) * 4u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int col = (ct0 + u) * 32 + l31;
-                yseq[(int64_t)co * a.sc + (int64_t)tile * TT + col] = yacc[u][r] + xr[co * XP + col];
+                const int cob = __builtin_amdgcn_readfirstlane(rt * 32 + (r & 3) + 8 * (r >> 2));
+                la_st(la_uni(yseq + (int64_t)cob * a.sc + (int64_t)tile * TT), loff, yacc[u][r] + xr[(cob + 4 * lh) * XP + col]);
             }
+        }
         __syncthreads();                             // xs / qs / red are rewritten by the next tile
     }
 }
@@ -447,6 +484,7 @@ int linattn_block_impl(const float* x, const float* gn_stats, const float* gn_ga
     SDC_REQUIRE(post_mode < 0 || g_post, SDC_ENULL, "sdc_linattn_block: post norm needs its gain");
     const int64_t nseq = (int64_t)outer * inner;
     SDC_REQUIRE(nseq < 65536, SDC_EINVAL, "sdc_linattn_block: outer*inner must be < 65536");
+    SDC_REQUIRE(sc > 0 && sc < (1ll << 27), SDC_EINVAL, "sdc_linattn_block: channel stride must stay below 2^27 elements (32-bit lane offsets)");
     LaArgs a;
     a.x = x; a.g_pre = g_pre; a.wqkv = wqkv; a.wo = wo; a.bo = bo; a.g_post = g_post; a.y = y;
     a.gn_stats = gn_stats; a.gn_gamma = gn_gamma; a.gn_beta = gn_beta; a.gn_res = gn_res; a.gn_G = gn_G; a.gn_hout = nullptr;
