@@ -128,7 +128,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 // (register cap by tile: the 64 x 256 tile spilled 21-24 registers under the 4-wave cap and is 4 % faster at 3 waves without them; the
 // 128 x 128 tile spills 15-25 too but is 4 % slower at 3 waves -- measured on the sub-pixel / strided convs of the smoke net)
 template <int BM, int BN, int WM, int WN, bool FAST>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((BM == 64 && BN == 256) ? 3 : 4))) void conv_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((BM == 64 && BN == 256) ? 3 : 4))) SDC_NO_DS_MERGE void conv_kernel(const ConvArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int BROWS = BK * BN / NT;   // B-tile elements per thread
