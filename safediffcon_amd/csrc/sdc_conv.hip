@@ -666,9 +666,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BKT == 8 ? 4
     __syncthreads();
     const int am = wm * (TM * 32) + l31;
 
-    for (int st = 0; st < nstages; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nstages) load_stage();
+    // (the LDS buffer of a stage as a compile-time constant, body instantiated per buffer: LDS addresses are lane offset + immediate)
+    auto stage = [&](auto bufc, const bool more) __attribute__((always_inline)) {
+        constexpr int buf = decltype(bufc)::value;
+        if (more) load_stage();
         // The fragments of tap kw+1 are read (all of them, ahead of the fence) while the MFMAs of tap kw run: left to itself
         // the scheduler sinks every LDS read next to its use and the wave waits out the LDS latency once per 4 MFMAs.
         float af[2][BK / 2][TM], bf[2][BK / 2][TN];
@@ -696,8 +697,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BKT == 8 ? 4
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][ks][i], bf[set][ks][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (st + 1 < nstages) store_stage(buf ^ 1);
+        if (more) store_stage(buf ^ 1);
         __syncthreads();
+    };
+    {
+        constexpr std::integral_constant<int, 0> B0{};
+        constexpr std::integral_constant<int, 1> B1{};
+        int st = 0;
+        for (; st + 2 <= nstages; st += 2) { stage(B0, true); stage(B1, st + 2 < nstages); }
+        if (st < nstages) stage(B0, false);
     }
     conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
 }
