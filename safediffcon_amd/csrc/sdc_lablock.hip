@@ -63,6 +63,9 @@ __device__ __forceinline__ la_gptr la_uni(const float* p) {
 __device__ __forceinline__ float la_ld(la_gptr base, uint32_t byte_off) { return *(la_gptr)((la_gcptr)base + byte_off); }
 __device__ __forceinline__ void la_st(la_gptr base, uint32_t byte_off, float v) { *(la_gptr)((la_gcptr)base + byte_off) = v; }
 
+// max(a, b, c) in one instruction (fmaxf(fmaxf()) came out as v_max_f32 pairs plus a canonicalising v_max x, x per input: 45 for 32)
+__device__ __forceinline__ float la_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 template <int C>
 __device__ __forceinline__ void fetch_tile(const float* __restrict__ xb, int64_t sc, int tid, float (&v)[C / 4]) {
     constexpr int CG = C / 4;
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) SDC_NO_DS_MERGE void la_blk_
         // online softmax over tokens, per d
         float tmax = kacc[0][0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(kacc[0][r], kacc[1][r]));
+        for (int r = 0; r < 16; ++r) tmax = la_max3(tmax, kacc[0][r], kacc[1][r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(mrun, tmax);
         const float f = __expf(mrun - mnew);
@@ -365,9 +368,9 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) SDC_NO_DS_MERGE void la_blk_
         // softmax over d (the 32 rows of the head) per token, times dim_head^-0.5
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            float m = qacc[j][0];
+            float m = fmaxf(qacc[j][0], qacc[j][1]);
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, qacc[j][r]);
+            for (int r = 2; r < 16; r += 2) m = la_max3(m, qacc[j][r], qacc[j][r + 1]);
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             float s = 0.f;
 #pragma unroll
