@@ -190,6 +190,7 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) yacc[i][r] = 0.f;
+#pragma unroll
         for (int head = 0; head < ((TA_DBG(a) & 1) ? 0 : 4); ++head) {
             const float* wh = wl + (head & 1) * 8192;
             __syncthreads();                           // xn / this head's weights are in LDS; every wave is done with the other buffer
