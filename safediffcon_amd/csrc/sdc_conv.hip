@@ -431,8 +431,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void co
     __syncthreads();
     const int l31 = lane & 31, lh = lane >> 5;
     const int am = wm * (TM * 32) + l31, bn = wn * (TN * 32) + l31;
-    for (int kc = 0; kc < nchunks; ++kc) {
-        const int buf = kc & 1;
+    // (the LDS buffer of a chunk is a compile-time constant, body instantiated per buffer: LDS addresses = lane offset + immediate)
+    auto chunk = [&](auto bufc, const int kc) __attribute__((always_inline)) {
+        constexpr int buf = decltype(bufc)::value;
         float af[BK / 2][TM], bf[BK / 2][TN];
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
@@ -452,6 +453,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void co
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
         __syncthreads();
+    };
+    {
+        constexpr std::integral_constant<int, 0> B0{};
+        constexpr std::integral_constant<int, 1> B1{};
+        int kc = 0;
+        for (; kc + 2 <= nchunks; kc += 2) { chunk(B0, kc); chunk(B1, kc + 1); }
+        if (kc < nchunks) chunk(B0, kc);
     }
     conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
 }
