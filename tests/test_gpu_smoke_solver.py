@@ -174,4 +174,6 @@ def test_c4_sample_then_score_check_end_to_end():
     assert np.isfinite(mse).all() and np.isfinite(n_l2).all() and (safe_target[np.isfinite(safe_target)] >= 0).all()
     # each trajectory's score is its own: the same call on the first two samples alone
     res2 = ss.multi_evaluate(pred[:2].clone(), state[:2].to(dev), Q=0.01, safe_bound=0.1)
-    assert np.array_equal(res2[0], J_target[:2], equal_nan=True) and np.array_equal(res2[6], mse[:2])
+    # (the rollout's fields are batch-independent bit for bit -- test_vs_oracle_on_fresh_inputs_and_batch_independence; the MSE is a
+    # torch float64 reduction whose summation order may follow the batch shape: equal to rounding)
+    assert np.array_equal(res2[0], J_target[:2], equal_nan=True) and np.allclose(res2[6], mse[:2], rtol=1e-12, atol=0.0)
