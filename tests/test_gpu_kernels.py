@@ -854,3 +854,46 @@ def test_linattn_block_with_groupnorm_on_load(plan_cls, Cc, F_, hw, res):
         outs.append(y.clone())
         assert torch.isfinite(y).all()
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=8, cin=256, cout=256, W=128, G=1),                              # tokamak level 0 (single-tap form, 16 stages)
+    dict(B=128, cin=256, cout=256, W=128, G=1),                            # the same at the C3 batch: the 128 x 128 tile instance
+    dict(B=128, cin=48, cout=128, W=128),                                  # ... and its general form (3 stages)
+    dict(B=8, cin=512, cin1=512, cout=512, W=32, residual=True),           # up path: skip concat (two inputs), residual
+    dict(B=16, cin=1024, cout=2048, W=16, G=1),                            # deepest level: 16-wide rows
+    dict(B=3, cin=48, cout=160, W=64, G=1),                                # Cin = 3 stages (odd: the general form), ragged Cout (128 + 32)
+    dict(B=2, cin=32, cout=96, W=256, residual=True),                      # 2 stages, rows longer than a tile, ragged Cout
+    dict(B=4, cin=16, cin1=32, cout=64, W=128),                            # 3 stages over two inputs
+])
+def test_conv1d_f23_default_mode(plan_cls, case):
+    """Conv1d k3 on the default (precision 4) path: F(2,3) along W, `conv_wg_kernel` -- its single-tap specialisation (even stage
+    counts: gather offsets and padding mask formed once, compile-time LDS buffers, no zeroing of weight rows beyond Cout) and the
+    general form (odd stage counts) against fp64; GroupNorm statistics from the epilogue normalise like torch."""
+    from safediffcon_amd.engine import as5
+    B, cin, cin1, cout, W, G = case["B"], case["cin"], case.get("cin1", 0), case["cout"], case["W"], case.get("G", 0)
+    x, x1 = det_tensor((B, cin, W), 411), (det_tensor((B, cin1, W), 412) if cin1 else None)
+    w, b = det_tensor((cout, cin + cin1, 3), 413, 0.2 / (cin + cin1) ** 0.5 * 8), det_tensor((cout,), 414, 0.1)
+    xin = x if x1 is None else torch.cat((x, x1), 1)
+    ref = F.conv1d(xin.double(), w.double(), b.double(), padding=1)
+    res = det_tensor(tuple(ref.shape), 415) if case.get("residual") else None
+    if res is not None:
+        ref = ref + res.double()
+    plan = plan_cls(DEV, precision=4)
+    out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, (1, 1, 3),
+                    x1=None if x1 is None else as5(x1.to(DEV)), pad=(0, 0, 1), residual=None if res is None else as5(res.to(DEV)),
+                    gn_groups=G)
+    buf, share = C.create_string_buffer(128), C.c_double(0)
+    assert plan.lib.sdc_conv_describe(C.byref(plan.calls[0][1][0]._obj), buf, 128, C.byref(share)) == 0
+    assert buf.value.decode().startswith("conv_wg_kernel") and abs(share.value - 2 / 3) < 1e-12, buf.value
+    if G:
+        gam, bet = 1 + 0.3 * det_tensor((cout,), 416), 0.2 * det_tensor((cout,), 417)
+        y = plan.pool.get(tuple(out.shape))
+        plan.gn_silu(out, gam.to(DEV), bet.to(DEV), G, out=y)
+    _run(plan)
+    e = (out.cpu().reshape(ref.shape).double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"[measured] conv1d {buf.value.decode()} {case}: rel err vs fp64 {e:.2e}")
+    assert e < 3e-6, e
+    if G:
+        want = F.silu(F.group_norm(ref, G, gam.double(), bet.double(), eps=1e-5))
+        assert (y.cpu().reshape(want.shape).double() - want).abs().max().item() < 2e-5
