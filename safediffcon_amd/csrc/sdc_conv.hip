@@ -362,8 +362,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void co
     const SdcConvDesc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int n0 = xcd_tile(blockIdx.x, gridDim.x) * BN;
-    const int m0 = blockIdx.y * BM;
+    // one-dimensional grid, m fastest among the logical ids an XCD runs back to back: the m-tiles of a position tile (3 for the
+    // 128 -> 384 q/k/v projections) read the same activation tile -- dispatched a whole grid row apart (blockIdx.y = m) every one
+    // of them fetched it from HBM again (PMC: 1.5 x the algorithmic bytes)
+    const int MT = (d.Cout + BM - 1) / BM;
+    const int lb = xcd_tile(blockIdx.x, gridDim.x);
+    const int n0 = (lb / MT) * BN;
+    const int m0 = (lb % MT) * BM;
     const int64_t S = (int64_t)d.oD * d.oH * d.oW;
 
     // per-thread constant parts of the addresses (bytes): (row of the chunk) * channel stride + position offset
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void co
 
 template <int BM, int BN, int WM, int WN>
 void launch_pw(const ConvArgs& a, hipStream_t s) {
-    dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
+    dim3 grid(((a.Ntot + BN - 1) / BN) * ((a.d.Cout + BM - 1) / BM));
     hipLaunchKernelGGL((conv_pw_kernel<BM, BN, WM, WN>), grid, dim3(NT), 0, s, a);
 }
 
