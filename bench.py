@@ -43,6 +43,17 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 T_DDPM = 1000
 DEFAULT_B = {"c2": 256, "c3": 128, "c4": 64}
+# `extra` lines of the N = 1 run: key -> (workload, U-Net dim (0 = the BASELINE width), batch, why it is there)
+EXTRA_WORKLOADS = {
+    "c2": ("c2", 0, 256, "BASELINE configs[1]"),
+    "c3": ("c3", 0, 128, "BASELINE configs[2]"),
+    "c4": ("c4", 0, 64, "BASELINE configs[3]"),
+    "c2_turbo": ("c2", 128, 256, "configs[1] with the only shipped-checkpoint net, Unet2D dim 128 (1D/configs/inference_config.py:125-134)"),
+    "c3_turbo": ("c3", 128, 128, "configs[2] with Unet1D dim 128 (tokamak/configs/inference_config.py:118-141 'turbo')"),
+    "c3_small": ("c3", 64, 128, "configs[2] with Unet1D dim 64 (tokamak/configs/inference_config.py:76, the default)"),
+    "c2_shard8": ("c2", 0, 32, "per-rank batch of configs[1] sharded over 8 GPUs (SURVEY 8e)"),
+    "c3_shard8": ("c3", 0, 16, "per-rank batch of configs[2] sharded over 8 GPUs (SURVEY 8e)"),
+}
 PMC_FILES = ("r4_pmc_traffic.json",)      # stamped with the kernel-source hash they were collected on (tools/pmc_to_json.py)
 
 
@@ -757,23 +768,39 @@ def worker(a):
                 "projected_seconds_per_full_pass": round(W["cal_batches"] * T_DDPM * msc / 1e3, 1),
                 "score_allgather_quantile_ms": round(tq * 1e3, 3), "Q_on_partial_trajectories": round(Qc, 6)}
             del pred
-            # the other single-GPU BASELINE configs, a few steps each through the same harness
-            for other in [w for w in ("c2", "c3", "c4") if w != wl and w in a.extra_workloads.split(",")]:
-                W2 = workload(other, 0, DEFAULT_B[other], dev, rank, world, prec)
+            # the other single-GPU BASELINE configs, the widths the reference ships besides them (Unet2D dim 128 "turbo",
+            # 1D/configs/inference_config.py:125-134; Unet1D dim 128 / 64, tokamak/configs/inference_config.py:118-141, :76) and the
+            # per-rank batches of an 8-way shard of the 1-D configs ("weight re-reads dominate -- report it"), a few
+            # steps each through the same harness
+            for key in [w for w in a.extra_workloads.split(",") if w and w != wl]:
+                if key not in EXTRA_WORKLOADS:
+                    raise SystemExit(f"--extra-workloads: unknown entry {key!r} (known: {sorted(EXTRA_WORKLOADS)})")
+                other, dim2, B2, why = EXTRA_WORKLOADS[key]
+                W2 = workload(other, dim2, B2, dev, rank, world, prec, cal_steps=(a.cal_steps if key in ("c2", "c3", "c4") else 0))
                 S2 = W2["prep"]()
                 S2.init()
                 dt2 = timed(S2, 3, a.extra_steps)
                 ok2 = bool(torch.isfinite(S2.x).all().item())
-                # the dominant kernel of this workload against its roofline, like the headline's (PMC traffic: profiles/r4_pmc_traffic.json)
+                # the dominant kernel of this workload against its roofline, like the headline's (PMC traffic: profiles/r*_pmc_traffic.json)
                 r2 = build_roofline(S2, lib, side.cuda_stream, dt2 / a.extra_steps * 1e3, other)
                 S2.close()
-                extra[other] = {"workload": W2["desc"], "batch": DEFAULT_B[other], "steps": a.extra_steps,
-                                "ms_per_step": round(dt2 / a.extra_steps * 1e3, 4),
-                                "value": round(DEFAULT_B[other] / (T_DDPM * dt2 / a.extra_steps), 4), "unit": "trajectories/s", "finite": ok2,
-                                "roofline": {k: r2[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "effective_tflops",
-                                                                "traffic", "traffic_source", "algorithmic_bytes_per_launch",
-                                                                "launches_per_step", "avg_launch_ms", "share_of_step")}}
+                ms2 = dt2 / a.extra_steps * 1e3
+                wbytes = 4 * sum(p_.numel() for p_ in W2["gd"].model.parameters())
+                extra[key] = {"workload": W2["desc"], "why": why, "batch": B2, "steps": a.extra_steps,
+                              "ms_per_step": round(ms2, 4), "ms_per_trajectory_step": round(ms2 / B2, 5),
+                              "value": round(B2 / (T_DDPM * dt2 / a.extra_steps), 4), "unit": "trajectories/s", "finite": ok2,
+                              # reading every weight once per step at the 8 TB/s HBM peak, as a share of the measured step: what a
+                              # weight-bandwidth-bound step would show as ~1 (the packed Winograd taps are 16/9 - 64/27 x larger)
+                              "weights_mb": round(wbytes / 1e6, 1),
+                              "weight_read_share_of_step_at_hbm_peak": round(wbytes / 8e12 / (ms2 * 1e-3), 4),
+                              "roofline": {k: r2[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "effective_tflops",
+                                                              "traffic", "traffic_source", "algorithmic_bytes_per_launch",
+                                                              "launches_per_step", "avg_launch_ms", "share_of_step")},
+                              "stages": r2["stages"], "all_kernels": r2["all_kernels"] if key not in ("c2", "c3", "c4") else None}
+                if extra[key]["all_kernels"] is None:
+                    del extra[key]["all_kernels"]
                 del W2, S2
+                torch.cuda.empty_cache()
             if a.other_precisions:
                 def other_prec(mode):
                     W["gd"].model.precision = mode
@@ -918,7 +945,8 @@ def main():
                     help="conv arithmetic: fp32 MFMA with Winograd F(2x2x2,3x3x3) / F(2x2,3x3) / F(2,3) on the 3-tap convs (default), "
                          "without the depth transform, F(2,3) along W only, or the fp32 direct form everywhere")
     ap.add_argument("--no-extra", action="store_true", help="skip the calibration sample and the other workloads at N=1")
-    ap.add_argument("--extra-workloads", default="c2,c3", help="other configs reported under `extra` at N=1")
+    ap.add_argument("--extra-workloads", default="c2,c3,c2_turbo,c3_turbo,c3_small,c2_shard8,c3_shard8",
+                    help="other configs reported under `extra` at N=1 (keys of EXTRA_WORKLOADS)")
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--cal-steps", type=int, default=5)
     ap.add_argument("--other-precisions", action="store_true", help="also time precision 0 / 3 on the headline workload")

@@ -137,7 +137,7 @@ int sdc_gn_apply(const float* x, const float* stats, const float* gamma, const f
                  const int32_t* t_dev, int64_t ss_t_stride, int64_t ss_b_stride, int64_t ss_off,
                  const float* residual, float* y, int B, int C, int G, int64_t S, void* stream);
 
-/* GroupNorm statistics + apply in ONE launch for small groups (sdc_gn_fused_ok: (C/G)*S <= 32768, B*G >= 64): the deep levels
+/* GroupNorm statistics + apply in ONE launch for small groups (sdc_gn_fused_ok: (C/G)*S <= 32768, whatever the batch): the deep levels
  * of Unet2D / Unet1D, 1D/model/unet.py:128-147.  Arguments as sdc_gn_apply (fp64 statistics like sdc_gn_stats). */
 int sdc_gn_fused_ok(int B, int C, int G, int64_t S);
 int sdc_gn_fused(const float* x, const float* gamma, const float* beta, const float* ss, const int32_t* t_dev,
@@ -371,6 +371,17 @@ int sdc_act_bwd(const float* x, const float* gy, float* gx, int64_t n, int kind,
 
 /* VJP of nearest-neighbour upsampling by (fh, fw) in {1,2}^2 over the last two axes: gx (rows,H,W) from g (rows,H*fh,W*fw) */
 int sdc_sumpool2(const float* g, float* gx, int64_t rows, int H, int W, int fh, int fw, void* stream);
+
+/* ------------------------------------------------- weight content stamp */
+/* out_dev[0] = order-independent 64-bit checksum over n device spans of 32-bit words (span index, word index and bits all
+ * enter it).  The host wrapper stamps a plan's packed weights with it: `p.data.lerp_()` / `p.data = ...` (the reference's EMA
+ * updates, 2d/video_diffusion_pytorch/video_diffusion_pytorch_conv3d.py:121-124; ema_pytorch in 1D/model/trainer.py,
+ * tokamak/model/trainer.py) change the parameters without moving any autograd version counter.  spans_dev, out_dev: device memory. */
+typedef struct {
+    const void* ptr;          /* 4-byte aligned device address */
+    int64_t nwords;           /* 32-bit words */
+} SdcSpan;
+int sdc_checksum_spans(const SdcSpan* spans_dev, int n, uint64_t* out_dev, void* stream);
 
 /* ----------------------------------------------------------------- graphs */
 int sdc_graph_begin(void* stream);

@@ -511,6 +511,32 @@ def gen_wide(which):
         save("smoke_unet_wide", dim=64, x_seed=311, t=t, eps=eps, weight_seed=310, **spec_arrays(spec))
 
 
+def gen_turbo(which):
+    """The widths the reference ships configurations for besides the BASELINE ones: 1D `Unet2D(dim=128)` --
+    "turbo", the only shipped-checkpoint config (1D/configs/inference_config.py:125-134) -- and tokamak `Unet1D(dim=128)`
+    (turbo, tokamak/configs/inference_config.py:118-141) / `Unet1D(dim=64)` (the default, :76).  One eps per width through
+    the REAL reference; inputs are det_tensor(seed) (regenerated by the tests), only eps is stored."""
+    if which == "burgers":
+        sys.path.insert(0, os.path.join(REF, "1D"))
+        from model.unet import Unet2D
+        net = Unet2D(dim=128, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+        spec = load_det(net, seed=120)
+        x, t = det_tensor((2, 3, 16, 128), 121), torch.tensor([17, 903])
+        with torch.no_grad():
+            eps = net(x, t)
+        save("burgers_unet_turbo", dim=128, x_seed=121, t=t, eps=eps, weight_seed=120, **spec_arrays(spec))
+    else:
+        sys.path.insert(0, os.path.join(REF, "tokamak"))
+        from model.unet import Unet1D
+        for name, dim, ws in (("tokamak_unet_turbo", 128, 220), ("tokamak_unet_small", 64, 230)):
+            net = Unet1D(dim=dim, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+            spec = load_det(net, seed=ws)
+            x, t = det_tensor((2, 12, 128), ws + 1), torch.tensor([5, 512])
+            with torch.no_grad():
+                eps = net(x, t)
+            save(name, dim=dim, x_seed=ws + 1, t=t, eps=eps, weight_seed=ws, **spec_arrays(spec))
+
+
 def gen_long(which):
     """One FULL-SCHEDULE (T = 1000) guided DDPM trajectory per tree through the REAL reference at dim 8: the real 1000-entry
     coefficient tables are walked end to end (posterior_log_variance clamp at t = 0, sqrt_recipm1 at t = 999), the conditioning
@@ -651,11 +677,13 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which == "all":
-        for w in ("burgers", "tokamak", "smoke", "burgers_wide", "tokamak_wide", "smoke_wide", "burgers_long", "tokamak_long",
+        for w in ("burgers", "tokamak", "smoke", "burgers_wide", "tokamak_wide", "smoke_wide", "burgers_turbo", "tokamak_turbo", "burgers_long", "tokamak_long",
                   "smoke_long", "burgers_grad", "tokamak_grad", "smoke_grad"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     elif which.endswith("_wide"):
         gen_wide(which[:-5])
+    elif which.endswith("_turbo"):
+        gen_turbo(which[:-6])
     elif which.endswith("_long"):
         gen_long(which[:-5])
     elif which.endswith("_grad"):

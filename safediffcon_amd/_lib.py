@@ -42,6 +42,10 @@ class SdcPackItem(C.Structure):
         ("tap_magic", C.c_uint32), ("_pad", C.c_int32), ("n", C.c_int64 * 5)]
 
 
+class SdcSpan(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("nwords", C.c_int64)]
+
+
 class SdcKstarMlp(C.Structure):
     _fields_ = [("nlayers", C.c_int32), ("width", C.c_int32 * 7), ("act", C.c_int32 * 6), ("params", C.c_void_p), ("stride", C.c_int64)]
 
@@ -119,6 +123,7 @@ SIGNATURES = {
     "sdc_smoke_rollout": (C.c_int, [_f32p, _f32p, _i64, _i64, _f32p, _i64, _f32p, _i64, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _stream]),
+    "sdc_checksum_spans": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _stream]),
     "sdc_graph_begin": (C.c_int, [_stream]),
     "sdc_graph_end": (C.c_int, [_stream, C.POINTER(C.c_void_p)]),
     "sdc_graph_launch": (C.c_int, [C.c_void_p, _stream]),

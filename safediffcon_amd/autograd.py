@@ -25,6 +25,8 @@ import ctypes as C
 import functools
 import math
 
+import threading
+
 import torch
 from torch.autograd import Function
 
@@ -99,7 +101,13 @@ def _transposed_422(x, w, bias, cout):
     return out
 
 
-_ARENA = [None]          # the PackArena of the net whose training forward is being recorded (Trainer.step)
+class _ArenaSlot(threading.local):
+    """the PackArena of the net whose training forward is being recorded (Trainer.step) -- per thread: two nets trained from two
+    host threads must not see each other's arena (the backward of a recorded graph carries its arena in ctx, not in this slot)"""
+    cur = None
+
+
+_ARENA = _ArenaSlot()
 
 
 class ConvFn(Function):
@@ -117,7 +125,7 @@ class ConvFn(Function):
         ctx.has_bias = b is not None
         bb = None if b is None else b.detach().contiguous()
         wd = w.detach()
-        ctx.arena = arena = _ARENA[0] if (_ARENA[0] is not None and grad_ops.PackArena.cacheable(w)) else None
+        ctx.arena = arena = _ARENA.cur if (_ARENA.cur is not None and grad_ops.PackArena.cacheable(w)) else None
         if kind == "conv":
             return conv_raw(x, grad_ops.pack_conv_weight(wd, prec, arena=arena), bb, w.shape[0], _k5(w), x1=x1, stride=stride, pad=pad, up=up)
         if kind == "convT422":
@@ -310,11 +318,11 @@ class Trainer:
     def step(self, device):
         """one training forward: every packed conv weight refreshed by one launch, conv nodes bound to this net's arena"""
         self.arena.begin(device)
-        prev, _ARENA[0] = _ARENA[0], self.arena
+        prev, _ARENA.cur = _ARENA.cur, self.arena
         try:
             yield
         finally:
-            _ARENA[0] = prev
+            _ARENA.cur = prev
 
     def P(self, key):
         return self.net.P(key)

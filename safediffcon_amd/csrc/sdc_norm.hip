@@ -600,9 +600,12 @@ extern "C" int sdc_chan_norm(const float* x, const float* g, const float* residu
     // 64-position tiles for long rows only; shorter rows take the 16-lane form (more, smaller workgroups: those launches
     // are latency-bound, not bandwidth-bound).  The choice depends on the row length alone, never on the batch, so a
     // trajectory's rounding does not depend on how many others share the launch.
-    const bool al16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
-    if (S >= 1024 && S % 4 == 0 && al16 && C <= 512) {
-        // (row length and width alone decide, never the batch)
+    if (S >= 1024 && S % 4 == 0 && C <= 512) {
+        // (row length and width alone decide, never the batch -- and never the buffer address: the vector form sums in another
+        // order for C > 128, so a fallback on misaligned pointers would make a trajectory's rounding depend on where the pool
+        // placed its buffers; rows of S % 4 == 0 floats must therefore start 16-byte aligned)
+        const bool al16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
+        SDC_REQUIRE(al16, SDC_EALIGN, "sdc_chan_norm: x, y and residual must be 16-byte aligned when S >= 1024, S %% 4 == 0 and C <= 512");
         const int64_t S4 = S / 4;
         if (C <= 128)
             hipLaunchKernelGGL((chan_norm_vec_kernel<64>), dim3((unsigned)((S4 + 63) / 64), B), dim3(NT), 0, sdc::as_stream(stream), x, g, residual, y, C, S, mode, eps);

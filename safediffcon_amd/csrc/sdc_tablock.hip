@@ -307,9 +307,18 @@ extern "C" int sdc_tattn_block(const float* x, const float* g_pre, const float* 
     static std::atomic<uint64_t> attr{0};
     SDC_LDS_OPTIN(attr, ta_block_kernel, 160 * 1024, "sdc_tattn_block");
     // one persistent workgroup per CU (157 KB of LDS: one fits), at most one per pixel group
-    int dev = 0, ncu = 256;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    // (the CU count of a device is queried once, like the LDS opt-in: no runtime query per launch, no guessed grid)
+    static std::atomic<int> ncu_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { sdc::set_error("sdc_tattn_block: hipGetDevice failed"); return SDC_EHIP; }
+    int ncu = ncu_of[dev].load(std::memory_order_acquire);
+    if (ncu <= 0) {
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) {
+            sdc::set_error("sdc_tattn_block: cannot read the CU count of device %d", dev);
+            return SDC_EHIP;
+        }
+        ncu_of[dev].store(ncu, std::memory_order_release);
+    }
     const unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);
     hipLaunchKernelGGL(ta_block_kernel, dim3(grid), dim3(NT), ldsb, sdc::as_stream(stream), a);
     return sdc::check_launch("sdc_tattn_block");

@@ -124,10 +124,11 @@ class Plan:
         self.device = torch.device(device)
         self.lib = _lib.get_lib()
         # conv algorithm (include/sdc.h): 0 direct fp32 MFMA | 2 fp32 Winograd F(2,3) along W | 3 F(2x2,3x3) over (H, W) where
-        # covered, else as 2 | 4 (default of the nets) F(2x2x2,3x3x3) over (D, H, W) where covered, else as 3
+        # covered, else as 2 | 4 (default of the nets) F(2x2x2,3x3x3) over (D, H, W) where covered, else as 3 | 5 (opt-in) as 4,
+        # with F(4,3) along W for the (1,1,3) convs (Conv1d k3: half the direct MFMA work at 3x the rounding error)
         self.precision = int(precision)
         if self.precision not in (0, 2, 3, 4, 5):
-            raise ValueError(f"precision must be 0, 2, 3 or 4 (got {precision})")
+            raise ValueError(f"precision must be 0, 2, 3, 4 or 5 (got {precision})")
         self.calls = []          # (fn, args, keepalive)
         self.pool = Pool(self.device)
         self.keep = []           # descriptors / tensors that must outlive the plan

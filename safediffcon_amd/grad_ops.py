@@ -247,8 +247,13 @@ class PackArena:
         self.fresh = False
         if self.table is not None:
             n, nb, lds = self.launch
-            check(_lib.get_lib().sdc_pack_batch_run(self.table.data_ptr(), n, nb, lds, torch.cuda.current_stream(device).cuda_stream),
-                  "sdc_pack_batch_run")
+            cur = torch.cuda.current_stream(device)
+            # the buffer may have been allocated under another stream (the sampler's private one in the differentiable last DDIM
+            # step, the default one in p_losses): tell the allocator about every stream that packs or reads it, so that a later
+            # _rebuild cannot hand its memory out while this stream's work is pending
+            self.buf.record_stream(cur)
+            self.table.record_stream(cur)
+            check(_lib.get_lib().sdc_pack_batch_run(self.table.data_ptr(), n, nb, lds, cur.cuda_stream), "sdc_pack_batch_run")
             self.fresh = True
 
     def get(self, w5, precision, flip):
@@ -257,6 +262,7 @@ class PackArena:
         ent = self.index.get(k)
         if ent is not None and self.fresh and self.buf.device == w5.device:
             self.used.add(k)
+            self.buf.record_stream(torch.cuda.current_stream(w5.device))
             return self.buf[ent[0]:ent[0] + ent[1]]
         if k not in self.meta:
             self.pending[k] = (w5, int(precision), bool(flip))

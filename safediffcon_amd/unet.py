@@ -17,7 +17,7 @@ import os
 import torch
 from torch import nn
 
-from ._lib import check
+from ._lib import check, get_lib
 from .engine import Plan, as5
 
 HEADS, DIM_HEAD = 4, 32
@@ -271,6 +271,9 @@ class _HipUNet(nn.Module):
         # smoke net: the ResnetBlock in front of a fused LinearAttention block hands it its raw conv output; GroupNorm + SiLU +
         # residual add happen on the attention kernels' tile loads (False = a separate sdc_gn_apply pass, for A/B checks)
         self.fuse_gn_into_linattn = True
+        # entry() compares a device checksum of the parameters with the packed plan's (sees `.data` writes; one small launch +
+        # an 8-byte read-back per forward / sample call, never inside the graph-replayed loop)
+        self.content_stamp = True
         # nearest-x2 upsample + 3x3 conv as four sub-pixel 2x2 convs with merged taps (4/9 of the multiply-adds; the merged
         # weights change the summation order by ~1e-7 relative); False = one conv with the upsampling folded into its gather
         self.subpixel_upsample = True
@@ -340,14 +343,39 @@ class _HipUNet(nn.Module):
         self.refresh()
         return r
 
+    def _stamp_tensors(self):
+        return [t for t in list(self.parameters()) + list(self.buffers()) if t.is_cuda and t.numel() and t.element_size() == 4]
+
+    def _content_stamp(self):
+        """64-bit checksum of every parameter and buffer as they are in device memory now (`sdc_checksum_spans`: one launch,
+        one 8-byte read-back).  The only stamp that sees writes made behind autograd's back: `p.data.copy_()` / `p.data.lerp_()`
+        (ema_pytorch, used by 1D/model/trainer.py and tokamak/model/trainer.py) bump no version counter, and `p.data = ...`
+        (the 2-D tree's EMA, video_diffusion_pytorch_conv3d.py:121-124) leaves `_version` at 0 while the allocator hands the
+        same two addresses back in turn."""
+        ts = self._stamp_tensors()
+        if not ts:
+            return 0
+        from ._lib import SdcSpan
+        dev = ts[0].device
+        key = tuple((t.data_ptr(), t.numel()) for t in ts)
+        tab = getattr(self, "_span_tab", None)
+        if tab is None or tab[0] != key:
+            arr = (SdcSpan * len(ts))(*[SdcSpan(t.data_ptr(), t.numel()) for t in ts])
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            tab = self._span_tab = (key, host.to(dev), torch.zeros(1, dtype=torch.int64, device=dev))
+        lib = get_lib()
+        check(lib.sdc_checksum_spans(tab[1].data_ptr(), len(ts), tab[2].data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+              "sdc_checksum_spans")
+        return int(tab[2].item())
+
     def _weights_stamp(self):
-        """changes whenever a parameter is written in place (optimizer.step, load_state_dict, p.data.copy_: the autograd
-        version counters only grow) or re-seated (p.data = ...)"""
-        v, h = 0, 0
-        for p in self.parameters():
-            v += p._version
-            h ^= p.data_ptr()
-        return (v, h)
+        """(cheap host part, content part).  The host part -- every parameter's (address, autograd version) -- moves on
+        optimizer.step(), load_state_dict and re-seating to a new address; the content part (`content_stamp`, default on) also
+        catches the writes the host part cannot see (see `_content_stamp`).  With `content_stamp = False` a caller that writes
+        through `.data` must call `refresh()` itself."""
+        host = hash(tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        dev = next(self.parameters()).device
+        return (host, self._content_stamp() if (self.content_stamp and dev.type == "cuda") else 0)
 
     def _refresh_entry(self, e, stamp):
         e["plan"].refresh_weights()
@@ -356,10 +384,11 @@ class _HipUNet(nn.Module):
         e["wstamp"] = stamp
 
     def refresh(self):
-        """Re-pack weights of every cached plan now.  Optional: `entry()` -- hence `forward`, `sample` and the fine-tuning
-        path -- re-packs a plan by itself when the parameters have changed since it was packed (the reference's loops
-        call optimizer.step() and sample again without any such call: 1D/inference/inference_ft.py:183-187,
-        tokamak/inference/pipeline.py:238-263, 2d/inference_2d.py:267-279)."""
+        """Re-pack weights of every cached plan now.  Optional while `content_stamp` is on (the default): `entry()` -- hence
+        `forward`, `sample` and the fine-tuning path -- compares a content checksum of the parameters with the one taken when a
+        plan packed them and re-packs by itself (the reference's loops call optimizer.step() / ema.update() and sample again
+        without any such call: 1D/inference/inference_ft.py:183-187, tokamak/inference/pipeline.py:238-263,
+        2d/inference_2d.py:267-279).  Mandatory after `.data` writes when `content_stamp` has been switched off."""
         stamp = self._weights_stamp()
         for e in self._plans.values():
             self._refresh_entry(e, stamp)
