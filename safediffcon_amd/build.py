@@ -7,6 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsdc_hip.so")
 SOURCES = ["sdc_api.hip", "sdc_conv.hip", "sdc_conv_wino.hip", "sdc_norm.hip", "sdc_attn.hip", "sdc_lablock.hip", "sdc_tablock.hip", "sdc_step.hip", "sdc_solver.hip", "sdc_grad.hip", "sdc_attn_bwd.hip", "sdc_kstar.hip", "sdc_smoke.hip"]
+HEADERS = ["sdc_common.h", "sdc_conv.h", "sdc_conv_wino3s.inc"]      # csrc files the translation units include
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -16,7 +17,7 @@ def source_hash():
     bench.py can tell a record collected on other kernels from a current one (no git on the GPU box)"""
     import hashlib
     h = hashlib.sha256()
-    for f in SOURCES + ["sdc_common.h", "sdc_conv.h"]:
+    for f in SOURCES + HEADERS:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     with open(os.path.join(HERE, "..", "include", "sdc.h"), "rb") as fh:
@@ -45,7 +46,7 @@ def build_experiments(verbose=True):
 def build(force=False, verbose=True, jobs=4):
     """compile the translation units (up to `jobs` hipcc processes at a time) and link libsdc_hip.so"""
     from concurrent.futures import ThreadPoolExecutor
-    hdrs = [os.path.join(CSRC, "sdc_common.h"), os.path.join(CSRC, "sdc_conv.h"), os.path.join(HERE, "..", "include", "sdc.h")]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(HERE, "..", "include", "sdc.h")]
     objs, todo = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

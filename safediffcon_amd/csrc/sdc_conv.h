@@ -72,6 +72,7 @@ constexpr int W2_BM = 64;         // output channels per workgroup
 constexpr int W2_TILES = 64;      // 2x2 tiles per workgroup
 constexpr int W2_NBUF = 2;        // LDS stage buffers
 constexpr int W2_ASZ = 16 * W2_SK * W2_BM, W2_BSZ = 16 * W2_SK * W2_TILES;    // floats per stage: U tile, V tile
+constexpr int W3S_TILES = 32;     // 2x2 tiles per workgroup of conv_wg3s_kernel (two workgroups per CU)
 
 inline int64_t span5(const int64_t* st, int b, int c, int dd, int h, int w) {
     return (int64_t)(b - 1) * st[0] + (int64_t)(c - 1) * st[1] + (int64_t)(dd - 1) * st[2] + (int64_t)(h - 1) * st[3] + (int64_t)(w - 1) * st[4];
@@ -82,5 +83,7 @@ bool wg2_ok(const SdcConvDesc& d, bool small, bool rowhalo);
 bool wg3_ok(const SdcConvDesc& d, bool small, bool rowhalo);
 int launch_wg2(const ConvArgs& a, hipStream_t s);
 int launch_wg3(const ConvArgs& a, hipStream_t s);
+bool wg3s_ok(const SdcConvDesc& d, bool small, bool rowhalo);
+int launch_wg3s(const ConvArgs& a, hipStream_t s);
 
 }  // namespace sdcconv

@@ -1665,6 +1665,8 @@ extern "C" int sdc_conv_gnparts(const SdcConvDesc* dp, int G) {
     const int64_t ntot = (int64_t)dp->B * dp->oD * dp->oH * dp->oW;
     static const int no_wg2 = exp_env("SDC_NO_WG2");
     static const int no_wg3 = exp_env("SDC_NO_WG3");
+    static const int old_wg3 = exp_env("SDC_WG3_OLD");
+    if (!no_wg2 && !no_wg3 && !old_wg3 && wg3s_ok(*dp, conv_small(*dp), !no_rh)) return gn_parts_for(*dp, WgPick{22, W2_BM, W3S_TILES * 8, false}, G);
     if (!no_wg2 && !no_wg3 && wg3_ok(*dp, conv_small(*dp), !no_rh)) return gn_parts_for(*dp, WgPick{21, W2_BM, W2_TILES * 8, false}, G);
     if (!no_wg2 && wg2_ok(*dp, conv_small(*dp), !no_rh)) return gn_parts_for(*dp, WgPick{20, W2_BM, W2_TILES * 4, false}, G);
     return gn_parts_for(*dp, wg_pick(*dp, ntot, conv_small(*dp), !no_rh), G);
@@ -1746,7 +1748,24 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
     auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
     static const int no_wg2 = exp_env("SDC_NO_WG2");
     static const int no_wg3 = exp_env("SDC_NO_WG3");
-    // fp32 Winograd F(2x2x2,3x3x3): 3x3x3 stride-1 convs over whole rows, plane pairs
+    // fp32 Winograd F(2x2x2,3x3x3), two workgroups per CU (round 5): 3x3x3 stride-1 convs over whole rows, plane pairs
+    static const int old_wg3 = exp_env("SDC_WG3_OLD");
+    if (!no_wg2 && !no_wg3 && !old_wg3 && wg3s_ok(d, small, a.rowhalo != 0) && reinterpret_cast<uintptr_t>(wp) % 16 == 0 &&
+        reinterpret_cast<uintptr_t>(x0) % 16 == 0 && (d.Cin1 == 0 || reinterpret_cast<uintptr_t>(x1) % 16 == 0) &&
+        reinterpret_cast<uintptr_t>(y) % 8 == 0 && !residual) {
+        a.vec2 = 1;
+        a.wg2 = wp + (int64_t)a.Ktot * d.Cout + (int64_t)(a.Ktot / 3 * 4) * d.Cout + (int64_t)(a.Ktot / 9 * 16) * d.Cout;
+        if (gn_part) {
+            a.gn_nparts = gn_parts_for(d, WgPick{22, W2_BM, W3S_TILES * 8, false}, gn_G);
+            SDC_REQUIRE(a.gn_nparts > 0, SDC_EINVAL, "sdc_conv_gn: shape not covered by the fused statistics (sdc_conv_gnparts returned 0)");
+            SDC_GN_PARTS_AGREE(a.gn_nparts);
+            a.gn_part = gn_part; a.gn_G = gn_G; a.gn_cpg = d.Cout / gn_G; a.gn_S = d.oD * d.oH * d.oW;
+        }
+        SDC_PICK(d.oW == 16 ? "conv_wg3s_kernel<16>" : (d.oW == 32 ? "conv_wg3s_kernel<32>" : "conv_wg3s_kernel<64>"), 8.0 / 27.0);
+        { const int rc_ = launch_wg3s(a, s); if (rc_) return rc_; }
+        return sdc::check_launch("sdc_conv[winograd 2x2x2, two workgroups per CU]");
+    }
+    // fp32 Winograd F(2x2x2,3x3x3), one workgroup per CU: the shapes the form above does not take
     if (!no_wg2 && !no_wg3 && wg3_ok(d, small, a.rowhalo != 0) && reinterpret_cast<uintptr_t>(wp) % 16 == 0 &&
         reinterpret_cast<uintptr_t>(x0) % 16 == 0 && (d.Cin1 == 0 || reinterpret_cast<uintptr_t>(x1) % 16 == 0) &&
         reinterpret_cast<uintptr_t>(y) % 8 == 0 && !residual) {

@@ -1072,6 +1072,8 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
     }
 }
 
+#include "sdc_conv_wino3s.inc"
+
 }  // namespace
 
 // coverage of the F(2x2x2,3x3x3) kernel (precision 4): the F(2x2,3x3) shapes with kD = 3, an even depth, whole 64-channel
@@ -1119,6 +1121,63 @@ int launch_wg3(const ConvArgs& a, hipStream_t s) {
     if (d.oW == 16) W3_LAUNCH(16, 0);
     else if (d.oW == 32) W3_LAUNCH(32, 0);
     else W3_LAUNCH(64, 0);
+    return SDC_OK;
+}
+
+// coverage of conv_wg3s_kernel (the two-workgroups-per-CU form of the F(2x2x2,3x3x3) kernel): what conv_wg3_kernel takes with 32
+// instead of 64 tiles per workgroup, and one channel stride for both inputs (the lane offsets of the gather are stage-invariant)
+bool wg3s_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
+    auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
+    // Where it is the faster of the two forms (same-box A/B at C4, B = 64, profiles/r5_ab_wg3s.log): rows of 64 (64 -> 64: 5.88 ->
+    // 5.58 ms, 64 + 64 -> 64: 10.30 -> 9.90) and rows of 32 with <= 64 input channels (64 -> 128: 2.85 -> 2.73).  With long K the
+    // one-workgroup form amortises its folds and cold start and keeps its advantage of half the operand traffic per MFMA
+    // (128 -> 128 @ 32: 5.12 / 5.07, 256 -> 256 @ 16: 4.78 / 4.93, 256 + 256 -> 128: 4.67 / 4.89).
+    static const int all = exp_env("SDC_WG3S_ALL");
+    const int cin = d.Cin0 + d.Cin1;
+    if (!(d.precision >= 4 && d.kD == 3 && d.oD % 2 == 0 && d.Cout % W2_BM == 0 &&
+          (d.oW == 64 || (d.oW == 32 && (cin <= 64 || all)) || (d.oW == 16 && all)))) return false;
+    SdcConvDesc e = d;
+    e.precision = 3;
+    if (!wg2_ok(e, small, rowhalo)) return false;
+    const int rp = W3S_TILES / (d.oW / 2);
+    const bool nores = d.rs[0] == 0 && d.rs[1] == 0 && d.rs[2] == 0 && d.rs[3] == 0 && d.rs[4] == 0;
+    const int64_t tiles = (int64_t)d.B * (d.oD / 2) * (d.oH / 2) * (d.oW / 2);
+    return (d.oH / 2) % rp == 0 && even(d.ys) && nores && (d.Cin1 == 0 || (d.x1s[1] == d.x0s[1] && d.x1s[2] == d.x0s[2])) && tiles / W3S_TILES * (d.Cout / W2_BM) < (1ll << 31) &&
+           // the park lanes add up to 3 channel strides to their 32-bit byte offset
+           span5(d.x0s, 1, 1, 1, d.iH, d.iW) + 3 * d.x0s[1] < (1ll << 29);
+}
+
+int launch_wg3s(const ConvArgs& a, hipStream_t s) {
+    const SdcConvDesc& d = a.d;
+    const int64_t tiles = (int64_t)d.B * (d.oD / 2) * (d.oH / 2) * (d.oW / 2);
+    dim3 grid((unsigned)((tiles / W3S_TILES) * (d.Cout / W2_BM)));
+#define W3S_LAUNCH(OWV, D)                                                                                                       \
+    do {                                                                                                                         \
+        static std::atomic<uint64_t> attr{0};                                                                                    \
+        SDC_LDS_OPTIN(attr, (conv_wg3s_kernel<OWV, D>), 80 * 1024, "sdc_conv[winograd 2x2x2, two workgroups per CU]");           \
+        hipLaunchKernelGGL((conv_wg3s_kernel<OWV, D>), grid, dim3(256), W3S_LDS_BYTES, s, a);                                    \
+    } while (0)
+#ifdef SDC_KERNEL_EXPERIMENTS
+    // kernel experiments (WRONG RESULTS): bits 1 no staging, 2 no read-back of the partial plane, 4 no folds, 8 no barrier,
+    // 16 no input transform / V park, 32 no global loads, 64 no stage address arithmetic, 128 no U park
+    static const int dbg = exp_env("SDC_WG3S_DBG");
+    if (d.oW == 64 && dbg) {
+        switch (dbg) {
+            case 1: W3S_LAUNCH(64, 1); break; case 2: W3S_LAUNCH(64, 2); break; case 4: W3S_LAUNCH(64, 4); break;
+            case 9: W3S_LAUNCH(64, 9); break; case 5: W3S_LAUNCH(64, 5); break; case 13: W3S_LAUNCH(64, 13); break;
+            case 16: W3S_LAUNCH(64, 16); break; case 32: W3S_LAUNCH(64, 32); break; case 64: W3S_LAUNCH(64, 64); break;
+            case 128: W3S_LAUNCH(64, 128); break; case 48: W3S_LAUNCH(64, 48); break; case 176: W3S_LAUNCH(64, 176); break;
+            case 240: W3S_LAUNCH(64, 240); break; case 8: W3S_LAUNCH(64, 8); break; case 256: W3S_LAUNCH(64, 256); break; case 512: W3S_LAUNCH(64, 512); break; case 1024: W3S_LAUNCH(64, 1024); break; case 1536: W3S_LAUNCH(64, 1536); break; case 269: W3S_LAUNCH(64, 269); break;
+            default: W3S_LAUNCH(64, 4); break;
+        }
+        return SDC_OK;
+    }
+#endif
+#ifdef SDC_KERNEL_EXPERIMENTS
+    if (d.oW == 16) { W3S_LAUNCH(16, 0); return SDC_OK; }        // (SDC_WG3S_ALL: never dispatched by the shipping library)
+#endif
+    if (d.oW == 32) W3S_LAUNCH(32, 0);
+    else W3S_LAUNCH(64, 0);
     return SDC_OK;
 }
 

@@ -427,7 +427,7 @@ def test_conv_winograd_3d_mode(plan_cls, case):
         if prec == 4 and G:
             refn = F.silu(F.group_norm(ref, G, gam.double(), bet.double(), 1e-5))
             torch.testing.assert_close(y.cpu().reshape(ref.shape).double(), refn, rtol=1e-4, atol=2e-5)
-    assert names[4].startswith("conv_wg3_kernel") and abs(share.value - 8 / 27) < 1e-12 and not names[0].startswith("conv_wg")
+    assert names[4].startswith("conv_wg3") and abs(share.value - 8 / 27) < 1e-12 and not names[0].startswith("conv_wg")
     scale = ref.abs().max().item()
     e0 = (outs[0] - ref).abs().max().item() / scale
     e4 = (outs[4] - ref).abs().max().item() / scale
@@ -504,7 +504,7 @@ def test_conv_default_mode_over_a_sweep_of_shapes(plan_cls):
             refn = F.silu(F.group_norm(ref, G, gam.double(), bet.double(), 1e-5))
             torch.testing.assert_close(y.cpu().double(), refn, rtol=1e-4, atol=3e-5)
     print(f"[measured] kernels picked over the sweep: {picks}")
-    assert len(picks) >= 3 and picks.get("conv_wg3_kernel", 0) >= 8, picks
+    assert len(picks) >= 3 and (picks.get("conv_wg3_kernel", 0) + picks.get("conv_wg3s_kernel", 0)) >= 8, picks
 
 
 def test_conv_winograd_2d_strided_output_and_residual(plan_cls):

@@ -21,6 +21,8 @@ shapes = [("c4 L0 64->64", 3, B3, 64, 0, 64, (32, 64, 64)), ("c4 L0 64+64->64", 
           ("c2 L0 64->64", 2, B2, 64, 0, 64, (16, 128)), ("c2 L1 128->128", 2, B2, 128, 0, 128, (8, 64)),
           ("c2 L2 256->256", 2, B2, 256, 0, 256, (4, 32)), ("c2 L3 512->512", 2, B2, 512, 0, 512, (2, 16))]
 modes = [int(m) for m in os.environ.get("MODES", "2,3").split(",")]
+if os.environ.get("SHAPES"):      # e.g. SHAPES=0,2: only these rows of the table
+    shapes = [shapes[int(i)] for i in os.environ["SHAPES"].split(",")]
 s = torch.cuda.current_stream().cuda_stream
 for name, nd, B, c0, c1, co, sp in shapes:
     x = torch.randn(B, c0, *sp, device=dev)
