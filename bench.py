@@ -497,8 +497,17 @@ def finetune_step(name, batch, dim, dev, steps=3, eager=True):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps * 1e3
     ms_hip = timeit(hip_step)
+    # the same step captured once in a hipGraph and replayed (sdc.GraphedLossStep): no host work per launch
+    ms_graph = None
+    try:
+        gstep = sdc.GraphedLossStep(gd, state, weight=w, t=t, noise=noise)
+        ms_graph = timeit(lambda: gstep())
+        del gstep
+    except Exception as e:                           # noqa: BLE001  (report, do not fail the line)
+        ms_graph = f"capture failed: {str(e)[:120]}"
     out = dict(what="loss = mean(w_b p_losses_b(state)); loss.backward()  (U-Net forward + backward, all parameter gradients)",
                batch=batch, hip_ms=round(ms_hip, 2), hip_ms_per_sample=round(ms_hip / batch, 2),
+               hip_graph_ms=(round(ms_graph, 2) if isinstance(ms_graph, float) else ms_graph),
                backward="every node on libsdc_hip.so kernels in both directions (conv data gradient on the forward Winograd kernels, "
                         "sdc_conv_wgrad, sdc_gn_silu_bwd, sdc_chan_norm_bwd, sdc_attn_bwd, sdc_linattn_bwd, sdc_act_bwd)")
     if not eager:

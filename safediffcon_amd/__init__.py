@@ -7,6 +7,7 @@ Drop-in classes (same names / signatures as the reference):
   ConformalCalculator, conformal helpers                  (safediffcon_amd.conformal)
   control_trajectories (Burgers rollout)                  (safediffcon_amd.solvers)
   KSTARSolver, control_trajectories, evaluate_samples     (safediffcon_amd.kstar: the tokamak score check)
+  GraphedLossStep                                         (safediffcon_amd.train_graph: a fine-tuning step as one hipGraph)
 
 All compute goes through libsdc_hip.so (include/sdc.h); importing this package
 does not load it, the first kernel call does -- and raises if it is missing.
@@ -15,5 +16,6 @@ from .unet import Unet2D, Unet1D, Unet3D_with_Conv3D                            
 from .diffusion import (GaussianDiffusion, GaussianDiffusionBurgers, GaussianDiffusionTokamak,   # noqa: F401
                         GaussianDiffusionSmoke, GuidanceSpec, BurgersGuidance, TokamakGuidance, SmokeGuidance,
                         schedule_tables)
+from .train_graph import GraphedLossStep                                               # noqa: F401
 
 __version__ = "0.1.0"

@@ -1167,7 +1167,7 @@ int launch_wg3s(const ConvArgs& a, hipStream_t s) {
             case 9: W3S_LAUNCH(64, 9); break; case 5: W3S_LAUNCH(64, 5); break; case 13: W3S_LAUNCH(64, 13); break;
             case 16: W3S_LAUNCH(64, 16); break; case 32: W3S_LAUNCH(64, 32); break; case 64: W3S_LAUNCH(64, 64); break;
             case 128: W3S_LAUNCH(64, 128); break; case 48: W3S_LAUNCH(64, 48); break; case 176: W3S_LAUNCH(64, 176); break;
-            case 240: W3S_LAUNCH(64, 240); break; case 8: W3S_LAUNCH(64, 8); break; case 256: W3S_LAUNCH(64, 256); break; case 512: W3S_LAUNCH(64, 512); break; case 1024: W3S_LAUNCH(64, 1024); break; case 1536: W3S_LAUNCH(64, 1536); break; case 269: W3S_LAUNCH(64, 269); break;
+            case 240: W3S_LAUNCH(64, 240); break; case 8: W3S_LAUNCH(64, 8); break; case 256: W3S_LAUNCH(64, 256); break; case 512: W3S_LAUNCH(64, 512); break; case 1024: W3S_LAUNCH(64, 1024); break; case 1536: W3S_LAUNCH(64, 1536); break; case 8192: W3S_LAUNCH(64, 8192); break; case 16384: W3S_LAUNCH(64, 16384); break; case 269: W3S_LAUNCH(64, 269); break;
             default: W3S_LAUNCH(64, 4); break;
         }
         return SDC_OK;

@@ -893,7 +893,12 @@ __global__ __launch_bounds__(NT) void chan_norm_gaing_kernel(const float* __rest
     acc = sdc::wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) gpart[(int64_t)c * B + slab] = (red[0] + red[1]) + (red[2] + red[3]);      // [C][B], slabs >= nslab stay 0
+    if (threadIdx.x == 0) gpart[(int64_t)c * B + slab] = (red[0] + red[1]) + (red[2] + red[3]);      // [C][B]
+    // the entries of the slabs that do not exist: zeroed here, by slab 0's workgroup (a hipMemsetAsync in front of this launch
+    // was not reliably replayed when the call was recorded by a stream capture -- safediffcon_amd/train_graph.py: the gain
+    // gradients of a replayed fine-tuning step then summed whatever the graph's memory pool had left there)
+    if (slab == 0)
+        for (int j = nslab + threadIdx.x; j < B; j += NT) gpart[(int64_t)c * B + j] = 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------ small element-wise VJPs
@@ -1031,8 +1036,7 @@ extern "C" int sdc_chan_norm_bwd(const float* x, const float* gy, const float* g
         hipLaunchKernelGGL(chan_norm_bwd_kernel<16>, grid, dim3(NT), 0, s, x, gy, g, gx, pstat, C, S, mode, eps);
     }
     const int ns = cn_slabs(B, C);
-    // partial layout [C][B]: slabs beyond ns stay zero
-    (void)hipMemsetAsync(gpart, 0, (size_t)C * B * sizeof(float), s);
+    // partial layout [C][B]: the entries of slabs beyond ns are zeroed by the kernel itself
     hipLaunchKernelGGL(chan_norm_gaing_kernel, dim3((unsigned)C, (unsigned)ns), dim3(NT), 0, s, x, gy, pstat, gpart, B, C, S, ns);
     return sdc::check_launch("sdc_chan_norm_bwd");
 }

@@ -11,6 +11,7 @@ is no torch.nn op and no CPU path.  Weights live in ordinary ``nn.Parameter``s, 
 into kernel layouts when a plan is built (``refresh()`` after weights change).
 """
 import ctypes as C
+import functools
 import math
 import os
 
@@ -174,15 +175,22 @@ def sinusoid_table(times, dim, theta=10000.0):
     return _sinusoid(times.detach().cpu(), dim, theta)
 
 
+@functools.lru_cache(maxsize=32)
+def _sinusoid_freqs(n, device, theta):
+    """exp(-log(theta) / (n - 1) * arange(n)) formed on the host in fp32 like the reference's, kept per device: a fresh
+    host-to-device copy per call would drain the stream and cannot be recorded by a stream capture (safediffcon_amd/train_graph.py)"""
+    return torch.exp(torch.arange(n) * -(math.log(theta) / (n - 1))).to(device)
+
+
 def _sinusoid(t, dim, theta=10000.0):
     """rows on t's device; the frequency vector is always formed on the host (fp32 exp), like the LUT's"""
     half = dim // 2
-    f = torch.exp(torch.arange(half) * -(math.log(theta) / (half - 1))).to(t.device)
+    f = _sinusoid_freqs(half, t.device, theta)
     a = t[:, None] * f[None, :]
     if dim % 2 == 0:
         return torch.cat((a.sin(), a.cos()), dim=-1)
     half1 = (dim + 1) // 2
-    f1 = torch.exp(torch.arange(half1) * -(math.log(theta) / (half1 - 1))).to(t.device)
+    f1 = _sinusoid_freqs(half1, t.device, theta)
     return torch.cat((a.sin(), (t[:, None] * f1[None, :]).cos()), dim=-1)
 
 

@@ -252,3 +252,67 @@ def test_chan_norm_refuses_misaligned_vector_rows():
     rc = lib.sdc_chan_norm(buf.data_ptr() + 4, g.data_ptr(), None, y.data_ptr(), B, C_, S, 0, 1e-5, st)
     assert rc == -2 and "16-byte aligned" in _lib.last_error()
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------ the fine-tuning step under one hipGraph
+@pytest.mark.parametrize("tree", ["tokamak", "burgers"])
+def test_graphed_finetune_step_equals_eager_and_sees_optimizer_steps(tree):
+    """sdc.GraphedLossStep: loss = mean(w * p_losses(state, t, noise)); loss.backward() captured once and replayed -- loss and
+    every parameter gradient equal the eager step's bit for bit (the same kernels on the same buffers), and an eager
+    optimizer.step() between two replays is seen by the next replay (the weights are packed inside the captured step):
+    tokamak/inference/pipeline.py:238-263, 1D/inference/inference_ft.py:183-226."""
+    torch.manual_seed(0)
+    if tree == "tokamak":
+        net = sdc.Unet1D(dim=32, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+        shape = (12, 128)
+        mk = lambda n: sdc.GaussianDiffusionTokamak(n, seq_length=128, nt=122, timesteps=50).to(DEV)
+    else:
+        net = sdc.Unet2D(dim=16, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+        shape = (3, 16, 128)
+        mk = lambda n: sdc.GaussianDiffusionBurgers(n, seq_length=(16, 128), timesteps=50, temporal=True, use_conv2d=True,
+                                                    is_condition_u0=True, is_condition_uT=True, condition_idx=10).to(DEV)
+    net.load_state_dict(det_params(_spec(net), 41))
+    net.to(DEV)
+    gd = mk(net)
+    B = 8
+    state = det_tensor((B, *shape), 42, 0.3).to(DEV)
+    w = (det_tensor((B,), 43, 0.2) + 1.0).to(DEV)
+    t = torch.randint(0, 50, (B,), generator=torch.Generator().manual_seed(44)).to(DEV)
+    noise = det_tensor((B, *shape), 45).to(DEV)
+    params = [p for p in net.parameters() if p.requires_grad]
+
+    def eager(st_, w_, t_, n_):
+        for p in params:
+            p.grad = None
+        loss = (w_ * gd.p_losses(st_, t_, noise=n_, mean=False)).mean()
+        loss.backward()
+        return loss.detach().clone(), [p.grad.detach().clone() for p in params]
+    l0, g0 = eager(state, w, t, noise)
+    step = sdc.GraphedLossStep(gd, state, weight=w, t=t, noise=noise)
+    l1 = step(state, w, t, noise).clone()
+    assert torch.equal(l0, l1)
+    worst = max((a - b).abs().max().item() for a, b in zip(g0, step.grads))
+    print(f"[measured] {tree}: graphed vs eager fine-tuning step: loss {l1.item():.6f}, max |grad diff| {worst:.1e}")
+    assert worst == 0.0
+    # new inputs through the captured buffers
+    state2, t2 = det_tensor((B, *shape), 46, 0.3).to(DEV), torch.randint(0, 50, (B,), generator=torch.Generator().manual_seed(47)).to(DEV)
+    l2 = step(state2, None, t2, None).clone()
+    g2 = [g.clone() for g in step.grads]
+    le, ge = eager(state2, w, t2, noise)
+    assert torch.equal(l2, le) and all(torch.equal(a, b) for a, b in zip(g2, ge))
+    # an eager optimizer step between two replays is seen: the replay after it equals an eager step on the new weights
+    for p in params:
+        p.grad = None
+    for p, g in zip(params, g2):
+        p.grad = g.clone()
+    torch.optim.SGD(params, lr=1e-4).step()                   # (a small step: the random-init net blows up under a large one)
+    l3 = step(state2, None, t2, None).clone()
+    g3 = [g.clone() for g in step.grads]
+    le3, ge3 = eager(state2, w, t2, noise)
+    assert not torch.equal(l3, l2) and torch.equal(l3, le3) and all(torch.equal(a, b) for a, b in zip(g3, ge3))
+    # ... and the sampler that shares the net follows (content stamp), as the reference's alternation sample <-> fine-tune needs
+    x, tt = det_tensor((2, *shape), 48).to(DEV), torch.tensor([3, 40], device=DEV)
+    fresh = type(net)(dim=net.dim, dim_mults=(1, 2, 4, 8), channels=shape[0], resnet_block_groups=1)
+    fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
+    fresh.to(DEV)
+    assert torch.equal(net(x, tt), fresh(x, tt))
