@@ -54,7 +54,7 @@ EXTRA_WORKLOADS = {
     "c2_shard8": ("c2", 0, 32, "per-rank batch of configs[1] sharded over 8 GPUs (SURVEY 8e)"),
     "c3_shard8": ("c3", 0, 16, "per-rank batch of configs[2] sharded over 8 GPUs (SURVEY 8e)"),
 }
-PMC_FILES = ("r4_pmc_traffic.json",)      # stamped with the kernel-source hash they were collected on (tools/pmc_to_json.py)
+PMC_FILES = ("r5_pmc_traffic.json",)      # stamped with the kernel-source hash they were collected on (tools/pmc_to_json.py)
 
 
 # --------------------------------------------------------------------------- launcher (N > 1 without a torchrun parent)

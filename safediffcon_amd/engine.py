@@ -7,6 +7,7 @@ call list is either replayed from Python or captured into one hipGraph.
 Nothing in this file computes on the CPU or through torch ops on the hot path.
 """
 import ctypes as C
+import functools
 import os
 import math
 
@@ -32,6 +33,12 @@ def as5(t):
     return t
 
 
+@functools.lru_cache(maxsize=16)
+def _up2_merge(parity, device):
+    """tap-merging matrix of the sub-pixel form of nearest-x2 upsampling + 3-tap conv, kept per device (no host-to-device copy per call)"""
+    return torch.tensor([[1, 0, 0], [0, 1, 1]] if parity == 0 else [[1, 1, 0], [0, 0, 1]], dtype=torch.float64, device=device)
+
+
 def pack_conv_weight(t, kind="conv", precision=0):
     """Kernel layout of a conv weight (include/sdc.h, SdcConvDesc.precision):
     nn.Conv{1,2,3}d weight (Cout,Cin,*k) -> Wp [taps*Cin][Cout], followed for precision >= 2 by the Winograd taps;
@@ -50,7 +57,11 @@ def pack_conv_weight(t, kind="conv", precision=0):
             t5 = as5(t)                                   # (Cin, Cout, 1, 4, 4)
             kh = (3, 1) if ph == 0 else (2, 0)
             kw = (3, 1) if pw == 0 else (2, 0)
-            sub = t5[:, :, 0][:, :, list(kh)][:, :, :, list(kw)]       # (Cin, Cout, 2, 2)
+            # (taps (3, 1) = the odd taps reversed, (2, 0) = the even ones reversed -- as slices: indexing with a Python list
+            # builds an index tensor on the host and copies it over, which drains the stream every call and cannot be recorded by a
+            # stream capture (safediffcon_amd/train_graph.py))
+            sub = t5[:, :, 0][:, :, (1 - ph)::2][:, :, :, (1 - pw)::2].flip(2, 3)          # (Cin, Cout, 2, 2)
+            assert kh == ((3, 1) if ph == 0 else (2, 0)) and kw == ((3, 1) if pw == 0 else (2, 0))
             return sub.permute(2, 3, 0, 1).reshape(-1, sub.shape[1]).contiguous()
         if isinstance(kind, tuple) and kind[0] == "up2_sub":
             # nearest x2 upsampling + 3x3 conv (pad 1), output parity (ph, pw): rows 2i+ph of the upsampled image see
@@ -58,8 +69,7 @@ def pack_conv_weight(t, kind="conv", precision=0):
             # (W0, W1+W2) on rows (i-1, i)  /  (W0+W1, W2) on rows (i, i+1); same along W.  9 taps -> 4.
             _, ph, pw = kind
             t5 = as5(t).to(torch.float64)                 # (Cout, Cin, 1, 3, 3)
-            mh = torch.tensor([[1, 0, 0], [0, 1, 1]] if ph == 0 else [[1, 1, 0], [0, 0, 1]], dtype=torch.float64, device=t5.device)
-            mw = torch.tensor([[1, 0, 0], [0, 1, 1]] if pw == 0 else [[1, 1, 0], [0, 0, 1]], dtype=torch.float64, device=t5.device)
+            mh, mw = _up2_merge(ph, t5.device), _up2_merge(pw, t5.device)
             sub = torch.einsum("ah,bw,oihw->oiab", mh, mw, t5[:, :, 0])                 # (Cout, Cin, 2, 2)
             return sub.permute(2, 3, 1, 0).reshape(-1, sub.shape[0]).to(torch.float32).contiguous()
         if kind == "unshuffle":

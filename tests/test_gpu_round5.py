@@ -255,7 +255,7 @@ def test_chan_norm_refuses_misaligned_vector_rows():
 
 
 # ------------------------------------------------------------------ the fine-tuning step under one hipGraph
-@pytest.mark.parametrize("tree", ["tokamak", "burgers"])
+@pytest.mark.parametrize("tree", ["tokamak", "burgers", "smoke"])
 def test_graphed_finetune_step_equals_eager_and_sees_optimizer_steps(tree):
     """sdc.GraphedLossStep: loss = mean(w * p_losses(state, t, noise)); loss.backward() captured once and replayed -- loss and
     every parameter gradient equal the eager step's bit for bit (the same kernels on the same buffers), and an eager
@@ -266,11 +266,15 @@ def test_graphed_finetune_step_equals_eager_and_sees_optimizer_steps(tree):
         net = sdc.Unet1D(dim=32, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
         shape = (12, 128)
         mk = lambda n: sdc.GaussianDiffusionTokamak(n, seq_length=128, nt=122, timesteps=50).to(DEV)
-    else:
+    elif tree == "burgers":
         net = sdc.Unet2D(dim=16, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
         shape = (3, 16, 128)
         mk = lambda n: sdc.GaussianDiffusionBurgers(n, seq_length=(16, 128), timesteps=50, temporal=True, use_conv2d=True,
                                                     is_condition_u0=True, is_condition_uT=True, condition_idx=10).to(DEV)
+    else:           # 2d/inference_2d.py:267-279 (the transposed-conv upsampling and the temporal attention's bias gather are in this one)
+        net = sdc.Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2, 4), channels=7)
+        shape = (8, 7, 16, 16)
+        mk = lambda n: sdc.GaussianDiffusionSmoke(n, image_size=16, frames=8, timesteps=50, loss_type="l2").to(DEV)
     net.load_state_dict(det_params(_spec(net), 41))
     net.to(DEV)
     gd = mk(net)
@@ -312,7 +316,10 @@ def test_graphed_finetune_step_equals_eager_and_sees_optimizer_steps(tree):
     assert not torch.equal(l3, l2) and torch.equal(l3, le3) and all(torch.equal(a, b) for a, b in zip(g3, ge3))
     # ... and the sampler that shares the net follows (content stamp), as the reference's alternation sample <-> fine-tune needs
     x, tt = det_tensor((2, *shape), 48).to(DEV), torch.tensor([3, 40], device=DEV)
-    fresh = type(net)(dim=net.dim, dim_mults=(1, 2, 4, 8), channels=shape[0], resnet_block_groups=1)
+    if tree == "smoke":
+        fresh = sdc.Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2, 4), channels=7)
+    else:
+        fresh = type(net)(dim=net.dim, dim_mults=(1, 2, 4, 8), channels=shape[0], resnet_block_groups=1)
     fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
     fresh.to(DEV)
     assert torch.equal(net(x, tt), fresh(x, tt))

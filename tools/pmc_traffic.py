@@ -2,7 +2,8 @@
 """Workload for the FETCH_SIZE / WRITE_SIZE / SQ PMC passes (rocprofv3 --kernel-trace --pmc ... -- python3 tools/pmc_traffic.py):
  (1) a calibration launch with a KNOWN byte count (sdc_act over n floats reads 4n and writes 4n bytes, dword per lane),
  (2) the kernels of the C4 step the bench prices, a few launches each, at the C4 shapes (B = 64 by default):
-       conv_wg3<64>  64->64  3x3x3 at (B,64,32,64,64)   + GroupNorm statistics          (level-0 ResnetBlock conv)
+       conv_wg3s<64> 64->64  3x3x3 at (B,64,32,64,64)   + GroupNorm statistics          (level-0 ResnetBlock conv)
+       conv_wg3s<32> 64->128 3x3x3 at (B,64,32,32,32)
        conv_wg3<32>  128->128 3x3x3 at (B,128,32,32,32)
        conv_wg3<16>  256->256 3x3x3 at (B,256,32,16,16)
        gn_apply      GroupNorm apply + SiLU on the level-0 tensor, in place
@@ -39,7 +40,8 @@ def conv3(cin, cout, sp, tag):
     return x, out
 
 
-x0, out0 = conv3(64, 64, (32, 64, 64), "conv_wg3_kernel<64")
+x0, out0 = conv3(64, 64, (32, 64, 64), "conv_wg3s_kernel<64")          # round 5: rows of 64 run the two-workgroups-per-CU form
+conv3(64, 128, (32, 32, 32), "conv_wg3s_kernel<32")                   # ... and rows of 32 with <= 64 input channels
 conv3(128, 128, (32, 32, 32), "conv_wg3_kernel<32")
 conv3(256, 256, (32, 16, 16), "conv_wg3_kernel<16")
 gm, bt = torch.ones(64, device=dev), torch.zeros(64, device=dev)
