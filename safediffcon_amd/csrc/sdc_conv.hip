@@ -469,6 +469,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void co
     conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
 }
 
+#include "sdc_conv_pw2.inc"
+
 template <int BM, int BN, int WM, int WN>
 void launch_pw(const ConvArgs& a, hipStream_t s) {
     dim3 grid(((a.Ntot + BN - 1) / BN) * ((a.d.Cout + BM - 1) / BM));
@@ -1841,6 +1843,16 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
             reinterpret_cast<uintptr_t>(x0) % 16 == 0 && (d.Cin1 == 0 || reinterpret_cast<uintptr_t>(x1) % 16 == 0) &&
             reinterpret_cast<uintptr_t>(wp) % 16 == 0) {
             const int64_t b64x128 = (int64_t)((a.Ntot + 127) / 128) * ((d.Cout + 63) / 64);
+            // two-workgroups-per-CU form with interleaved tiles (round 5): whole 128-channel blocks, 16-byte aligned dense rows of y
+            // (and of the residual), enough 128 x 256 tiles for two rounds of the chip
+            static const int no_pw2 = exp_env("SDC_NO_PW2");
+            const bool al16 = reinterpret_cast<uintptr_t>(y) % 16 == 0 && d.ys[0] % 4 == 0 && d.ys[1] % 4 == 0 &&
+                              (!residual || (reinterpret_cast<uintptr_t>(residual) % 16 == 0 && d.rs[0] % 4 == 0 && d.rs[1] % 4 == 0));
+            if (!no_pw2 && d.Cout % 128 == 0 && a.ydense && al16 && (int64_t)((a.Ntot + 255) / 256) * (d.Cout / 128) >= 1024) {
+                SDC_PICK("conv_pw2_kernel<2,2>", 1.0);
+                launch_pw2<2, 2>(a, s);
+                return sdc::check_launch("sdc_conv[pointwise, two workgroups per CU]");
+            }
             if (d.Cout > 64 && a.Ntot >= 128 * 256) { SDC_PICK("conv_pw_kernel<128,128,2,2>", 1.0); launch_pw<128, 128, 2, 2>(a, s); }
             else if (d.Cout <= 64 && a.Ntot >= 256 * 1024) { SDC_PICK("conv_pw_kernel<64,256,1,4>", 1.0); launch_pw<64, 256, 1, 4>(a, s); }
             else if (b64x128 >= 1024) { SDC_PICK("conv_pw_kernel<64,128,2,2>", 1.0); launch_pw<64, 128, 2, 2>(a, s); }
