@@ -1850,7 +1850,12 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
                               (!residual || (reinterpret_cast<uintptr_t>(residual) % 16 == 0 && d.rs[0] % 4 == 0 && d.rs[1] % 4 == 0));
             if (!no_pw2 && d.Cout % 128 == 0 && a.ydense && al16 && (int64_t)((a.Ntot + 255) / 256) * (d.Cout / 128) >= 1024) {
                 SDC_PICK("conv_pw2_kernel<2,2>", 1.0);
-                launch_pw2<2, 2>(a, s);
+                { const int rc_ = launch_pw2<2, 2>(a, s); if (rc_) return rc_; }
+                return sdc::check_launch("sdc_conv[pointwise, two workgroups per CU]");
+            }
+            if (!no_pw2 && d.Cout == 64 && a.ydense && al16 && (a.Ntot + 511) / 512 >= 1024) {
+                SDC_PICK("conv_pw2_kernel<1,4>", 1.0);
+                { const int rc_ = launch_pw2<1, 4>(a, s); if (rc_) return rc_; }
                 return sdc::check_launch("sdc_conv[pointwise, two workgroups per CU]");
             }
             if (d.Cout > 64 && a.Ntot >= 128 * 256) { SDC_PICK("conv_pw_kernel<128,128,2,2>", 1.0); launch_pw<128, 128, 2, 2>(a, s); }

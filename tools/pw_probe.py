@@ -13,7 +13,8 @@ dev = "cuda:0"
 shapes = [("to_qkv 128->384 L1", 128, 384, (32, 32, 32), False), ("to_out 128->128 L1 +res", 128, 128, (32, 32, 32), True),
           ("to_qkv 256->384 L2", 256, 384, (32, 16, 16), False), ("to_out 128->256 L2 +res", 128, 256, (32, 16, 16), True),
           ("res_conv 64->128 L1", 64, 128, (32, 32, 32), False), ("res_conv 128->256 L2", 128, 256, (32, 16, 16), False),
-          ("res_conv 512->128 L1 (2 inputs)", 256, 128, (32, 32, 32), False)]
+          ("res_conv 512->128 L1 (2 inputs)", 256, 128, (32, 32, 32), False),
+          ("res_conv 128->64 L0", 128, 64, (32, 64, 64), False), ("final 1x1 64->64 L0", 64, 64, (32, 64, 64), False)]
 s = torch.cuda.current_stream().cuda_stream
 tot = 0.0
 for name, cin, cout, sp, res in shapes:
