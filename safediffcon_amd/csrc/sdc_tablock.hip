@@ -58,13 +58,21 @@ __device__ __forceinline__ gptr_t uni(const float* p) {
 __device__ __forceinline__ float ldu(gptr_t base, uint32_t byte_off) { return *(gptr_t)((gcptr_t)base + byte_off); }
 __device__ __forceinline__ void stu(gptr_t base, uint32_t byte_off, float v) { *(gptr_t)((gcptr_t)base + byte_off) = v; }
 
+// packed rotary step: x = (x0, x1), cs = (cos, sin) -> (x0 cos - x1 sin, x1 cos + x0 sin) in two VALU instructions
+typedef float ta2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ta2 ta_rot(ta2 x, ta2 cs) {
+    ta2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(x), "v"(cs));                       // (x0 c, x1 c)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "v"(cs), "v"(t));   // (-x1 s + x0 c, x0 s + x1 c)
+    return r;
+}
+
 __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
     extern __shared__ float lds[];
     float* const xs = lds;                        // [64][XP]   xn, later the y image
     float* const biasT = xs + C * XP;             // [4][32][33]  [head][key][query]
-    float* const rotc = biasT + 4 * 32 * 33;      // [32][16]
-    float* const rots = rotc + 32 * 16;           // [32][16]
-    float* const red = rots + 32 * 16;            // [2][2][256] LayerNorm partials
+    float* const rotcs = biasT + 4 * 32 * 33;     // [16 m][32 frames][2]: (cos, sin) pairs, one conflict-free 8-byte read per rotation
+    float* const red = rotcs + 2 * 32 * 16;       // [2][2][256] LayerNorm partials
     float* const wl = red + 1024;                 // [2][8192] weights of one head: Wq | Wk | Wv ([64 c][32 d] each) | Wo ([32 d][64 co])
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -125,13 +133,13 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = tid + i * NT, h = e >> 10, q = (e >> 5) & 31, kk = e & 31;
-            biasT[(h * 32 + kk) * 33 + q] = biasreg[i];
+            // (bias / scale: the q * scale of the reference is applied to the finished scores, inside the softmax's exponent --
+            // S = scale (q k^T + bias / scale) -- instead of to the 32 x 32 q tile of every head: 16 multiplications per head less)
+            biasT[(h * 32 + kk) * 33 + q] = biasreg[i] * 5.65685424949238f;
         }
-        rotc[tid] = rr.x;
-        rots[tid] = rr.y;
+        *reinterpret_cast<float2*>(rotcs + (((tid & 15) * 32) + (tid >> 4)) * 2) = rr;      // tid = frame * 16 + m
     }
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every arbitration against its SIMD partner otherwise
-    const float scale = 0.17677669529663687f;
     const int hw = wave;                           // this wave's pixel of the tile
 
     // q, k [32 d][32 f]: A = W[c][d = l31] from LDS, B = xn[c][f]; V is formed transposed (operands swapped: [frame rows]
@@ -198,53 +206,50 @@ __global__ __launch_bounds__(NT) void ta_block_kernel(const TaArgs a) {
             f32x16 pr[3];
             project3(wh, pr);
             if (head < 3 || more) park_head((head + 1) & 1);
-            // q * scale, rotary on (d = 2m, 2m+1) pairs = registers (r, r+1) for even r; frame = l31
+            // rotary on (d = 2m, 2m+1) pairs = registers (r, r+1) for even r; frame = l31.  Two packed operations per pair:
+            // (x0, x1) -> (x0 c, x1 c) -> (x0 c - x1 s, x1 c + x0 s); the (cos, sin) pair is one 8-byte LDS read.  (The q * scale
+            // of the reference rides on the softmax exponent below.)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const int m = crow(r, lh) >> 1;
-                const float cs = rotc[l31 * 16 + m], sn = rots[l31 * 16 + m];
-                const float q0 = pr[0][r] * scale, q1 = pr[0][r + 1] * scale;
-                pr[0][r] = q0 * cs - q1 * sn; pr[0][r + 1] = q1 * cs + q0 * sn;
-                const float k0 = pr[1][r], k1 = pr[1][r + 1];
-                pr[1][r] = k0 * cs - k1 * sn; pr[1][r + 1] = k1 * cs + k0 * sn;
+                const ta2 cs = *reinterpret_cast<const ta2*>(rotcs + (m * 32 + l31) * 2);
+                ta2 q = {pr[0][r], pr[0][r + 1]}, k = {pr[1][r], pr[1][r + 1]};
+                q = ta_rot(q, cs);
+                k = ta_rot(k, cs);
+                pr[0][r] = q.x; pr[0][r + 1] = q.y;
+                pr[1][r] = k.x; pr[1][r + 1] = k.y;
             }
             // The products chain through registers: with the contraction index walked in accumulator-row order (step r covers
             // rows crow(r, 0) | crow(r, 1) on the two half-waves), register r of one product's accumulator IS the operand
             // fragment of the next -- K, Q, V^T, S^T and O^T never visit LDS.
-            // S^T[key][query] = sum_d K[d][key] Q[d][query]: A = K registers, B = Q registers (two half chains)
-            f32x16 acc, acc2;
+            // S^T[key][query] / scale = bias / scale + sum_d K[d][key] Q[d][query]: A = K registers, B = Q registers; ONE chain that
+            // starts from the bias (a dependent fp32 MFMA issues every 64 cycles, its latency: two half chains and their sum bought
+            // nothing and cost 48 VALU instructions per head)
+            f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[r] = biasT[(head * 32 + crow(r, lh)) * 33 + l31];
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[1][r], pr[0][r], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[1][r + 1], pr[0][r + 1], acc2, 0, 0, 0);
-            }
+            for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[1][r], pr[0][r], acc, 0, 0, 0);
             float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[r] += acc2[r] + biasT[(head * 32 + crow(r, lh)) * 33 + l31];
-                mx = fmaxf(mx, acc[r]);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // p = exp(scale (acc - mx)) = exp2(acc * (scale log2 e) - mx * (scale log2 e)): one fma + v_exp per element
+            const float SL = 0.17677669529663687f * 1.4426950408889634f;
+            const float nmx = -mx * SL;
             float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[r] = sdc::softmax_exp(acc[r] - mx); sum += acc[r]; }
+            for (int r = 0; r < 16; ++r) { acc[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], SL, nmx)); sum += acc[r]; }
             sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.0f / sum;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] *= inv;
-            // O^T[d][query] = sum_key V^T[key][d] P[key][query]: A = V^T registers, B = P registers
-            f32x16 oacc, oacc2;
+            // O^T[d][query] = sum_key V^T[key][d] P[key][query]: A = V^T registers, B = P registers (one chain)
+            f32x16 oacc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { oacc[r] = 0.f; oacc2[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[2][r], acc[r], oacc, 0, 0, 0);
-                oacc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[2][r + 1], acc[r + 1], oacc2, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[r] += oacc2[r];
+            for (int r = 0; r < 16; ++r) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[2][r], acc[r], oacc, 0, 0, 0);
             // y[co][f] += sum_d Wo[co][head*32 + d] O^T[d][f]:  A = Wo fragments (w1, d in accumulator-row order), B = O^T registers
 #pragma unroll
             for (int r = 0; r < 16; ++r) {             // Wo rows d in accumulator-row order
