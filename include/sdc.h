@@ -372,6 +372,22 @@ int sdc_act_bwd(const float* x, const float* gy, float* gx, int64_t n, int kind,
 /* VJP of nearest-neighbour upsampling by (fh, fw) in {1,2}^2 over the last two axes: gx (rows,H,W) from g (rows,H*fh,W*fw) */
 int sdc_sumpool2(const float* g, float* gx, int64_t rows, int H, int W, int fh, int fw, void* stream);
 
+/* ------------------------------------------------- nn.Linear over a batch of rows (fine-tuning path) */
+/* The time MLP and the ResnetBlocks' scale/shift MLPs (1D/model/unet.py:300-305, :158-162; tokamak/model/unet.py likewise;
+ * 2d/video_diffusion_pytorch/video_diffusion_pytorch_conv3d.py:212-216, :399-404) run forward and backward in every fine-tuning
+ * step (the samplers read them from a per-timestep table).  w is the nn.Linear weight [M][K] as torch stores it; rows of x / y /
+ * gy / gx may be strided (strides in floats).  K, M and the strides must be multiples of 4 and the pointers 16-byte aligned
+ * (SDC_EINVAL otherwise: the caller then uses sdc_conv / sdc_conv_wgrad, which take any shape).  Fixed summation order, no atomics.
+ *   sdc_linear        y[r][m]  = bias[m] + sum_k x[r][k] w[m][k]          (bias may be null)
+ *   sdc_linear_dgrad  gx[r][k] = sum_m gy[r][m] w[m][k]
+ *   sdc_linear_wgrad  gw[m][k] = sum_r gy[r][m] x[r][k],  gbias[m] = sum_r gy[r][m]   (gbias may be null; gw contiguous [M][K]) */
+int sdc_linear(const float* x, const float* w, const float* bias, float* y, int rows, int K, int M, int64_t x_stride,
+               int64_t y_stride, void* stream);
+int sdc_linear_dgrad(const float* gy, const float* w, float* gx, int rows, int K, int M, int64_t gy_stride, int64_t gx_stride,
+                     void* stream);
+int sdc_linear_wgrad(const float* gy, const float* x, float* gw, float* gbias, int rows, int K, int M, int64_t gy_stride,
+                     int64_t x_stride, void* stream);
+
 /* ------------------------------------------------- weight content stamp */
 /* out_dev[0] = order-independent 64-bit checksum over n device spans of 32-bit words (span index, word index and bits all
  * enter it).  The host wrapper stamps a plan's packed weights with it: `p.data.lerp_()` / `p.data = ...` (the reference's EMA

@@ -123,6 +123,9 @@ SIGNATURES = {
     "sdc_smoke_rollout": (C.c_int, [_f32p, _f32p, _i64, _i64, _f32p, _i64, _f32p, _i64, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _stream]),
+    "sdc_linear": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64, _i64, _stream]),
+    "sdc_linear_dgrad": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64, _i64, _stream]),
+    "sdc_linear_wgrad": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64, _i64, _stream]),
     "sdc_checksum_spans": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _stream]),
     "sdc_graph_begin": (C.c_int, [_stream]),
     "sdc_graph_end": (C.c_int, [_stream, C.POINTER(C.c_void_p)]),

@@ -109,6 +109,28 @@ class _ArenaSlot(threading.local):
 
 _ARENA = _ArenaSlot()
 
+# The weight gradient and the data gradient of a conv both start from gy and meet only in autograd's accumulation: on the small
+# grids of the 1-D nets neither fills the chip (a C3 layer is 12 800 positions = 100 workgroups for 256 CUs), so the backward of
+# a conv node forks -- weight gradient on a side stream, data gradient on the node's stream -- and joins before it returns.
+# Under stream capture (train_graph.GraphedLossStep) the fork / join becomes two branches of the hipGraph.
+OVERLAP_WGRAD = True
+
+
+class _SideSlot(threading.local):
+    streams = None
+
+
+_SIDE = _SideSlot()
+
+
+def _side_stream(dev):
+    if _SIDE.streams is None:
+        _SIDE.streams = {}
+    s = _SIDE.streams.get(dev.index)
+    if s is None:
+        s = _SIDE.streams[dev.index] = torch.cuda.Stream(dev)
+    return s
+
 
 class ConvFn(Function):
     """y = conv(x [| x1], w) + b for every conv form of the three U-Nets.  cfg = (kind, stride, pad, up, precision):
@@ -144,12 +166,18 @@ class ConvFn(Function):
         k = _k5(w)
         c0 = x.shape[1]
         if kind == "conv":
+            fork = None
             if need_w or ctx.has_bias:
-                gw, gb = grad_ops.conv_wgrad(gy, x, k, stride, pad, up, bias=ctx.has_bias)
-                if x1 is not None:
-                    gw1, _ = grad_ops.conv_wgrad(gy, x1, k, stride, pad, up, bias=False)
-                    gw = torch.cat((gw, gw1), dim=1)
-                gw = gw.reshape(w.shape)
+                if OVERLAP_WGRAD and (need_x or need_x1):
+                    main = torch.cuda.current_stream(gy.device)
+                    fork = _side_stream(gy.device)
+                    fork.wait_stream(main)
+                with torch.cuda.stream(fork) if fork is not None else contextlib.nullcontext():
+                    gw, gb = grad_ops.conv_wgrad(gy, x, k, stride, pad, up, bias=ctx.has_bias)
+                    if x1 is not None:
+                        gw1, _ = grad_ops.conv_wgrad(gy, x1, k, stride, pad, up, bias=False)
+                        gw = torch.cat((gw, gw1), dim=1)
+                    gw = gw.reshape(w.shape)
             if need_x or need_x1:
                 w5 = as5(wd)
                 if stride == (1, 1, 1):
@@ -167,6 +195,11 @@ class ConvFn(Function):
                                   out=torch.empty((gy.shape[0], w5.shape[1], *x.shape[2:]), dtype=torch.float32, device=gy.device))
                 gx = ga[:, :c0]
                 gx1 = ga[:, c0:] if x1 is not None else None
+            if fork is not None:
+                main.wait_stream(fork)                     # join: gy / x stay referenced by this frame until here
+                for g_ in (gw, gb):
+                    if g_ is not None:
+                        g_.record_stream(main)             # allocated on the side stream, consumed (accumulated) on the node's
         elif kind == "convT422":
             # y[2i - 1 + k] += x[i] w[k]:  dw = wgrad(G = x, X = gy);  dx[i] = sum_k gy[2i - 1 + k] w[k] (a stride-2 conv, no flip)
             if need_w or ctx.has_bias:
@@ -189,6 +222,72 @@ class ConvFn(Function):
                         wt = w4[:, :, p1, p2].t().reshape(c4 // 4, co, 1, 1, 1).contiguous()
                         conv_raw(gy, pack_conv_weight(wt, "conv"), None, c4 // 4, (1, 1, 1), out=gx[:, :, :, p1::2, p2::2])
         return gx, gx1, gw, gb, None
+
+
+def _linear_ok(x, w):
+    """sdc_linear's shapes: nn.Linear on (B, K[, 1, 1, 1]) rows, K and M multiples of 4 (every MLP of the three U-Nets at dim >= 4)"""
+    return (x.dim() in (2, 5) and all(s == 1 for s in x.shape[2:]) and all(s == 1 for s in w.shape[2:])
+            and w.shape[1] % 4 == 0 and w.shape[0] % 4 == 0 and x.shape[1] == w.shape[1])
+
+
+class LinearFn(Function):
+    """y = x W^T + b on a batch of rows: the time MLP and the ResnetBlocks' scale/shift MLPs (1D/model/unet.py:300-305, :158-162;
+    conv3d.py:212-216, :399-404) on sdc_linear / sdc_linear_dgrad / sdc_linear_wgrad -- kernels shaped by the weight matrix
+    (16 of its rows per workgroup) instead of the conv kernels' position tiles, which see 64 positions here.  The parameter is read
+    where it lives: nothing is packed."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        lib = _lib.get_lib()
+        B, K, M = x.shape[0], w.shape[1], w.shape[0]
+        x2 = x.detach().reshape(B, K).contiguous()
+        w2 = w.detach().reshape(M, K).contiguous()
+        y = torch.empty((B, M), dtype=torch.float32, device=x.device)
+        check(lib.sdc_linear(x2.data_ptr(), w2.data_ptr(), 0 if b is None else b.detach().contiguous().data_ptr(), y.data_ptr(),
+                             B, K, M, K, M, _stream(x)), "sdc_linear")
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = b is not None
+        ctx.xshape = x.shape
+        return y.reshape(B, M, *x.shape[2:])
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.get_lib()
+        x2, w = ctx.saved_tensors
+        B, K = x2.shape
+        M = w.shape[0]
+        g2 = gy.reshape(B, M).contiguous()
+        gx = gw = gb = None
+        fork = None
+        if ctx.needs_input_grad[1] or ctx.has_bias:
+            if OVERLAP_WGRAD and ctx.needs_input_grad[0]:
+                main = torch.cuda.current_stream(gy.device)
+                fork = _side_stream(gy.device)
+                fork.wait_stream(main)
+            with torch.cuda.stream(fork) if fork is not None else contextlib.nullcontext():
+                gw = torch.empty((M, K), dtype=torch.float32, device=gy.device)
+                gb = torch.empty(M, dtype=torch.float32, device=gy.device) if ctx.has_bias else None
+                check(lib.sdc_linear_wgrad(g2.data_ptr(), x2.data_ptr(), gw.data_ptr(), 0 if gb is None else gb.data_ptr(), B, K, M, M, K,
+                                           _stream(gy)), "sdc_linear_wgrad")
+                gw = gw.reshape(w.shape)
+        if ctx.needs_input_grad[0]:
+            w2 = w.detach().reshape(M, K).contiguous()
+            gx = torch.empty((B, K), dtype=torch.float32, device=gy.device)
+            check(lib.sdc_linear_dgrad(g2.data_ptr(), w2.data_ptr(), gx.data_ptr(), B, K, M, M, K, _stream(gy)), "sdc_linear_dgrad")
+            gx = gx.reshape(ctx.xshape)
+        if fork is not None:
+            main.wait_stream(fork)
+            for g_ in (gw, gb):
+                if g_ is not None:
+                    g_.record_stream(main)
+        return gx, gw, gb
+
+
+def linear(x, w, b):
+    """nn.Linear node: LinearFn where its kernels take the shape, the 1x1x1 conv node otherwise (any shape)"""
+    if _linear_ok(x, w):
+        return LinearFn.apply(x, w, b)
+    return ConvFn.apply(x, None, w, b, ("conv", (1, 1, 1), (0, 0, 0), (1, 1, 1), 0))
 
 
 class GNSiLUFn(Function):
@@ -342,8 +441,7 @@ class Trainer:
         """ResnetBlock: conv3d.py:206-230 / 1D/model/unet.py:149-180"""
         ss = None
         if cond is not None and self.net.has(f"{prefix}.mlp.1.weight"):
-            e = ConvFn.apply(cond, None, self.P(f"{prefix}.mlp.1.weight"), self.P(f"{prefix}.mlp.1.bias"),
-                             ("conv", (1, 1, 1), (0, 0, 0), (1, 1, 1), 0))
+            e = linear(cond, self.P(f"{prefix}.mlp.1.weight"), self.P(f"{prefix}.mlp.1.bias"))
             ss = e.reshape(e.shape[0], e.shape[1])
         h = self.gn(f"{prefix}.block1.norm", self.conv(f"{prefix}.block1.proj", x, x1), ss)
         g = self.conv(f"{prefix}.block2.proj", h)
@@ -358,10 +456,9 @@ class Trainer:
         from .unet import _sinusoid
         dim = self.net.dim
         emb = _sinusoid(t.detach().to(self.net.device()).float(), dim).reshape(t.shape[0], dim, 1, 1, 1).contiguous()
-        cfg = ("conv", (1, 1, 1), (0, 0, 0), (1, 1, 1), 0)
-        h = ConvFn.apply(emb, None, self.P("time_mlp.1.weight").reshape(4 * dim, dim, 1, 1, 1), self.P("time_mlp.1.bias"), cfg)
+        h = linear(emb, self.P("time_mlp.1.weight").reshape(4 * dim, dim, 1, 1, 1), self.P("time_mlp.1.bias"))
         h = ActFn.apply(h, 1)
-        h = ConvFn.apply(h, None, self.P("time_mlp.3.weight").reshape(4 * dim, 4 * dim, 1, 1, 1), self.P("time_mlp.3.bias"), cfg)
+        h = linear(h, self.P("time_mlp.3.weight").reshape(4 * dim, 4 * dim, 1, 1, 1), self.P("time_mlp.3.bias"))
         return ActFn.apply(h, 0)
 
     # ---- attention blocks as chains of HIP nodes (norm -> 1x1 conv -> core -> 1x1 conv [-> norm] + x)

@@ -323,3 +323,81 @@ def test_graphed_finetune_step_equals_eager_and_sees_optimizer_steps(tree):
     fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
     fresh.to(DEV)
     assert torch.equal(net(x, tt), fresh(x, tt))
+
+
+@pytest.mark.parametrize("tree", ["tokamak", "burgers"])
+def test_forked_conv_backward_equals_serial(tree):
+    """ConvFn.backward runs the weight gradient on a side stream beside the data gradient (autograd.OVERLAP_WGRAD): the same
+    kernels on the same operands, so loss and every parameter gradient equal the serial order's bit for bit -- three times in a
+    row (a missing join or a buffer recycled across the two streams would show as a difference between repeats)."""
+    from safediffcon_amd import autograd as ag
+    torch.manual_seed(0)
+    if tree == "tokamak":
+        net = sdc.Unet1D(dim=32, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+        shape = (12, 128)
+        gd = sdc.GaussianDiffusionTokamak(net, seq_length=128, nt=122, timesteps=50)
+    else:
+        net = sdc.Unet2D(dim=16, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1)
+        shape = (3, 16, 128)
+        gd = sdc.GaussianDiffusionBurgers(net, seq_length=(16, 128), timesteps=50, temporal=True, use_conv2d=True,
+                                          is_condition_u0=True, is_condition_uT=True, condition_idx=10)
+    net.load_state_dict(det_params(_spec(net), 61))
+    gd = gd.to(DEV)
+    B = 16
+    state = det_tensor((B, *shape), 62, 0.3).to(DEV)
+    t = torch.randint(0, 50, (B,), generator=torch.Generator().manual_seed(63)).to(DEV)
+    noise = det_tensor((B, *shape), 64).to(DEV)
+    params = [p for p in net.parameters() if p.requires_grad]
+
+    def run():
+        for p in params:
+            p.grad = None
+        loss = gd.p_losses(state, t, noise=noise, mean=False).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), [p.grad.detach().clone() for p in params]
+    assert ag.OVERLAP_WGRAD
+    try:
+        ag.OVERLAP_WGRAD = False
+        l0, g0 = run()
+    finally:
+        ag.OVERLAP_WGRAD = True
+    for _ in range(3):
+        l1, g1 = run()
+        assert torch.equal(l0, l1)
+        assert all(torch.equal(a, b) for a, b in zip(g0, g1))
+
+
+@pytest.mark.parametrize("rows,K,M", [(64, 1024, 4096), (64, 256, 128), (1, 8, 32), (100, 260, 36), (16, 32, 16), (130, 64, 1028)])
+def test_linear_kernels_against_fp64(rows, K, M):
+    """sdc_linear / sdc_linear_dgrad / sdc_linear_wgrad (the MLPs of the fine-tuning path) against fp64 torch on the same operands,
+    ragged sizes included (rows not a multiple of 16 / 64, K and M not multiples of 16 / 64 / 256); strided rows; bit-reproducible"""
+    from safediffcon_amd import _lib
+    lib = _lib.get_lib()
+    st = torch.cuda.current_stream().cuda_stream
+    x = det_tensor((rows, K + 4), 71).to(DEV)[:, :K]            # row stride K + 4
+    w = det_tensor((M, K), 72, 0.2).to(DEV)
+    b = det_tensor((M,), 73).to(DEV)
+    gy = det_tensor((rows, M), 74).to(DEV)
+    y = torch.full((rows, M + 8), 7.0, device=DEV)
+    assert lib.sdc_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), rows, K, M, x.stride(0), y.stride(0), st) == 0
+    ref = x.double() @ w.double().t() + b.double()
+    tol = 2e-6 * (1 + ref.abs().max().item()) * max(1.0, K ** 0.5 / 8)
+    assert (y[:, :M].double() - ref).abs().max().item() <= tol
+    assert torch.all(y[:, M:] == 7.0)                                # nothing written past a row
+    gx = torch.empty((rows, K), device=DEV)
+    assert lib.sdc_linear_dgrad(gy.data_ptr(), w.data_ptr(), gx.data_ptr(), rows, K, M, M, K, st) == 0
+    ref = gy.double() @ w.double()
+    assert (gx.double() - ref).abs().max().item() <= 2e-6 * (1 + ref.abs().max().item()) * max(1.0, M ** 0.5 / 8)
+    gw, gb = torch.empty((M, K), device=DEV), torch.empty(M, device=DEV)
+    xc = x.contiguous()
+    assert lib.sdc_linear_wgrad(gy.data_ptr(), xc.data_ptr(), gw.data_ptr(), gb.data_ptr(), rows, K, M, M, K, st) == 0
+    ref = gy.double().t() @ xc.double()
+    assert (gw.double() - ref).abs().max().item() <= 2e-6 * (1 + ref.abs().max().item()) * max(1.0, rows ** 0.5 / 8)
+    assert (gb.double() - gy.double().sum(0)).abs().max().item() <= 1e-5 * (1 + rows ** 0.5)
+    gw2, gb2 = torch.empty_like(gw), torch.empty_like(gb)
+    assert lib.sdc_linear_wgrad(gy.data_ptr(), xc.data_ptr(), gw2.data_ptr(), gb2.data_ptr(), rows, K, M, M, K, st) == 0
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    # shapes outside the contract are refused, not mis-computed
+    assert lib.sdc_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), rows, K - 1, M, x.stride(0), y.stride(0), st) == -1 and "multiples of 4" in _lib.last_error()
+    torch.cuda.synchronize()
