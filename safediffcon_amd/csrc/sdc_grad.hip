@@ -508,10 +508,14 @@ int launch_wgrad_mkh_bkp(const WgradArgs& a, dim3 grid, hipStream_t s) {
 // out[i] = sum_s part[s][i] in a fixed order.  KG = 1: a thread per element, splits in sequence (loads four deep).  KG = 4 (many
 // splits over a small gradient): wave g of the workgroup sums the splits s = g (mod 4) of 64 elements, wave 0 adds the four
 // partial sums in order -- the chain of dependent HBM latencies is what this reduction costs, not its bytes.
+// A second table (the bias partials of the same weight gradient) rides in the same launch: workgroups nb1 .. take it.
 template <int KG>
-__global__ __launch_bounds__(NT) void sum_splits_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int nsplit) {
+__global__ __launch_bounds__(NT) void sum_splits_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int nsplit,
+                                                        const float* __restrict__ part2, float* __restrict__ out2, int64_t n2, unsigned nb1) {
     const int g = KG == 1 ? 0 : (int)(threadIdx.x >> 6);
-    const int64_t i = KG == 1 ? (int64_t)blockIdx.x * NT + threadIdx.x : (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    unsigned blk = blockIdx.x;
+    if (blk >= nb1) { blk -= nb1; part = part2; out = out2; n = n2; }
+    const int64_t i = KG == 1 ? (int64_t)blk * NT + threadIdx.x : (int64_t)blk * 64 + (threadIdx.x & 63);
     float s = 0.0f;
     if (i < n) {
         int k = g;
@@ -536,11 +540,14 @@ __global__ __launch_bounds__(NT) void sum_splits_kernel(const float* __restrict_
     }
 }
 
-void launch_sum_splits(const float* part, float* out, int64_t n, int nsplit, hipStream_t s) {
+void launch_sum_splits(const float* part, float* out, int64_t n, int nsplit, hipStream_t s, const float* part2 = nullptr,
+                       float* out2 = nullptr, int64_t n2 = 0) {
+    const int per = nsplit >= 8 ? 64 : NT;
+    const unsigned nb1 = (unsigned)((n + per - 1) / per), nb2 = part2 ? (unsigned)((n2 + per - 1) / per) : 0u;
     if (nsplit >= 8)
-        hipLaunchKernelGGL(sum_splits_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(NT), 0, s, part, out, n, nsplit);
+        hipLaunchKernelGGL(sum_splits_kernel<4>, dim3(nb1 + nb2), dim3(NT), 0, s, part, out, n, nsplit, part2, out2, n2, nb1);
     else
-        hipLaunchKernelGGL(sum_splits_kernel<1>, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, s, part, out, n, nsplit);
+        hipLaunchKernelGGL(sum_splits_kernel<1>, dim3(nb1 + nb2), dim3(NT), 0, s, part, out, n, nsplit, part2, out2, n2, nb1);
 }
 
 int wgrad_splits(const SdcWgradDesc& d, int* rows_per_split) {
@@ -610,8 +617,7 @@ extern "C" int sdc_conv_wgrad(const SdcWgradDesc* dp, const float* g, const floa
     int rc = sdc::check_launch("sdc_conv_wgrad");
     if (rc || a.nsplit == 1) return rc;
     {
-        launch_sum_splits(a.part, dw, nw, a.nsplit, s);
-        if (dbias) launch_sum_splits(a.bpart, dbias, (int64_t)d.M, a.nsplit, s);
+        launch_sum_splits(a.part, dw, nw, a.nsplit, s, dbias ? a.bpart : nullptr, dbias, (int64_t)d.M);
     }
     return sdc::check_launch("sdc_conv_wgrad[reduce]");
 }
@@ -739,10 +745,9 @@ int gn_bwd_ysplit(int nrows, int64_t S) {
 }
 
 // group means of (k A1, k A2), k = gamma (1 + sc): one workgroup per (b, g) -> gstat[b][g] = (m1, m2)
-__global__ __launch_bounds__(NT) void gn_bwd_group_kernel(const float* __restrict__ rows, const float* __restrict__ gamma,
-                                                         const float* __restrict__ ss, int64_t ss_b_stride, float* __restrict__ gstat,
-                                                         int C, int G, int64_t S) {
-    const int bg = blockIdx.x;
+__device__ __forceinline__ void gn_bwd_group_body(const int bg, const float* __restrict__ rows, const float* __restrict__ gamma,
+                                                  const float* __restrict__ ss, int64_t ss_b_stride, float* __restrict__ gstat,
+                                                  int C, int G, int64_t S) {
     const int b = bg / G, g = bg - b * G;
     const int cpg = C / G;
     double s1 = 0.0, s2 = 0.0;
@@ -933,12 +938,12 @@ __global__ __launch_bounds__(NT) void sumpool_kernel(const float* __restrict__ g
 
 // parameter gradients from the row table: a workgroup owns 64 channels, wave g the samples b = g (mod 4) (fixed order, the four
 // partial sums added in order):  dgamma[c] = sum_b (1 + sc) A2, dbeta[c] = sum_b (1 + sc) A1, dss[b] = [gamma A2 + beta A1 (C) | A1 (C)]
-__global__ __launch_bounds__(NT) void gn_bwd_param_kernel(const float* __restrict__ rows, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, const float* __restrict__ ss,
-                                                         int64_t ss_b_stride, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                         float* __restrict__ dss, int B, int C) {
+__device__ __forceinline__ void gn_bwd_param_body(const int blk, const float* __restrict__ rows, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, const float* __restrict__ ss,
+                                                  int64_t ss_b_stride, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                  float* __restrict__ dss, int B, int C) {
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int c = blk * 64 + lane;
     const bool live = c < C;
     float sg = 0.0f, sb = 0.0f;
     if (live) {
@@ -958,6 +963,18 @@ __global__ __launch_bounds__(NT) void gn_bwd_param_kernel(const float* __restric
         dgamma[c] = (sh[0][0][lane] + sh[0][1][lane]) + (sh[0][2][lane] + sh[0][3][lane]);
         dbeta[c] = (sh[1][0][lane] + sh[1][1][lane]) + (sh[1][2][lane] + sh[1][3][lane]);
     }
+}
+
+// both small passes over the row table in ONE launch (neither depends on the other): workgroups 0 .. B G - 1 form the group means,
+// the rest the parameter gradients -- in a fine-tuning step of the 1-D nets a launch costs more than either pass
+__global__ __launch_bounds__(NT) void gn_bwd_group_param_kernel(const float* __restrict__ rows, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ ss,
+                                                               int64_t ss_b_stride, float* __restrict__ gstat, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ dss, int B, int C, int G,
+                                                               int64_t S) {
+    const int nbg = B * G;
+    if ((int)blockIdx.x < nbg) gn_bwd_group_body((int)blockIdx.x, rows, gamma, ss, ss_b_stride, gstat, C, G, S);
+    else gn_bwd_param_body((int)blockIdx.x - nbg, rows, gamma, beta, ss, ss_b_stride, dgamma, dbeta, dss, B, C);
 }
 
 extern "C" size_t sdc_gn_silu_bwd_floats(int B, int C, int G, int64_t S) {
@@ -991,7 +1008,8 @@ extern "C" int sdc_gn_silu_bwd(const float* h, const float* gy, const float* sta
         hipLaunchKernelGGL(gn_bwd_rows_kernel<1>, dim3((unsigned)nrows), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss, ss_b_stride, rows, nrows, C, G, S);
     else
         hipLaunchKernelGGL(gn_bwd_rows_kernel<4>, dim3((unsigned)((nrows + 3) / 4)), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss, ss_b_stride, rows, nrows, C, G, S);
-    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((unsigned)(B * G)), dim3(NT), 0, s, rows, gamma, ss, ss_b_stride, gstat, C, G, S);
+    hipLaunchKernelGGL(gn_bwd_group_param_kernel, dim3((unsigned)(B * G + (dgamma ? (C + 63) / 64 : 0))), dim3(NT), 0, s, rows, gamma, beta,
+                       ss, ss_b_stride, gstat, dgamma, dbeta, dss, B, C, G, S);
     const int64_t total = (int64_t)nrows * S;
     if (S >= 1024) {
         int ysplit = (int)((S + NT * 8 - 1) / (NT * 8));
@@ -1003,9 +1021,6 @@ extern "C" int sdc_gn_silu_bwd(const float* h, const float* gy, const float* sta
         hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3((unsigned)blocks), dim3(NT), 0, s, h, gy, stats, gamma, beta, ss, ss_b_stride,
                            gstat, gh, C, G, S, total);
     }
-    if (dgamma)
-        hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)((C + 63) / 64)), dim3(NT), 0, s, rows, gamma, beta, ss, ss_b_stride,
-                           dgamma, dbeta, dss, B, C);
     return sdc::check_launch("sdc_gn_silu_bwd");
 }
 

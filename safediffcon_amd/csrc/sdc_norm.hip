@@ -11,8 +11,11 @@ constexpr int NT = 256;
 // (sum, sum of squares) so that var = E[x^2] - mean^2 keeps fp32-level accuracy for any mean/std
 // ratio; partials of all splits are combined by the last-arriving split via plain fp64 slots
 // + a second tiny kernel (deterministic order, no atomics).
+// stats != null (one split per group): thread 0 goes on to the (mean, rstd) pair with gn_finalize_kernel's arithmetic -- the same
+// bits, one launch less (the fine-tuning forward of the 1-D nets: 38 GroupNorms per step, each a few microseconds of work).
 __global__ __launch_bounds__(NT) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part,
-                                                        int64_t n_per_group, int nsplit) {
+                                                        int64_t n_per_group, int nsplit, float* __restrict__ stats = nullptr,
+                                                        double inv_n = 0.0, float eps = 0.f) {
     const int grp = blockIdx.x / nsplit;
     const int sp = blockIdx.x % nsplit;
     const int64_t chunk = (n_per_group + nsplit - 1) / nsplit;
@@ -47,6 +50,13 @@ __global__ __launch_bounds__(NT) void gn_partial_kernel(const float* __restrict_
         for (int w = 0; w < NT / 64; ++w) { ts += sh[0][w]; tq += sh[1][w]; }
         part[(int64_t)blockIdx.x * 2] = ts;
         part[(int64_t)blockIdx.x * 2 + 1] = tq;
+        if (stats) {
+            const double mean = ts * inv_n;
+            double var = tq * inv_n - mean * mean;
+            if (var < 0) var = 0;
+            stats[blockIdx.x * 2] = (float)mean;
+            stats[blockIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
     }
 }
 
@@ -467,7 +477,11 @@ extern "C" int sdc_gn_stats(const float* x, float* stats, int B, int C, int G, i
     const size_t off = (((size_t)ngroups * 2 * sizeof(float)) + 15) & ~(size_t)15;
     double* part = reinterpret_cast<double*>(reinterpret_cast<char*>(stats) + off);
     hipStream_t s = sdc::as_stream(stream);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(ngroups * nsplit), dim3(NT), 0, s, x, part, n, nsplit);
+    if (nsplit == 1) {
+        hipLaunchKernelGGL(gn_partial_kernel, dim3(ngroups), dim3(NT), 0, s, x, part, n, 1, stats, 1.0 / (double)n, eps);
+        return sdc::check_launch("sdc_gn_stats");
+    }
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(ngroups * nsplit), dim3(NT), 0, s, x, part, n, nsplit, (float*)nullptr, 0.0, 0.f);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((ngroups + 63) / 64), dim3(64), 0, s, part, stats, ngroups, nsplit,
                        1.0 / (double)n, eps);
     return sdc::check_launch("sdc_gn_stats");
