@@ -32,6 +32,7 @@ struct WgradArgs {
     int rows_per_split;     // output rows (b, od, oh) per split
     int nsplit, Mt, Nt;
     int lgD, lgH, lgW;      // log2 of the nearest-upsample factors of X
+    int nch;                // wgrad_mkh_kernel: column chunks of a row (grid.z); the partial copies are [nsplit * nch]
 };
 
 template <int KW, int SW, int BKP, bool FOLD = false>
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
     const int mt = tb / a.Nt;
     const int m0 = mt * 64, n0 = nt * 64;
     const int split = blockIdx.y;
+    const int c0 = (int)blockIdx.z * BKP;         // rows longer than one chunk (BKP = 64): chunk blockIdx.z is one more partial copy
     const int R = d.B * d.oD * d.oH;
     const int r_lo = split * a.rows_per_split;
     const int r_hi = min(R, r_lo + a.rows_per_split);
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
         const bool gneed = grow >= st.oh0 && grow < st.oh1 && (bv || want_bias);
         const bool xneed = bv && st.t >= 0 && st.t < d.iH;
         if (gneed) {
-            const int p0 = GPT * gq;
+            const int p0 = c0 + GPT * gq;
             const float* gp = a.g + (int64_t)b * d.gs[0] + (int64_t)od * d.gs[2] + (int64_t)grow * d.gs[3] + g_moff + (int64_t)p0 * d.gs[4];
             const int left = gm_ok ? d.oW - p0 : 0;
             if (gvec && left >= GPT) {
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
             const float* xp = a.x + (int64_t)b * d.xs[0] + (int64_t)(idu >> a.lgD) * d.xs[2] + (int64_t)st.t * d.xs[3];
 #pragma unroll
             for (int i = 0; i < NBL; ++i) {
-                const int iwu = xj[i] - d.pW;
+                const int iwu = c0 + xj[i] - d.pW;
                 const bool ok = xn_ok[i] && iwu >= 0 && iwu < iWu;
                 xreg[i] = ok ? xp[x_noff[i] + (int64_t)(iwu >> a.lgW) * d.xs[4]] : 0.0f;
             }
@@ -448,7 +450,8 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
     }
 
     const int taps = d.kD * KH * KW;
-    float* P = a.part + (int64_t)split * d.M * d.N * taps;
+    const int copy = split * a.nch + (int)blockIdx.z;
+    float* P = a.part + (int64_t)copy * d.M * d.N * taps;
     const int n = n0 + wn * 32 + l31;
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
     if (want_bias) {
         bsum += __shfl_xor(bsum, 1, 64);
         bsum += __shfl_xor(bsum, 2, 64);
-        if (gq == 0 && gm_ok) a.bpart[(int64_t)split * d.M + m0 + gm] = bsum;
+        if (gq == 0 && gm_ok) a.bpart[(int64_t)copy * d.M + m0 + gm] = bsum;
     }
 }
 
@@ -485,8 +488,11 @@ __global__ __launch_bounds__(NT) void wgrad_mkh_kernel(const WgradArgs a) {
 bool wgrad_mkh_ok(const SdcWgradDesc& d) {
     const bool k3 = d.kW == 3 && d.kH == 3 && d.pH == 1 && d.pW == 1;
     const bool k7 = d.kW == 7 && d.kH == 7 && d.pH == 3 && d.N * 7 <= 64;
-    return (k3 || k7) && d.sW == 1 && d.sH == 1 && d.uH == 1 && d.iH == d.oH && (d.oW == 16 || d.oW == 32 || d.oW == 64);
+    return (k3 || k7) && d.sW == 1 && d.sH == 1 && d.uH == 1 && d.iH == d.oH &&
+           (d.oW == 16 || d.oW == 32 || d.oW == 64 || (k3 && d.oW > 64 && d.oW % 64 == 0 && d.oW <= 1024));
 }
+// rows longer than 64 positions go through the merged-kh kernel in chunks of 64 columns: each chunk is one more partial copy
+int wgrad_chunks(const SdcWgradDesc& d) { return wgrad_mkh_ok(d) && d.oW > 64 ? d.oW / 64 : 1; }
 
 template <int KH, int KW, int BKP, bool FOLD>
 int launch_wgrad_mkh(const WgradArgs& a, dim3 grid, hipStream_t s) {
@@ -500,7 +506,7 @@ int launch_wgrad_mkh(const WgradArgs& a, dim3 grid, hipStream_t s) {
 
 template <int KH, int KW, bool FOLD>
 int launch_wgrad_mkh_bkp(const WgradArgs& a, dim3 grid, hipStream_t s) {
-    if (a.d.oW == 64) return launch_wgrad_mkh<KH, KW, 64, FOLD>(a, grid, s);
+    if (a.d.oW % 64 == 0) return launch_wgrad_mkh<KH, KW, 64, FOLD>(a, grid, s);
     if (a.d.oW == 32) return launch_wgrad_mkh<KH, KW, 32, FOLD>(a, grid, s);
     return launch_wgrad_mkh<KH, KW, 16, FOLD>(a, grid, s);
 }
@@ -519,6 +525,13 @@ __global__ __launch_bounds__(NT) void sum_splits_kernel(const float* __restrict_
     float s = 0.0f;
     if (i < n) {
         int k = g;
+        for (; k + 7 * KG < nsplit; k += 8 * KG) {             // eight loads in flight, added in split order (as below)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(k + u * KG) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
         for (; k + 3 * KG < nsplit; k += 4 * KG) {
             const float v0 = part[(int64_t)k * n + i], v1 = part[(int64_t)(k + KG) * n + i];
             const float v2 = part[(int64_t)(k + 2 * KG) * n + i], v3 = part[(int64_t)(k + 3 * KG) * n + i];
@@ -552,13 +565,17 @@ void launch_sum_splits(const float* part, float* out, int64_t n, int nsplit, hip
 
 int wgrad_splits(const SdcWgradDesc& d, int* rows_per_split) {
     const int Mt = (d.M + 63) / 64, Nt = (d.N + 63) / 64;
-    const int64_t tiles = (int64_t)Mt * Nt * d.kD * (wgrad_mkh_ok(d) ? 1 : d.kH);
+    const int nch = wgrad_chunks(d);
+    const int64_t tiles = (int64_t)Mt * Nt * d.kD * (wgrad_mkh_ok(d) ? 1 : d.kH) * nch;
     const int R = d.B * d.oD * d.oH;
     // splits: ~3 workgroups per CU in flight (a layer with few tiles and long rows is otherwise a handful of workgroups); every
     // split writes, and the reduction re-reads, a full copy of the gradient, at HBM rate: cheap beside idle CUs, bounded at 256 MB
-    int64_t want = (768 + tiles - 1) / tiles;
+    // (the merged-kh kernel on rows of >= 64 positions holds 135 KB of LDS -- one workgroup per CU: one round of 256 workgroups,
+    // rather than three rounds of short ones that each pay the ring's fill and a partial copy; rows of 32: two per CU)
+    const int64_t target = wgrad_mkh_ok(d) && d.kH == 3 ? (d.oW >= 64 ? 256 : (d.oW == 32 ? 512 : 768)) : 768;
+    int64_t want = (target + tiles - 1) / tiles;
     const int64_t nw = (int64_t)d.M * d.N * d.kD * d.kH * d.kW;
-    const int64_t cap = (64ll << 20) / nw;
+    const int64_t cap = (64ll << 20) / (nw * nch);
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     if (want > R) want = R;
@@ -576,7 +593,8 @@ extern "C" size_t sdc_conv_wgrad_bytes(const SdcWgradDesc* dp) {
     int rps = 0;
     const int ns = wgrad_splits(*dp, &rps);
     const size_t taps = (size_t)dp->kD * dp->kH * dp->kW;
-    return ((size_t)ns * dp->M * dp->N * taps + (size_t)ns * dp->M) * sizeof(float);
+    const size_t nc = (size_t)ns * wgrad_chunks(*dp);
+    return (nc * dp->M * dp->N * taps + nc * dp->M) * sizeof(float);
 }
 
 extern "C" int sdc_conv_wgrad(const SdcWgradDesc* dp, const float* g, const float* x, float* dw, float* dbias, void* work,
@@ -595,12 +613,14 @@ extern "C" int sdc_conv_wgrad(const SdcWgradDesc* dp, const float* g, const floa
     a.Mt = (d.M + 63) / 64; a.Nt = (d.N + 63) / 64;
     const int64_t nw = (int64_t)d.M * d.N * d.kD * d.kH * d.kW;
     // one split: the workgroups write the gradient itself (no partial copy, no reduction pass)
-    a.part = a.nsplit == 1 ? dw : static_cast<float*>(work);
-    a.bpart = dbias ? (a.nsplit == 1 ? dbias : static_cast<float*>(work) + (int64_t)a.nsplit * nw) : nullptr;
+    a.nch = wgrad_chunks(d);
+    const int ncopy = a.nsplit * a.nch;
+    a.part = ncopy == 1 ? dw : static_cast<float*>(work);
+    a.bpart = dbias ? (ncopy == 1 ? dbias : static_cast<float*>(work) + (int64_t)ncopy * nw) : nullptr;
     const bool mkh = wgrad_mkh_ok(d);
     const int64_t tiles = (int64_t)a.Mt * a.Nt * d.kD * (mkh ? 1 : d.kH);
     SDC_REQUIRE(tiles < (1ll << 31) && a.nsplit < 65536, SDC_EINVAL, "sdc_conv_wgrad: grid too large");
-    dim3 grid((unsigned)tiles, (unsigned)a.nsplit);
+    dim3 grid((unsigned)tiles, (unsigned)a.nsplit, (unsigned)a.nch);
     hipStream_t s = sdc::as_stream(stream);
     int lrc;
     if (mkh) lrc = d.kW == 3 ? launch_wgrad_mkh_bkp<3, 3, false>(a, grid, s) : launch_wgrad_mkh_bkp<7, 7, true>(a, grid, s);
@@ -615,9 +635,9 @@ extern "C" int sdc_conv_wgrad(const SdcWgradDesc* dp, const float* g, const floa
     }
     if (lrc) return lrc;
     int rc = sdc::check_launch("sdc_conv_wgrad");
-    if (rc || a.nsplit == 1) return rc;
+    if (rc || ncopy == 1) return rc;
     {
-        launch_sum_splits(a.part, dw, nw, a.nsplit, s, dbias ? a.bpart : nullptr, dbias, (int64_t)d.M);
+        launch_sum_splits(a.part, dw, nw, ncopy, s, dbias ? a.bpart : nullptr, dbias, (int64_t)d.M);
     }
     return sdc::check_launch("sdc_conv_wgrad[reduce]");
 }

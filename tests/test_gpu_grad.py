@@ -36,6 +36,9 @@ CASES = [
     dict(nd=2, B=7, cin=32, cout=48, sp=(1, 32), k=3, pad=1),
     dict(nd=3, B=1, cin=64, cout=64, sp=(5, 2, 64), k=(1, 3, 3), pad=(0, 1, 1)),
     dict(nd=3, B=2, cin=128, cout=128, sp=(4, 64, 64), k=3, pad=1),
+    # rows of 128 / 192 through the merged-kh kernel as chunks of 64 columns (each chunk one more partial copy), bias included
+    dict(nd=2, B=2, cin=40, cout=72, sp=(5, 192), k=3, pad=1),
+    dict(nd=3, B=1, cin=64, cout=64, sp=(2, 6, 128), k=3, pad=1),
     # ... and its tap-folded 7 x 7 form (stems): seven row taps per workgroup, eight-slot X ring
     dict(nd=3, B=2, cin=7, cout=64, sp=(3, 20, 64), k=(1, 7, 7), pad=(0, 3, 3)),
     dict(nd=2, B=2, cin=3, cout=64, sp=(9, 64), k=7, pad=3),
