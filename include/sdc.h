@@ -102,6 +102,15 @@ typedef struct SdcConvDesc {
 int sdc_conv(const SdcConvDesc* d, const float* x0, const float* x1, const float* wp, const float* bias,
              const float* residual, float* y, void* stream);
 
+/* sdc_conv for grids that leave most of the chip idle (the fine-tuning step, SURVEY 8f: batch 64 puts the deep 3x3 convs of the
+ * Burgers net on 32-128 workgroups for 256 CUs): the input channels of an F(2x2,3x3) conv are split over up to 8 workgroups per
+ * output tile, the partial outputs go to `work` (sdc_conv_splitk_bytes(d) bytes, 16-byte aligned; 0 = this conv is not split: the
+ * call is then exactly sdc_conv) and are summed in split order -- deterministic, but the split depends on the batch, so a
+ * sample's rounding depends on the batch it rides in: the samplers use sdc_conv only.  No fused residual. */
+size_t sdc_conv_splitk_bytes(const SdcConvDesc* d);
+int sdc_conv_splitk(const SdcConvDesc* d, const float* x0, const float* x1, const float* wp, const float* bias, float* y,
+                    float* work, size_t work_bytes, void* stream);
+
 /* Host-side query (measurement tooling, launches nothing): which kernel template instance sdc_conv would run for this
  * descriptor, and the share of the direct-form multiply-adds 2*B*P*Cout*Cin*taps that it issues on the matrix cores
  * (1 for the direct kernels, 2/3 for Winograd F(2,3) along W, 4/9 for F(2x2,3x3), 8/27 for F(2x2x2,3x3x3)). */

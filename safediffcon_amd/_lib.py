@@ -123,6 +123,8 @@ SIGNATURES = {
     "sdc_smoke_rollout": (C.c_int, [_f32p, _f32p, _i64, _i64, _f32p, _i64, _f32p, _i64, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _stream]),
+    "sdc_conv_splitk_bytes": (C.c_size_t, [C.POINTER(SdcConvDesc)]),
+    "sdc_conv_splitk": (C.c_int, [C.POINTER(SdcConvDesc), _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_size_t, _stream]),
     "sdc_linear": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64, _i64, _stream]),
     "sdc_linear_dgrad": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64, _i64, _stream]),
     "sdc_linear_wgrad": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64, _i64, _stream]),

@@ -38,6 +38,9 @@ HEADS, DIM_HEAD = 4, 32
 HID = HEADS * DIM_HEAD
 
 
+SPLIT_SMALL_GRIDS = True        # conv_raw: sdc_conv_splitk where it applies (A/B switch for tools/ft_time.py)
+
+
 def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -80,6 +83,14 @@ def conv_raw(x, wp, bias, cout, k, *, x1=None, stride=(1, 1, 1), pad=(0, 0, 0), 
     d.ys[:] = tuple(int(s) for s in out.stride())
     d.rs[:] = tuple(int(s) for s in residual.stride()) if residual is not None else (0,) * 5
     p = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+    # the fine-tuning step's batch leaves the deep 3x3 convs of the Burgers net on 32-128 workgroups: the input channels are then
+    # split over several workgroups per tile (sdc_conv_splitk; the samplers never split -- a sample's rounding would depend on
+    # the batch it rides in)
+    nsplit = int(lib.sdc_conv_splitk_bytes(C.byref(d))) if (SPLIT_SMALL_GRIDS and residual is None) else 0
+    if nsplit:
+        work = torch.empty(nsplit // 4, dtype=torch.float32, device=x.device)
+        check(lib.sdc_conv_splitk(C.byref(d), p(x), p(x1), p(wp), p(bias), p(out), work.data_ptr(), nsplit, _stream(x)), "sdc_conv_splitk")
+        return out
     check(lib.sdc_conv(C.byref(d), p(x), p(x1), p(wp), p(bias), p(residual), p(out), _stream(x)), "sdc_conv")
     return out
 

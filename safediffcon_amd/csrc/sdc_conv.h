@@ -58,6 +58,10 @@ struct ConvArgs {
     // GroupNorm partial sums of the output (sdc_conv_gn): fp64 (sum, sum of squares) per (sample, group, part)
     double* gn_part;
     int gn_G, gn_cpg, gn_nparts, gn_S;
+    // conv_wg2_kernel, sdc_conv_splitk only: ksplit workgroups share an output tile, each over Cin / ksplit input channels; y is then
+    // the partial buffer [ksplit][B][Cout][oD][oH][oW] (d.ys its dense strides), ypart_elems the size of one partial copy
+    int ksplit;
+    int64_t ypart_elems;
 };
 
 // Position-tile numbering: workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  Neighbouring
@@ -82,6 +86,7 @@ inline int64_t span5(const int64_t* st, int b, int c, int dd, int h, int w) {
 bool wg2_ok(const SdcConvDesc& d, bool small, bool rowhalo);
 bool wg3_ok(const SdcConvDesc& d, bool small, bool rowhalo);
 int launch_wg2(const ConvArgs& a, hipStream_t s);
+int wg2_ksplit(const SdcConvDesc& d);         // Cin split sdc_conv_splitk would use for this conv (1: none)
 int launch_wg3(const ConvArgs& a, hipStream_t s);
 bool wg3s_ok(const SdcConvDesc& d, bool small, bool rowhalo);
 int launch_wg3s(const ConvArgs& a, hipStream_t s);

@@ -1651,14 +1651,49 @@ bool conv_small(const SdcConvDesc& d) {
     return span(d.x0s, d.B, d.iD, d.iH, d.iW) < (1ll << 30) && (d.Cin1 == 0 || span(d.x1s, d.B, d.iD, d.iH, d.iW) < (1ll << 30));
 }
 
+// y (strided) = sum over the splits, in split order, of the dense partial copies of sdc_conv_splitk
+__global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict__ part, float* __restrict__ y, int S, int64_t elems, int C,
+                                                         int oD, int oH, int oW, int64_t s0, int64_t s1, int64_t s2, int64_t s3, int64_t s4) {
+    typedef float nf4 __attribute__((ext_vector_type(4)));
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q * 4 >= elems) return;
+    nf4 acc = *reinterpret_cast<const nf4*>(part + q * 4);
+    for (int k = 1; k < S; ++k) acc += *reinterpret_cast<const nf4*>(part + (int64_t)k * elems + q * 4);
+    int64_t r = q * 4;
+    const int w = (int)(r % oW); r /= oW;
+    const int h = (int)(r % oH); r /= oH;
+    const int dd = (int)(r % oD); r /= oD;
+    const int c = (int)(r % C);
+    const int64_t b = r / C;
+    float* o = y + b * s0 + c * s1 + dd * s2 + h * s3 + w * s4;
+    o[0] = acc.x; o[s4] = acc.y; o[2 * s4] = acc.z; o[3 * s4] = acc.w;
+}
+
 int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const float* wp, const float* bias,
-              const float* residual, float* y, double* gn_part, int gn_G, void* stream);
+              const float* residual, float* y, double* gn_part, int gn_G, void* stream, float* split_work = nullptr, size_t split_bytes = 0);
 
 }  // namespace
 
 extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1, const float* wp, const float* bias,
                         const float* residual, float* y, void* stream) {
     return conv_impl(dp, x0, x1, wp, bias, residual, y, nullptr, 0, stream);
+}
+
+// Same conv as sdc_conv (no fused residual), for grids that leave most CUs idle -- the fine-tuning step at batch 64 runs the deep
+// 3x3 convs of the Burgers net on 64 workgroups: the input channels are split over up to 8 workgroups per output tile, the
+// partial outputs go to `work` and are summed in split order (deterministic).  Other shapes: exactly sdc_conv.
+extern "C" size_t sdc_conv_splitk_bytes(const SdcConvDesc* dp) {
+    if (!dp || dp->precision < 3) return 0;
+    static const int no_rh = exp_env("SDC_NO_ROWHALO");
+    const SdcConvDesc& d = *dp;
+    if (wg3s_ok(d, conv_small(d), !no_rh) || wg3_ok(d, conv_small(d), !no_rh) || !wg2_ok(d, conv_small(d), !no_rh)) return 0;
+    const int S = wg2_ksplit(d);
+    return S > 1 ? (size_t)S * d.B * d.Cout * d.oD * d.oH * d.oW * sizeof(float) : 0;
+}
+
+extern "C" int sdc_conv_splitk(const SdcConvDesc* dp, const float* x0, const float* x1, const float* wp, const float* bias, float* y,
+                               float* work, size_t work_bytes, void* stream) {
+    return conv_impl(dp, x0, x1, wp, bias, nullptr, y, nullptr, 0, stream, work, work_bytes);
 }
 
 extern "C" int sdc_conv_gnparts(const SdcConvDesc* dp, int G) {
@@ -1697,7 +1732,7 @@ extern "C" int sdc_conv_describe(const SdcConvDesc* dp, char* name, size_t cap, 
 namespace {
 
 int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const float* wp, const float* bias,
-              const float* residual, float* y, double* gn_part, int gn_G, void* stream) {
+              const float* residual, float* y, double* gn_part, int gn_G, void* stream, float* split_work, size_t split_bytes) {
     SDC_REQUIRE(dp && x0 && wp && y, SDC_ENULL, "sdc_conv: null pointer");
     const SdcConvDesc& d = *dp;
     SDC_REQUIRE(d.B > 0 && d.Cin0 > 0 && d.Cin1 >= 0 && d.Cout > 0, SDC_EINVAL, "sdc_conv: bad channel/batch counts");
@@ -1745,6 +1780,7 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
     }
     a.wg2 = nullptr;
     a.gn_part = nullptr; a.gn_G = a.gn_cpg = a.gn_nparts = a.gn_S = 0;
+    a.ksplit = 1; a.ypart_elems = 0;
     const bool fast = (d.Cin0 % BK == 0) && (d.Cin1 % BK == 0) && small && d.Cout < (1 << 30);
     hipStream_t s = sdc::as_stream(stream);
     auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
@@ -1798,6 +1834,22 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
         }
         SDC_PICK(d.oW == 16 ? "conv_wg2_kernel<16>" : (d.oW == 32 ? "conv_wg2_kernel<32>" : (d.oW == 64 ? "conv_wg2_kernel<64>" : "conv_wg2_kernel<128>")),
                  4.0 / 9.0);
+        // sdc_conv_splitk: Cin split over ksplit workgroups per tile into the caller's partial buffer, summed in split order
+        const int S = (split_work && !gn_part && !residual && !tl_describe) ? wg2_ksplit(d) : 1;
+        if (S > 1) {
+            const int64_t elems = (int64_t)d.B * d.Cout * d.oD * d.oH * d.oW;
+            SDC_REQUIRE(split_bytes >= (size_t)S * elems * sizeof(float), SDC_EINVAL, "sdc_conv_splitk: workspace too small");
+            SDC_REQUIRE(reinterpret_cast<uintptr_t>(split_work) % 16 == 0, SDC_EINVAL, "sdc_conv_splitk: workspace must be 16-byte aligned");
+            ConvArgs p = a;
+            p.ksplit = S; p.ypart_elems = elems; p.y = split_work; p.vec2 = 1;
+            p.d.ys[4] = 1; p.d.ys[3] = d.oW; p.d.ys[2] = (int64_t)d.oH * d.oW; p.d.ys[1] = p.d.ys[2] * d.oD; p.d.ys[0] = p.d.ys[1] * d.Cout;
+            SDC_REQUIRE(span5(p.d.ys, d.B, 8, d.oD, d.oH, d.oW) < (1ll << 30), SDC_EINVAL, "sdc_conv_splitk: partial copy too large");
+            { const int rc_ = launch_wg2(p, s); if (rc_) return rc_; }
+            const int64_t nq = elems / 4;                     // oW is a multiple of 16 here
+            hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, (const float*)split_work, y, S, elems,
+                               d.Cout, d.oD, d.oH, d.oW, d.ys[0], d.ys[1], d.ys[2], d.ys[3], d.ys[4]);
+            return sdc::check_launch("sdc_conv_splitk[winograd 2x2]");
+        }
         { const int rc_ = launch_wg2(a, s); if (rc_) return rc_; }
         return sdc::check_launch("sdc_conv[winograd 2x2]");
     }

@@ -120,7 +120,11 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     const int l31 = lane & 31, lh = lane >> 5;
     const int MT = (d.Cout + BM - 1) / BM;
     // consecutive logical blocks (one XCD, dispatched back to back) share an input tile: m fastest
-    const int lb = xcd_tile(blockIdx.x, gridDim.x);
+    // Cin split (sdc_conv_splitk: the fine-tuning path on grids that leave most CUs idle): ksp workgroups share an output tile
+    const int ksp = a.ksplit;
+    const int lb_all = xcd_tile(blockIdx.x, gridDim.x);
+    const int split = ksp > 1 ? lb_all % ksp : 0;
+    const int lb = ksp > 1 ? lb_all / ksp : lb_all;
     const int m0 = (lb % MT) * BM;
     const int tile0 = (lb / MT) * W2_TILES;
     const int H2 = d.oH >> 1;
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
 
     w2f2 braw[NIT][4][TPL];       // [item][source row j][column pair]
     nfloat4 areg[8];
-    int s_kd = 0, s_ci = 0;
+    int s_kd = 0, s_ci = split * (a.Cin / ksp);
     const int64_t xs1_0 = d.x0s[1], xs1_1 = d.x1s[1];
     const int xs2_0 = (int)d.x0s[2], xs2_1 = (int)d.x1s[2];
     const int cin0 = d.Cin0, cin = a.Cin, kDn = d.kD, coutn = d.Cout, pDn = d.pD;
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
     // The bias is the start value of component (j, xi) = (1, 1): A^T M A hands that component to each of the 2x2 outputs with
     // coefficient +1.  Register r of a lane is channel m0 + 32 wm + 8 (r >> 2) + 4 lh + (r & 3).
-    if (a.bias) {
+    if (a.bias && split == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = m0 + wm * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         }
     }
 
-    const int nstages = d.kD * (a.Cin / SK);
+    const int nstages = d.kD * (a.Cin / SK) / ksp;
     nfloat4 fa[2][4];             // [set][chunk j]: U components (j, xi = 0..3) of this lane's (k, m)
     nfloat4 fv[2][4];             // [set][j]:       V components (j, xi = 0..3) of this lane's (k, tile)
     auto read_a = [&](const float* Ak, int set, int q) { fa[set][q] = *reinterpret_cast<const nfloat4*>(Ak + aoff[q]); };
@@ -428,6 +432,7 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
     // its operands already paired; its results are the two adjacent outputs of a row), two 8-byte stores from a scalar
     // channel base stepped by the channel stride, 4 packed ops for the GroupNorm sums.
     const bool v2 = a.vec2;
+    float* const ybase = a.y + (int64_t)split * a.ypart_elems;
     const bool gn = a.gn_part != nullptr;
     double gv[8];                                           // 8-row block g4: gv[2 g4] = sum, gv[2 g4 + 1] = sum of squares
 #pragma unroll
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
         typedef __attribute__((address_space(1))) float* gwfloat_p;
         typedef __attribute__((address_space(1))) nfloat2* gwfloat2_p;
         if (full && v2 && !a.res && rp0 + RP <= RPtot) {
-            gwchar_p yb = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(a.y + (int64_t)cob * ycs);
+            gwchar_p yb = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(ybase + (int64_t)cob * ycs);
             const int64_t rstep = ycs * 4, gstep = ycs * 20;                // bytes: the next row, the first row of the next block
             const uint32_t yoff1 = yoff + yrow;
 #pragma unroll
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(256) void conv_wg2_kernel(const ConvArgs a) {
                         }
                     }
                     if (pok && rok) {
-                        const gwchar_p yb = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(a.y + (int64_t)coc * ycs);
+                        const gwchar_p yb = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(ybase + (int64_t)coc * ycs);
                         if (v2) {
                             *(gwfloat2_p)(yb + yoff) = nfloat2{y00, y01};
                             *(gwfloat2_p)(yb + yoff + yrow) = nfloat2{y10, y11};
@@ -586,13 +591,26 @@ bool wg2_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
            (d.Cin1 == 0 || (d.x1s[0] % 4 == 0 && d.x1s[1] % 4 == 0 && d.x1s[2] % 4 == 0));
 }
 
+// Cin split of sdc_conv_splitk: only where the plain launch leaves more than half of the 256 CUs without a workgroup; every split
+// keeps >= 4 stages (the pipeline's prologue and tail are two of them) and whole stages of 8 channels.  Depends on the batch (the
+// tile count does): a sample's rounding then depends on the batch it rides in, which is why the samplers never use it (sdc.h).
+int wg2_ksplit(const SdcConvDesc& d) {
+    if (d.kD != 1) return 1;
+    const int64_t tiles = (int64_t)d.B * d.oD * (d.oH / 2) * (d.oW / 2);
+    const int64_t nb = ((tiles + W2_TILES - 1) / W2_TILES) * ((d.Cout + W2_BM - 1) / W2_BM);
+    const int cin = d.Cin0 + d.Cin1;
+    int S = 1;
+    while (S < 8 && nb * S * 2 <= 256 && cin % (W2_SK * S * 2) == 0 && cin / (W2_SK * S * 2) >= 4) S *= 2;
+    return S;
+}
+
 int launch_wg2(const ConvArgs& a, hipStream_t s) {
     const SdcConvDesc& d = a.d;
     const int64_t tiles = (int64_t)d.B * d.oD * (d.oH / 2) * (d.oW / 2);
     const int MT = (d.Cout + W2_BM - 1) / W2_BM;
-    dim3 grid((unsigned)(((tiles + W2_TILES - 1) / W2_TILES) * MT));
+    dim3 grid((unsigned)(((tiles + W2_TILES - 1) / W2_TILES) * MT * a.ksplit));
     const size_t lds = (size_t)W2_NBUF * (W2_ASZ + W2_BSZ) * sizeof(float) + 4 * 8 * sizeof(double);     // stage buffers + GroupNorm scratch
-    const bool odd_stages = ((d.kD * (a.Cin / W2_SK)) & 1) != 0;
+    const bool odd_stages = ((d.kD * (a.Cin / W2_SK) / a.ksplit) & 1) != 0;
 #define W2_LAUNCH(OWV, D)                                                                                                        \
     do {                                                                                                                         \
         static std::atomic<uint64_t> attr{0};                                                                                    \

@@ -401,3 +401,37 @@ def test_linear_kernels_against_fp64(rows, K, M):
     # shapes outside the contract are refused, not mis-computed
     assert lib.sdc_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), rows, K - 1, M, x.stride(0), y.stride(0), st) == -1 and "multiples of 4" in _lib.last_error()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,c0,c1,cout,H,W", [(4, 512, 0, 512, 2, 16), (8, 256, 0, 256, 4, 32), (4, 256, 256, 256, 4, 32),
+                                             (2, 64, 0, 128, 8, 64), (3, 128, 64, 64, 2, 16), (2, 96, 0, 64, 4, 16)])
+def test_conv_splitk_equals_plain_conv(B, c0, c1, cout, H, W):
+    """sdc_conv_splitk (the fine-tuning path's 3x3 convs on grids that leave most CUs idle: Cin split over 2-8 workgroups per
+    tile, partial outputs summed in split order) against sdc_conv on the same operands: same values up to the summation order,
+    against fp64 torch, bit-reproducible, strided output view; convs it does not split are exactly sdc_conv."""
+    from safediffcon_amd import autograd as ag, grad_ops
+    import torch.nn.functional as F
+    x = det_tensor((B, c0, 1, H, W), 81).to(DEV)
+    x1 = det_tensor((B, c1, 1, H, W), 82).to(DEV) if c1 else None
+    w = det_tensor((cout, c0 + c1, 1, 3, 3), 83, 0.05).to(DEV)
+    b = det_tensor((cout,), 84).to(DEV)
+    wp = grad_ops.pack_conv_weight(w, 4)
+
+    def run(split, out=None):
+        ag.SPLIT_SMALL_GRIDS = split
+        try:
+            return ag.conv_raw(x, wp, b, cout, (1, 3, 3), x1=x1, pad=(0, 1, 1), out=out)
+        finally:
+            ag.SPLIT_SMALL_GRIDS = True
+    y0, y1 = run(False), run(True)
+    xin = x if x1 is None else torch.cat((x, x1), 1)
+    ref = F.conv2d(xin[:, :, 0].double(), w[:, :, 0].double(), b.double(), padding=1)[:, :, None]
+    scale = ref.abs().max().item()
+    e0, e1 = (y0.double() - ref).abs().max().item() / scale, (y1.double() - ref).abs().max().item() / scale
+    print(f"[measured] split-K conv {c0}+{c1}->{cout} @{H}x{W} B={B}: rel err plain {e0:.1e}, split {e1:.1e}")
+    assert e0 < 5e-6 and e1 < 5e-6
+    assert torch.equal(y1, run(True))
+    big = torch.full((B, cout + 8, 1, H, W), 3.0, device=DEV)            # a channel-slice view as the output
+    run(True, out=big[:, 4:4 + cout])
+    assert torch.equal(big[:, 4:4 + cout], y1) and torch.all(big[:, :4] == 3.0) and torch.all(big[:, 4 + cout:] == 3.0)
+    torch.cuda.synchronize()

@@ -39,7 +39,8 @@ def step():
 for _ in range(2):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU], with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     step()
 torch.cuda.synchronize()
 WATCH = ("aten::copy_", "aten::add", "aten::add_", "aten::cat", "aten::mul", "aten::sum", "aten::clone", "aten::fill_", "aten::zero_",
@@ -49,10 +50,11 @@ for ev in prof.events():
     if ev.name not in WATCH:
         continue
     where = "(autograd engine / no python frame)"
-    for fr in ev.stack:
-        if "safediffcon_amd" in fr and "profiler" not in fr:
-            where = fr.split("safediffcon_amd/")[-1]
-            break
+    frames = [fr for fr in ev.stack if "safediffcon_amd/" in fr]
+    if frames:
+        where = " <- ".join(fr.split("safediffcon_amd/")[-1] for fr in frames[:2])
+    elif ev.stack:
+        where = "(no repo frame) " + ev.stack[0][-60:]
     cnt[(ev.name, where)] += 1
 for (name, where), n in cnt.most_common(45):
     print(f"{n:5d}  {name:14s} {where}")
