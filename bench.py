@@ -836,6 +836,12 @@ def worker(a):
         if world == 1 and not a.no_extra and not a.no_finetune:
             with torch.enable_grad():
                 extra["finetune_step"] = finetune_step(wl, a.finetune_batch or {"c2": 64, "c3": 64, "c4": 4}[wl], a.dim, dev)
+                if wl == "c4":
+                    # the 1-D nets' steps ride in the default line too (C3 <= 25 ms, C2 <= 22 ms at B = 64, the
+                    # replayed-hipGraph form `hip_graph_ms` being what a fine-tuning loop runs)
+                    for other in ("c2", "c3"):
+                        torch.cuda.empty_cache()
+                        extra[f"finetune_step_{other}"] = finetune_step(other, 64, 0, dev)
         if world == 1 and not a.no_extra and wl == "c3":
             extra["kstar_score_check"] = kstar_score_check(B, dev)
         if world == 1 and not a.no_extra and wl == "c4":
