@@ -1146,14 +1146,12 @@ int launch_wg3(const ConvArgs& a, hipStream_t s) {
 // instead of 64 tiles per workgroup, and one channel stride for both inputs (the lane offsets of the gather are stage-invariant)
 bool wg3s_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
     auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
-    // Where it is the faster of the two forms (same-box A/B at C4, B = 64, profiles/r5_ab_wg3s.log): rows of 64 (64 -> 64: 5.88 ->
-    // 5.58 ms, 64 + 64 -> 64: 10.30 -> 9.90) and rows of 32 with <= 64 input channels (64 -> 128: 2.85 -> 2.73).  With long K the
-    // one-workgroup form amortises its folds and cold start and keeps its advantage of half the operand traffic per MFMA
-    // (128 -> 128 @ 32: 5.12 / 5.07, 256 -> 256 @ 16: 4.78 / 4.93, 256 + 256 -> 128: 4.67 / 4.89).
-    static const int all = exp_env("SDC_WG3S_ALL");
-    const int cin = d.Cin0 + d.Cin1;
-    if (!(d.precision >= 4 && d.kD == 3 && d.oD % 2 == 0 && d.Cout % W2_BM == 0 &&
-          (d.oW == 64 || (d.oW == 32 && (cin <= 64 || all)) || (d.oW == 16 && all)))) return false;
+    // Every row length the one-workgroup form takes.  Same-box A/B at C4, B = 64 (profiles/r5_ab_wg3s.log): rows of 64 and rows of 32
+    // win in isolation on every box (64 -> 64: 5.74 -> 5.33 ms, 64 -> 128 @ 32: 2.72 -> 2.55, 128 -> 128 @ 32: 4.91 -> 4.79); with
+    // long K on rows of 16 the two forms are within 3 % of each other either way, box by box (256 -> 256: 4.70 / 4.70 and 4.78 / 4.93,
+    // 256 + 256 -> 128: 4.59 / 4.69) -- but this one moves 2.9 x the algorithmic bytes through the fabric where the other moves
+    // 4.2 - 5.6 x, and inside the power-limited step that decides: the whole C4 step is 0.3 - 0.9 % shorter with it on all widths.
+    if (!(d.precision >= 4 && d.kD == 3 && d.oD % 2 == 0 && d.Cout % W2_BM == 0 && (d.oW == 64 || d.oW == 32 || d.oW == 16))) return false;
     SdcConvDesc e = d;
     e.precision = 3;
     if (!wg2_ok(e, small, rowhalo)) return false;
@@ -1192,9 +1190,19 @@ int launch_wg3s(const ConvArgs& a, hipStream_t s) {
     }
 #endif
 #ifdef SDC_KERNEL_EXPERIMENTS
-    if (d.oW == 16) { W3S_LAUNCH(16, 0); return SDC_OK; }        // (SDC_WG3S_ALL: never dispatched by the shipping library)
+    if ((d.oW == 16 || d.oW == 32) && dbg) {
+        if (d.oW == 16) switch (dbg) {
+            case 1: W3S_LAUNCH(16, 1); break; case 4: W3S_LAUNCH(16, 4); break; case 5: W3S_LAUNCH(16, 5); break;
+            case 16: W3S_LAUNCH(16, 16); break; case 32: W3S_LAUNCH(16, 32); break; default: W3S_LAUNCH(16, 13); break;
+        } else switch (dbg) {
+            case 1: W3S_LAUNCH(32, 1); break; case 4: W3S_LAUNCH(32, 4); break; case 5: W3S_LAUNCH(32, 5); break;
+            case 16: W3S_LAUNCH(32, 16); break; case 32: W3S_LAUNCH(32, 32); break; default: W3S_LAUNCH(32, 13); break;
+        }
+        return SDC_OK;
+    }
 #endif
-    if (d.oW == 32) W3S_LAUNCH(32, 0);
+    if (d.oW == 16) W3S_LAUNCH(16, 0);
+    else if (d.oW == 32) W3S_LAUNCH(32, 0);
     else W3S_LAUNCH(64, 0);
     return SDC_OK;
 }
