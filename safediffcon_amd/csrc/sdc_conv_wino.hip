@@ -1146,12 +1146,16 @@ int launch_wg3(const ConvArgs& a, hipStream_t s) {
 // instead of 64 tiles per workgroup, and one channel stride for both inputs (the lane offsets of the gather are stage-invariant)
 bool wg3s_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
     auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
-    // Every row length the one-workgroup form takes.  Same-box A/B at C4, B = 64 (profiles/r5_ab_wg3s.log): rows of 64 and rows of 32
-    // win in isolation on every box (64 -> 64: 5.74 -> 5.33 ms, 64 -> 128 @ 32: 2.72 -> 2.55, 128 -> 128 @ 32: 4.91 -> 4.79); with
-    // long K on rows of 16 the two forms are within 3 % of each other either way, box by box (256 -> 256: 4.70 / 4.70 and 4.78 / 4.93,
-    // 256 + 256 -> 128: 4.59 / 4.69) -- but this one moves 2.9 x the algorithmic bytes through the fabric where the other moves
-    // 4.2 - 5.6 x, and inside the power-limited step that decides: the whole C4 step is 0.3 - 0.9 % shorter with it on all widths.
-    if (!(d.precision >= 4 && d.kD == 3 && d.oD % 2 == 0 && d.Cout % W2_BM == 0 && (d.oW == 64 || d.oW == 32 || d.oW == 16))) return false;
+    // Rows of 64 and of 32.  Same-box A/B at C4, B = 64 (profiles/r5_ab_wg3s.log): they win in isolation on every box (64 -> 64:
+    // 5.74 -> 5.33 ms, 64 -> 128 @ 32: 2.72 -> 2.55, 128 -> 128 @ 32: 4.91 -> 4.79) and move fewer bytes through the fabric (PMC:
+    // 2.9 x the algorithmic bytes against 4.0 x at rows of 64, 3.6 x against 4.2 x at 128 -> 128).  Rows of 16 (256 channels and
+    // more) stay with the one-workgroup form: the two are within 3 % of each other either way, box by box (256 -> 256: 4.70 / 4.70
+    // and 4.78 / 4.93, 256 + 256 -> 128: 4.59 / 4.69), the whole step is the same to 0.15 % (238.1 / 237.7 ms), and with four
+    // channel tiles per position tile and half the positions per workgroup this form fetches more (6.5 x against 5.6 x).
+    static const int all = exp_env("SDC_WG3S_ALL");
+    if (!(d.precision >= 4 && d.kD == 3 && d.oD % 2 == 0 && d.Cout % W2_BM == 0 && (d.oW == 64 || d.oW == 32 || (d.oW == 16 && all)))) return false;
+    static const int no32w = exp_env("SDC_WG3S_NO32WIDE");     // (experiments build: A/B of the rule)
+    if (no32w && d.oW == 32 && d.Cin0 + d.Cin1 > 64) return false;
     SdcConvDesc e = d;
     e.precision = 3;
     if (!wg2_ok(e, small, rowhalo)) return false;
@@ -1200,9 +1204,9 @@ int launch_wg3s(const ConvArgs& a, hipStream_t s) {
         }
         return SDC_OK;
     }
+    if (d.oW == 16) { W3S_LAUNCH(16, 0); return SDC_OK; }        // (SDC_WG3S_ALL: never dispatched by the shipping library)
 #endif
-    if (d.oW == 16) W3S_LAUNCH(16, 0);
-    else if (d.oW == 32) W3S_LAUNCH(32, 0);
+    if (d.oW == 32) W3S_LAUNCH(32, 0);
     else W3S_LAUNCH(64, 0);
     return SDC_OK;
 }

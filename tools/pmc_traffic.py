@@ -40,9 +40,9 @@ def conv3(cin, cout, sp, tag):
     return x, out
 
 
-x0, out0 = conv3(64, 64, (32, 64, 64), "conv_wg3s_kernel<64")          # round 5: every row length runs the two-workgroups-per-CU form
+x0, out0 = conv3(64, 64, (32, 64, 64), "conv_wg3s_kernel<64")          # round 5: rows of 64 and 32 run the two-workgroups-per-CU form
 conv3(128, 128, (32, 32, 32), "conv_wg3s_kernel<32")                  # (one shape per instance: the counters are averaged per kernel name)
-conv3(256, 256, (32, 16, 16), "conv_wg3s_kernel<16")
+conv3(256, 256, (32, 16, 16), "conv_wg3_kernel<16")
 gm, bt = torch.ones(64, device=dev), torch.zeros(64, device=dev)
 plan.gn_silu(out0, gm, bt, 8)
 cases["gn_apply_kernel"] = dict(algorithmic=8 * out0.numel(), shape=f"GroupNorm apply + SiLU in place on ({B},64,32,64,64)")
