@@ -43,6 +43,20 @@ class GraphedLossStep:
                 for p in params:
                     p.grad = None
                 self._body()
+            if optimizer is not None:
+                # torch optimizers create their state (moments, step counters) lazily in the first step(): inside the capture
+                # that would record the zero-fills and replay them every step.  One step here creates the state; the parameters
+                # are put back and the state tensors zeroed in place (the fresh state of Adam / AdamW / SGD with momentum), so
+                # the first replay is the optimizer's first step.
+                with torch.no_grad():
+                    saved = [p.detach().clone() for p in params]
+                    optimizer.step()
+                    for p, q in zip(params, saved):
+                        p.copy_(q)
+                    for st in optimizer.state.values():
+                        for v in st.values():
+                            if torch.is_tensor(v):
+                                v.zero_()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         for p in params:

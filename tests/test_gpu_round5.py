@@ -435,3 +435,41 @@ def test_conv_splitk_equals_plain_conv(B, c0, c1, cout, H, W):
     run(True, out=big[:, 4:4 + cout])
     assert torch.equal(big[:, 4:4 + cout], y1) and torch.all(big[:, :4] == 3.0) and torch.all(big[:, 4 + cout:] == 3.0)
     torch.cuda.synchronize()
+
+
+def test_graphed_step_with_captured_adam_equals_eager_adam():
+    """sdc.GraphedLossStep(optimizer=torch.optim.Adam(capturable=True)): the optimizer step is recorded behind the backward pass
+    and replayed with it -- three replays against three eager steps of a twin net with its own Adam: the
+    parameters agree to rounding (capturable Adam keeps its step count on the device; same update formula)."""
+    torch.manual_seed(0)
+
+    def make():
+        net = sdc.Unet1D(dim=32, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+        net.load_state_dict(det_params(_spec(net), 91))
+        return net, sdc.GaussianDiffusionTokamak(net, seq_length=128, nt=122, timesteps=50).to(DEV)
+    (net_a, gd_a), (net_b, gd_b) = make(), make()
+    B = 8
+    state = det_tensor((B, 12, 128), 92, 0.3).to(DEV)
+    w = (det_tensor((B,), 93, 0.2) + 1.0).to(DEV)
+    t = torch.randint(0, 50, (B,), generator=torch.Generator().manual_seed(94)).to(DEV)
+    noise = det_tensor((B, 12, 128), 95).to(DEV)
+    pa = [p for p in net_a.parameters() if p.requires_grad]
+    pb = [p for p in net_b.parameters() if p.requires_grad]
+    opt_a = torch.optim.Adam(pa, lr=1e-4, capturable=True)
+    opt_b = torch.optim.Adam(pb, lr=1e-4, capturable=True)
+    step = sdc.GraphedLossStep(gd_a, state, weight=w, t=t, noise=noise, optimizer=opt_a)
+    # the warm-up passes of the constructor ran backward only (no optimizer step): both nets still hold the same weights
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb))
+    losses = []
+    for _ in range(3):
+        losses.append(step(state, w, t, noise).item())
+        for p in pb:
+            p.grad = None
+        lb = (w * gd_b.p_losses(state, t, noise=noise, mean=False)).mean()
+        lb.backward()
+        opt_b.step()
+        assert abs(losses[-1] - lb.item()) <= 1e-6 * max(1.0, abs(lb.item()))
+    worst = max(((a - b).abs().max() / (b.abs().max() + 1e-12)).item() for a, b in zip(pa, pb))
+    print(f"[measured] captured Adam vs eager Adam after 3 steps: losses {losses}, worst relative parameter difference {worst:.1e}")
+    assert worst < 1e-5
+    assert losses[2] < losses[0]
