@@ -33,6 +33,15 @@ import subprocess
 import sys
 import time
 
+# Same-box A/B of two BUILDS of the library (tools/ab_step.sh, tools/_r5_ab_*.sh): SDC_LIB_PATH=<libsdc_hip_exp.so | a previous commit's
+# build> is handed to the package's explicit hook before anything loads the library, and the line reports it (`library`).  The
+# package itself reads no environment variable; without the variable this is the in-tree library the tests load.
+LIBRARY_OVERRIDE = os.environ.get("SDC_LIB_PATH") or None
+if LIBRARY_OVERRIDE:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from safediffcon_amd import _lib as _sdc_lib_sel
+    _sdc_lib_sel.use_library(LIBRARY_OVERRIDE)
+
 # RCCL / CUDA-tensor sharing between the ranks of one node needs dmabuf IPC on this driver (set before anything touches HIP;
 # the GPU boxes export it already, a bare `torchrun bench.py` on another machine may not)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -922,6 +931,7 @@ def worker(a):
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(step_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "library": ("safediffcon_amd/libsdc_hip.so (in-tree build)" if not LIBRARY_OVERRIDE else f"OVERRIDE (A/B run): {LIBRARY_OVERRIDE}"),
             "config": {"workload": W["desc"], "batch_per_gpu": B, "global_batch": world * B, "ddpm_timesteps": T_DDPM,
                        "step": "one denoising step of the whole batch (U-Net + guidance + posterior update), hipGraph replay",
                        "parallelism": f"batch-sharded x{world}, no data-path collective", "conv_precision": a.precision,

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SDC_LIB_PATH") or os.path.join(_HERE, "libsdc_hip.so")   # override: kernel experiments only
+LIB_PATH = os.path.join(_HERE, "libsdc_hip.so")
 
 SDC_MODEL_BURGERS, SDC_MODEL_TOKAMAK, SDC_MODEL_SMOKE = 0, 1, 2
 
@@ -144,6 +144,16 @@ _lib = None
 
 class SdcError(RuntimeError):
     pass
+
+
+def use_library(path):
+    """Kernel experiments only (tools/, bench.py's A/B runs): load another BUILD of libsdc_hip.so -- the experiments library of
+    `python -m safediffcon_amd.build --experiments`, or a previous commit's -- instead of the in-tree one.  Must be called before
+    the first get_lib(); nothing in the package calls it and no environment variable reaches the loader."""
+    global LIB_PATH
+    if _lib is not None:
+        raise SdcError("use_library() after the library has been loaded")
+    LIB_PATH = os.path.abspath(path)
 
 
 def get_lib():

@@ -34,7 +34,8 @@ def _stale(out, deps):
 
 def build_experiments(verbose=True):
     """libsdc_hip_exp.so: the same sources with -DSDC_KERNEL_EXPERIMENTS (dispatch overrides and the result-changing debug
-    modes of tools/*_probe.py, read from SDC_* environment variables).  Load it with SDC_LIB_PATH; never shipped or tested."""
+    modes of tools/*_probe.py, read from SDC_* environment variables).  The tools load it through _lib.use_library (SDC_LIB_PATH in tools/ and bench.py);
+    never shipped or tested."""
     out = os.path.join(HERE, "libsdc_hip_exp.so")
     cmd = [HIPCC, *FLAGS, "-DSDC_KERNEL_EXPERIMENTS", "-shared", *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
     if verbose:

@@ -74,3 +74,22 @@ def test_kstar_lstm_surrogate_end_to_end_against_a_torch_module_chain():
     err = np.max(np.abs(got - want)) / max(1.0, np.abs(want).max())
     print(f"[measured] oracle.kstar.lstm_net vs torch.nn module chain on the real weights: {err:.2e}")
     assert err < 2e-5
+
+
+def test_package_loader_reads_no_environment_variable():
+    """the product loader must not honour SDC_LIB_PATH -- only tools/ and bench.py hand it to the explicit hook
+    `_lib.use_library` (and bench.py reports it); the hook refuses to switch once the library is loaded"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from safediffcon_amd import _lib; import os; "
+            "assert _lib.LIB_PATH == os.path.join(os.path.dirname(_lib.__file__), 'libsdc_hip.so'), _lib.LIB_PATH; "
+            "_lib.get_lib(); "
+            "\ntry:\n    _lib.use_library('/tmp/other.so'); raise SystemExit('switched after load')\nexcept _lib.SdcError:\n    pass\n"
+            "print('ok')")
+    env = dict(os.environ, SDC_LIB_PATH="/nonexistent/libsdc_hip.so")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-400:]
+    src = open(os.path.join(root, "safediffcon_amd", "_lib.py")).read()
+    assert "os.environ" not in src and "getenv" not in src

@@ -3,6 +3,7 @@
 noise: the HIP sampler against the oracle's loop + functional net executed by PyTorch-ROCm eager on the same device (held to
 the CPU oracle in tests/test_gpu_strawman.py).  Too long for the test suite (the eager side runs ~0.3 s per step); run once per
 round, log under profiles/.  Reference: 2d/ddpm/diffusion_2d.py:288-322.  usage: python tools/c4_t1000_parity.py [B] [T]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os
 import sys
 import time

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Host-side cost of the un-captured / graph-replayed Unet2D.__call__ path.  usage: call_profile.py"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """time sdc_chan_norm on the C4 attention pre-norm tensors and check it against torch.  usage: cn_probe.py"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

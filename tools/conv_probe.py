@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-call timing of every sdc_conv launch in a U-Net plan (HIP events), for kernel tuning.
 usage: python tools/conv_probe.py [burgers|tokamak|smoke] [B] [dim]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import ctypes as C
 import os
 import sys

@@ -2,6 +2,7 @@
 """Full-length (1000-step) guided smoke trajectories at production width, B=2, identical Philox noise, in the default conv
 mode (4: Winograd over D, H, W) and in the direct fp32 mode (0: k-ordered FMA chains, the arithmetic closest to the
 reference's): how far rounding-order differences drift over a whole reverse process.  usage: python tools/drift_probe.py [T]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os
 import sys
 import time

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """which python lines of a fine-tuning step launch torch's own kernels (copies, adds, cats ...):
 python tools/ft_aten_ops.py [c2|c3] -- torch.profiler with stacks, aten ops grouped by the innermost safediffcon_amd frame"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import collections
 import os
 import sys

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """where the host time of one fine-tuning step goes: python tools/ft_cpu_profile.py [c2|c3|c4] [batch]  (cProfile, top by own time)"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import cProfile
 import os
 import pstats

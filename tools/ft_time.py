@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """time one fine-tuning step (bench.finetune_step) of a workload: python tools/ft_time.py [c2|c3|c4] [batch]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import json
 import os
 import sys

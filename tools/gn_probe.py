@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """time sdc_gn_apply on the C4 level-0 tensor.  usage: gn_probe.py [B]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Fixed per-workgroup cost of conv_wg2_kernel: the same tensor through the 3x3x3 conv (K = 3 Cin) and the 1x3x3 conv
 (K = Cin), precision 3.  usage: python tools/kd_probe.py [B]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os
 import sys
 

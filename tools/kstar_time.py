@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """time the KSTAR rollout (sdc_kstar_rollout) for a batch of control sequences: python tools/kstar_time.py [B ...]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os
 import sys
 import time

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Run one fused LinearAttention block N times (for rocprofv3 kernel stats).  usage: la_probe.py B C n [F] [reps]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Launch one conv shape N times (for PMC / trace passes).  usage: one_conv.py Cin Cout k H W B [reps]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

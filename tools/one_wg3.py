@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One 3x3x3 conv + GroupNorm statistics launch (C4 level-0 shape by default) in precision 4 / 3, a few repetitions:
 the workload for PMC passes on the F(2x2x2,3x3x3) kernel.  usage: python tools/one_wg3.py [B] [cin] [cout] [D H W]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os
 import sys
 

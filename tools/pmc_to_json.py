@@ -2,6 +2,7 @@
 """FETCH_SIZE / WRITE_SIZE / SQ passes of tools/pmc_traffic.py -> profiles/r5_pmc_traffic.json + r5_pmc_mfma_busy.json, stamped
 with the hash of the kernel sources they were collected on (safediffcon_amd.build.source_hash; bench.py refuses a stale record).
 usage: python tools/pmc_to_json.py <fetch_dir> <write_dir> <sq_dir> <cases.json> <out_traffic.json> <out_busy.json>"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import csv
 import glob
 import json

@@ -11,6 +11,7 @@
        conv_pw       1x1x1 conv 128->384 at (B,128,32,32,32) (to_qkv of the width-128 temporal attention)
  It writes the algorithmic bytes of every case to <out dir>/pmc_cases.json for tools/pmc_to_json.py.
 usage: python3 tools/pmc_traffic.py [batch] [cases.json]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import json
 import os
 import sys

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """timing of the 1x1x1 conv shapes of the C4 step (B = 64 by default): python tools/pw_probe.py [B]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os
 import sys
 

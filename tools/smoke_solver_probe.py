@@ -1,4 +1,5 @@
 """GPU probe: sdc_smoke_rollout against the reference fixtures (errors) and its time per batch size."""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os, sys, time
 import numpy as np
 import torch

@@ -3,6 +3,7 @@
 For each stage: time, algorithmic FLOP and bytes (SURVEY 8d definitions: read input + write output + weights,
 fp32), the MFMA FLOPs actually issued (Winograd forms issue fewer), achieved TFLOP/s and GB/s against the MI355X peaks.
 usage: python tools/stage_report.py [burgers|tokamak|smoke] [B] [dim] > profiles/<name>.md"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os
 import sys
 

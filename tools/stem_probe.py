@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """time the 7x7x7 stem conv of the smoke net (Cin 7 -> 64 at 32x64x64).  usage: stem_probe.py [B]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Run the fused temporal-attention block N times.  usage: ta_probe.py B H W [reps]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

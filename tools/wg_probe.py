@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of the 3x3 / 3x3x3 conv shapes of C4 and C2 in the fp32 conv modes (0 direct, 2 Winograd along W, 3 Winograd
 over H and W), one process, same box.  usage: python tools/wg_probe.py [B3d] [B2d]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import ctypes as C
 import os
 import sys

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """time sdc_conv_wgrad on one conv shape: python tools/wgrad_probe.py B Cin Cout D H W kD kH kW [reps]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os
 import sys
 

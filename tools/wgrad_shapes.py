@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """print the weight-gradient calls (shapes, strides, time) of one fine-tuning step: python tools/wgrad_shapes.py [c2|c3|c4] [batch]"""
+import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
 import os
 import sys
 
