@@ -71,9 +71,14 @@ __device__ __forceinline__ void fetch_tile(const float* __restrict__ xb, int64_t
     constexpr int CG = C / 4;
     const int tok = tid & 63, grp = __builtin_amdgcn_readfirstlane(tid >> 6);
     la_gptr rp = la_uni(xb + (int64_t)(grp * CG) * sc);
+    // (the lane offset passes through an empty asm before every access: left alone its zero-extension is hoisted out of the loop as a
+    // 64-bit register pair and every load forms its address with a v_lshl_add_u64 -- 16 per tile here -- instead of taking the
+    // scalar base + 32-bit offset form)
+    uint32_t off = (uint32_t)tok * 4u;
 #pragma unroll
     for (int k = 0; k < CG; ++k) {
-        v[k] = la_ld(rp, (uint32_t)tok * 4u);
+        asm volatile("" : "+v"(off));
+        v[k] = la_ld(rp, off);
         rp += sc;
         asm volatile("" : "+s"(rp));
     }
@@ -90,9 +95,11 @@ __device__ __forceinline__ void gn_apply_tile(float (&v)[C / 4], const float* __
     float rv[CG];                                   // the residual tile is requested first: it travels under the SiLUs
     if (rb) {
         la_gptr rp = la_uni(rb + (int64_t)(__builtin_amdgcn_readfirstlane(grp) * CG) * sc);
+        uint32_t off = (uint32_t)tok * 4u;
 #pragma unroll
         for (int k = 0; k < CG; ++k) {
-            rv[k] = la_ld(rp, (uint32_t)tok * 4u);
+            asm volatile("" : "+v"(off));
+            rv[k] = la_ld(rp, off);
             rp += sc;
             asm volatile("" : "+s"(rp));
         }
@@ -215,9 +222,11 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) SDC_NO_DS_MERGE void la_blk_
             float* hb = a.gn_hout + o * a.so + i * a.si + (int64_t)tile * TT;
             constexpr int CG = C / 4;
             la_gptr hp = la_uni(hb + (int64_t)(__builtin_amdgcn_readfirstlane(tid >> 6) * CG) * a.sc);
+            uint32_t hoff = (uint32_t)(tid & 63) * 4u;
 #pragma unroll
             for (int k = 0; k < CG; ++k) {
-                la_st(hp, (uint32_t)(tid & 63) * 4u, xv[k]);
+                asm volatile("" : "+v"(hoff));
+                la_st(hp, hoff, xv[k]);
                 hp += a.sc;
                 asm volatile("" : "+s"(hp));
             }
@@ -447,10 +456,11 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) SDC_NO_DS_MERGE void la_blk_
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
             const int col = (ct0 + u) * 32 + l31;
-            const uint32_t loff = (uint32_t)((int64_t)(4 * lh) * a.sc + col) * 4u;
+            uint32_t loff = (uint32_t)((int64_t)(4 * lh) * a.sc + col) * 4u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cob = __builtin_amdgcn_readfirstlane(rt * 32 + (r & 3) + 8 * (r >> 2));
+                asm volatile("" : "+v"(loff));
                 la_st(la_uni(yseq + (int64_t)cob * a.sc + (int64_t)tile * TT), loff, yacc[u][r] + xr[(cob + 4 * lh) * XP + col]);
             }
         }
