@@ -22,6 +22,7 @@ constexpr int NT = 256;
 constexpr int TT = 64;            // tokens per tile
 constexpr int XP = TT + 1;        // LDS pitch of a token row (odd: conflict-free when lanes walk channels)
 constexpr int HID = 128;
+constexpr float LOG2E = 1.4426950408889634f;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct LaArgs {
@@ -252,17 +253,23 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) SDC_NO_DS_MERGE void la_blk_
         const float f = __expf(mrun - mnew);
         mrun = mnew;
         float ps = 0.f;
+        // exp(k - m) as exp2(k log2e - m log2e): one multiply-add in front of the v_exp instead of a subtraction and a multiplication
+        const float nml = -mnew * LOG2E;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            kacc[0][r] = __expf(kacc[0][r] - mnew);
-            kacc[1][r] = __expf(kacc[1][r] - mnew);
+            kacc[0][r] = __builtin_amdgcn_exp2f(fmaf(kacc[0][r], LOG2E, nml));
+            kacc[1][r] = __builtin_amdgcn_exp2f(fmaf(kacc[1][r], LOG2E, nml));
             ps += kacc[0][r] + kacc[1][r];
         }
         psum = psum * f + ps;
+        // the running maximum settles after a few tiles: when no lane's moved, f is exactly 1 everywhere and the rescaling of the
+        // NCT x 16 accumulator registers (a multiplication by 1: the same bits) is skipped -- a wave-uniform branch
+        if (__builtin_amdgcn_ballot_w64(f != 1.0f)) {
 #pragma unroll
-        for (int t = 0; t < NCT; ++t)
+            for (int t = 0; t < NCT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) macc[t][r] *= f;
+                for (int r = 0; r < 16; ++r) macc[t][r] *= f;
+        }
         // M^T[c][d] += sum_tok xn[c][tok] p[tok][d]; step (j, r) covers tokens j*32 + crow(r, 0) | crow(r, 1)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -382,10 +389,11 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) SDC_NO_DS_MERGE void la_blk_
             for (int r = 2; r < 16; r += 2) m = la_max3(m, qacc[j][r], qacc[j][r + 1]);
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             float s = 0.f;
+            const float nml = -m * LOG2E;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { qacc[j][r] = __expf(qacc[j][r] - m); s += qacc[j][r]; }
+            for (int r = 0; r < 16; ++r) { qacc[j][r] = __builtin_amdgcn_exp2f(fmaf(qacc[j][r], LOG2E, nml)); s += qacc[j][r]; }
             s += __shfl_xor(s, 32, 64);
-            const float f = 0.17677669529663687f / s;
+            const float f = 0.17677669529663687f * __builtin_amdgcn_rcpf(s);      // (reciprocal instruction: the IEEE division is ten more)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 qs[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XP + j * 32 + l31] = qacc[j][r] * f;
