@@ -416,8 +416,13 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) SDC_NO_DS_MERGE void la_blk_
 #pragma unroll
             for (int u = 0; u < TPW; ++u) {
                 float s = 0.f;
+                if (a.post_mode == 0) {              // (uniform branch: a per-element select computed both forms, 16 v_cndmask per tile)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s += (a.post_mode == 0) ? yacc[u][r] : yacc[u][r] * yacc[u][r];
+                    for (int r = 0; r < 16; ++r) s += yacc[u][r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += yacc[u][r] * yacc[u][r];
+                }
                 s += __shfl_xor(s, 32, 64);
                 if (lh == 0) red[rt * TT + (ct0 + u) * 32 + l31] = s;
             }
@@ -465,11 +470,17 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) SDC_NO_DS_MERGE void la_blk_
         for (int u = 0; u < TPW; ++u) {
             const int col = (ct0 + u) * 32 + l31;
             uint32_t loff = (uint32_t)((int64_t)(4 * lh) * a.sc + col) * 4u;
+            // running scalar row base: rows rt*32 + (r & 3) + 8 (r >> 2) are +1, +1, +1, +5 channel strides apart (formed per row from
+            // (cob, tile) the base cost ~6 scalar instructions per store, 190 per tile at width 64 -- a wave issues one instruction
+            // per four cycles whatever its kind)
+            la_gptr yrow = la_uni(yseq + (int64_t)(rt * 32) * a.sc + (int64_t)tile * TT);
+            const float* xrow = xr + (rt * 32 + 4 * lh) * XP + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int cob = __builtin_amdgcn_readfirstlane(rt * 32 + (r & 3) + 8 * (r >> 2));
                 asm volatile("" : "+v"(loff));
-                la_st(la_uni(yseq + (int64_t)cob * a.sc + (int64_t)tile * TT), loff, yacc[u][r] + xr[(cob + 4 * lh) * XP + col]);
+                la_st(yrow, loff, yacc[u][r] + xrow[((r & 3) + 8 * (r >> 2)) * XP]);
+                yrow += ((r & 3) == 3 ? 5 : 1) * a.sc;
+                asm volatile("" : "+s"(yrow));
             }
         }
         __syncthreads();                             // xs / qs / red are rewritten by the next tile
