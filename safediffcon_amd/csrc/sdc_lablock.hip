@@ -136,31 +136,48 @@ __device__ __forceinline__ void norm_tile(float (&v)[C / 4], const float* __rest
 #pragma unroll
         for (int k = 0; k < CG; ++k) xr[(grp * CG + k) * XP + tok] = v[k];
     }
-    float s = 0.f;
+    // the element-wise chains run on register pairs (v_pk_add / v_pk_fma / v_pk_mul: half the instructions; CG is even)
+    typedef float la_f2 __attribute__((ext_vector_type(2)));
+    la_f2 s2 = {0.f, 0.f};
     if (mode == 0) {
 #pragma unroll
-        for (int k = 0; k < CG; ++k) s += v[k];
-        red[grp * TT + tok] = s;
+        for (int k = 0; k < CG; k += 2) s2 += la_f2{v[k], v[k + 1]};
+        red[grp * TT + tok] = s2.x + s2.y;
         __syncthreads();
         const float mean = (red[tok] + red[TT + tok] + red[2 * TT + tok] + red[3 * TT + tok]) * (1.0f / C);
-        float q = 0.f;
+        const la_f2 m2 = {mean, mean};
+        la_f2 q2 = {0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < CG; ++k) { v[k] -= mean; q += v[k] * v[k]; }
-        red[(4 + grp) * TT + tok] = q;
+        for (int k = 0; k < CG; k += 2) {
+            const la_f2 d2 = la_f2{v[k], v[k + 1]} - m2;
+            v[k] = d2.x; v[k + 1] = d2.y;
+            q2 += d2 * d2;
+        }
+        red[(4 + grp) * TT + tok] = q2.x + q2.y;
         __syncthreads();
         const float var = (red[4 * TT + tok] + red[5 * TT + tok] + red[6 * TT + tok] + red[7 * TT + tok]) * (1.0f / C);
         const float rstd = rsqrtf(var + eps);
+        const la_f2 r2 = {rstd, rstd};
 #pragma unroll
-        for (int k = 0; k < CG; ++k) xs[(grp * CG + k) * XP + tok] = v[k] * rstd * g[grp * CG + k];
+        for (int k = 0; k < CG; k += 2) {
+            const la_f2 o2 = la_f2{v[k], v[k + 1]} * r2 * la_f2{g[grp * CG + k], g[grp * CG + k + 1]};
+            xs[(grp * CG + k) * XP + tok] = o2.x;
+            xs[(grp * CG + k + 1) * XP + tok] = o2.y;
+        }
     } else {
 #pragma unroll
-        for (int k = 0; k < CG; ++k) s += v[k] * v[k];
-        red[grp * TT + tok] = s;
+        for (int k = 0; k < CG; k += 2) { const la_f2 d2 = {v[k], v[k + 1]}; s2 += d2 * d2; }
+        red[grp * TT + tok] = s2.x + s2.y;
         __syncthreads();
         const float nrm = sqrtf(red[tok] + red[TT + tok] + red[2 * TT + tok] + red[3 * TT + tok]);
         const float f = sqrtf((float)C) / fmaxf(nrm, 1e-12f);
+        const la_f2 f2 = {f, f};
 #pragma unroll
-        for (int k = 0; k < CG; ++k) xs[(grp * CG + k) * XP + tok] = v[k] * f * g[grp * CG + k];
+        for (int k = 0; k < CG; k += 2) {
+            const la_f2 o2 = la_f2{v[k], v[k + 1]} * f2 * la_f2{g[grp * CG + k], g[grp * CG + k + 1]};
+            xs[(grp * CG + k) * XP + tok] = o2.x;
+            xs[(grp * CG + k + 1) * XP + tok] = o2.y;
+        }
     }
     __syncthreads();
 }
@@ -388,15 +405,27 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) SDC_NO_DS_MERGE void la_blk_
 #pragma unroll
             for (int r = 2; r < 16; r += 2) m = la_max3(m, qacc[j][r], qacc[j][r + 1]);
             m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float s = 0.f;
+            typedef float la_f2 __attribute__((ext_vector_type(2)));
             const float nml = -m * LOG2E;
+            const la_f2 l2 = {LOG2E, LOG2E}, n2 = {nml, nml};
+            la_f2 s2 = {0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { qacc[j][r] = __builtin_amdgcn_exp2f(fmaf(qacc[j][r], LOG2E, nml)); s += qacc[j][r]; }
+            for (int r = 0; r < 16; r += 2) {      // (register pairs: packed multiply-add in front of the two v_exp, packed sum)
+                const la_f2 e2 = la_f2{qacc[j][r], qacc[j][r + 1]} * l2 + n2;
+                const la_f2 p2 = {__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
+                qacc[j][r] = p2.x; qacc[j][r + 1] = p2.y;
+                s2 += p2;
+            }
+            float s = s2.x + s2.y;
             s += __shfl_xor(s, 32, 64);
             const float f = 0.17677669529663687f * __builtin_amdgcn_rcpf(s);      // (reciprocal instruction: the IEEE division is ten more)
+            const la_f2 f2 = {f, f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                qs[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XP + j * 32 + l31] = qacc[j][r] * f;
+            for (int r = 0; r < 16; r += 2) {
+                const la_f2 o2 = la_f2{qacc[j][r], qacc[j][r + 1]} * f2;
+                qs[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XP + j * 32 + l31] = o2.x;
+                qs[(wave * 32 + ((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * lh) * XP + j * 32 + l31] = o2.y;
+            }
         }
         __syncthreads();
         // y[co][tok] = sum_hd T[co][hd] q[hd][tok]
@@ -437,10 +466,17 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) SDC_NO_DS_MERGE void la_blk_
             if (a.post_mode == 0) {
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) {
+                    typedef float la_f2 __attribute__((ext_vector_type(2)));
                     const float mean = st[u] * (1.0f / C);
-                    float q = 0.f;
+                    const la_f2 m2 = {mean, mean};
+                    la_f2 q2 = {0.f, 0.f};
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { yacc[u][r] -= mean; q += yacc[u][r] * yacc[u][r]; }
+                    for (int r = 0; r < 16; r += 2) {
+                        const la_f2 d2 = la_f2{yacc[u][r], yacc[u][r + 1]} - m2;
+                        yacc[u][r] = d2.x; yacc[u][r + 1] = d2.y;
+                        q2 += d2 * d2;
+                    }
+                    float q = q2.x + q2.y;
                     q += __shfl_xor(q, 32, 64);
                     if (lh == 0) red[(4 + rt) * TT + (ct0 + u) * 32 + l31] = q;
                 }
@@ -451,8 +487,14 @@ __global__ __launch_bounds__(NT, (C == 64 ? 2 : 1)) SDC_NO_DS_MERGE void la_blk_
 #pragma unroll
                     for (int w = 0; w < NRT; ++w) q += red[(4 + w) * TT + (ct0 + u) * 32 + l31];
                     const float rstd = rsqrtf(q * (1.0f / C) + a.eps);
+                    typedef float la_f2 __attribute__((ext_vector_type(2)));
+                    const la_f2 r2 = {rstd, rstd};
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) yacc[u][r] = yacc[u][r] * rstd * bg[C + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+                    for (int r = 0; r < 16; r += 2) {
+                        const la_f2 o2 = la_f2{yacc[u][r], yacc[u][r + 1]} * r2 *
+                                         la_f2{bg[C + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh], bg[C + rt * 32 + ((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * lh]};
+                        yacc[u][r] = o2.x; yacc[u][r + 1] = o2.y;
+                    }
                 }
             } else {
 #pragma unroll
