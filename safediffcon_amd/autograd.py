@@ -86,13 +86,30 @@ def conv_raw(x, wp, bias, cout, k, *, x1=None, stride=(1, 1, 1), pad=(0, 0, 0), 
     # the fine-tuning step's batch leaves the deep 3x3 convs of the Burgers net on 32-128 workgroups: the input channels are then
     # split over several workgroups per tile (sdc_conv_splitk; the samplers never split -- a sample's rounding would depend on
     # the batch it rides in)
-    nsplit = int(lib.sdc_conv_splitk_bytes(C.byref(d))) if (SPLIT_SMALL_GRIDS and residual is None) else 0
+    nsplit = int(lib.sdc_conv_splitk_bytes(C.byref(d))) if (SPLIT_SMALL_GRIDS and residual is None
+                                                             and not getattr(_BATCH_INVARIANT, "on", False)) else 0
     if nsplit:
         work = torch.empty(nsplit // 4, dtype=torch.float32, device=x.device)
         check(lib.sdc_conv_splitk(C.byref(d), p(x), p(x1), p(wp), p(bias), p(out), work.data_ptr(), nsplit, _stream(x)), "sdc_conv_splitk")
         return out
     check(lib.sdc_conv(C.byref(d), p(x), p(x1), p(wp), p(bias), p(residual), p(out), _stream(x)), "sdc_conv")
     return out
+
+
+_BATCH_INVARIANT = threading.local()
+
+
+@contextlib.contextmanager
+def batch_invariant():
+    """inside: conv_raw never splits the input channels over workgroups (the split factor depends on the batch).  The samplers'
+    differentiable last DDIM step runs forward_train under it, so that a sampled trajectory's bits do not depend on the batch it
+    rides in (include/sdc.h: "the samplers use sdc_conv only")."""
+    prev = getattr(_BATCH_INVARIANT, "on", False)
+    _BATCH_INVARIANT.on = True
+    try:
+        yield
+    finally:
+        _BATCH_INVARIANT.on = prev
 
 
 def _k5(w):
@@ -238,7 +255,9 @@ class ConvFn(Function):
 def _linear_ok(x, w):
     """sdc_linear's shapes: nn.Linear on (B, K[, 1, 1, 1]) rows, K and M multiples of 4 (every MLP of the three U-Nets at dim >= 4)"""
     return (x.dim() in (2, 5) and all(s == 1 for s in x.shape[2:]) and all(s == 1 for s in w.shape[2:])
-            and w.shape[1] % 4 == 0 and w.shape[0] % 4 == 0 and x.shape[1] == w.shape[1])
+            and w.shape[1] % 4 == 0 and w.shape[0] % 4 == 0 and x.shape[1] == w.shape[1]
+            # sdc_linear reads float4s: a misaligned view (a slice of a bigger tensor) takes the 1x1x1 conv node instead
+            and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
 
 class LinearFn(Function):

@@ -369,8 +369,10 @@ class _SamplerBase(nn.Module):
         row = S.coef[S.nsteps - 1] if S.ddim else S.coef[0]
         t_last = int(S.ttab[S.nsteps - 1].item()) if S.ddim else 0
         a, b, k = row[0], row[1], row[5]
+        from .autograd import batch_invariant
         with torch.enable_grad():
-            eps = self.model.forward_train(x, torch.full((S.B,), t_last, device=x.device, dtype=torch.long))
+            with batch_invariant():           # no batch-dependent channel split: a trajectory's bits do not depend on its batch
+                eps = self.model.forward_train(x, torch.full((S.B,), t_last, device=x.device, dtype=torch.long))
             x0 = (a * x - b * eps).clamp(-1.0, 1.0)
             if guide is not None:
                 g = guide(x0.detach().clone().requires_grad_())        # (the reference differentiates J on a detached clone)

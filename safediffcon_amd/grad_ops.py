@@ -184,7 +184,8 @@ class PackArena:
     records which (parameter, precision, flip) layouts a step asked for; from the next step on ``begin()`` packs all of
     them in one launch into one buffer and ``get()`` hands out slices.  Only ``nn.Parameter`` storage is cached (a weight
     computed inside the graph has no stable address); the arena holds a reference to every source tensor, so a table entry
-    never points at freed memory, and entries nobody asked for in two consecutive steps are dropped."""
+    never points at freed memory, and entries nobody asked for in two consecutive steps are dropped -- unless a captured
+    graph replays the arena's launch (`freeze`): then buffer and table stay exactly as captured."""
 
     def __init__(self):
         self.index = {}        # key -> (offset, numel) in self.buf
@@ -195,6 +196,16 @@ class PackArena:
         self.buf = self.table = None
         self.launch = None     # (n, total_blocks, lds_bytes)
         self.fresh = False     # the buffer holds this step's weights
+        self.frozen = 0        # captured graphs that replay sdc_pack_batch_run on this buf / table (GraphedLossStep)
+
+    def freeze(self):
+        """a captured graph has baked in the addresses of buf and table: from now on the arena neither drops nor reallocates
+        them (layouts asked for later are packed one by one by the caller, as in the first step) until every holder thaws"""
+        self.frozen += 1
+        return self.buf, self.table
+
+    def thaw(self):
+        self.frozen = max(0, self.frozen - 1)
 
     @staticmethod
     def cacheable(w):
@@ -242,7 +253,7 @@ class PackArena:
         for k in self.idle:
             self.idle[k] = 0 if k in self.used else self.idle[k] + 1
         self.used = set()
-        if self.pending or any(n >= 2 for n in self.idle.values()):
+        if not self.frozen and (self.pending or any(n >= 2 for n in self.idle.values())):
             self._rebuild(device)
         self.fresh = False
         if self.table is not None:
@@ -264,7 +275,7 @@ class PackArena:
             self.used.add(k)
             self.buf.record_stream(torch.cuda.current_stream(w5.device))
             return self.buf[ent[0]:ent[0] + ent[1]]
-        if k not in self.meta:
+        if k not in self.meta and not self.frozen:       # (frozen: no table change is coming, do not pin the source tensor)
             self.pending[k] = (w5, int(precision), bool(flip))
         return None
 

@@ -46,27 +46,61 @@ class GraphedLossStep:
             if optimizer is not None:
                 # torch optimizers create their state (moments, step counters) lazily in the first step(): inside the capture
                 # that would record the zero-fills and replay them every step.  One step here creates the state; the parameters
-                # are put back and the state tensors zeroed in place (the fresh state of Adam / AdamW / SGD with momentum), so
-                # the first replay is the optimizer's first step.
+                # are put back and the state THIS step created is zeroed in place (the fresh state of Adam / AdamW / SGD with
+                # momentum), so the first replay is the optimizer's first step.  State the optimizer already had (it has
+                # trained before) is restored from clones: its moments and step counts carry on.
                 with torch.no_grad():
                     saved = [p.detach().clone() for p in params]
+                    had = {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                           for p, st in optimizer.state.items()}
                     optimizer.step()
                     for p, q in zip(params, saved):
                         p.copy_(q)
-                    for st in optimizer.state.values():
-                        for v in st.values():
+                    for p, st in optimizer.state.items():
+                        old = had.get(p)
+                        for k, v in st.items():
                             if torch.is_tensor(v):
-                                v.zero_()
+                                if old is not None and torch.is_tensor(old.get(k)):
+                                    v.copy_(old[k])
+                                else:
+                                    v.zero_()
+                            elif old is not None and k in old:
+                                st[k] = old[k]
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         for p in params:
             p.grad = None                            # captured backward allocates the .grad tensors in the graph's pool
+        # The captured sdc_pack_batch_run bakes in the addresses of the net's PackArena buffer and pointer table (allocated in the
+        # warm-up, outside the graph's pool).  Freeze the arena for this object's lifetime and hold both tensors: forward-only
+        # calls on the same net between replays (validation under no_grad, sample(enable_grad=True)) would otherwise let
+        # PackArena.begin() rebuild and free them under the graph.
+        self._arena = diffusion.model._trainer().arena
+        self._pinned = self._arena.freeze()
+        self.params = params
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss, self.per_sample = self._body()
-            if optimizer is not None:
-                optimizer.step()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss, self.per_sample = self._body()
+                if optimizer is not None:
+                    optimizer.step()
+        except BaseException:
+            self._arena.thaw()
+            self._arena = None
+            raise
         self.grads = [p.grad for p in params]
+
+    def close(self):
+        """drop the graph and let the net's PackArena rebuild again"""
+        if getattr(self, "_arena", None) is not None:
+            self._arena.thaw()
+            self._arena = None
+        self.graph = self._pinned = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                            # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def _body(self):
         gd = self.gd
@@ -93,5 +127,12 @@ class GraphedLossStep:
             if self.noise is None:
                 raise ValueError("this step was captured drawing its own noise")
             self.noise.copy_(noise)
+        if self.graph is None:
+            raise RuntimeError("GraphedLossStep was closed")
         self.graph.replay()
+        # an eager optimizer's zero_grad() (set_to_none=True is torch's default, and the reference's loops call it) drops the
+        # captured .grad tensors from the parameters: the replay has just written them, seat them again so step() sees them
+        for p, g in zip(self.params, self.grads):
+            if p.grad is not g:
+                p.grad = g
         return self.loss

@@ -383,7 +383,15 @@ class _HipUNet(nn.Module):
         through `.data` must call `refresh()` itself."""
         host = hash(tuple((p.data_ptr(), p._version) for p in self.parameters()))
         dev = next(self.parameters()).device
-        return (host, self._content_stamp() if (self.content_stamp and dev.type == "cuda") else 0)
+        if not (self.content_stamp and dev.type == "cuda"):
+            return (host, 0)
+        # Cost: one small launch + one blocking 8-byte read-back per model(x, t) / sample() call (not per denoising step).  Under a
+        # caller's stream capture a read-back is illegal: the last checksum taken outside the capture stands (a capture records
+        # the packed weights' addresses, which a re-pack refreshes in place, so replays still see later re-packs).
+        if torch.cuda.is_current_stream_capturing():
+            return (host, getattr(self, "_last_content", 0))
+        self._last_content = self._content_stamp()
+        return (host, self._last_content)
 
     def _refresh_entry(self, e, stamp):
         e["plan"].refresh_weights()
