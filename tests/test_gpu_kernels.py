@@ -897,3 +897,98 @@ def test_conv1d_f23_default_mode(plan_cls, case):
     if G:
         want = F.silu(F.group_norm(ref, G, gam.double(), bet.double(), eps=1e-5))
         assert (y.cpu().reshape(want.shape).double() - want).abs().max().item() < 2e-5
+
+
+# ------------------------------------------------------------------ round 6: the round-5 dispatches, pinned by name
+def _describe(plan, i=0):
+    buf, share = C.create_string_buffer(128), C.c_double(0)
+    assert plan.lib.sdc_conv_describe(C.byref(plan.calls[i][1][0]._obj), buf, 128, C.byref(share)) == 0
+    return buf.value.decode(), share.value
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=1, cin=16, cout=64, sp=(2, 4, 64), G=0, want="conv_wg3s_kernel<64>"),                 # rows of 64, one input, no statistics
+    dict(B=2, cin=64, cout=64, sp=(4, 6, 64), cin1=64, G=8, want="conv_wg3s_kernel<64>"),        # 64 + 64 -> 64 (ups), GN epilogue
+    dict(B=1, cin=24, cout=128, sp=(6, 8, 64), G=1, want="conv_wg3s_kernel<64>"),                # Cout 128: two channel tiles per position tile
+    dict(B=2, cin=32, cout=64, sp=(2, 8, 32), G=8, want="conv_wg3s_kernel<32>"),                 # rows of 32: two row pairs per workgroup
+    dict(B=1, cin=16, cout=128, sp=(4, 4, 32), cin1=16, G=4, want="conv_wg3s_kernel<32>"),       # rows of 32, two inputs, Cout 128
+    dict(B=1, cin=32, cout=64, sp=(2, 16, 16), G=0, want="conv_wg3_kernel<16>"),                 # rows of 16 stay with the one-workgroup form
+    dict(B=1, cin=16, cout=64, sp=(3, 4, 64), G=0, want="conv_wg2_kernel"),                      # odd depth: F(2x2,3x3) over (H, W)
+    dict(B=1, cin=16, cout=64, sp=(5, 8, 32), G=8, want="conv_wg2_kernel"),                      # odd depth with statistics
+    dict(B=1, cin=16, cout=64, sp=(2, 6, 32), G=0, want="conv_wg2_kernel"),                      # 3 row pairs: not a whole number of 32-tile workgroups
+])
+def test_conv_wg3s_dispatch_is_pinned_and_matches_fp64(plan_cls, case):
+    """the two-workgroups-per-CU F(2x2x2,3x3x3) kernel is THE kernel compared with fp64 here: sdc_conv_describe names it for rows
+    of 64 and 32 (one and two inputs, with and without the GroupNorm epilogue, Cout 64 / 128), rows of 16 name conv_wg3_kernel,
+    odd depths and ragged row-pair counts fall to conv_wg2_kernel -- each against torch in fp64 (gate 1e-5 of the output scale)."""
+    from safediffcon_amd.engine import as5
+    B, cin, cout, sp, cin1, G = case["B"], case["cin"], case["cout"], case["sp"], case.get("cin1", 0), case["G"]
+    x, x1 = det_tensor((B, cin, *sp), 601), (det_tensor((B, cin1, *sp), 602) if cin1 else None)
+    w, b = det_tensor((cout, cin + cin1, 3, 3, 3), 603, 0.2), det_tensor((cout,), 604, 0.1)
+    ref = F.conv3d((x if x1 is None else torch.cat((x, x1), 1)).double(), w.double(), b.double(), padding=1)
+    plan = plan_cls(DEV, precision=4)
+    out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, (3, 3, 3),
+                    x1=None if x1 is None else as5(x1.to(DEV)), pad=(1, 1, 1), gn_groups=G)
+    name, share = _describe(plan)
+    assert name.startswith(case["want"]), (name, case["want"])
+    assert abs(share - (8 / 27 if "wg3" in case["want"] else 4 / 9)) < 1e-12
+    y = None
+    if G:
+        assert plan.calls[0][0] is plan.lib.sdc_conv_gn          # the statistics come out of the conv's epilogue
+        gam, bet = det_tensor((cout,), 605, 0.3) + 1.0, det_tensor((cout,), 606, 0.2)
+        y = plan.pool.get(tuple(out.shape))
+        plan.gn_silu(out, gam.to(DEV), bet.to(DEV), G, out=y)
+    _run(plan)
+    _run(plan)                                                    # (y is scratch while the kernel runs: a replay must not see the old result)
+    e = (out.cpu().reshape(ref.shape).double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"[measured] {name}: rel err vs fp64 {e:.2e}")
+    assert e < 1e-5, (name, e)
+    if G:
+        refn = F.silu(F.group_norm(ref, G, gam.double(), bet.double(), 1e-5))
+        torch.testing.assert_close(y.cpu().reshape(ref.shape).double(), refn, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=8, cin=32, cout=128, sp=(32, 32, 32), want="conv_pw2_kernel<2,2>"),                          # exactly 1024 tiles of 128 x 256
+    dict(B=3, cin=48, cout=128, sp=(8, 121, 92), residual=True, want="conv_pw2_kernel<2,2>"),           # ragged last position tile, residual
+    dict(B=2, cin=16, cout=384, sp=(8, 128, 128), cin1=16, want="conv_pw2_kernel<2,2>"),                # two inputs, three channel blocks
+    dict(B=4, cin=32, cout=64, sp=(8, 128, 128), want="conv_pw2_kernel<1,4>"),                          # Cout 64: 64 x 512 tiles
+    dict(B=5, cin=128, cout=64, sp=(4, 164, 164), residual=True, want="conv_pw2_kernel<1,4>"),          # ragged, residual, K = 128 (8 chunks)
+    dict(B=8, cin=32, cout=96, sp=(32, 32, 32), want="conv_pw_kernel"),                                 # Cout % 128 != 0: the older kernel
+    dict(B=2, cin=32, cout=128, sp=(16, 32, 32), want="conv_pw_kernel"),                                # < 1024 tiles: the older kernel
+])
+def test_conv_pw2_dispatch_is_pinned_and_matches_fp64(plan_cls, case):
+    """the interleaved-tile 1x1 kernel by name (`<2,2>` and `<1,4>`; residual; ragged position counts; two inputs) against fp64
+    torch, and -- DESIGN 3.7's claim -- BIT-identical to conv_pw_kernel: the same call into an output buffer whose batch stride is
+    not a multiple of 4 floats takes the older kernel (its k-ordered fp32 FMA chains are the same)."""
+    from safediffcon_amd.engine import as5
+    B, cin, cout, sp, cin1 = case["B"], case["cin"], case["cout"], case["sp"], case.get("cin1", 0)
+    x, x1 = det_tensor((B, cin, *sp), 611), (det_tensor((B, cin1, *sp), 612) if cin1 else None)
+    w, b = det_tensor((cout, cin + cin1, 1, 1, 1), 613, 0.2), det_tensor((cout,), 614, 0.1)
+    res = det_tensor((B, cout, *sp), 615) if case.get("residual") else None
+    xd, x1d, wd, bd = x.to(DEV), (None if x1 is None else x1.to(DEV)), w.to(DEV), b.to(DEV)
+    resd = None if res is None else res.to(DEV)
+    ref = F.conv3d((xd if x1d is None else torch.cat((xd, x1d), 1)).double(), wd.double(), bd.double())
+    if resd is not None:
+        ref = ref + resd.double()
+    outs = {}
+    for tag in ("aligned", "shifted"):
+        plan = plan_cls(DEV, precision=4)
+        out = None
+        if tag == "shifted":
+            n = cout * sp[0] * sp[1] * sp[2]
+            wide = torch.zeros(B, n + 1, device=DEV)              # batch stride n + 1: rows of y no longer 16-byte aligned
+            out = wide[:, :n].view(B, cout, *sp)
+        out = plan.conv(as5(xd), plan.conv_weight(wd), bd, cout, (1, 1, 1), x1=None if x1d is None else as5(x1d),
+                        residual=None if resd is None else as5(resd), out=out)
+        name, _ = _describe(plan)
+        if tag == "aligned":
+            assert name.startswith(case["want"]), (name, case["want"])
+        else:
+            assert name.startswith("conv_pw_kernel"), name
+        _run(plan)
+        outs[tag] = out.reshape(ref.shape).clone()
+    e = (outs["aligned"].double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"[measured] {case['want']}: rel err vs fp64 {e:.2e}")
+    assert e < 3e-6, e
+    assert torch.equal(outs["aligned"], outs["shifted"])
