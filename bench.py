@@ -98,8 +98,9 @@ def shard_config(name, B, world):
                 alpha={"c2": 0.98, "c3": 0.9, "c4": 0.04}[name])
 
 
-def workload(name, dim, B, dev, rank, world, precision=4, cal_steps=5):
-    """-> dict(desc, gd, prep() -> _Loop, conformal=dict(Q, n_cal, alpha, ms), calib(...) -> calibration-mode _Loop)"""
+def workload(name, dim, B, dev, rank, world, precision=4, cal_steps=5, split_small=False):
+    """-> dict(desc, gd, prep() -> _Loop, conformal=dict(Q, n_cal, alpha, ms), calib(...) -> calibration-mode _Loop)
+    split_small: the net's small-batch plan (net.split_small_grids, the `*_shard8_split` extras)"""
     import torch
     import safediffcon_amd as sdc
     from safediffcon_amd import conformal
@@ -159,6 +160,7 @@ def workload(name, dim, B, dev, rank, world, precision=4, cal_steps=5):
                              w_groundtruth=wgt, nablaJ=None, enable_grad=False, _prepare=True)
         cal_B, cal_batches = 250, 4
         net.precision = precision
+        net.split_small_grids = bool(split_small)
         cf = quantile("burgers", sampled_pred(calib, cal_B, truth), truth, [500.0, 0.8 ** 2, 0.0, 10.0], 0.98)
         guid.Q = cf["Q"]
         desc = f"C2: 1D Burgers Unet2D dim={dim} (1,2,4,8) state (B,3,16,128), guided 1000-step DDPM, conformal quantile on"
@@ -182,6 +184,7 @@ def workload(name, dim, B, dev, rank, world, precision=4, cal_steps=5):
                              nablaJ=None, enable_grad=False, _prepare=True)
         cal_B, cal_batches = 125, 8
         net.precision = precision
+        net.split_small_grids = bool(split_small)
         cf = quantile("tokamak", sampled_pred(calib, cal_B, truth), truth, [0.0, 1.0, 0.01, 4.98, 0.0], 0.9, target=tgt_cal)
         desc = f"C3: tokamak Unet1D dim={dim} (1,2,4,8) state (B,12,128), guided 1000-step DDPM"
     elif name == "c4":
@@ -198,6 +201,7 @@ def workload(name, dim, B, dev, rank, world, precision=4, cal_steps=5):
             return gd.sample(batch_size=Bc, design_fn=None, enable_grad=False, init=init[:Bc], control=control, _prepare=True)
         cal_B, cal_batches = 25, 8
         net.precision = precision
+        net.split_small_grids = bool(split_small)
         truth = (0.3 * torch.randn(n_cal, 32, 7, 64, 64, generator=g1)).to(dev)
         cf = quantile("smoke", sampled_pred(calib, cal_B, truth), truth, [0.9, 0.1, 0.0, 100.0], 0.04, smoke=True)
         del truth

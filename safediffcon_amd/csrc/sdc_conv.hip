@@ -743,9 +743,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BKT == 8 ? 4
 //     y0 = m0+m1+m2+m3+m4,  y1 = (m1-m2) + 2(m3-m4),  y2 = (m1+m2) + 4(m3+m4),  y3 = (m1-m2) + 8(m3-m4) + m5.
 template <int TM, int TP, int BM, int BN, int WM, int WN, int NX = 4>
 __device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[NX][TM][TP], int mw, int pw, int lane,
-                                            float* scratch, int wave, int m0, int n0, bool active = true) {
+                                            float* scratch, int wave, int m0, int n0, bool active = true, float* ybase = nullptr) {
     constexpr int NO = NX == 6 ? 4 : 2;
     const SdcConvDesc& d = a.d;
+    float* const yb = ybase ? ybase : a.y;       // (sdc_conv_splitk: this split's partial copy)
     const int l31 = lane & 31, lh = lane >> 5;
     const bool v2 = a.vec2;
     const bool gn = a.gn_part != nullptr;
@@ -799,7 +800,7 @@ __device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[NX]
                     yv[2] = (s12 + 4.0f * s34) + bv[rr] + rv[2];
                     yv[3] = ((d12 + 8.0f * d34) + m5) + bv[rr] + rv[3];
                     if (pok && co < d.Cout) {
-                        float* yp = a.y + yoff + co * d.ys[1];
+                        float* yp = yb + yoff + co * d.ys[1];
                         if (v2) {
                             *reinterpret_cast<float2*>(yp) = make_float2(yv[0], yv[1]);
                             *reinterpret_cast<float2*>(yp + 2) = make_float2(yv[2], yv[3]);
@@ -835,7 +836,7 @@ __device__ __forceinline__ void wg_epilogue(const ConvArgs& a, f32x16 (&acc)[NX]
                 const float y0 = ((m0 + m1) + m2) + bv[rr] + r0[rr];
                 const float y1 = ((m1 - m2) - m3) + bv[rr] + r1[rr];
                 if (pok && co < d.Cout) {
-                    float* yp = a.y + yoff + co * d.ys[1];
+                    float* yp = yb + yoff + co * d.ys[1];
                     if (v2) *reinterpret_cast<float2*>(yp) = make_float2(y0, y1);
                     else { yp[0] = y0; yp[d.ys[4]] = y1; }
                     if (gn) { gs[i][rr >> 2] += (double)y0 + (double)y1; gq[i][rr >> 2] += (double)y0 * y0 + (double)y1 * y1; }
@@ -1021,7 +1022,11 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
     float breg[KROWS][NCOL];
     float4 areg[NA4];
     uint32_t mbits = 0;
-    int s_kd = 0, s_kh = 0, s_ci = 0;
+    // sdc_conv_splitk on the single-tap-row form (P1; the 1-D nets at small batch leave their layers on 64 workgroups): blockIdx.z
+    // workgroups share an output tile, each over Cin / ksplit input channels; y is then this split's dense partial copy
+    const int ksp = P1 ? a.ksplit : 1;
+    const int kbeg = ksp > 1 ? (int)blockIdx.z * (a.Cin / ksp) : 0, kend = ksp > 1 ? kbeg + a.Cin / ksp : a.Cin;
+    int s_kd = 0, s_kh = 0, s_ci = kbeg;
 
     // The fetch of a stage is cut into NSL pieces that are issued BETWEEN the MFMA groups of the main loop (a
     // workgroup's loads all at once keep the CU's one vector-memory pipe -- 64 B/clk -- busy for hundreds of cycles
@@ -1053,7 +1058,7 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
             for (int t = 0; t < NCOL; ++t) l_off[t] = first ? p1_off0[t] : p1_off1[t];
             mbits = p1_bits;
             s_ci += SK;
-            if (s_ci >= a.Cin) s_ci = 0;
+            if (s_ci >= kend) s_ci = kbeg;
             return;
         }
         l_tap = s_kd * d.kH + s_kh;
@@ -1128,7 +1133,7 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][i][j][r] = 0.0f;
 
-    const int nstages = d.kD * d.kH * (a.Cin / SK);
+    const int nstages = d.kD * d.kH * ((kend - kbeg) / SK);
     {   // prologue: the fetches of the first two stages travel together (stage 0 in a register set that dies here, before
         // the accumulators come alive) -- one memory round trip before the first MFMA instead of two
         float breg0[KROWS][NCOL];
@@ -1273,7 +1278,8 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
         }
         __syncthreads();
     }
-    wg_epilogue<TM, TP, BM, BN, WM, WN, NX>(a, acc, m0 + wm * (TM * 32), n0 / NO + wn * (TP * 32), lane, ldsw, wv, m0, n0, kh == 0);
+    wg_epilogue<TM, TP, BM, BN, WM, WN, NX>(a, acc, m0 + wm * (TM * 32), n0 / NO + wn * (TP * 32), lane, ldsw, wv, m0, n0, kh == 0,
+                                            ksp > 1 ? a.y + (int64_t)blockIdx.z * a.ypart_elems : nullptr);
 }
 
 
@@ -1519,8 +1525,9 @@ int launch_f43(const ConvArgs& a, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int SK, int NTH = 256, bool UPS = false, int NX = 4, int KS = 1>
 int launch_wg(const ConvArgs& a, hipStream_t s) {
-    const bool p1 = !UPS && a.d.kD * a.d.kH == 1 && ((a.Cin / SK) & 1) == 0;       // (single tap row, an even number of stages)
-    dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM);
+    const bool p1 = !UPS && a.d.kD * a.d.kH == 1 && ((a.Cin / SK / a.ksplit) & 1) == 0;       // (single tap row, an even number of stages)
+    SDC_REQUIRE(a.ksplit == 1 || p1, SDC_EINVAL, "sdc_conv_splitk: the 1-D split needs the single-tap-row kernel");
+    dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM, a.ksplit);
     constexpr int KSMAX = BN + (BN / 16) * 2;
     constexpr int NCOLH = (KSMAX + 63) / 64;
     constexpr size_t STAGE = (2u * NX * SK * BM + 2u * SK * (NCOLH * 64 + 8)) * sizeof(float);
@@ -1644,6 +1651,20 @@ int gn_parts_for(const SdcConvDesc& d, const WgPick& w, int G) {
     return (int)(S / w.bn) * (cpg >= w.bm ? cpg / w.bm : 1);
 }
 
+// Cin split of sdc_conv_splitk on the 1-D F(2,3) form (conv_wg_kernel<64,128,...,ks2> on its single-tap-row path): as wg2_ksplit --
+// only where the plain launch leaves more than half of the 256 CUs without a workgroup; every split keeps >= 4 stages and an even
+// number of whole 16-channel stages.  Depends on the batch (the tile count does).
+int wg1_ksplit(const SdcConvDesc& d, const WgPick& w, int64_t ntot) {
+    if (w.pick != 3 || w.ups || d.kD * d.kH != 1 || d.precision == 5) return 1;
+    const int64_t nb = ((ntot + 127) / 128) * ((d.Cout + 63) / 64);
+    if (nb >= 256) return 1;                      // (launch_wg's 128 x 128 / 64 x 256 tiles take the bigger grids)
+    const int cin = d.Cin0 + d.Cin1;
+    if ((cin / 16) & 1) return 1;
+    int S = 1;
+    while (S < 8 && nb * S * 2 <= 256 && cin % (32 * S * 2) == 0 && cin / (16 * S * 2) >= 4) S *= 2;
+    return S;
+}
+
 bool conv_small(const SdcConvDesc& d) {
     auto span = [](const int64_t* st, int b, int dd, int h, int w) {
         return (int64_t)(b - 1) * st[0] + (int64_t)(dd - 1) * st[2] + (int64_t)(h - 1) * st[3] + (int64_t)(w - 1) * st[4];
@@ -1653,7 +1674,8 @@ bool conv_small(const SdcConvDesc& d) {
 
 // y (strided) = sum over the splits, in split order, of the dense partial copies of sdc_conv_splitk
 __global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict__ part, float* __restrict__ y, int S, int64_t elems, int C,
-                                                         int oD, int oH, int oW, int64_t s0, int64_t s1, int64_t s2, int64_t s3, int64_t s4) {
+                                                         int oD, int oH, int oW, int64_t s0, int64_t s1, int64_t s2, int64_t s3, int64_t s4,
+                                                         const float* __restrict__ bias = nullptr) {
     typedef float nf4 __attribute__((ext_vector_type(4)));
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q * 4 >= elems) return;
@@ -1665,6 +1687,7 @@ __global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict
     const int dd = (int)(r % oD); r /= oD;
     const int c = (int)(r % C);
     const int64_t b = r / C;
+    if (bias) acc += bias[c];                    // (the 1-D form: its splits carry no bias)
     float* o = y + b * s0 + c * s1 + dd * s2 + h * s3 + w * s4;
     o[0] = acc.x; o[s4] = acc.y; o[2 * s4] = acc.z; o[3 * s4] = acc.w;
 }
@@ -1683,11 +1706,16 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
 // 3x3 convs of the Burgers net on 64 workgroups: the input channels are split over up to 8 workgroups per output tile, the
 // partial outputs go to `work` and are summed in split order (deterministic).  Other shapes: exactly sdc_conv.
 extern "C" size_t sdc_conv_splitk_bytes(const SdcConvDesc* dp) {
-    if (!dp || dp->precision < 3) return 0;
+    if (!dp || dp->precision < 2) return 0;          // (the 1-D F(2,3) form is precision 2; wg2_ok asks for >= 3 itself)
     static const int no_rh = exp_env("SDC_NO_ROWHALO");
     const SdcConvDesc& d = *dp;
-    if (wg3s_ok(d, conv_small(d), !no_rh) || wg3_ok(d, conv_small(d), !no_rh) || !wg2_ok(d, conv_small(d), !no_rh)) return 0;
-    const int S = wg2_ksplit(d);
+    if (wg3s_ok(d, conv_small(d), !no_rh) || wg3_ok(d, conv_small(d), !no_rh)) return 0;
+    int S;
+    if (wg2_ok(d, conv_small(d), !no_rh)) S = wg2_ksplit(d);
+    else {
+        const int64_t ntot = (int64_t)d.B * d.oD * d.oH * d.oW;
+        S = (d.oW % 4 == 0 && d.ys[4] == 1) ? wg1_ksplit(d, wg_pick(d, ntot, conv_small(d), !no_rh), ntot) : 1;
+    }
     return S > 1 ? (size_t)S * d.B * d.Cout * d.oD * d.oH * d.oW * sizeof(float) : 0;
 }
 
@@ -1869,6 +1897,23 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
             else if (wgp.pick == 7) { SDC_PICK("conv_wg_kernel<64,256,2,4,16,512,ups>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 256, 2, 4, 16, 512, true>(a, s); if (rc_) return rc_; } }
             else { SDC_PICK("conv_wg_kernel<64,128,2,2,16,256,ups>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 128, 2, 2, 16, 256, true>(a, s); if (rc_) return rc_; } }
             return sdc::check_launch("sdc_conv[winograd,upsample]");
+        }
+        // sdc_conv_splitk on the 1-D form: Cin split over S workgroups per tile into the caller's partial buffer, summed in split
+        // order (+ bias) by splitk_sum_kernel
+        const int S1d = (split_work && !gn_part && !residual && !tl_describe && d.oW % 4 == 0 && d.ys[4] == 1) ? wg1_ksplit(d, wgp, ntot) : 1;
+        if (S1d > 1) {
+            const int64_t elems = (int64_t)d.B * d.Cout * d.oD * d.oH * d.oW;
+            SDC_REQUIRE(split_bytes >= (size_t)S1d * elems * sizeof(float), SDC_EINVAL, "sdc_conv_splitk: workspace too small");
+            SDC_REQUIRE(reinterpret_cast<uintptr_t>(split_work) % 16 == 0, SDC_EINVAL, "sdc_conv_splitk: workspace must be 16-byte aligned");
+            ConvArgs p = a;
+            p.ksplit = S1d; p.ypart_elems = elems; p.y = split_work; p.vec2 = 1; p.bias = nullptr;
+            p.d.ys[4] = 1; p.d.ys[3] = d.oW; p.d.ys[2] = (int64_t)d.oH * d.oW; p.d.ys[1] = p.d.ys[2] * d.oD; p.d.ys[0] = p.d.ys[1] * d.Cout;
+            SDC_PICK("conv_wg_kernel<64,128,2,2,16,512,ks2>", 2.0 / 3.0);
+            { const int rc_ = launch_wg<64, 128, 2, 2, 16, 512, false, 4, 2>(p, s); if (rc_) return rc_; }
+            const int64_t nq = elems / 4;
+            hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, (const float*)split_work, y, S1d, elems,
+                               d.Cout, d.oD, d.oH, d.oW, d.ys[0], d.ys[1], d.ys[2], d.ys[3], d.ys[4], bias);
+            return sdc::check_launch("sdc_conv_splitk[winograd 1-D]");
         }
         if (wgp.pick == 13) { SDC_PICK("conv_f43_kernel<128,128,4,16,F43>", 0.5); { const int rc_ = launch_f43<128, 128, 4, 16>(a, s); if (rc_) return rc_; } }
         else if (wgp.pick == 6) { SDC_PICK("conv_wg_kernel<128,128,4,2,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<128, 128, 4, 2, 16, 512>(a, s); if (rc_) return rc_; } }

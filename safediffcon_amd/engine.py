@@ -148,6 +148,7 @@ class Plan:
         self._gn_parts = {}      # out.data_ptr() -> (partial-sum buffer, parts per (sample, group), groups) left by sdc_conv_gn
         self.fuse_gn_stats = True    # False: separate statistics pass after every conv (A/B checks)
         self.fuse_gn_small = True    # False: small groups take the three-launch path (partial, finalize, apply)
+        self.split_small_grids = False   # True: sdc_conv_splitk where a conv's grid leaves most CUs idle (net.split_small_grids)
 
     # ------------------------------------------------------------------ execution
     def run(self, stream):
@@ -238,6 +239,15 @@ class Plan:
         if residual is not None:
             assert tuple(residual.shape) == tuple(out.shape)
         self.keep += [d, x, x1, wp, bias, residual, out]     # the call list holds raw pointers only
+        if self.split_small_grids and residual is None:
+            # a grid that leaves most of the chip idle (small batch, deep level): Cin split over several workgroups per tile.  The
+            # statistics of a following GroupNorm then come from its own kernel (these tensors are small: sdc_gn_fused)
+            nsplit = int(self.lib.sdc_conv_splitk_bytes(C.byref(d)))
+            if nsplit:
+                work = torch.empty(nsplit // 4, dtype=torch.float32, device=self.device)
+                self.keep.append(work)
+                self._emit(self.lib.sdc_conv_splitk, C.byref(d), _ptr(x), _ptr(x1), _ptr(wp), _ptr(bias), _ptr(out), _ptr(work), nsplit)
+                return out
         nparts = int(self.lib.sdc_conv_gnparts(C.byref(d), gn_groups)) if (gn_groups and self.fuse_gn_stats) else 0
         if nparts > 0:
             parts = torch.empty(B * gn_groups * nparts * 2, dtype=torch.float64, device=self.device)

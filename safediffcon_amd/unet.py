@@ -285,6 +285,11 @@ class _HipUNet(nn.Module):
         # nearest-x2 upsample + 3x3 conv as four sub-pixel 2x2 convs with merged taps (4/9 of the multiply-adds; the merged
         # weights change the summation order by ~1e-7 relative); False = one conv with the upsampling folded into its gather
         self.subpixel_upsample = True
+        # small-batch samplers (an 8-way shard of the 1-D configs leaves B = 16-32 per GPU): where a 3-tap conv's grid
+        # leaves more than half of the CUs idle its input channels are split over 2-8 workgroups per tile (sdc_conv_splitk, summed
+        # in split order: deterministic).  The split factor depends on the batch, so with it ON a trajectory's rounding depends on
+        # the batch it rides in (fp32 sums in another order: ~1e-7); OFF (default) the samplers use sdc_conv only.
+        self.split_small_grids = False
         self.forward_graph = True    # model(x, t) replays a captured hipGraph; False = launch the call list every time
         self._side = None
         self.dim = dim
@@ -417,7 +422,7 @@ class _HipUNet(nn.Module):
         """Plan for an input of `shape` whose conditioning table has `rows` rows: one row per sample
         (lut=False, forward(x, time)) or one row per timestep read through a device-side t (lut=True, samplers)."""
         key = (tuple(shape), rows, bool(lut), int(self.precision), bool(self.fuse_linattn), bool(self.subpixel_upsample),
-               bool(self.fuse_gn_into_linattn))
+               bool(self.fuse_gn_into_linattn), bool(self.split_small_grids))
         stamp = self._weights_stamp()
         ent = self._plans.get(key)
         if ent is not None and ent["wstamp"] != stamp:        # parameters changed since this plan packed them
@@ -428,6 +433,7 @@ class _HipUNet(nn.Module):
                 raise RuntimeError("safediffcon_amd runs on MI355X only: move the model to a cuda (HIP) device; "
                                    "there is no CPU fallback")
             plan = Plan(dev, precision=self.precision)
+            plan.split_small_grids = bool(self.split_small_grids)
             x = torch.zeros(shape, dtype=torch.float32, device=dev)
             eps = torch.zeros(shape, dtype=torch.float32, device=dev)
             b = _Builder(self, plan)

@@ -18,8 +18,11 @@ EXTRA_WORKLOADS = {
     "c3_small": ("c3", 64, 128, "configs[2] with Unet1D dim 64 (tokamak/configs/inference_config.py:76, the default)"),
     "c2_shard8": ("c2", 0, 32, "per-rank batch of configs[1] sharded over 8 GPUs (SURVEY 8e)"),
     "c3_shard8": ("c3", 0, 16, "per-rank batch of configs[2] sharded over 8 GPUs (SURVEY 8e)"),
+    # the same with net.split_small_grids = True: Cin of the 3-tap convs split over workgroups where the grid leaves CUs idle
+    "c2_shard8_split": ("c2", 0, 32, "c2_shard8 with the small-batch plan (net.split_small_grids)", True),
+    "c3_shard8_split": ("c3", 0, 16, "c3_shard8 with the small-batch plan (net.split_small_grids)", True),
 }
-ALL_EXTRA_WORKLOADS = "c2,c3,c2_turbo,c3_turbo,c3_small,c2_shard8,c3_shard8"
+ALL_EXTRA_WORKLOADS = "c2,c3,c2_turbo,c3_turbo,c3_small,c2_shard8,c3_shard8,c2_shard8_split,c3_shard8_split"
 
 
 def strawman(step_seconds, name, batch, steps, dim, dev):
@@ -251,8 +254,9 @@ def run_extras(ctx, a, W, wl, B, prec, dev, step_ms):
         if key not in EXTRA_WORKLOADS:
             raise SystemExit(f"--extra-workloads: unknown entry {key!r} (known: {sorted(EXTRA_WORKLOADS)})")
         t_ph = time.perf_counter()
-        other, dim2, B2, why = EXTRA_WORKLOADS[key]
-        W2 = ctx.workload(other, dim2, B2, dev, ctx.rank, ctx.world, prec, cal_steps=(a.cal_steps if key in ("c2", "c3", "c4") else 0))
+        other, dim2, B2, why = EXTRA_WORKLOADS[key][:4]
+        W2 = ctx.workload(other, dim2, B2, dev, ctx.rank, ctx.world, prec, cal_steps=(a.cal_steps if key in ("c2", "c3", "c4") else 0),
+                          split_small=len(EXTRA_WORKLOADS[key]) > 4 and EXTRA_WORKLOADS[key][4])
         S2 = W2["prep"]()
         S2.init()
         dt2 = ctx.timed(S2, 3, a.extra_steps)

@@ -19,12 +19,13 @@ def conv_kernel_of(lib, d):
 
 def classify(lib, fn, a):
     """-> dict(stage, kernel, flops, issued, bytes)"""
-    if fn is lib.sdc_conv or fn is lib.sdc_conv_gn:
+    if fn is lib.sdc_conv or fn is lib.sdc_conv_gn or fn is lib.sdc_conv_splitk:
         d = a[0]._obj
         P = d.B * d.oD * d.oH * d.oW
         cin, taps = d.Cin0 + d.Cin1, d.kD * d.kH * d.kW
         nin = d.B * cin * d.iD * d.iH * d.iW
-        by = 4.0 * (nin + P * d.Cout * (2 if a[5] else 1) + taps * cin * d.Cout)
+        split = fn is lib.sdc_conv_splitk             # (x0, x1, wp, bias, y, work, bytes): no residual; + the partial copies
+        by = 4.0 * (nin + P * d.Cout * (2 if (not split and a[5]) else 1) + taps * cin * d.Cout)
         kern, share = conv_kernel_of(lib, d)
         kind = f"conv {d.kD}x{d.kH}x{d.kW}" + (" (up/transposed)" if d.uH > 1 else "") + (" s2" if d.sH > 1 else "")
         if "conv_wg3" in kern:
@@ -37,6 +38,9 @@ def classify(lib, fn, a):
             kind += " [Winograd F(2,3) along W]"
         if fn is lib.sdc_conv_gn:
             kind += " + GroupNorm statistics in the epilogue"
+        if split:
+            kind += " [Cin split over workgroups + sum]"
+            kern += " splitk"
         fl = 2.0 * P * d.Cout * cin * taps
         return dict(stage=kind, kernel=kern, flops=fl, issued=fl * share, bytes=by)
     if fn is lib.sdc_gn_finalize:
