@@ -1042,7 +1042,10 @@ __global__ __launch_bounds__(NTH) void conv_wg_kernel(const ConvArgs a) {
 #pragma unroll
         for (int t = 0; t < NCOL; ++t) {
             const bool ok = smask[t] & 1u;
-            p1_off0[t] = ok ? (uint32_t)v0[t] * 4u : 0u;
+            // (UPS with one tap row: the source row of tap kh = 0 is the same for every stage too)
+            int src = v0[t];
+            if constexpr (UPS) src += hoff[t][0];
+            p1_off0[t] = ok ? (uint32_t)src * 4u : 0u;
             p1_off1[t] = ok ? (uint32_t)(two ? v1[t] : v0[t]) * 4u : 0u;
             p1_bits |= (ok ? 1u : 0u) << t;
         }
@@ -1525,7 +1528,8 @@ int launch_f43(const ConvArgs& a, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int SK, int NTH = 256, bool UPS = false, int NX = 4, int KS = 1>
 int launch_wg(const ConvArgs& a, hipStream_t s) {
-    const bool p1 = !UPS && a.d.kD * a.d.kH == 1 && ((a.Cin / SK / a.ksplit) & 1) == 0;       // (single tap row, an even number of stages)
+    // (single tap row, an even number of stages; the upsampling gather only where a split asks for it: 1-D nets at small batch)
+    const bool p1 = (!UPS || a.ksplit > 1) && a.d.kD * a.d.kH == 1 && ((a.Cin / SK / a.ksplit) & 1) == 0;
     SDC_REQUIRE(a.ksplit == 1 || p1, SDC_EINVAL, "sdc_conv_splitk: the 1-D split needs the single-tap-row kernel");
     dim3 grid((a.Ntot + BN - 1) / BN, (a.d.Cout + BM - 1) / BM, a.ksplit);
     constexpr int KSMAX = BN + (BN / 16) * 2;
@@ -1536,7 +1540,7 @@ int launch_wg(const ConvArgs& a, hipStream_t s) {
     constexpr size_t lds = STAGE > PART ? STAGE : PART;
     static_assert(lds <= 160u * 1024u, "stage buffers / k-split partials exceed the LDS");
     static std::atomic<uint64_t> attr{0}, attr1{0};
-    if constexpr (!UPS) {
+    if constexpr (!UPS || (BM == 64 && BN == 128 && NTH == 256)) {
         if (p1) {
             SDC_LDS_OPTIN(attr1, (conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS, NX, KS, true>), 160 * 1024, "sdc_conv[winograd]");
             hipLaunchKernelGGL((conv_wg_kernel<BM, BN, WM, WN, SK, NTH, UPS, NX, KS, true>), grid, dim3(NTH), lds, s, a);
@@ -1655,7 +1659,7 @@ int gn_parts_for(const SdcConvDesc& d, const WgPick& w, int G) {
 // only where the plain launch leaves more than half of the 256 CUs without a workgroup; every split keeps >= 4 stages and an even
 // number of whole 16-channel stages.  Depends on the batch (the tile count does).
 int wg1_ksplit(const SdcConvDesc& d, const WgPick& w, int64_t ntot) {
-    if (w.pick != 3 || w.ups || d.kD * d.kH != 1 || d.precision == 5) return 1;
+    if (w.pick != 3 || d.kD * d.kH != 1 || d.precision == 5 || (w.ups && (d.uH != 1 || d.iH != 1))) return 1;
     const int64_t nb = ((ntot + 127) / 128) * ((d.Cout + 63) / 64);
     if (nb >= 256) return 1;                      // (launch_wg's 128 x 128 / 64 x 256 tiles take the bigger grids)
     const int cin = d.Cin0 + d.Cin1;
@@ -1892,12 +1896,6 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
             SDC_GN_PARTS_AGREE(a.gn_nparts);
             a.gn_part = gn_part; a.gn_G = gn_G; a.gn_cpg = d.Cout / gn_G; a.gn_S = d.oD * d.oH * d.oW;
         }
-        if (wgp.ups) {
-            if (wgp.pick == 6) { SDC_PICK("conv_wg_kernel<128,128,4,2,16,512,ups>", 2.0 / 3.0); { const int rc_ = launch_wg<128, 128, 4, 2, 16, 512, true>(a, s); if (rc_) return rc_; } }
-            else if (wgp.pick == 7) { SDC_PICK("conv_wg_kernel<64,256,2,4,16,512,ups>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 256, 2, 4, 16, 512, true>(a, s); if (rc_) return rc_; } }
-            else { SDC_PICK("conv_wg_kernel<64,128,2,2,16,256,ups>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 128, 2, 2, 16, 256, true>(a, s); if (rc_) return rc_; } }
-            return sdc::check_launch("sdc_conv[winograd,upsample]");
-        }
         // sdc_conv_splitk on the 1-D form: Cin split over S workgroups per tile into the caller's partial buffer, summed in split
         // order (+ bias) by splitk_sum_kernel
         const int S1d = (split_work && !gn_part && !residual && !tl_describe && d.oW % 4 == 0 && d.ys[4] == 1) ? wg1_ksplit(d, wgp, ntot) : 1;
@@ -1908,12 +1906,23 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
             ConvArgs p = a;
             p.ksplit = S1d; p.ypart_elems = elems; p.y = split_work; p.vec2 = 1; p.bias = nullptr;
             p.d.ys[4] = 1; p.d.ys[3] = d.oW; p.d.ys[2] = (int64_t)d.oH * d.oW; p.d.ys[1] = p.d.ys[2] * d.oD; p.d.ys[0] = p.d.ys[1] * d.Cout;
-            SDC_PICK("conv_wg_kernel<64,128,2,2,16,512,ks2>", 2.0 / 3.0);
-            { const int rc_ = launch_wg<64, 128, 2, 2, 16, 512, false, 4, 2>(p, s); if (rc_) return rc_; }
+            if (wgp.ups) {
+                SDC_PICK("conv_wg_kernel<64,128,2,2,16,256,ups>", 2.0 / 3.0);
+                { const int rc_ = launch_wg<64, 128, 2, 2, 16, 256, true>(p, s); if (rc_) return rc_; }
+            } else {
+                SDC_PICK("conv_wg_kernel<64,128,2,2,16,512,ks2>", 2.0 / 3.0);
+                { const int rc_ = launch_wg<64, 128, 2, 2, 16, 512, false, 4, 2>(p, s); if (rc_) return rc_; }
+            }
             const int64_t nq = elems / 4;
             hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, (const float*)split_work, y, S1d, elems,
                                d.Cout, d.oD, d.oH, d.oW, d.ys[0], d.ys[1], d.ys[2], d.ys[3], d.ys[4], bias);
             return sdc::check_launch("sdc_conv_splitk[winograd 1-D]");
+        }
+        if (wgp.ups) {
+            if (wgp.pick == 6) { SDC_PICK("conv_wg_kernel<128,128,4,2,16,512,ups>", 2.0 / 3.0); { const int rc_ = launch_wg<128, 128, 4, 2, 16, 512, true>(a, s); if (rc_) return rc_; } }
+            else if (wgp.pick == 7) { SDC_PICK("conv_wg_kernel<64,256,2,4,16,512,ups>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 256, 2, 4, 16, 512, true>(a, s); if (rc_) return rc_; } }
+            else { SDC_PICK("conv_wg_kernel<64,128,2,2,16,256,ups>", 2.0 / 3.0); { const int rc_ = launch_wg<64, 128, 2, 2, 16, 256, true>(a, s); if (rc_) return rc_; } }
+            return sdc::check_launch("sdc_conv[winograd,upsample]");
         }
         if (wgp.pick == 13) { SDC_PICK("conv_f43_kernel<128,128,4,16,F43>", 0.5); { const int rc_ = launch_f43<128, 128, 4, 16>(a, s); if (rc_) return rc_; } }
         else if (wgp.pick == 6) { SDC_PICK("conv_wg_kernel<128,128,4,2,16,512>", 2.0 / 3.0); { const int rc_ = launch_wg<128, 128, 4, 2, 16, 512>(a, s); if (rc_) return rc_; } }

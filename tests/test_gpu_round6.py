@@ -228,3 +228,30 @@ def test_small_batch_plan_eps_vs_oracle_and_graph(tree, dim, B):
     # the first two samples riding in a smaller batch: bit-equal with the switch off, not required with it on
     net.split_small_grids = False
     assert torch.equal(net(x[:2].contiguous(), t[:2]), plain[:2])
+
+
+@pytest.mark.parametrize("B,cin,cout,L", [(16, 2048, 1024, 16), (16, 512, 256, 64), (300, 512, 256, 64)])
+def test_conv1d_upsample_splitk_equals_plain_conv(B, cin, cout, L):
+    """tokamak Upsample (nearest x2 + Conv1d k3, tokamak/model/unet.py:24-28) with the upsampling folded into the conv's gather:
+    sdc_conv_splitk splits its input channels at small batch like the plain 1-D convs; against sdc_conv and fp64 torch."""
+    import torch.nn.functional as F
+    from safediffcon_amd import autograd as ag, grad_ops
+    x = det_tensor((B, cin, 1, 1, L), 85).to(DEV)
+    w = det_tensor((cout, cin, 1, 1, 3), 86, 0.05).to(DEV)
+    b = det_tensor((cout,), 87).to(DEV)
+    wp = grad_ops.pack_conv_weight(w, 4)
+
+    def run(split):
+        ag.SPLIT_SMALL_GRIDS = split
+        try:
+            return ag.conv_raw(x, wp, b, cout, (1, 1, 3), pad=(0, 0, 1), up=(1, 1, 2))
+        finally:
+            ag.SPLIT_SMALL_GRIDS = True
+    y0, y1 = run(False), run(True)
+    ref = F.conv1d(F.interpolate(x[:, :, 0, 0].double(), scale_factor=2, mode="nearest"), w[:, :, 0, 0].double(), b.double(), padding=1)[:, :, None, None]
+    scale = ref.abs().max().item()
+    e0, e1 = (y0.double() - ref).abs().max().item() / scale, (y1.double() - ref).abs().max().item() / scale
+    splits = not torch.equal(y0, y1)
+    print(f"[measured] 1-D upsample split-K conv {cin}->{cout} L={L}->{2 * L} B={B}: rel err plain {e0:.1e}, split {e1:.1e} ({'split' if splits else 'not split'})")
+    assert e0 < 5e-6 and e1 < 5e-6 and torch.equal(y1, run(True))
+    assert splits == (B < 100)
