@@ -654,13 +654,13 @@ def headline(a, world, B, value, step_ms, W, roof, cpu, clocks, cf, backend, ran
         out["gpu_sensors"] = {k: clocks[k] for k in ("sclk_mhz_median", "sclk_mhz_min", "power_w_mean", "power_w_max") if k in clocks}
     if LIBRARY_OVERRIDE:
         out["library"] = f"OVERRIDE (A/B run): {LIBRARY_OVERRIDE}"
-    if extra:
-        # one number per extra workload; the rest of each block is in the side file
-        out["extra"] = {k: ({"ms_per_step": v["ms_per_step"], "value": v["value"], "frac": v["roofline"]["frac"]}
-                            if "roofline" in v else
-                            {kk: v[kk] for kk in ("ms_per_step", "hip_ms", "hip_graph_ms", "hip_speedup_per_trajectory",
-                                                  "seconds_for_one_1000_step_sample", "trajectories_per_s", "seconds") if kk in v})
-                        for k, v in extra.items() if isinstance(v, dict) and k != "phases_s"}
+    # one number per extra workload; the rest of each block is in the side file
+    brief = {k: ({"ms_per_step": v["ms_per_step"], "value": v["value"], "frac": v["roofline"]["frac"]} if "roofline" in v else
+                 {kk: v[kk] for kk in ("ms_per_step", "hip_ms", "hip_graph_ms", "hip_speedup_per_trajectory",
+                                       "seconds_for_one_1000_step_sample", "trajectories_per_s", "seconds") if kk in v})
+             for k, v in extra.items() if isinstance(v, dict) and k != "phases_s"}
+    if brief:
+        out["extra"] = brief
     out["extra_file"] = extra_file
     line = json.dumps(out)
     if len(line) > HEADLINE_MAX_BYTES:                        # never print a line the driver cannot parse: shed the optional keys
