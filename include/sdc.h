@@ -155,6 +155,17 @@ int sdc_gn_fused(const float* x, const float* gamma, const float* beta, const fl
                  int64_t ss_t_stride, int64_t ss_b_stride, int64_t ss_off, const float* residual, float* y, int B, int C, int G,
                  int64_t S, float eps, void* stream);
 
+/* GroupNorm apply + SiLU (+ residual) of the LAST ResnetBlock inside the 1x1(x1) output conv that is its only reader
+ * (2d/video_diffusion_pytorch/video_diffusion_pytorch_conv3d.py:468-471 `final_conv`, 1D/model/unet.py:376-378,
+ * tokamak/model/unet.py:355-357): y[b, o, pos] = bias[o] + sum_c w[o][c] * (SiLU((h[b, c, pos] - mean) * rstd * gamma[c] + beta[c]) +
+ * residual[b, c, pos]) in one streaming pass -- the normalised tensor is never written.  h / residual contiguous (B, C, S), 16-byte
+ * aligned; stats from sdc_gn_stats / sdc_gn_finalize; w = the nn.Conv weight (Cout, C) as it lies, Cout <= 16; y through strides:
+ * element (b, o, s) at b * ys0 + o * ys1 + (s / plane) * ys2 + s % plane, plane = H * W (the smoke net writes eps frame-major);
+ * plane and the strides multiples of 4 floats.  HBM-bound: 4 * (2 C + Cout) bytes per position. */
+int sdc_gn_pointwise_out(const float* h, const float* stats, const float* gamma, const float* beta, const float* residual,
+                         const float* w, const float* bias, float* y, int B, int C, int G, int Cout, int64_t S, int64_t plane,
+                         int64_t ys0, int64_t ys1, int64_t ys2, void* stream);
+
 /* ------------------------------------------------------- channel norms */
 /* mode 0: channel LayerNorm, gain only, (x-mean)*rsqrt(var+eps)*g   1D/model/unet.py:53-63, conv3d.py:165-174
  * mode 1: RMSNorm  x / max(||x||_2,1e-12) * g * sqrt(C)            tokamak/model/unet.py:45-51

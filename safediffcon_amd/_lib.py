@@ -74,6 +74,8 @@ SIGNATURES = {
     "sdc_gn_fused_ok": (C.c_int, [C.c_int, C.c_int, C.c_int, _i64]),
     "sdc_gn_fused": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i32p, _i64, _i64, _i64, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64,
                                C.c_float, _stream]),
+    "sdc_gn_pointwise_out": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _i64,
+                                       _i64, _i64, _i64, _i64, _stream]),
     "sdc_chan_norm": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, _i64, C.c_int, C.c_float, _stream]),
     "sdc_linattn": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, _i64, _i64, _i64,
                               _i64, _stream]),

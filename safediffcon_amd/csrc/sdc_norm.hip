@@ -458,6 +458,80 @@ __global__ __launch_bounds__(NT) void act_kernel(const float* x, float* y, int64
 // with room for ngroups*2 floats + ngroups*nsplit*2 doubles (see safediffcon_amd/engine.py).
 constexpr int MAX_SPLIT = 16;
 
+// ---------------------------------------------------------------- GroupNorm apply + SiLU + residual INSIDE the output conv
+// The last ResnetBlock of a U-Net feeds only `final_conv`, a 1x1(x1) conv to a handful of channels (smoke: Conv3d(64, 7, 1),
+// conv3d.py:468-471; Burgers / tokamak: 1D/model/unet.py:376-378): instead of one HBM pass that writes the normalised tensor and a
+// conv that reads it back, one streaming kernel reads the raw conv output h and the residual, forms v = SiLU(GN(h)) + res per
+// element and accumulates the CO outputs of its four positions in registers: 4 (2 C + CO) bytes per position instead of 4 (4 C + CO).
+// grid = (position vectors, samples); a thread owns four adjacent positions; the channel constants and the weight row of a channel
+// are wave-uniform (scalar loads).  Output through strides (the smoke net writes eps frame-major).
+// (held to 128 registers = four waves per SIMD: left alone the compiler keeps 32 loads in flight in 394 registers and runs one
+// workgroup per CU -- 1.2 TB/s.  The channel constants and weight rows come from LDS (one broadcast read each): as scalar loads
+// they serialised the loop on s_waitcnt.)
+template <int CO>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8))) void gn_pw_out_kernel(
+    const float* __restrict__ h, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ res, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y, int C, int G, int Cout,
+    int64_t S, int64_t plane, int64_t ys0, int64_t ys1, int64_t ys2) {
+    typedef float nf4 __attribute__((ext_vector_type(4)));
+    extern __shared__ float gpw_lds[];                    // [C][2 + CO]: mul, add, w[0..CO)
+    constexpr int RW = 2 + CO;
+    const int b = blockIdx.y;
+    const int cpg = C / G;
+    for (int i = threadIdx.x; i < C * RW; i += NT) {
+        const int c = i / RW, k = i - c * RW;
+        const int g = c / cpg;
+        const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+        const float mul = rstd * gamma[c];
+        gpw_lds[i] = k == 0 ? mul : (k == 1 ? beta[c] - mean * mul : (k - 2 < Cout ? w[(int64_t)(k - 2) * C + c] : 0.0f));
+    }
+    __syncthreads();
+    const int64_t si = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (si >= (S >> 2)) return;
+    const int64_t cs4 = S >> 2;
+    const nf4* h4 = reinterpret_cast<const nf4*>(h + (int64_t)b * C * S) + si;
+    const nf4* r4 = reinterpret_cast<const nf4*>((res ? res : h) + (int64_t)b * C * S) + si;
+    const float rk = res ? 1.0f : 0.0f;
+    nf4 acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+        const float bv = (bias && o < Cout) ? bias[o] : 0.0f;
+        acc[o] = nf4{bv, bv, bv, bv};
+    }
+    constexpr int UN = 4;                                 // channels in flight per thread: 8 x 16-byte loads (C % 4 == 0: host check)
+#pragma unroll 1
+    for (int c0 = 0; c0 < C; c0 += UN) {
+        nf4 hv[UN], rv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            hv[u] = __builtin_nontemporal_load(h4 + (int64_t)(c0 + u) * cs4);
+            rv[u] = __builtin_nontemporal_load(r4 + (int64_t)(c0 + u) * cs4);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const float* row = gpw_lds + (c0 + u) * RW;
+            const float mul = row[0], add = row[1];
+            nf4 v;
+            v.x = fmaf(rk, rv[u].x, sdc::silu_f(fmaf(hv[u].x, mul, add)));
+            v.y = fmaf(rk, rv[u].y, sdc::silu_f(fmaf(hv[u].y, mul, add)));
+            v.z = fmaf(rk, rv[u].z, sdc::silu_f(fmaf(hv[u].z, mul, add)));
+            v.w = fmaf(rk, rv[u].w, sdc::silu_f(fmaf(hv[u].w, mul, add)));
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                const float wv = row[2 + o];
+                acc[o].x = fmaf(wv, v.x, acc[o].x); acc[o].y = fmaf(wv, v.y, acc[o].y);
+                acc[o].z = fmaf(wv, v.z, acc[o].z); acc[o].w = fmaf(wv, v.w, acc[o].w);
+            }
+        }
+    }
+    const int64_t s0 = si << 2;
+    const int64_t d = s0 / plane, hw = s0 - d * plane;    // the four positions lie in one (H, W) plane: plane % 4 == 0 (host check)
+    float* yb = y + (int64_t)b * ys0 + d * ys2 + hw;
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+        if (o < Cout) *reinterpret_cast<nf4*>(yb + (int64_t)o * ys1) = acc[o];
+}
+
 }  // namespace
 
 extern "C" size_t sdc_gn_stats_bytes(int B, int G) {
@@ -495,6 +569,29 @@ extern "C" int sdc_gn_finalize(const double* parts, float* stats, int B, int G, 
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((ngroups + 63) / 64), dim3(64), 0, sdc::as_stream(stream), parts, stats, ngroups,
                        nparts, 1.0 / (double)n_per_group, eps);
     return sdc::check_launch("sdc_gn_finalize");
+}
+
+extern "C" int sdc_gn_pointwise_out(const float* h, const float* stats, const float* gamma, const float* beta, const float* residual,
+                                    const float* w, const float* bias, float* y, int B, int C, int G, int Cout, int64_t S,
+                                    int64_t plane, int64_t ys0, int64_t ys1, int64_t ys2, void* stream) {
+    SDC_REQUIRE(h && stats && gamma && beta && w && y, SDC_ENULL, "sdc_gn_pointwise_out: null pointer");
+    SDC_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && C % 4 == 0 && C <= 2048 && S > 0 && Cout > 0 && Cout <= 16, SDC_EINVAL,
+                "sdc_gn_pointwise_out: bad shape B=%d C=%d G=%d Cout=%d (C %% 4 == 0, C <= 2048, Cout <= 16)", B, C, G, Cout);
+    SDC_REQUIRE(plane > 0 && S % plane == 0 && plane % 4 == 0 && ys0 % 4 == 0 && ys1 % 4 == 0 && ys2 % 4 == 0, SDC_EINVAL,
+                "sdc_gn_pointwise_out: the (H, W) plane and the output strides must be multiples of 4 floats");
+    SDC_REQUIRE((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(y)) % 16 == 0,
+                SDC_EALIGN, "sdc_gn_pointwise_out: h, residual and y must be 16-byte aligned");
+    SDC_REQUIRE(B <= 65535 && (S / 4 + NT - 1) / NT < (1ll << 31), SDC_EINVAL, "sdc_gn_pointwise_out: grid too large");
+    hipStream_t s = sdc::as_stream(stream);
+    dim3 grid((unsigned)((S / 4 + NT - 1) / NT), (unsigned)B);
+#define SDC_GNPW(COV) hipLaunchKernelGGL(gn_pw_out_kernel<COV>, grid, dim3(NT), (size_t)C * (2 + COV) * sizeof(float), s, h, stats, gamma, beta, \
+                                         residual, w, bias, y, C, G, Cout, S, plane, ys0, ys1, ys2)
+    if (Cout <= 4) SDC_GNPW(4);
+    else if (Cout <= 8) SDC_GNPW(8);
+    else if (Cout <= 12) SDC_GNPW(12);
+    else SDC_GNPW(16);
+#undef SDC_GNPW
+    return sdc::check_launch("sdc_gn_pointwise_out");
 }
 
 extern "C" int sdc_gn_fused_ok(int B, int C, int G, int64_t S) {

@@ -344,6 +344,35 @@ class Plan:
             self._emit(self.lib.sdc_gn_stats, _ptr(x), _ptr(st), B, Cc, groups, S, eps)
         return st
 
+    def gn_apply_deferred(self, x, gn):
+        """the apply pass of a GroupNorm whose statistics gn_stats_deferred took: x <- SiLU(GN(x)) (+ residual), in place"""
+        st, gamma, beta, groups, res = gn
+        B, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (B * Cc)
+        self.keep += [x, st, gamma, beta, res]
+        self._emit(self.lib.sdc_gn_apply, _ptr(x), _ptr(st), _ptr(gamma), _ptr(beta), 0, 0, 0, 0, 0, _ptr(res), _ptr(x), B, Cc, groups, S)
+        return x
+
+    def gn_pointwise_out(self, x, gn, w, bias, out):
+        """final_conv on the RAW conv output x of the last ResnetBlock: gn = (stats, gamma, beta, groups, residual) as handed out by
+        resnet(defer_gn=True); GroupNorm apply + SiLU + residual happen on the kernel's loads (sdc_gn_pointwise_out).  w = the conv
+        weight (Cout, C) flat, out a 5-D view whose (H, W) planes are dense.  None when the shape is outside the kernel's contract."""
+        st, gamma, beta, groups, res = gn
+        B, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (B * Cc)
+        cout = out.shape[1]
+        plane = out.shape[3] * out.shape[4]
+        ys = _s5(out)
+        ok = (x.is_contiguous() and (res is None or res.is_contiguous()) and cout <= 16 and Cc % 4 == 0 and Cc <= 2048 and plane % 4 == 0 and ys[4] == 1 and
+              ys[3] == out.shape[4] and all(v % 4 == 0 for v in ys[:3]) and out.data_ptr() % 16 == 0 and
+              tuple(out.shape[2:]) == tuple(x.shape[2:]))
+        if not ok:
+            return None
+        self.keep += [x, st, gamma, beta, res, w, bias, out]
+        self._emit(self.lib.sdc_gn_pointwise_out, _ptr(x), _ptr(st), _ptr(gamma), _ptr(beta), _ptr(res), _ptr(w), _ptr(bias), _ptr(out),
+                   B, Cc, groups, cout, S, plane, ys[0], ys[1], ys[2])
+        return out
+
     def linattn_block(self, x, g_pre, wqkv, wo, bo, g_post, outer, inner, n, strides, pre_mode, post_mode, eps=1e-5, gn=None):
         """Residual(PreNorm(LinearAttention)) in one call (dim 64 / 128, n % 64 == 0); returns y shaped like x.
         gn = (stats, gamma, beta, groups, residual): x is the RAW conv output of the producing ResnetBlock, whose GroupNorm +

@@ -229,6 +229,27 @@ class _Builder:
         return self.plan.conv(x, self.W(wkey, kind), b, cout, k, x1=x1, stride=stride, pad=pad, up=up,
                               up_mode=1 if kind == "convT" else 0, residual=residual, out=out, gn_groups=gn_groups)
 
+    def final_conv(self, res_prefix, conv_prefix, h, groups, x1, out):
+        """last ResnetBlock + the 1x1(x1) output conv into `out`; fused (Plan.gn_pointwise_out) where the net allows and the
+        kernel's contract holds, else the block's own GroupNorm pass followed by the conv"""
+        pool = self.plan.pool
+        if self.net.fuse_final_conv:
+            g, gn, rbuf = self.resnet(res_prefix, h, groups, x1=x1, defer_gn=True)
+            wv, bv = self.V(f"{conv_prefix}.weight"), self.V(f"{conv_prefix}.bias")
+            if self.plan.gn_pointwise_out(g, gn, wv, bv, out) is not None:
+                pool.put(g)
+                if rbuf is not None:
+                    pool.put(rbuf)
+                return
+            self.plan.gn_apply_deferred(g, gn)       # outside the kernel's contract: the block's own pass from the same statistics
+            if rbuf is not None:
+                pool.put(rbuf)
+            f = g
+        else:
+            f = self.resnet(res_prefix, h, groups, x1=x1)
+        self.conv(f, conv_prefix, out=out)
+        pool.put(f)
+
     def gn(self, x, prefix, groups, residual=None, cond_off=None):
         self.plan.gn_silu(x, self.V(f"{prefix}.weight"), self.V(f"{prefix}.bias"), groups, residual=residual)
         if cond_off is not None:
@@ -290,6 +311,9 @@ class _HipUNet(nn.Module):
         # in split order: deterministic).  The split factor depends on the batch, so with it ON a trajectory's rounding depends on
         # the batch it rides in (fp32 sums in another order: ~1e-7); OFF (default) the samplers use sdc_conv only.
         self.split_small_grids = False
+        # the last ResnetBlock's GroupNorm apply + SiLU + residual inside the 1x1 output conv that is its only reader (one streaming
+        # pass, the normalised tensor is never written: sdc_gn_pointwise_out); False = sdc_gn_apply + sdc_conv (A/B checks)
+        self.fuse_final_conv = True
         self.forward_graph = True    # model(x, t) replays a captured hipGraph; False = launch the call list every time
         self._side = None
         self.dim = dim
@@ -422,7 +446,7 @@ class _HipUNet(nn.Module):
         """Plan for an input of `shape` whose conditioning table has `rows` rows: one row per sample
         (lut=False, forward(x, time)) or one row per timestep read through a device-side t (lut=True, samplers)."""
         key = (tuple(shape), rows, bool(lut), int(self.precision), bool(self.fuse_linattn), bool(self.subpixel_upsample),
-               bool(self.fuse_gn_into_linattn), bool(self.split_small_grids))
+               bool(self.fuse_gn_into_linattn), bool(self.split_small_grids), bool(self.fuse_final_conv))
         stamp = self._weights_stamp()
         ent = self._plans.get(key)
         if ent is not None and ent["wstamp"] != stamp:        # parameters changed since this plan packed them
@@ -610,10 +634,8 @@ class _LucidUNet(_HipUNet):
             pool.put(y2)
             h = self._up(b, f"{p}.3", y3, i == nres - 1)
             pool.put(y3)
-        f = b.resnet("final_res_block", h, G, x1=r)
+        b.final_conv("final_res_block", "final_conv", h, G, r, e5)
         pool.put(h), pool.put(r)
-        b.conv(f, "final_conv", out=e5)
-        pool.put(f)
 
 
 class Unet2D(_LucidUNet):
@@ -822,7 +844,5 @@ class Unet3D_with_Conv3D(_HipUNet):
                 h = b.plan.conv_transpose_422(u4, lambda p=p: self.P(f"{p}.4.weight"), b.V(f"{p}.4.bias"),
                                               self.P(f"{p}.4.weight").shape[1])
                 pool.put(u4)
-        f = b.resnet("final_conv.0", h, G, x1=r)
+        b.final_conv("final_conv.0", "final_conv.1", h, G, r, e5)
         pool.put(h), pool.put(r)
-        b.conv(f, "final_conv.1", out=e5)
-        pool.put(f)

@@ -255,3 +255,67 @@ def test_conv1d_upsample_splitk_equals_plain_conv(B, cin, cout, L):
     print(f"[measured] 1-D upsample split-K conv {cin}->{cout} L={L}->{2 * L} B={B}: rel err plain {e0:.1e}, split {e1:.1e} ({'split' if splits else 'not split'})")
     assert e0 < 5e-6 and e1 < 5e-6 and torch.equal(y1, run(True))
     assert splits == (B < 100)
+
+
+# ------------------------------------------------------------------ the last GroupNorm apply inside the output conv
+@pytest.mark.parametrize("B,Cc,G,cout,sp,frame_major,res", [(2, 64, 8, 7, (4, 16, 16), True, True), (3, 64, 1, 3, (1, 16, 128), False, True),
+                                                            (2, 256, 1, 12, (1, 1, 128), False, True), (1, 24, 3, 16, (2, 8, 12), False, False)])
+def test_gn_pointwise_out_matches_fp64(B, Cc, G, cout, sp, frame_major, res):
+    """sdc_gn_pointwise_out: y = conv1x1(SiLU(GroupNorm(h)) + residual) in one pass (conv3d.py:468-471, 1D/model/unet.py:376-378)
+    against torch in fp64; output through strides (frame-major eps of the smoke net), Cout 3 / 7 / 12 / 16."""
+    import torch.nn.functional as F
+    from safediffcon_amd import _lib
+    lib = _lib.get_lib()
+    h = det_tensor((B, Cc, *sp), 201).to(DEV)
+    r = det_tensor((B, Cc, *sp), 202).to(DEV) if res else None
+    gam, bet = (det_tensor((Cc,), 203, 0.3) + 1.0).to(DEV), det_tensor((Cc,), 204, 0.2).to(DEV)
+    w, b = det_tensor((cout, Cc), 205, 0.2).to(DEV), det_tensor((cout,), 206, 0.1).to(DEV)
+    S = sp[0] * sp[1] * sp[2]
+    st = torch.empty((int(lib.sdc_gn_stats_bytes(B, G)) + 3) // 4, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.sdc_gn_stats(h.data_ptr(), st.data_ptr(), B, Cc, G, S, 1e-5, stream) == 0
+    if frame_major:      # (B, F, C, H, W) storage viewed as (B, C, F, H, W)
+        store = torch.full((B, sp[0], cout, sp[1], sp[2]), 7.0, device=DEV)
+        out = store.permute(0, 2, 1, 3, 4)
+    else:
+        out = torch.full((B, cout, *sp), 7.0, device=DEV)
+    ys = out.stride()
+    rc = lib.sdc_gn_pointwise_out(h.data_ptr(), st.data_ptr(), gam.data_ptr(), bet.data_ptr(), 0 if r is None else r.data_ptr(), w.data_ptr(),
+                                  b.data_ptr(), out.data_ptr(), B, Cc, G, cout, S, sp[1] * sp[2], ys[0], ys[1], ys[2], stream)
+    assert rc == 0, _lib.last_error()
+    v = F.silu(F.group_norm(h.double(), G, gam.double(), bet.double(), 1e-5))
+    if r is not None:
+        v = v + r.double()
+    ref = torch.einsum("oc,bcdhw->bodhw", w.double(), v) + b.double().view(1, -1, 1, 1, 1)
+    e = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"[measured] gn_pointwise_out C={Cc} G={G} -> {cout} {sp}: rel err vs fp64 {e:.2e}")
+    assert e < 3e-6
+    # contract violations are refused, not mis-computed
+    assert lib.sdc_gn_pointwise_out(h.data_ptr(), st.data_ptr(), gam.data_ptr(), bet.data_ptr(), 0, w.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                    B, Cc, G, 17, S, sp[1] * sp[2], ys[0], ys[1], ys[2], stream) == -1 and "Cout <= 16" in _lib.last_error()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("tree", ["smoke", "burgers", "tokamak"])
+def test_fused_final_conv_equals_the_two_pass_form(tree):
+    """net.fuse_final_conv (default on): eps with the last GroupNorm apply inside final_conv against the same net with the separate
+    sdc_gn_apply + sdc_conv passes -- same values up to the order of the 1x1 conv's sums -- and one launch fewer of sdc_gn_apply."""
+    if tree == "smoke":
+        net, shape = sdc.Unet3D_with_Conv3D(dim=16, dim_mults=(1, 2, 4), channels=7), (2, 4, 7, 16, 16)
+    elif tree == "burgers":
+        net, shape = sdc.Unet2D(dim=16, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=1), (2, 3, 16, 128)
+    else:
+        net, shape = sdc.Unet1D(dim=32, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1), (2, 12, 128)
+    net.load_state_dict(det_params(_spec(net), 78))
+    net.to(DEV)
+    x, t = det_tensor(shape, 79).to(DEV), torch.tensor([3, 700], device=DEV)
+    fused = net(x, t).clone()
+    names = [fn.__name__ for fn, _ in net.entry(shape, 2)["plan"].calls]
+    assert names.count("sdc_gn_pointwise_out") == 1
+    net.fuse_final_conv = False
+    plain = net(x, t).clone()
+    names0 = [fn.__name__ for fn, _ in net.entry(shape, 2)["plan"].calls]
+    assert "sdc_gn_pointwise_out" not in names0
+    err = (fused - plain).abs().max().item()
+    print(f"[measured] {tree}: fused final conv vs two-pass form: max|diff| {err:.2e} (|eps|max {plain.abs().max().item():.2f})")
+    assert err <= 2e-6 * max(1.0, plain.abs().max().item())

@@ -56,6 +56,10 @@ def classify(lib, fn, a):
         Bb, Cc, S = a[10], a[11], a[13]
         return dict(stage="groupnorm stats+apply+SiLU(+res), one launch", kernel="gn_fused", flops=11.0 * Bb * Cc * S, issued=0.0,
                     bytes=4.0 * Bb * Cc * S * (3 if a[8] else 2))
+    if fn is lib.sdc_gn_pointwise_out:
+        Bb, Cc, co, S = a[8], a[9], a[11], a[12]
+        return dict(stage="final ResnetBlock: GroupNorm apply+SiLU+res inside the 1x1 output conv", kernel="gn_pw_out",
+                    flops=Bb * S * Cc * (8.0 + 2.0 * co), issued=0.0, bytes=4.0 * Bb * S * ((2 if a[4] else 1) * Cc + co))
     if fn is lib.sdc_chan_norm:
         Bb, Cc, S = a[4], a[5], a[6]
         return dict(stage="channel LN/RMS(+res)", kernel="chan_norm", flops=8.0 * Bb * Cc * S, issued=0.0,
