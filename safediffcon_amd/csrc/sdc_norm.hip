@@ -76,6 +76,31 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, float* __res
     stats[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// the same with one WAVE per group (sdc_gn_finalize with many parts per group: the conv-epilogue sums of the smoke net's upper levels
+// are 128-590 pairs per (sample, group), and one thread walking them is a chain of dependent 8-byte loads: 22 us per launch, 30
+// launches per step).  Lane l sums parts l, l + 64, ... in order, then the lanes are summed in a fixed butterfly: deterministic and
+// independent of the batch, like the serial form (the two orders differ by ~1e-16 relative in fp64, below the fp32 result's rounding).
+__global__ __launch_bounds__(256) void gn_finalize_wave_kernel(const double* __restrict__ part, float* __restrict__ stats, int ngroups,
+                                                               int nsplit, double inv_n, float eps) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (g >= ngroups) return;
+    double s = 0, q = 0;
+    for (int i = lane; i < nsplit; i += 64) {
+        s += part[((int64_t)g * nsplit + i) * 2];
+        q += part[((int64_t)g * nsplit + i) * 2 + 1];
+    }
+    s = sdc::wave_sum(s);
+    q = sdc::wave_sum(q);
+    if (lane == 0) {
+        const double mean = s * inv_n;
+        double var = q * inv_n - mean * mean;
+        if (var < 0) var = 0;
+        stats[g * 2] = (float)mean;
+        stats[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 // ---------------------------------------------------------------- GroupNorm apply
 // grid.x = b*C + c (one channel row), grid.y walks 4-element vectors of that row.
 // STREAM (tensors far beyond the 256 MB Infinity Cache, i.e. the smoke net's upper levels): one vector per thread, no
@@ -566,8 +591,13 @@ extern "C" int sdc_gn_finalize(const double* parts, float* stats, int B, int G, 
     SDC_REQUIRE(parts && stats, SDC_ENULL, "sdc_gn_finalize: null pointer");
     SDC_REQUIRE(B > 0 && G > 0 && nparts > 0 && n_per_group > 0, SDC_EINVAL, "sdc_gn_finalize: bad shape");
     const int ngroups = B * G;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((ngroups + 63) / 64), dim3(64), 0, sdc::as_stream(stream), parts, stats, ngroups,
-                       nparts, 1.0 / (double)n_per_group, eps);
+    // (the form is chosen by the parts per group alone -- a property of the sample's geometry -- never by the batch)
+    if (nparts >= 32)
+        hipLaunchKernelGGL(gn_finalize_wave_kernel, dim3((ngroups + 3) / 4), dim3(256), 0, sdc::as_stream(stream), parts, stats, ngroups,
+                           nparts, 1.0 / (double)n_per_group, eps);
+    else
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((ngroups + 63) / 64), dim3(64), 0, sdc::as_stream(stream), parts, stats, ngroups,
+                           nparts, 1.0 / (double)n_per_group, eps);
     return sdc::check_launch("sdc_gn_finalize");
 }
 
