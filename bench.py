@@ -54,7 +54,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 T_DDPM = 1000
 DEFAULT_B = {"c2": 256, "c3": 128, "c4": 64}
 HEADLINE_MAX_BYTES = 6144                 # the last stdout line stays a headline the driver parses
-PMC_FILES = ("r5_pmc_traffic.json",)      # stamped with the kernel-source hash they were collected on (tools/pmc_to_json.py)
+PMC_FILES = ("r6_pmc_traffic.json",)      # stamped with the kernel-source hash they were collected on (tools/pmc_to_json.py)
 
 
 # --------------------------------------------------------------------------- launcher (N > 1 without a torchrun parent)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""FETCH_SIZE / WRITE_SIZE / SQ passes of tools/pmc_traffic.py -> profiles/r5_pmc_traffic.json + r5_pmc_mfma_busy.json, stamped
+"""FETCH_SIZE / WRITE_SIZE / SQ passes of tools/pmc_traffic.py -> profiles/r6_pmc_traffic.json + r6_pmc_mfma_busy.json, stamped
 with the hash of the kernel sources they were collected on (safediffcon_amd.build.source_hash; bench.py refuses a stale record).
 usage: python tools/pmc_to_json.py <fetch_dir> <write_dir> <sq_dir> <cases.json> <out_traffic.json> <out_busy.json>"""
 import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
@@ -47,7 +47,7 @@ cal = dict(kernel="act_kernel over 64Mi floats (dword per lane)", known_read_byt
            fetch_factor=round(n / (fa.get("FETCH_SIZE", 1) * 1024.0), 4), write_factor=round(n / (wa.get("WRITE_SIZE", 1) * 1024.0), 4),
            correction="bytes = FETCH_SIZE*1024*fetch_factor (gfx950 tallies 128-B requests at 64 B: factor 2, calibrated here on a known-size "
                       "stream in the same run), WRITE_SIZE*1024*write_factor")
-out = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/pmc_traffic.py {B}, MI355X, round 5",
+out = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/pmc_traffic.py {B}, MI355X, round 6",
        "kernel_source_hash": source_hash(), "calibration": cal}
 for sub, c in cases.items():
     if sub == "act_kernel":

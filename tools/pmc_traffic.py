@@ -9,6 +9,7 @@
        gn_apply      GroupNorm apply + SiLU on the level-0 tensor, in place
        ta_block      fused temporal-attention block at width 64 on the level-0 tensor
        conv_pw       1x1x1 conv 128->384 at (B,128,32,32,32) (to_qkv of the width-128 temporal attention)
+       gn_pw_out     the last GroupNorm apply inside final_conv 64->7 (round 6)
  It writes the algorithmic bytes of every case to <out dir>/pmc_cases.json for tools/pmc_to_json.py.
 usage: python3 tools/pmc_traffic.py [batch] [cases.json]"""
 import _libsel  # noqa: F401,E402  (SDC_LIB_PATH -> safediffcon_amd._lib.use_library, tools only)
@@ -58,6 +59,15 @@ x1 = torch.randn(B, 128, 32, 32, 32, device=dev)
 w1 = torch.randn(384, 128, 1, 1, 1, device=dev) * 0.1
 o1 = plan.conv(as5(x1), plan.conv_weight(w1), None, 384, (1, 1, 1))
 cases["conv_pw_kernel<128"] = dict(algorithmic=4 * (x1.numel() + o1.numel() + w1.numel()), shape=f"1x1x1 conv 128->384 at ({B},128,32,32,32)")
+# round 6: the last ResnetBlock's GroupNorm apply + SiLU + residual inside the 1x1x1 output conv (64 -> 7, frame-major eps)
+hf = torch.randn(B, 64, 32, 64, 64, device=dev)
+rf = torch.randn(B, 64, 32, 64, 64, device=dev)
+stf = plan.gn_stats_deferred(hf, 8)
+wf, bf = torch.randn(7 * 64, device=dev) * 0.1, torch.randn(7, device=dev)
+ef = torch.empty(B, 32, 7, 64, 64, device=dev).permute(0, 2, 1, 3, 4)
+assert plan.gn_pointwise_out(hf, (stf, gm, bt, 8, rf), wf, bf, ef) is not None
+cases["gn_pw_out_kernel"] = dict(algorithmic=4 * (hf.numel() + rf.numel() + ef.numel()),
+                                 shape=f"GroupNorm apply + SiLU + residual inside final_conv 64->7 on ({B},64,32,64,64)")
 # the dominant kernels of the other two single-GPU workloads, at their own batch sizes
 x2 = torch.randn(256, 64, 16, 128, device=dev)
 w2 = torch.randn(64, 64, 3, 3, device=dev) * 0.05
