@@ -319,3 +319,33 @@ def test_fused_final_conv_equals_the_two_pass_form(tree):
     err = (fused - plain).abs().max().item()
     print(f"[measured] {tree}: fused final conv vs two-pass form: max|diff| {err:.2e} (|eps|max {plain.abs().max().item():.2f})")
     assert err <= 2e-6 * max(1.0, plain.abs().max().item())
+
+
+def test_t1000_guided_trajectory_at_shipped_width_tokamak_turbo():
+    """the tokamak counterpart: T = 1000 guided DDPM at `Unet1D(dim=128)` "turbo" (tokamak/configs/inference_config.py:118-141)
+    against the oracle's loop + functional net under PyTorch-ROCm eager (tokamak/model/diffusion.py:310-372)."""
+    from oracle import nets as onets
+    from oracle import samplers as osam
+    from oracle import schedules as osched
+    from oracle.detweights import det_noise
+    net = sdc.Unet1D(dim=128, dim_mults=(1, 2, 4, 8), channels=12, resnet_block_groups=1)
+    P = det_params(_spec(net), 81)
+    net.load_state_dict(P)
+    net.to(DEV)
+    T, B = 1000, 2
+    gd = sdc.GaussianDiffusionTokamak(net, seq_length=128, nt=122, timesteps=T).to(DEV)
+    u0 = det_tensor((B, 3), 82, 0.1) + 0.6
+    uT = det_tensor((B, 2, 122), 83, 0.1) + 0.6
+    target = det_tensor((B, 3, 122), 84, 0.3) + 1.0
+    noise = det_noise((B, 12, 128), 94000)
+    args = dict(w_obj=0.3, w_safe=1.0, guidance_scaler=0.5, Q=0.05, safety_threshold=4.98)
+    out = gd.sample(batch_size=B, u_init=u0, u_final=uT, nablaJ=sdc.TokamakGuidance(target, 122, **args), enable_grad=False,
+                    noise=noise).cpu()
+    Pg = {k: v.to(DEV) for k, v in P.items()}
+    ref = osam.sample_tokamak(lambda a, b: onets.unet_tokamak(Pg, a, b.to(a.device), dim=128), osched.make_tables("cosine", T), B,
+                              lambda i: noise(i).to(DEV), u_init=u0.to(DEV), u_final=uT.to(DEV),
+                              nablaJ=osam.tokamak_guidance(target.to(DEV), 122, 0.05, 4.98, 0.3, 1.0, 0.5), enable_grad=False).cpu()
+    err = (out - ref).abs().max().item()
+    mse = ((out - ref) ** 2).mean().item()
+    print(f"[measured] C3-turbo width (dim 128), T = 1000 guided DDPM (B = 2) vs the eager-GPU oracle: max|err| {err:.3e}  MSE {mse:.3e}")
+    assert torch.isfinite(out).all() and err < 3e-5 and mse <= 2e-12
