@@ -153,7 +153,7 @@ def test_t1000_guided_trajectory_at_shipped_width_burgers_turbo():
     err = (out - ref).abs().max().item()
     mse = ((out - ref) ** 2).mean().item()
     print(f"[measured] C2-turbo width (dim 128), T = 1000 guided DDPM (B = 2) vs the eager-GPU oracle: max|err| {err:.3e}  MSE {mse:.3e}")
-    assert torch.isfinite(out).all() and err < 3e-5 and mse <= 1e-12
+    assert torch.isfinite(out).all() and err < 8e-6 and mse <= 2e-13          # measured on MI355X: 3.8e-6, 8.2e-14
 
 
 # ------------------------------------------------------------------ the small-batch sampler plan
@@ -348,4 +348,4 @@ def test_t1000_guided_trajectory_at_shipped_width_tokamak_turbo():
     err = (out - ref).abs().max().item()
     mse = ((out - ref) ** 2).mean().item()
     print(f"[measured] C3-turbo width (dim 128), T = 1000 guided DDPM (B = 2) vs the eager-GPU oracle: max|err| {err:.3e}  MSE {mse:.3e}")
-    assert torch.isfinite(out).all() and err < 3e-5 and mse <= 2e-12
+    assert torch.isfinite(out).all() and err < 7e-6 and mse <= 2e-13          # measured on MI355X: 3.0e-6, 6.9e-14
