@@ -1152,8 +1152,7 @@ bool wg3s_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
     // more) stay with the one-workgroup form: the two are within 3 % of each other either way, box by box (256 -> 256: 4.70 / 4.70
     // and 4.78 / 4.93, 256 + 256 -> 128: 4.59 / 4.69), the whole step is the same to 0.15 % (238.1 / 237.7 ms), and with four
     // channel tiles per position tile and half the positions per workgroup this form fetches more (6.5 x against 5.6 x).
-    static const int all = exp_env("SDC_WG3S_ALL");
-    if (!(d.precision >= 4 && d.kD == 3 && d.oD % 2 == 0 && d.Cout % W2_BM == 0 && (d.oW == 64 || d.oW == 32 || (d.oW == 16 && all)))) return false;
+    if (!(d.precision >= 4 && d.kD == 3 && d.oD % 2 == 0 && d.Cout % W2_BM == 0 && (d.oW == 64 || d.oW == 32))) return false;
     static const int no32w = exp_env("SDC_WG3S_NO32WIDE");     // (experiments build: A/B of the rule)
     if (no32w && d.oW == 32 && d.Cin0 + d.Cin1 > 64) return false;
     SdcConvDesc e = d;
@@ -1187,24 +1186,20 @@ int launch_wg3s(const ConvArgs& a, hipStream_t s) {
             case 9: W3S_LAUNCH(64, 9); break; case 5: W3S_LAUNCH(64, 5); break; case 13: W3S_LAUNCH(64, 13); break;
             case 16: W3S_LAUNCH(64, 16); break; case 32: W3S_LAUNCH(64, 32); break; case 64: W3S_LAUNCH(64, 64); break;
             case 128: W3S_LAUNCH(64, 128); break; case 48: W3S_LAUNCH(64, 48); break; case 176: W3S_LAUNCH(64, 176); break;
-            case 240: W3S_LAUNCH(64, 240); break; case 8: W3S_LAUNCH(64, 8); break; case 256: W3S_LAUNCH(64, 256); break; case 512: W3S_LAUNCH(64, 512); break; case 1024: W3S_LAUNCH(64, 1024); break; case 1536: W3S_LAUNCH(64, 1536); break; case 8192: W3S_LAUNCH(64, 8192); break; case 16384: W3S_LAUNCH(64, 16384); break; case 269: W3S_LAUNCH(64, 269); break;
+            case 240: W3S_LAUNCH(64, 240); break; case 8: W3S_LAUNCH(64, 8); break; case 256: W3S_LAUNCH(64, 256); break; case 512: W3S_LAUNCH(64, 512); break; case 1024: W3S_LAUNCH(64, 1024); break; case 1536: W3S_LAUNCH(64, 1536); break; case 269: W3S_LAUNCH(64, 269); break;
             default: W3S_LAUNCH(64, 4); break;
         }
         return SDC_OK;
     }
 #endif
 #ifdef SDC_KERNEL_EXPERIMENTS
-    if ((d.oW == 16 || d.oW == 32) && dbg) {
-        if (d.oW == 16) switch (dbg) {
-            case 1: W3S_LAUNCH(16, 1); break; case 4: W3S_LAUNCH(16, 4); break; case 5: W3S_LAUNCH(16, 5); break;
-            case 16: W3S_LAUNCH(16, 16); break; case 32: W3S_LAUNCH(16, 32); break; default: W3S_LAUNCH(16, 13); break;
-        } else switch (dbg) {
+    if (d.oW == 32 && dbg) {
+        switch (dbg) {
             case 1: W3S_LAUNCH(32, 1); break; case 4: W3S_LAUNCH(32, 4); break; case 5: W3S_LAUNCH(32, 5); break;
             case 16: W3S_LAUNCH(32, 16); break; case 32: W3S_LAUNCH(32, 32); break; default: W3S_LAUNCH(32, 13); break;
         }
         return SDC_OK;
     }
-    if (d.oW == 16) { W3S_LAUNCH(16, 0); return SDC_OK; }        // (SDC_WG3S_ALL: never dispatched by the shipping library)
 #endif
     if (d.oW == 32) W3S_LAUNCH(32, 0);
     else W3S_LAUNCH(64, 0);
