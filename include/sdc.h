@@ -104,8 +104,9 @@ int sdc_conv(const SdcConvDesc* d, const float* x0, const float* x1, const float
 
 /* sdc_conv for grids that leave most of the chip idle (the fine-tuning step, SURVEY 8f: batch 64 puts the deep 3x3 convs of the
  * Burgers net on 32-128 workgroups for 256 CUs; the samplers' small-batch plan, SURVEY 8e: an 8-way shard of the 1-D configs leaves
- * 16-32 trajectories per GPU): the input channels of an F(2x2,3x3) conv, or of a single-tap-row F(2,3) conv (Conv1d k3, with or
- * without the nearest x2 upsampling folded into its gather), are split over up to 8 workgroups per output tile, the partial outputs
+ * 16-32 trajectories per GPU): the input channels of an F(2x2,3x3) conv, of a single-tap-row F(2,3) conv (Conv1d k3, with or
+ * without the nearest x2 upsampling folded into its gather), or the (tap, channel) walk of a direct-form conv on its smallest tile
+ * (1x1, strided, sub-pixel), are split over up to 8 workgroups per output tile, the partial outputs
  * go to `work` (sdc_conv_splitk_bytes(d) bytes, 16-byte aligned; 0 = this conv is not split: the call is then exactly sdc_conv) and
  * are summed in split order -- deterministic, but the split depends on the batch, so a sample's rounding depends on the batch it
  * rides in: the samplers use sdc_conv only unless the caller opts in (net.split_small_grids).  No fused residual. */

@@ -24,8 +24,9 @@ namespace {
 // Bias / residual loads are issued as a batch (clamped addresses, no per-element branches) so the
 // workgroup pays one memory round trip per 16 outputs instead of sixteen.
 template <int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw, int lane) {
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], int mw, int nw, int lane, float* ybase = nullptr) {
     const SdcConvDesc& d = a.d;
+    float* const ay = ybase ? ybase : a.y;       // (sdc_conv_splitk: this split's partial copy)
     const int l31 = lane & 31, lh = lane >> 5;
     // Dense outputs (the usual case): a position decodes to (sample, offset inside the sample) with one float quotient and
     // a fix-up, the channel part of every address is scalar.  The general path below spends ~25 VALU instructions per
@@ -54,8 +55,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int cob = mw + i * 32;                    // wave-uniform; this lane's rows: cob + 4 lh + (rr & 3) + 8 (rr >> 2)
-            gwchar_p yb = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(a.y + (int64_t)cob * d.ys[1]);
-            gchar_p rb = (gchar_p)uniform_ptr(a.res ? a.res + (int64_t)cob * d.rs[1] : a.y);
+            gwchar_p yb = (gwchar_p)(__attribute__((address_space(1))) void*)uniform_ptr(ay + (int64_t)cob * d.ys[1]);
+            gchar_p rb = (gchar_p)uniform_ptr(a.res ? a.res + (int64_t)cob * d.rs[1] : ay);
             if (a.res) {
                 // bias and residual of the 16 rows as one batch of loads (one memory round trip per tile row, not sixteen)
                 float bv[16], rv[16][TN];
@@ -119,7 +120,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
                 const int co = cob + (rr & 3) + 8 * (rr >> 2);
-                if (pok && co < d.Cout) a.y[yoff + co * d.ys[1]] = acc[i][j][rr] + bv[rr] + rv[rr];
+                if (pok && co < d.Cout) ay[yoff + co * d.ys[1]] = acc[i][j][rr] + bv[rr] + rv[rr];
             }
         }
     }
@@ -193,7 +194,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((BM == 64 &&
 
     // FAST path walks (tap, channel-chunk) incrementally: no integer division and no 64-bit multiply per
     // chunk -- that VALU work otherwise competes with the fp32 MFMAs for the SIMD's issue slots.
+    // sdc_conv_splitk (FAST path only; small grids): blockIdx.z workgroups share an output tile, each over a contiguous range of the
+    // (tap, channel-chunk) walk; y is then this split's dense partial copy
+    const int ksp = FAST ? a.ksplit : 1;
+    const int nchunks_all = (a.Ktot + BK - 1) / BK;
+    const int kc0 = ksp > 1 ? (int)blockIdx.z * (nchunks_all / ksp) : 0;
     int f_kd = 0, f_kh = 0, f_kw = 0, f_ci = 0;
+    if (ksp > 1) {
+        const int k0 = kc0 * BK, tap0 = k0 / a.Cin, t2 = tap0 / d.kW;
+        f_ci = SDC_UNIFORM(k0 - tap0 * a.Cin);
+        f_kw = SDC_UNIFORM(tap0 - t2 * d.kW);
+        f_kh = SDC_UNIFORM(t2 % d.kH);
+        f_kd = SDC_UNIFORM(t2 / d.kH);
+    }
     bool f_ok = false;
     // per-thread 32-bit element offsets of (b, id, ih, iw) inside x0 / x1 for the current tap; the channel
     // part of every address is wave-uniform and stays in scalar registers (global_load saddr + voffset form)
@@ -202,7 +215,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((BM == 64 &&
     const int arow_u = __builtin_amdgcn_readfirstlane(arow0);
     // (BM = 32: a wave spans two weight rows, the second one is folded into the per-lane offset)
     const uint32_t a_v = (uint32_t)((arow0 - arow_u) * d.Cout + aco_c);
-    int a_k = arow_u;                   // weight row of this wave's first A load in the chunk in flight
+    int a_k = arow_u + kc0 * BK;        // weight row of this wave's first A load in the chunk in flight
     auto fast_tap = [&]() {
         int id, ih, iw;
         spatial_k(f_kd, f_kh, f_kw, f_ok, id, ih, iw);
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((BM == 64 &&
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nchunks = (a.Ktot + BK - 1) / BK;
+    const int nchunks = ksp > 1 ? nchunks_all / ksp : nchunks_all;
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
@@ -334,7 +347,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((BM == 64 &&
         __syncthreads();
     }
 
-    conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane,
+                          ksp > 1 ? a.y + (int64_t)blockIdx.z * a.ypart_elems : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -394,8 +408,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void co
         av[i] = (uint32_t)(((int64_t)row * d.Cout + (aok[i] ? m0 + c4 : 0)) * 4);
     }
     nfloat4 breg[NB4], areg[NA4];
+    // sdc_conv_splitk (small grids: the 1-D nets at a per-rank batch of 16-32): blockIdx.y workgroups share an output tile, each over
+    // Cin / ksplit input channels; y is then this split's dense partial copy
+    const int kc_base = a.ksplit > 1 ? (int)blockIdx.y * (a.Cin / BK / a.ksplit) : 0;
     auto load_chunk = [&](int kc) {
-        const int ci = kc * BK;
+        const int ci = (kc_base + kc) * BK;
         const gfloat_p wb = uniform_ptr(a.wp + (int64_t)ci * d.Cout);
 #pragma unroll
         for (int i = 0; i < NA4; ++i) areg[i] = *(gfloat4_p)((gchar_p)wb + av[i]);
@@ -429,7 +446,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nchunks = a.Cin / BK;
+    const int nchunks = a.Cin / BK / a.ksplit;
     load_chunk(0);
     store_chunk(0);
     if (nchunks > 1) load_chunk(1);
@@ -466,7 +483,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void co
         for (; kc + 2 <= nchunks; kc += 2) { chunk(B0, kc); chunk(B1, kc + 1); }
         if (kc < nchunks) chunk(B0, kc);
     }
-    conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    conv_epilogue<TM, TN>(a, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane,
+                          a.ksplit > 1 ? a.y + (int64_t)blockIdx.y * a.ypart_elems : nullptr);
 }
 
 #include "sdc_conv_pw2.inc"
@@ -1669,6 +1687,18 @@ int wg1_ksplit(const SdcConvDesc& d, const WgPick& w, int64_t ntot) {
     return S;
 }
 
+// Cin / tap split of sdc_conv_splitk on the direct-form kernels' smallest tile (conv_pw_kernel<64,64,2,2>, conv_kernel<64,64,2,2,FAST>):
+// 1x1 convs and the sub-pixel / strided / unshuffle convs of the 1-D and 2-D nets at small batch, where a layer is <= 128 workgroups
+// walking K = 2048-8192; every split keeps >= 8 chunks of 16.  (3-tap convs have their own forms above.)  Depends on the batch.
+int direct_ksplit(const SdcConvDesc& d, int64_t ntot, bool fast) {
+    if (!fast || d.Cout <= 32 || d.kW == 3) return 1;
+    const int64_t nb = ((ntot + 63) / 64) * ((d.Cout + 63) / 64);
+    const int chunks = d.kD * d.kH * d.kW * ((d.Cin0 + d.Cin1) / 16);
+    int S = 1;
+    while (S < 8 && nb * S * 2 <= 256 && chunks % (S * 2) == 0 && chunks / (S * 2) >= 8) S *= 2;
+    return S;
+}
+
 bool conv_small(const SdcConvDesc& d) {
     auto span = [](const int64_t* st, int b, int dd, int h, int w) {
         return (int64_t)(b - 1) * st[0] + (int64_t)(dd - 1) * st[2] + (int64_t)(h - 1) * st[3] + (int64_t)(w - 1) * st[4];
@@ -1710,7 +1740,7 @@ extern "C" int sdc_conv(const SdcConvDesc* dp, const float* x0, const float* x1,
 // 3x3 convs of the Burgers net on 64 workgroups: the input channels are split over up to 8 workgroups per output tile, the
 // partial outputs go to `work` and are summed in split order (deterministic).  Other shapes: exactly sdc_conv.
 extern "C" size_t sdc_conv_splitk_bytes(const SdcConvDesc* dp) {
-    if (!dp || dp->precision < 2) return 0;          // (the 1-D F(2,3) form is precision 2; wg2_ok asks for >= 3 itself)
+    if (!dp) return 0;                               // (every form below checks the precision it needs itself; the direct forms need none)
     static const int no_rh = exp_env("SDC_NO_ROWHALO");
     const SdcConvDesc& d = *dp;
     if (wg3s_ok(d, conv_small(d), !no_rh) || wg3_ok(d, conv_small(d), !no_rh)) return 0;
@@ -1718,7 +1748,10 @@ extern "C" size_t sdc_conv_splitk_bytes(const SdcConvDesc* dp) {
     if (wg2_ok(d, conv_small(d), !no_rh)) S = wg2_ksplit(d);
     else {
         const int64_t ntot = (int64_t)d.B * d.oD * d.oH * d.oW;
-        S = (d.oW % 4 == 0 && d.ys[4] == 1) ? wg1_ksplit(d, wg_pick(d, ntot, conv_small(d), !no_rh), ntot) : 1;
+        const WgPick wgp = wg_pick(d, ntot, conv_small(d), !no_rh);
+        if (wgp.pick) S = (d.oW % 4 == 0 && d.ys[4] == 1) ? wg1_ksplit(d, wgp, ntot) : 1;
+        else S = (d.oW % 4 == 0 && d.precision != 5)
+                     ? direct_ksplit(d, ntot, (d.Cin0 % 16 == 0) && (d.Cin1 % 16 == 0) && conv_small(d)) : 1;
     }
     return S > 1 ? (size_t)S * d.B * d.Cout * d.oD * d.oH * d.oW * sizeof(float) : 0;
 }
@@ -1943,11 +1976,38 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
     {
         const int64_t S = (int64_t)d.oD * d.oH * d.oW;
         auto dense = [&](const int64_t* st) { return st[4] == 1 && st[3] == d.iW && st[2] == (int64_t)d.iH * d.iW && st[0] % 4 == 0 && st[1] % 4 == 0; };
-        if (!no_pw && fast && d.kD * d.kH * d.kW == 1 && d.sD == 1 && d.sH == 1 && d.sW == 1 && d.uD == 1 && d.uH == 1 &&
+        const bool pw_shape = !no_pw && fast && d.kD * d.kH * d.kW == 1 && d.sD == 1 && d.sH == 1 && d.sW == 1 && d.uD == 1 && d.uH == 1 &&
             d.uW == 1 && d.up_mode == 0 && d.pD == 0 && d.pH == 0 && d.pW == 0 && d.oD == d.iD && d.oH == d.iH && d.oW == d.iW &&
             S % 4 == 0 && d.Cout % 4 == 0 && d.Cout > 32 && dense(d.x0s) && (d.Cin1 == 0 || dense(d.x1s)) &&
             reinterpret_cast<uintptr_t>(x0) % 16 == 0 && (d.Cin1 == 0 || reinterpret_cast<uintptr_t>(x1) % 16 == 0) &&
-            reinterpret_cast<uintptr_t>(wp) % 16 == 0) {
+            reinterpret_cast<uintptr_t>(wp) % 16 == 0;
+        // sdc_conv_splitk on the direct-form kernels' smallest tile: K split over Sd workgroups per tile into the caller's partial
+        // buffer, summed in split order (+ bias) by splitk_sum_kernel
+        const int Sd = (split_work && !residual && !tl_describe && d.oW % 4 == 0 && d.precision != 5) ? direct_ksplit(d, ntot, fast) : 1;
+        if (Sd > 1) {
+            const int64_t elems = (int64_t)d.B * d.Cout * d.oD * d.oH * d.oW;
+            SDC_REQUIRE(split_bytes >= (size_t)Sd * elems * sizeof(float), SDC_EINVAL, "sdc_conv_splitk: workspace too small");
+            SDC_REQUIRE(reinterpret_cast<uintptr_t>(split_work) % 16 == 0, SDC_EINVAL, "sdc_conv_splitk: workspace must be 16-byte aligned");
+            ConvArgs p = a;
+            p.ksplit = Sd; p.ypart_elems = elems; p.y = split_work; p.bias = nullptr; p.res = nullptr;
+            p.d.ys[4] = 1; p.d.ys[3] = d.oW; p.d.ys[2] = (int64_t)d.oH * d.oW; p.d.ys[1] = p.d.ys[2] * d.oD; p.d.ys[0] = p.d.ys[1] * d.Cout;
+            SDC_REQUIRE(span5(p.d.ys, d.B, d.Cout, d.oD, d.oH, d.oW) < (1ll << 30), SDC_EINVAL, "sdc_conv_splitk: partial copy too large");
+            p.ydense = S >= 128 && S < (1 << 24);
+            if (pw_shape) {
+                SDC_PICK("conv_pw_kernel<64,64,2,2>", 1.0);
+                dim3 grid((unsigned)(((a.Ntot + 63) / 64) * ((d.Cout + 63) / 64)), (unsigned)Sd);
+                hipLaunchKernelGGL((conv_pw_kernel<64, 64, 2, 2>), grid, dim3(NT), 0, s, p);
+            } else {
+                SDC_PICK("conv_kernel<64,64,2,2,true>", 1.0);
+                dim3 grid((unsigned)((a.Ntot + 63) / 64), (unsigned)((d.Cout + 63) / 64), (unsigned)Sd);
+                hipLaunchKernelGGL((conv_kernel<64, 64, 2, 2, true>), grid, dim3(NT), 0, s, p);
+            }
+            const int64_t nq = elems / 4;
+            hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, (const float*)split_work, y, Sd, elems,
+                               d.Cout, d.oD, d.oH, d.oW, d.ys[0], d.ys[1], d.ys[2], d.ys[3], d.ys[4], bias);
+            return sdc::check_launch("sdc_conv_splitk[direct]");
+        }
+        if (pw_shape) {
             const int64_t b64x128 = (int64_t)((a.Ntot + 127) / 128) * ((d.Cout + 63) / 64);
             // two-workgroups-per-CU form with interleaved tiles (round 5): whole 128-channel blocks, 16-byte aligned dense rows of y
             // (and of the residual), enough 128 x 256 tiles for two rounds of the chip

@@ -363,7 +363,9 @@ class Plan:
         cout = out.shape[1]
         plane = out.shape[3] * out.shape[4]
         ys = _s5(out)
-        ok = (x.is_contiguous() and (res is None or res.is_contiguous()) and cout <= 16 and Cc % 4 == 0 and Cc <= 2048 and plane % 4 == 0 and ys[4] == 1 and
+        # (a thread walks all C channels of its four positions: worth it where a sample has >= 1024 positions -- the tokamak net's 128
+        # positions per sample leave one 32-lane block per sample on a 256-channel walk: 150 us against ~30 for the two small kernels)
+        ok = (x.is_contiguous() and (res is None or res.is_contiguous()) and cout <= 16 and Cc % 4 == 0 and Cc <= 2048 and S >= 1024 and plane % 4 == 0 and ys[4] == 1 and
               ys[3] == out.shape[4] and all(v % 4 == 0 for v in ys[:3]) and out.data_ptr() % 16 == 0 and
               tuple(out.shape[2:]) == tuple(x.shape[2:]))
         if not ok:

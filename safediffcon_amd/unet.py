@@ -233,7 +233,8 @@ class _Builder:
         """last ResnetBlock + the 1x1(x1) output conv into `out`; fused (Plan.gn_pointwise_out) where the net allows and the
         kernel's contract holds, else the block's own GroupNorm pass followed by the conv"""
         pool = self.plan.pool
-        if self.net.fuse_final_conv:
+        # (decided up front from the geometry: below 1024 positions per sample the block's own one-launch GroupNorm is the better form)
+        if self.net.fuse_final_conv and h.shape[2] * h.shape[3] * h.shape[4] >= 1024:
             g, gn, rbuf = self.resnet(res_prefix, h, groups, x1=x1, defer_gn=True)
             wv, bv = self.V(f"{conv_prefix}.weight"), self.V(f"{conv_prefix}.bias")
             if self.plan.gn_pointwise_out(g, gn, wv, bv, out) is not None:
