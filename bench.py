@@ -563,7 +563,7 @@ def worker(a):
     extra = {}
     t_start = time.perf_counter()
     with torch.cuda.stream(side), torch.no_grad():
-        W = workload(wl, a.dim, B, dev, rank, world, prec, cal_steps=a.cal_steps)
+        W = workload(wl, a.dim, B, dev, rank, world, prec, cal_steps=a.cal_steps, split_small=a.split_small)
         torch.manual_seed(2 + rank)                            # noise: seed 2 (+rank)
         S = W["prep"]()
         S.init()
@@ -697,6 +697,7 @@ def main():
     ap.add_argument("--extra-file", default=os.path.join(ROOT, "bench_extra.json"),
                     help="side file for everything that is not the headline (named in the headline as `extra_file`)")
     ap.add_argument("--cpu-all-cores", action="store_true", help="cpu_baseline: also one step with a thread per physical core")
+    ap.add_argument("--split-small", action="store_true", help="the headline workload's net with split_small_grids (small-batch plan)")
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--cal-steps", type=int, default=5)
     ap.add_argument("--other-precisions", action="store_true", help="also time precision 0 / 3 on the headline workload")

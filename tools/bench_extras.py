@@ -21,6 +21,8 @@ EXTRA_WORKLOADS = {
     # the same with net.split_small_grids = True: Cin of the 3-tap convs split over workgroups where the grid leaves CUs idle
     "c2_shard8_split": ("c2", 0, 32, "c2_shard8 with the small-batch plan (net.split_small_grids)", True),
     "c3_shard8_split": ("c3", 0, 16, "c3_shard8 with the small-batch plan (net.split_small_grids)", True),
+    # (the narrow shipped nets at the full batch gain nothing from it: c3_small 2.15 -> 2.06 ms/step, c3_turbo 3.63 -> 3.61; their steps
+    # are so light that the box's clock management decides more -- one and the same plan has read 2.06 and 4.86 ms/step)
 }
 ALL_EXTRA_WORKLOADS = "c2,c3,c2_turbo,c3_turbo,c3_small,c2_shard8,c3_shard8,c2_shard8_split,c3_shard8_split"
 
