@@ -395,3 +395,21 @@ def test_conv_direct_splitk_equals_plain_conv(case):
     assert splits == case.get("split", True)
     if big1 is not None:                                            # nothing written beside the parity sub-grid
         assert torch.all(big1[:, :, :, 1::2, :] == 0) and torch.all(big1[:, :, :, :, 1::2] == 0)
+
+
+def test_fused_final_conv_falls_back_outside_the_kernels_contract():
+    """a net with more than 16 output channels: Plan.gn_pointwise_out declines, final_conv finishes the last ResnetBlock with the
+    block's own apply pass (from the statistics already taken) and runs the plain conv -- same result as with the switch off"""
+    net = sdc.Unet2D(dim=16, dim_mults=(1, 2, 4, 8), channels=20, resnet_block_groups=1)
+    net.load_state_dict(det_params(_spec(net), 88))
+    net.to(DEV)
+    shape = (2, 20, 16, 128)
+    x, t = det_tensor(shape, 89).to(DEV), torch.tensor([5, 600], device=DEV)
+    a = net(x, t).clone()
+    names = [fn.__name__ for fn, _ in net.entry(shape, 2)["plan"].calls]
+    assert "sdc_gn_pointwise_out" not in names and torch.isfinite(a).all()
+    net.fuse_final_conv = False
+    b = net(x, t).clone()
+    err = (a - b).abs().max().item()
+    print(f"[measured] final conv fallback vs plain path: max|diff| {err:.2e}")
+    assert err <= 1e-6 * max(1.0, b.abs().max().item())
