@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsdc_hip.so")
 SOURCES = ["sdc_api.hip", "sdc_conv.hip", "sdc_conv_wino.hip", "sdc_norm.hip", "sdc_attn.hip", "sdc_lablock.hip", "sdc_tablock.hip", "sdc_step.hip", "sdc_solver.hip", "sdc_grad.hip", "sdc_attn_bwd.hip", "sdc_kstar.hip", "sdc_smoke.hip", "sdc_linear.hip"]
-HEADERS = ["sdc_common.h", "sdc_conv.h", "sdc_conv_wino3s.inc", "sdc_conv_pw2.inc"]      # csrc files the translation units include
+HEADERS = ["sdc_common.h", "sdc_conv.h", "sdc_conv_wino3s.inc", "sdc_conv_wino2s.inc", "sdc_conv_pw2.inc"]      # csrc files the translation units include
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

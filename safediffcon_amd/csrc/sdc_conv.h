@@ -89,6 +89,8 @@ int launch_wg2(const ConvArgs& a, hipStream_t s);
 int wg2_ksplit(const SdcConvDesc& d);         // Cin split sdc_conv_splitk would use for this conv (1: none)
 int launch_wg3(const ConvArgs& a, hipStream_t s);
 bool wg3s_ok(const SdcConvDesc& d, bool small, bool rowhalo);
+bool wg2s_ok(const SdcConvDesc& d, bool small, bool rowhalo);
+int launch_wg2s(const ConvArgs& a, hipStream_t s);
 int launch_wg3s(const ConvArgs& a, hipStream_t s);
 
 }  // namespace sdcconv

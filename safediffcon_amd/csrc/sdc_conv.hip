@@ -1770,6 +1770,8 @@ extern "C" int sdc_conv_gnparts(const SdcConvDesc* dp, int G) {
     static const int old_wg3 = exp_env("SDC_WG3_OLD");
     if (!no_wg2 && !no_wg3 && !old_wg3 && wg3s_ok(*dp, conv_small(*dp), !no_rh)) return gn_parts_for(*dp, WgPick{22, W2_BM, W3S_TILES * 8, false}, G);
     if (!no_wg2 && !no_wg3 && wg3_ok(*dp, conv_small(*dp), !no_rh)) return gn_parts_for(*dp, WgPick{21, W2_BM, W2_TILES * 8, false}, G);
+    static const int no_wg2s = exp_env("SDC_NO_WG2S");
+    if (!no_wg2 && !no_wg2s && wg2s_ok(*dp, conv_small(*dp), !no_rh)) return gn_parts_for(*dp, WgPick{23, W2_BM, W3S_TILES * 4, false}, G);
     if (!no_wg2 && wg2_ok(*dp, conv_small(*dp), !no_rh)) return gn_parts_for(*dp, WgPick{20, W2_BM, W2_TILES * 4, false}, G);
     return gn_parts_for(*dp, wg_pick(*dp, ntot, conv_small(*dp), !no_rh), G);
 }
@@ -1883,6 +1885,24 @@ int conv_impl(const SdcConvDesc* dp, const float* x0, const float* x1, const flo
         SDC_PICK(d.oW == 16 ? "conv_wg3_kernel<16>" : (d.oW == 32 ? "conv_wg3_kernel<32>" : "conv_wg3_kernel<64>"), 8.0 / 27.0);
         { const int rc_ = launch_wg3(a, s); if (rc_) return rc_; }
         return sdc::check_launch("sdc_conv[winograd 2x2x2]");
+    }
+    // fp32 Winograd F(2x2,3x3), two workgroups per CU (round 6): 3x3 convs (kD = 1) over whole rows of 128 / 64 / 32 -- unless
+    // sdc_conv_splitk wants to split this conv (small grids keep the one-workgroup form and its Cin split)
+    static const int no_wg2s = exp_env("SDC_NO_WG2S");
+    if (!no_wg2 && !no_wg2s && wg2s_ok(d, small, a.rowhalo != 0) && reinterpret_cast<uintptr_t>(wp) % 16 == 0 &&
+        reinterpret_cast<uintptr_t>(x0) % 16 == 0 && (d.Cin1 == 0 || reinterpret_cast<uintptr_t>(x1) % 16 == 0) &&
+        reinterpret_cast<uintptr_t>(y) % 8 == 0 && !residual && !(split_work && wg2_ksplit(d) > 1)) {
+        a.vec2 = 1;
+        a.wg2 = wp + (int64_t)a.Ktot * d.Cout + (int64_t)(a.Ktot / 3 * 4) * d.Cout;
+        if (gn_part) {
+            a.gn_nparts = gn_parts_for(d, WgPick{23, W2_BM, W3S_TILES * 4, false}, gn_G);
+            SDC_REQUIRE(a.gn_nparts > 0, SDC_EINVAL, "sdc_conv_gn: shape not covered by the fused statistics (sdc_conv_gnparts returned 0)");
+            SDC_GN_PARTS_AGREE(a.gn_nparts);
+            a.gn_part = gn_part; a.gn_G = gn_G; a.gn_cpg = d.Cout / gn_G; a.gn_S = d.oD * d.oH * d.oW;
+        }
+        SDC_PICK(d.oW == 128 ? "conv_wg2s_kernel<128>" : (d.oW == 64 ? "conv_wg2s_kernel<64>" : "conv_wg2s_kernel<32>"), 4.0 / 9.0);
+        { const int rc_ = launch_wg2s(a, s); if (rc_) return rc_; }
+        return sdc::check_launch("sdc_conv[winograd 2x2, two workgroups per CU]");
     }
     // fp32 Winograd F(2x2,3x3) over (H, W): 3x3 / 3x3x3 stride-1 convs over whole rows
     if (!no_wg2 && wg2_ok(d, small, a.rowhalo != 0) && reinterpret_cast<uintptr_t>(wp) % 16 == 0 &&

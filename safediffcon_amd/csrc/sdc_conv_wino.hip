@@ -1091,6 +1091,7 @@ __global__ __launch_bounds__(256) void conv_wg3_kernel(const ConvArgs a) {
 }
 
 #include "sdc_conv_wino3s.inc"
+#include "sdc_conv_wino2s.inc"
 
 }  // namespace
 
@@ -1164,6 +1165,37 @@ bool wg3s_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
     return (d.oH / 2) % rp == 0 && even(d.ys) && nores && (d.Cin1 == 0 || (d.x1s[1] == d.x0s[1] && d.x1s[2] == d.x0s[2])) && tiles / W3S_TILES * (d.Cout / W2_BM) < (1ll << 31) &&
            // the park lanes add up to 3 channel strides to their 32-bit byte offset
            span5(d.x0s, 1, 1, 1, d.iH, d.iW) + 3 * d.x0s[1] < (1ll << 29);
+}
+
+// F(2x2,3x3) with two workgroups per CU (sdc_conv_wino2s.inc): what conv_wg2_kernel takes with kD = 1 at rows of 128 / 64 / 32, whole
+// 64-channel output tiles, whole 4-channel stages in pairs, no fused residual; rows of 32: two row pairs of one plane per workgroup
+bool wg2s_ok(const SdcConvDesc& d, bool small, bool rowhalo) {
+    auto even = [](const int64_t* st) { return st[4] == 1 && st[0] % 2 == 0 && st[1] % 2 == 0 && st[2] % 2 == 0 && st[3] % 2 == 0; };
+    if (!(d.precision >= 3 && d.kD == 1 && d.Cout % W2_BM == 0 && (d.oW == 128 || d.oW == 64 || d.oW == 32))) return false;
+    if (!wg2_ok(d, small, rowhalo)) return false;
+    const bool nores = d.rs[0] == 0 && d.rs[1] == 0 && d.rs[2] == 0 && d.rs[3] == 0 && d.rs[4] == 0;
+    const int64_t tiles = (int64_t)d.B * d.oD * (d.oH / 2) * (d.oW / 2);
+    return (d.oW != 32 || (d.oH / 2) % 2 == 0) && even(d.ys) && nores && (d.Cin1 == 0 || d.x1s[1] == d.x0s[1]) &&
+           tiles / W3S_TILES * (d.Cout / W2_BM) < (1ll << 31) && (int64_t)d.B * d.oD * (d.oH / 2) < (1 << 21) &&
+           // the park lanes add up to 3 channel strides to their 32-bit byte offset
+           span5(d.x0s, 1, 1, 1, d.iH, d.iW) + 3 * d.x0s[1] < (1ll << 29);
+}
+
+int launch_wg2s(const ConvArgs& a, hipStream_t s) {
+    const SdcConvDesc& d = a.d;
+    const int64_t tiles = (int64_t)d.B * d.oD * (d.oH / 2) * (d.oW / 2);
+    dim3 grid((unsigned)((tiles / W3S_TILES) * (d.Cout / W2_BM)));
+#define W2S_LAUNCH(OWV)                                                                                                          \
+    do {                                                                                                                         \
+        static std::atomic<uint64_t> attr{0};                                                                                    \
+        SDC_LDS_OPTIN(attr, (conv_wg2s_kernel<OWV>), 80 * 1024, "sdc_conv[winograd 2x2, two workgroups per CU]");                \
+        hipLaunchKernelGGL((conv_wg2s_kernel<OWV>), grid, dim3(256), W2S_LDS_BYTES, s, a);                                       \
+    } while (0)
+    if (d.oW == 128) W2S_LAUNCH(128);
+    else if (d.oW == 64) W2S_LAUNCH(64);
+    else W2S_LAUNCH(32);
+#undef W2S_LAUNCH
+    return SDC_OK;
 }
 
 int launch_wg3s(const ConvArgs& a, hipStream_t s) {

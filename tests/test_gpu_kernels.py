@@ -369,7 +369,8 @@ def test_conv_winograd_2d_mode(plan_cls, case):
         if prec == 3 and G:
             refn = F.silu(F.group_norm(ref, G, gam.double(), bet.double(), 1e-5))
             torch.testing.assert_close(y.cpu().reshape(ref.shape).double(), refn, rtol=1e-4, atol=2e-5)
-    assert names[3].startswith("conv_wg2_kernel") and not names[0].startswith("conv_wg")
+    # (round 6: kD = 1, Cout % 64 == 0, rows of 128 / 64 / 32 run the two-workgroups-per-CU form conv_wg2s_kernel)
+    assert names[3].startswith("conv_wg2") and not names[0].startswith("conv_wg")
     scale = ref.abs().max().item()
     e0 = (outs[0] - ref).abs().max().item() / scale
     e3 = (outs[3] - ref).abs().max().item() / scale
@@ -452,7 +453,7 @@ def test_conv_winograd_3d_falls_back_where_not_covered(plan_cls):
                         residual=None if res is None else as5(res.to(DEV)))
         buf = C.create_string_buffer(128)
         plan.lib.sdc_conv_describe(C.byref(plan.calls[0][1][0]._obj), buf, 128, None)
-        assert buf.value.decode().startswith("conv_wg2_kernel"), buf.value
+        assert buf.value.decode().startswith("conv_wg2"), buf.value      # (conv_wg2_kernel, or conv_wg2s_kernel for the (1, 3, 3) taps)
         _run(plan)
         e = (out.cpu().reshape(ref.shape).double() - ref).abs().max().item() / ref.abs().max().item()
         assert e < 1e-5, e
@@ -992,3 +993,53 @@ def test_conv_pw2_dispatch_is_pinned_and_matches_fp64(plan_cls, case):
     print(f"[measured] {case['want']}: rel err vs fp64 {e:.2e}")
     assert e < 3e-6, e
     assert torch.equal(outs["aligned"], outs["shifted"])
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, cin=8, cout=64, sp=(2, 128), G=0, want="conv_wg2s_kernel<128>"),                  # one row pair, two half-row workgroups, two stages
+    dict(B=3, cin=24, cout=128, sp=(6, 128), cin1=8, G=8, want="conv_wg2s_kernel<128>"),         # two inputs, two channel tiles, GN epilogue
+    dict(B=2, cin=64, cout=64, sp=(16, 128), G=1, want="conv_wg2s_kernel<128>"),                 # the Burgers level-0 conv
+    dict(B=2, cin=64, cout=64, sp=(8, 64), G=1, want="conv_wg2s_kernel<64>"),                    # rows of 64: one row pair per workgroup
+    dict(B=2, cin=16, cout=64, sp=(4, 32), G=0, want="conv_wg2s_kernel<32>"),                    # rows of 32: two row pairs per workgroup
+    dict(B=1, cin=32, cout=192, sp=(8, 32), cin1=32, G=3, want="conv_wg2s_kernel<32>"),          # rows of 32, two inputs, three channel tiles
+    dict(B=2, cin=16, cout=64, sp=(2, 4, 64), G=8, k3=(1, 3, 3), want="conv_wg2s_kernel<64>"),   # a Conv3d with (1, 3, 3) taps: planes are the D axis
+    dict(B=1, cin=16, cout=64, sp=(6, 32), G=0, want="conv_wg2_kernel"),                         # 3 row pairs of 32: not whole workgroups
+    dict(B=1, cin=16, cout=96, sp=(4, 64), G=0, want="conv_wg2_kernel"),                         # Cout % 64 != 0
+    dict(B=1, cin=20, cout=64, sp=(4, 64), G=0, want="conv_kernel"),                             # Cin % 8 != 0: the direct kernel
+])
+def test_conv_wg2s_dispatch_is_pinned_and_matches_fp64(plan_cls, case):
+    """the two-workgroups-per-CU F(2x2,3x3) kernel (round 6) by name -- rows of 128 (half-row workgroups with the
+    halo column at their inner end), 64 and 32, one and two inputs, with and without the GroupNorm epilogue -- against torch in fp64
+    (gate 1e-5 of the output scale); shapes outside its contract fall to conv_wg2_kernel."""
+    from safediffcon_amd.engine import as5
+    B, cin, cout, sp, cin1, G = case["B"], case["cin"], case["cout"], case["sp"], case.get("cin1", 0), case["G"]
+    nd = len(sp)
+    x, x1 = det_tensor((B, cin, *sp), 701), (det_tensor((B, cin1, *sp), 702) if cin1 else None)
+    if nd == 2:
+        w = det_tensor((cout, cin + cin1, 3, 3), 703, 0.2)
+        k3, p3 = (1, 3, 3), (0, 1, 1)
+    else:
+        w = det_tensor((cout, cin + cin1, 1, 3, 3), 703, 0.2)
+        k3, p3 = (1, 3, 3), (0, 1, 1)
+    b = det_tensor((cout,), 704, 0.1)
+    xin = x if x1 is None else torch.cat((x, x1), 1)
+    ref = (F.conv2d(xin.double(), w.double(), b.double(), padding=1) if nd == 2
+           else F.conv3d(xin.double(), w.double(), b.double(), padding=(0, 1, 1)))
+    plan = plan_cls(DEV, precision=4)
+    out = plan.conv(as5(x.to(DEV)), plan.conv_weight(w.to(DEV)), b.to(DEV), cout, k3,
+                    x1=None if x1 is None else as5(x1.to(DEV)), pad=p3, gn_groups=G)
+    name, share = _describe(plan)
+    assert name.startswith(case["want"]), (name, case["want"])
+    y = None
+    if G and "wg2" in name:
+        assert plan.calls[0][0] is plan.lib.sdc_conv_gn
+        gam, bet = det_tensor((cout,), 705, 0.3) + 1.0, det_tensor((cout,), 706, 0.2)
+        y = plan.pool.get(tuple(out.shape))
+        plan.gn_silu(out, gam.to(DEV), bet.to(DEV), G, out=y)
+    _run(plan)
+    e = (out.cpu().reshape(ref.shape).double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"[measured] {name}: rel err vs fp64 {e:.2e}")
+    assert e < 1e-5, (name, e)
+    if y is not None:
+        refn = F.silu(F.group_norm(ref, G, gam.double(), bet.double(), 1e-5))
+        torch.testing.assert_close(y.cpu().reshape(ref.shape).double(), refn, rtol=1e-4, atol=2e-5)
