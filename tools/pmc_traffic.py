@@ -72,7 +72,7 @@ cases["gn_pw_out_kernel"] = dict(algorithmic=4 * (hf.numel() + rf.numel() + ef.n
 x2 = torch.randn(256, 64, 16, 128, device=dev)
 w2 = torch.randn(64, 64, 3, 3, device=dev) * 0.05
 o2 = plan.conv(as5(x2), plan.conv_weight(w2), torch.randn(64, device=dev), 64, (1, 3, 3), pad=(0, 1, 1), gn_groups=1)
-cases["conv_wg2_kernel<128"] = dict(algorithmic=4 * (x2.numel() + o2.numel() + w2.numel()), workload="c2",
+cases["conv_wg2s_kernel<128"] = dict(algorithmic=4 * (x2.numel() + o2.numel() + w2.numel()), workload="c2",
                                     shape="C2: 64->64 3x3 at (256,64,16,128) + GN statistics (Burgers level 0)")
 x3 = torch.randn(128, 256, 128, device=dev)
 w3 = torch.randn(256, 256, 3, device=dev) * 0.03
